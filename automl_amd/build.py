@@ -1,0 +1,52 @@
+"""Builds the gfx950 shared library (C ABI in include/edet_hip.h) in-tree with hipcc."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(_HERE, 'libedet_hip.so')
+SOURCES = ['pw_gemm.hip', 'dwconv.hip', 'stem.hip', 'bn_se.hip', 'fuse.hip', 'loss_opt.hip', 'error.cpp']
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
+
+
+def _stale(target, deps):
+  if not os.path.exists(target):
+    return True
+  t = os.path.getmtime(target)
+  return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False):
+  """Compiles every HIP source for gfx950 and links libedet_hip.so; returns its path."""
+  hdrs = [os.path.join(CSRC, 'common.h'), os.path.join(_HERE, '..', 'include', 'edet_hip.h')]
+  objdir = os.path.join(CSRC, 'build')
+  os.makedirs(objdir, exist_ok=True)
+  jobs = []
+  for src in SOURCES:
+    s = os.path.join(CSRC, src)
+    o = os.path.join(objdir, os.path.splitext(src)[0] + '.o')
+    if force or _stale(o, [s] + hdrs):
+      cmd = [HIPCC] + FLAGS + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', s, '-o', o]
+      jobs.append(cmd)
+
+  def run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+      raise RuntimeError('hipcc failed: %s\n%s' % (' '.join(cmd), r.stderr))
+    if verbose and r.stderr:
+      sys.stderr.write(r.stderr)
+
+  if jobs:
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+      list(ex.map(run, jobs))
+  objs = [os.path.join(objdir, os.path.splitext(s)[0] + '.o') for s in SOURCES]
+  if force or jobs or _stale(LIB_PATH, objs):
+    run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs)
+  return LIB_PATH
+
+
+if __name__ == '__main__':
+  print(build_library(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,488 @@
+// BatchNorm statistics (forward finalize / backward reduce + finalize), block-output
+// materialisation, squeeze-and-excitation, and small elementwise helpers.
+//
+// Reference: efficientdet/utils.py:166-266 (BatchNorm classes, eps 1e-3, momentum 0.99),
+// efficientdet/tf2/util_keras.py:29-66, efficientdet/backbone/efficientnet_model.py:153-195 (SE),
+// :393-410 (project BN + identity skip).
+#include "common.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+
+// Row x channel-vector mapping with a *fixed* channel vector per thread, so per-channel partial
+// sums can live in registers: tpr = threads per row (power of two >= c/8, <= 256).
+struct RowMap {
+  int tpr, rpp;  // threads per row, rows per pass
+};
+inline RowMap row_map(int c) {
+  int nvec = c / 8, tpr = 1;
+  while (tpr < nvec && tpr < THREADS) tpr <<= 1;
+  RowMap m;
+  m.tpr = tpr;
+  m.rpp = THREADS / tpr;
+  return m;
+}
+inline int persistent_grid(int64_t rows, int rpp, int max_wg) {
+  int64_t passes = (rows + rpp - 1) / rpp;
+  int64_t g = (passes + 7) / 8;  // at least ~8 passes per workgroup
+  if (g < 1) g = 1;
+  if (g > max_wg) g = max_wg;
+  return (int)g;
+}
+
+// ------------------------------------------------------------------ forward statistics finalize
+__global__ void k_bn_finalize(const float* __restrict__ partials, int nparts, int c, double count,
+                              const float* gamma, const float* beta, float eps, float momentum,
+                              float* moving_mean, float* moving_var, float* scale, float* shift,
+                              float* mean_out, float* rstd_out) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double s = 0.0, s2 = 0.0;
+  for (int p = 0; p < nparts; ++p) {
+    s += (double)partials[((size_t)p * 2) * c + ch];
+    s2 += (double)partials[((size_t)p * 2 + 1) * c + ch];
+  }
+  const double mean = s / count;
+  double var = s2 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[ch] * rstd;
+  scale[ch] = sc;
+  shift[ch] = beta[ch] - (float)mean * sc;
+  mean_out[ch] = (float)mean;
+  rstd_out[ch] = rstd;
+  if (momentum >= 0.f && moving_mean) {
+    // Keras fused BatchNorm: moving variance is updated with the Bessel-corrected batch variance
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    moving_mean[ch] = moving_mean[ch] * momentum + (float)mean * (1.f - momentum);
+    moving_var[ch] = moving_var[ch] * momentum + (float)unbiased * (1.f - momentum);
+  }
+}
+
+__global__ void k_bn_eval(int c, const float* gamma, const float* beta, float eps,
+                          const float* moving_mean, const float* moving_var, float* scale, float* shift) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  const float sc = gamma[ch] * rsqrtf(moving_var[ch] + eps);
+  scale[ch] = sc;
+  shift[ch] = beta[ch] - moving_mean[ch] * sc;
+}
+
+// ------------------------------------------------------------------ backward reduce / finalize
+template <typename T>
+__global__ __launch_bounds__(THREADS) void k_bn_bwd_reduce(const T* __restrict__ dz, const T* __restrict__ y,
+                                                          int64_t rows, int c, int ld, const float* mean,
+                                                          const float* rstd, float* partials, RowMap m) {
+  const int tid = threadIdx.x;
+  const int cv = tid % m.tpr, rr = tid / m.tpr;
+  const int c0 = cv * 8;
+  const bool ok = c0 < c;
+  float mu[8], rs[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { mu[e] = 0.f; rs[e] = 0.f; s1[e] = s2[e] = 0.f; }
+  if (ok) { loadf8(mean + c0, mu); loadf8(rstd + c0, rs); }
+  for (int64_t r = (int64_t)blockIdx.x * m.rpp + rr; r < rows; r += (int64_t)gridDim.x * m.rpp) {
+    if (!ok) continue;
+    float g[8], x[8];
+    load8<T>(dz + r * ld + c0, g);
+    load8<T>(y + r * ld + c0, x);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] += g[e]; s2[e] += g[e] * (x[e] - mu[e]) * rs[e]; }
+  }
+  extern __shared__ float red[];  // [2][c]
+  for (int i = tid; i < 2 * c; i += THREADS) red[i] = 0.f;
+  __syncthreads();
+  if (ok) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { atomicAdd(&red[c0 + e], s1[e]); atomicAdd(&red[c + c0 + e], s2[e]); }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * c; i += THREADS) partials[(size_t)blockIdx.x * 2 * c + i] = red[i];
+}
+
+__global__ void k_bn_bwd_finalize(const float* __restrict__ partials, int nparts, int c, double count,
+                                  const float* gamma, const float* mean, const float* rstd,
+                                  float* dgamma, float* dbeta, float* a, float* b, float* cc) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int p = 0; p < nparts; ++p) {
+    s1 += (double)partials[((size_t)p * 2) * c + ch];
+    s2 += (double)partials[((size_t)p * 2 + 1) * c + ch];
+  }
+  if (dbeta) dbeta[ch] += (float)s1;
+  if (dgamma) dgamma[ch] += (float)s2;
+  const double m1 = s1 / count, m2 = s2 / count;
+  const double g = gamma[ch], r = rstd[ch], mu = mean[ch];
+  // dy = g*r*(dz - m1 - xhat*m2), xhat = (y - mu)*r
+  a[ch] = (float)(g * r);
+  b[ch] = (float)(-g * r * r * m2);
+  cc[ch] = (float)(-g * r * m1 + g * r * r * m2 * mu);
+}
+
+// ------------------------------------------------------------------ out = y*scale+shift (+res)
+template <typename T>
+__global__ void k_bn_res(const edet_tview_t y, const T* __restrict__ res, T* __restrict__ out, int ldo,
+                         int64_t rows) {
+  const int nvec = y.c / 8;
+  const int64_t total = rows * nvec;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = q / nvec;
+    const int c0 = (int)(q - r * nvec) * 8;
+    float x[8];
+    load8<T>(reinterpret_cast<const T*>(y.data) + r * y.ld + c0, x);
+    ViewCoef vc;
+    view_load_coef(y, c0, vc);
+    view_apply(y, vc, c0, 0, x);
+    if (res) {
+      float rr[8];
+      load8<T>(res + r * ldo + c0, rr);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] += rr[e];
+    }
+    store8<T>(out + r * ldo + c0, x);
+  }
+}
+
+template <typename T>
+__global__ void k_add(T* __restrict__ dst, const T* __restrict__ src, int64_t rows, int c, int ld, int beta) {
+  const int nvec = c / 8;
+  const int64_t total = rows * nvec;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = q / nvec;
+    const int c0 = (int)(q - r * nvec) * 8;
+    float x[8];
+    load8<T>(src + r * ld + c0, x);
+    if (beta) {
+      float d[8];
+      load8<T>(dst + r * ld + c0, d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] += d[e];
+    }
+    store8<T>(dst + r * ld + c0, x);
+  }
+}
+
+// ------------------------------------------------------------------ squeeze-and-excitation
+// pooled_sum[n][c] += sum over this workgroup's pixels of view(in)
+template <typename T>
+__global__ __launch_bounds__(THREADS) void k_se_pool(const edet_tview_t in, float* pooled, int wg_per_img,
+                                                    RowMap m) {
+  const int tid = threadIdx.x;
+  const int n = blockIdx.x / wg_per_img, part = blockIdx.x % wg_per_img;
+  const int cv = tid % m.tpr, rr = tid / m.tpr;
+  const int c0 = cv * 8;
+  const bool ok = c0 < in.c;
+  const int hw = in.h * in.w;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  ViewCoef vc;
+  if (ok) view_load_coef(in, c0, vc);
+  edet_tview_t v = in;
+  v.gate = nullptr;
+  const T* base = reinterpret_cast<const T*>(in.data) + (size_t)n * hw * in.ld;
+  if (ok) {
+    for (int r = part * m.rpp + rr; r < hw; r += wg_per_img * m.rpp) {
+      float x[8];
+      load8<T>(base + (size_t)r * in.ld + c0, x);
+      view_apply(v, vc, c0, n, x);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += x[e];
+    }
+  }
+  extern __shared__ float red[];  // [c]
+  for (int i = tid; i < in.c; i += THREADS) red[i] = 0.f;
+  __syncthreads();
+  if (ok) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(&red[c0 + e], s[e]);
+  }
+  __syncthreads();
+  for (int i = tid; i < in.c; i += THREADS) atomicAdd(&pooled[(size_t)n * in.c + i], red[i]);
+}
+
+// one workgroup per image
+__global__ __launch_bounds__(THREADS) void k_se_fc(const float* __restrict__ pooled, int c, int se, float inv_hw,
+                                                  const float* w1, const float* b1, const float* w2,
+                                                  const float* b2, float* hidden_pre, float* gate) {
+  extern __shared__ float sm[];  // p[c], h[se]
+  float* p = sm;
+  float* h = sm + c;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < c; i += THREADS) p[i] = pooled[(size_t)n * c + i] * inv_hw;
+  __syncthreads();
+  for (int j = tid; j < se; j += THREADS) {
+    float acc = b1[j];
+    for (int i = 0; i < c; ++i) acc = fmaf(p[i], w1[(size_t)i * se + j], acc);
+    hidden_pre[(size_t)n * se + j] = acc;
+    h[j] = swishf_(acc);
+  }
+  __syncthreads();
+  for (int i = tid; i < c; i += THREADS) {
+    float acc = b2[i];
+    for (int j = 0; j < se; ++j) acc = fmaf(h[j], w2[(size_t)j * c + i], acc);
+    gate[(size_t)n * c + i] = sigmoidf_(acc);
+  }
+}
+
+// per image: dgate -> dpre2, dh, dpre1, dpool.  scratch: dpre2 [n][c] then dpre1 [n][se]
+__global__ __launch_bounds__(THREADS) void k_se_fc_bwd_img(const float* __restrict__ hidden_pre,
+                                                          const float* __restrict__ gate,
+                                                          const float* __restrict__ dgate, int nimg, int c,
+                                                          int se, float inv_hw, const float* w1,
+                                                          const float* w2, float* dpool, float* scratch) {
+  extern __shared__ float sm[];  // dpre2[c], dpre1[se]
+  float* d2 = sm;
+  float* d1 = sm + c;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  float* dpre2_g = scratch + (size_t)n * c;
+  float* dpre1_g = scratch + (size_t)nimg * c + (size_t)n * se;
+  for (int i = tid; i < c; i += THREADS) {
+    const float g = gate[(size_t)n * c + i];
+    const float v = dgate[(size_t)n * c + i] * g * (1.f - g);
+    d2[i] = v;
+    dpre2_g[i] = v;
+  }
+  __syncthreads();
+  for (int j = tid; j < se; j += THREADS) {
+    float acc = 0.f;
+    for (int i = 0; i < c; ++i) acc = fmaf(d2[i], w2[(size_t)j * c + i], acc);
+    const float v = acc * swish_gradf_(hidden_pre[(size_t)n * se + j]);
+    d1[j] = v;
+    dpre1_g[j] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < c; i += THREADS) {
+    float acc = 0.f;
+    for (int j = 0; j < se; ++j) acc = fmaf(d1[j], w1[(size_t)i * se + j], acc);
+    dpool[(size_t)n * c + i] = acc * inv_hw;
+  }
+}
+
+// parameter gradients: one thread per channel i (and per hidden unit j for db1)
+__global__ void k_se_fc_bwd_par(const float* __restrict__ pooled, const float* __restrict__ hidden_pre,
+                                const float* __restrict__ scratch, int nimg, int c, int se, float inv_hw,
+                                float* dw1, float* db1, float* dw2, float* db2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float* dpre2 = scratch;
+  const float* dpre1 = scratch + (size_t)nimg * c;
+  if (i < c) {
+    float sb2 = 0.f;
+    for (int n = 0; n < nimg; ++n) sb2 += dpre2[(size_t)n * c + i];
+    db2[i] += sb2;
+    for (int j = 0; j < se; ++j) {
+      float a1 = 0.f, a2 = 0.f;
+      for (int n = 0; n < nimg; ++n) {
+        a1 = fmaf(pooled[(size_t)n * c + i] * inv_hw, dpre1[(size_t)n * se + j], a1);
+        a2 = fmaf(swishf_(hidden_pre[(size_t)n * se + j]), dpre2[(size_t)n * c + i], a2);
+      }
+      dw1[(size_t)i * se + j] += a1;
+      dw2[(size_t)j * c + i] += a2;
+    }
+  }
+  if (i < se) {
+    float sb1 = 0.f;
+    for (int n = 0; n < nimg; ++n) sb1 += dpre1[(size_t)n * se + i];
+    db1[i] += sb1;
+  }
+}
+
+// g (in place, holds D) -> dz = (D*gate + dpool)*act'(z); BN backward stat partials
+template <typename T>
+__global__ __launch_bounds__(THREADS) void k_se_gate_bwd(const edet_tview_t in, T* g, const float* dpool,
+                                                        const float* mean, const float* rstd,
+                                                        float* partials, int wg_per_img, RowMap m) {
+  const int tid = threadIdx.x;
+  const int n = blockIdx.x / wg_per_img, part = blockIdx.x % wg_per_img;
+  const int cv = tid % m.tpr, rr = tid / m.tpr;
+  const int c0 = cv * 8;
+  const bool ok = c0 < in.c;
+  const int hw = in.h * in.w;
+  float s1[8], s2[8], sc[8], sh[8], mu[8], rs[8], gt[8], dp[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = s2[e] = 0.f; sc[e] = 1.f; sh[e] = 0.f; mu[e] = 0.f; rs[e] = 1.f; gt[e] = 1.f; dp[e] = 0.f; }
+  if (ok) {
+    if (in.scale) { loadf8(in.scale + c0, sc); loadf8(in.shift + c0, sh); }
+    loadf8(mean + c0, mu);
+    loadf8(rstd + c0, rs);
+    loadf8(in.gate + (size_t)n * in.c + c0, gt);
+    loadf8(dpool + (size_t)n * in.c + c0, dp);
+    const size_t base = (size_t)n * hw * in.ld;
+    for (int r = part * m.rpp + rr; r < hw; r += wg_per_img * m.rpp) {
+      const size_t off = base + (size_t)r * in.ld + c0;
+      float d[8], x[8];
+      load8<T>(g + off, d);
+      load8<T>(reinterpret_cast<const T*>(in.data) + off, x);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float z = fmaf(x[e], sc[e], sh[e]);
+        const float da = fmaf(d[e], gt[e], dp[e]);
+        d[e] = in.act == EDET_ACT_SWISH ? da * swish_gradf_(z) : da;
+        s1[e] += d[e];
+        s2[e] += d[e] * (x[e] - mu[e]) * rs[e];
+      }
+      store8<T>(g + off, d);
+    }
+  }
+  extern __shared__ float red[];  // [2][c]
+  for (int i = tid; i < 2 * in.c; i += THREADS) red[i] = 0.f;
+  __syncthreads();
+  if (ok) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { atomicAdd(&red[c0 + e], s1[e]); atomicAdd(&red[in.c + c0 + e], s2[e]); }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * in.c; i += THREADS) partials[(size_t)blockIdx.x * 2 * in.c + i] = red[i];
+}
+
+inline int ew_grid(int64_t total) {
+  int64_t g = (total + THREADS - 1) / THREADS;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int edet_bn_finalize(const float* partials, int nparts, int c, double count,
+                                const float* gamma, const float* beta, float eps, float momentum,
+                                float* moving_mean, float* moving_var, float* scale, float* shift,
+                                float* mean, float* rstd, void* stream) {
+  EDET_CHECK(partials && gamma && beta && scale && shift && mean && rstd, "edet_bn_finalize: null pointer");
+  k_bn_finalize<<<cdiv(c, 128), 128, 0, to_stream(stream)>>>(partials, nparts, c, count, gamma, beta, eps,
+                                                            momentum, moving_mean, moving_var, scale, shift,
+                                                            mean, rstd);
+  EDET_LAUNCH_CHECK("edet_bn_finalize");
+  return 0;
+}
+
+extern "C" int edet_bn_eval(int c, const float* gamma, const float* beta, float eps,
+                            const float* moving_mean, const float* moving_var, float* scale, float* shift,
+                            void* stream) {
+  EDET_CHECK(gamma && beta && moving_mean && moving_var && scale && shift, "edet_bn_eval: null pointer");
+  k_bn_eval<<<cdiv(c, 128), 128, 0, to_stream(stream)>>>(c, gamma, beta, eps, moving_mean, moving_var, scale, shift);
+  EDET_LAUNCH_CHECK("edet_bn_eval");
+  return 0;
+}
+
+extern "C" int edet_bn_bwd_reduce(const void* dz, const void* y, int64_t rows, int c, int ld,
+                                  const float* mean, const float* rstd, float* stat_partials,
+                                  int* nparts_out, int dtype, void* stream) {
+  EDET_CHECK(dz && y && mean && rstd && stat_partials, "edet_bn_bwd_reduce: null pointer");
+  EDET_CHECK(c % 8 == 0 && ld % 8 == 0 && c <= 2048, "edet_bn_bwd_reduce: c/ld must be multiples of 8, c <= 2048");
+  const RowMap m = row_map(c);
+  const int grid = persistent_grid(rows, m.rpp, 512);
+  if (nparts_out) *nparts_out = grid;
+  const size_t lds = (size_t)2 * c * sizeof(float);
+  if (dtype == EDET_BF16)
+    k_bn_bwd_reduce<bf16_t><<<grid, THREADS, lds, to_stream(stream)>>>((const bf16_t*)dz, (const bf16_t*)y, rows, c, ld, mean, rstd, stat_partials, m);
+  else if (dtype == EDET_F32)
+    k_bn_bwd_reduce<float><<<grid, THREADS, lds, to_stream(stream)>>>((const float*)dz, (const float*)y, rows, c, ld, mean, rstd, stat_partials, m);
+  else EDET_CHECK(false, "edet_bn_bwd_reduce: bad dtype %d", dtype);
+  EDET_LAUNCH_CHECK("edet_bn_bwd_reduce");
+  return 0;
+}
+
+extern "C" int edet_bn_bwd_finalize(const float* partials, int nparts, int c, double count,
+                                    const float* gamma, const float* mean, const float* rstd,
+                                    float* dgamma, float* dbeta, float* dbias,
+                                    float* a, float* b, float* cc, void* stream) {
+  EDET_CHECK(partials && gamma && mean && rstd && a && b && cc, "edet_bn_bwd_finalize: null pointer");
+  (void)dbias;  // d(bias before BatchNorm) is analytically zero: BN removes the mean
+  k_bn_bwd_finalize<<<cdiv(c, 128), 128, 0, to_stream(stream)>>>(partials, nparts, c, count, gamma, mean, rstd,
+                                                                dgamma, dbeta, a, b, cc);
+  EDET_LAUNCH_CHECK("edet_bn_bwd_finalize");
+  return 0;
+}
+
+extern "C" int edet_bn_res(const edet_tview_t* y, const void* residual, void* out, int ldo,
+                           int dtype, void* stream) {
+  EDET_CHECK(y && y->data && out, "edet_bn_res: null pointer");
+  EDET_CHECK(y->c % 8 == 0 && y->ld % 8 == 0 && ldo % 8 == 0, "edet_bn_res: c/ld % 8");
+  const int64_t rows = (int64_t)y->n * y->h * y->w;
+  const int grid = ew_grid(rows * (y->c / 8));
+  if (dtype == EDET_BF16) k_bn_res<bf16_t><<<grid, THREADS, 0, to_stream(stream)>>>(*y, (const bf16_t*)residual, (bf16_t*)out, ldo, rows);
+  else if (dtype == EDET_F32) k_bn_res<float><<<grid, THREADS, 0, to_stream(stream)>>>(*y, (const float*)residual, (float*)out, ldo, rows);
+  else EDET_CHECK(false, "edet_bn_res: bad dtype %d", dtype);
+  EDET_LAUNCH_CHECK("edet_bn_res");
+  return 0;
+}
+
+extern "C" int edet_add(void* dst, const void* src, int64_t rows, int c, int ld, int beta,
+                        int dtype, void* stream) {
+  EDET_CHECK(dst && src, "edet_add: null pointer");
+  EDET_CHECK(c % 8 == 0 && ld % 8 == 0, "edet_add: c/ld % 8");
+  const int grid = ew_grid(rows * (c / 8));
+  if (dtype == EDET_BF16) k_add<bf16_t><<<grid, THREADS, 0, to_stream(stream)>>>((bf16_t*)dst, (const bf16_t*)src, rows, c, ld, beta);
+  else if (dtype == EDET_F32) k_add<float><<<grid, THREADS, 0, to_stream(stream)>>>((float*)dst, (const float*)src, rows, c, ld, beta);
+  else EDET_CHECK(false, "edet_add: bad dtype %d", dtype);
+  EDET_LAUNCH_CHECK("edet_add");
+  return 0;
+}
+
+static int se_wg_per_img(int n, int hw, int rpp) {
+  int passes = cdiv(hw, rpp);
+  int w = 1024 / (n > 0 ? n : 1);
+  if (w < 1) w = 1;
+  if (w > passes) w = passes;
+  if (w > 64) w = 64;
+  return w;
+}
+
+extern "C" int edet_se_pool(const edet_tview_t* in, float* pooled_sum, int dtype, void* stream) {
+  EDET_CHECK(in && in->data && pooled_sum, "edet_se_pool: null pointer");
+  EDET_CHECK(in->c % 8 == 0 && in->ld % 8 == 0 && in->c <= 2048, "edet_se_pool: c/ld");
+  const RowMap m = row_map(in->c);
+  const int wpi = se_wg_per_img(in->n, in->h * in->w, m.rpp);
+  const size_t lds = (size_t)in->c * sizeof(float);
+  if (dtype == EDET_BF16) k_se_pool<bf16_t><<<in->n * wpi, THREADS, lds, to_stream(stream)>>>(*in, pooled_sum, wpi, m);
+  else if (dtype == EDET_F32) k_se_pool<float><<<in->n * wpi, THREADS, lds, to_stream(stream)>>>(*in, pooled_sum, wpi, m);
+  else EDET_CHECK(false, "edet_se_pool: bad dtype %d", dtype);
+  EDET_LAUNCH_CHECK("edet_se_pool");
+  return 0;
+}
+
+extern "C" int edet_se_fc(const float* pooled_sum, int n, int c, int se, float inv_hw,
+                          const float* w1, const float* b1, const float* w2, const float* b2,
+                          float* hidden_pre, float* gate, void* stream) {
+  EDET_CHECK(pooled_sum && w1 && b1 && w2 && b2 && hidden_pre && gate, "edet_se_fc: null pointer");
+  k_se_fc<<<n, THREADS, (size_t)(c + se) * sizeof(float), to_stream(stream)>>>(pooled_sum, c, se, inv_hw, w1, b1, w2, b2, hidden_pre, gate);
+  EDET_LAUNCH_CHECK("edet_se_fc");
+  return 0;
+}
+
+extern "C" int edet_se_fc_bwd(const float* pooled_sum, const float* hidden_pre, const float* gate,
+                              const float* dgate, int n, int c, int se, float inv_hw,
+                              const float* w1, const float* w2,
+                              float* dw1, float* db1, float* dw2, float* db2,
+                              float* dpool, float* scratch, void* stream) {
+  EDET_CHECK(pooled_sum && hidden_pre && gate && dgate && w1 && w2 && dw1 && db1 && dw2 && db2 && dpool && scratch,
+             "edet_se_fc_bwd: null pointer");
+  k_se_fc_bwd_img<<<n, THREADS, (size_t)(c + se) * sizeof(float), to_stream(stream)>>>(hidden_pre, gate, dgate, n, c, se, inv_hw, w1, w2, dpool, scratch);
+  const int tot = c > se ? c : se;
+  k_se_fc_bwd_par<<<cdiv(tot, 64), 64, 0, to_stream(stream)>>>(pooled_sum, hidden_pre, scratch, n, c, se, inv_hw, dw1, db1, dw2, db2);
+  EDET_LAUNCH_CHECK("edet_se_fc_bwd");
+  return 0;
+}
+
+extern "C" int edet_se_gate_bwd(const edet_tview_t* in, void* g, const float* dpool,
+                                const float* mean, const float* rstd,
+                                float* stat_partials, int* nparts_out, int dtype, void* stream) {
+  EDET_CHECK(in && in->data && in->gate && g && dpool && mean && rstd && stat_partials, "edet_se_gate_bwd: null pointer");
+  EDET_CHECK(in->c % 8 == 0 && in->ld % 8 == 0 && in->c <= 2048, "edet_se_gate_bwd: c/ld");
+  const RowMap m = row_map(in->c);
+  int wpi = se_wg_per_img(in->n, in->h * in->w, m.rpp);
+  while (in->n * wpi > EDET_MAX_PARTS && wpi > 1) --wpi;
+  EDET_CHECK(in->n * wpi <= EDET_MAX_PARTS, "edet_se_gate_bwd: batch %d exceeds %d partial rows", in->n, EDET_MAX_PARTS);
+  if (nparts_out) *nparts_out = in->n * wpi;
+  const size_t lds = (size_t)2 * in->c * sizeof(float);
+  if (dtype == EDET_BF16) k_se_gate_bwd<bf16_t><<<in->n * wpi, THREADS, lds, to_stream(stream)>>>(*in, (bf16_t*)g, dpool, mean, rstd, stat_partials, wpi, m);
+  else if (dtype == EDET_F32) k_se_gate_bwd<float><<<in->n * wpi, THREADS, lds, to_stream(stream)>>>(*in, (float*)g, dpool, mean, rstd, stat_partials, wpi, m);
+  else EDET_CHECK(false, "edet_se_gate_bwd: bad dtype %d", dtype);
+  EDET_LAUNCH_CHECK("edet_se_gate_bwd");
+  return 0;
+}

@@ -1,0 +1,176 @@
+// Shared device helpers for the gfx950 EfficientDet kernels (wave64, NHWC, fp32 math).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/edet_hip.h"
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+// ---------------------------------------------------------------- error handling
+void edet_set_error(const char* fmt, ...);
+#define EDET_CHECK(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      edet_set_error(__VA_ARGS__);       \
+      return -1;                         \
+    }                                    \
+  } while (0)
+#define EDET_LAUNCH_CHECK(name)                                          \
+  do {                                                                   \
+    hipError_t e_ = hipGetLastError();                                   \
+    if (e_ != hipSuccess) {                                              \
+      edet_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+      return -2;                                                         \
+    }                                                                    \
+  } while (0)
+
+// ---------------------------------------------------------------- scalar conversions
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even fp32 -> bf16 (NaN stays NaN)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+
+// ---------------------------------------------------------------- 8-element vector I/O
+// p must be 16-byte aligned for bf16 (8 elems) and fp32 (2 x float4).
+template <typename T> __device__ __forceinline__ void load8(const T* p, float v[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float v[8]) {
+  float4 a = *reinterpret_cast<const float4*>(p);
+  float4 b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float v[8]) {
+  uint4 a = *reinterpret_cast<const uint4*>(p);
+  v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+  v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+  v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+  v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float v[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float v[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float v[8]) {
+  uint4 a;
+  a.x = pack2bf(v[0], v[1]); a.y = pack2bf(v[2], v[3]);
+  a.z = pack2bf(v[4], v[5]); a.w = pack2bf(v[6], v[7]);
+  *reinterpret_cast<uint4*>(p) = a;
+}
+__device__ __forceinline__ void loadf8(const float* p, float v[8]) { load8<float>(p, v); }
+
+// ---------------------------------------------------------------- 4-element vector I/O
+// 8-byte aligned for bf16, 16-byte aligned for fp32.
+template <typename T> __device__ __forceinline__ void load4(const T* p, float v[4]);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float v[4]) {
+  float4 a = *reinterpret_cast<const float4*>(p);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float v[4]) {
+  uint2 a = *reinterpret_cast<const uint2*>(p);
+  v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+  v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float v[4]);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float v[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float v[4]) {
+  uint2 a;
+  a.x = pack2bf(v[0], v[1]); a.y = pack2bf(v[2], v[3]);
+  *reinterpret_cast<uint2*>(p) = a;
+}
+
+// ---------------------------------------------------------------- activations
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
+// d/dx x*sigmoid(x) = s * (1 + x * (1 - s))
+__device__ __forceinline__ float swish_gradf_(float x) {
+  float s = sigmoidf_(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+
+// Activated-view element transform for 8 consecutive channels starting at c0.
+// img = image index of the row (only used when gate != NULL).
+struct ViewCoef {
+  float scale[8], shift[8];
+};
+__device__ __forceinline__ void view_load_coef(const edet_tview_t& v, int c0, ViewCoef& k) {
+  if (v.scale) {
+    loadf8(v.scale + c0, k.scale);
+    loadf8(v.shift + c0, k.shift);
+  }
+}
+// x (raw) -> z (pre-activation) -> value
+__device__ __forceinline__ void view_apply(const edet_tview_t& v, const ViewCoef& k, int c0,
+                                           int img, float x[8]) {
+  if (v.scale) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], k.scale[e], k.shift[e]);
+  }
+  if (v.act == EDET_ACT_SWISH) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = swishf_(x[e]);
+  }
+  if (v.gate) {
+    float g[8];
+    loadf8(v.gate + (size_t)img * v.c + c0, g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] *= g[e];
+  }
+}
+
+struct GradCoef {
+  float a[8], b[8], cc[8];
+};
+__device__ __forceinline__ void grad_load_coef(const edet_gview_t& g, int c0, GradCoef& k) {
+  if (g.a) {
+    loadf8(g.a + c0, k.a);
+    loadf8(g.b + c0, k.b);
+    loadf8(g.cc + c0, k.cc);
+  }
+}
+// loads dy for 8 channels at element offset `off` (= row*ld + c0)
+template <typename T>
+__device__ __forceinline__ void grad_load(const edet_gview_t& g, const GradCoef& k, size_t off,
+                                          float dy[8]) {
+  load8<T>(reinterpret_cast<const T*>(g.dz) + off, dy);
+  if (g.a) {
+    float y[8];
+    load8<T>(reinterpret_cast<const T*>(g.y) + off, y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dy[e] = fmaf(k.a[e], dy[e], fmaf(k.b[e], y[e], k.cc[e]));
+  }
+}
+
+// TF 'SAME' geometry
+__host__ __device__ inline int same_out(int in, int s) { return (in + s - 1) / s; }
+__host__ __device__ inline int same_pad_before(int in, int k, int s) {
+  int out = (in + s - 1) / s;
+  int total = (out - 1) * s + k - in;
+  if (total < 0) total = 0;
+  return total / 2;
+}
+
+static inline hipStream_t to_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

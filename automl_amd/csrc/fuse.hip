@@ -1,0 +1,365 @@
+// BiFPN weighted feature fusion with the resampling of its inputs folded in.
+//
+//   out = act( sum_i wn_i * R_i(view_i) ),  R in {identity, nearest-upsample, max-pool 3x3/s2 'SAME'}
+//
+// One elementwise pass: every input is read once (the pooled input 9 taps from L1/L2), BatchNorm
+// of the producing 1x1 conv is applied on load, the fused + activated result is written once.
+// Reference: efficientdet/tf2/efficientdet_keras.py:75-121 (fuse_features: fastattn / sum),
+// :254-263 (MaxPooling2D pool=stride+1, 'SAME'), :272-281 (resize_nearest_neighbor),
+// :214-217 (activation before the separable conv); efficientdet/efficientdet_arch.py:418-475.
+#include "common.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+
+struct FuseArgs {
+  edet_tview_t in[3];
+  int mode[3];
+  int pad_t[3], pad_l[3];
+  int nin;
+  const float* wn;  // [3] normalised weights (device)
+  int act;
+  int n, oh, ow, c, ldo;
+};
+
+// affine-only view value (fusion inputs never carry an activation or gate)
+__device__ __forceinline__ void affine8(const edet_tview_t& v, const ViewCoef& k, float x[8]) {
+  if (v.scale) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], k.scale[e], k.shift[e]);
+  }
+}
+
+// value of resampled input i at output pixel (n, oy, ox), channels c0..c0+7
+template <typename T>
+__device__ __forceinline__ void sample_input(const FuseArgs& a, int i, const ViewCoef& k, int n, int oy,
+                                             int ox, int c0, float x[8]) {
+  const edet_tview_t& v = a.in[i];
+  const T* base = reinterpret_cast<const T*>(v.data);
+  if (a.mode[i] == EDET_RS_IDENTITY) {
+    load8<T>(base + ((size_t)(n * v.h + oy) * v.w + ox) * v.ld + c0, x);
+    affine8(v, k, x);
+  } else if (a.mode[i] == EDET_RS_UP2) {
+    int sy = (int)(((int64_t)oy * v.h) / a.oh), sx = (int)(((int64_t)ox * v.w) / a.ow);
+    sy = sy < v.h - 1 ? sy : v.h - 1;
+    sx = sx < v.w - 1 ? sx : v.w - 1;
+    load8<T>(base + ((size_t)(n * v.h + sy) * v.w + sx) * v.ld + c0, x);
+    affine8(v, k, x);
+  } else {  // max-pool 3x3 stride 2, padding excluded
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = -INFINITY;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int sy = oy * 2 - a.pad_t[i] + ky;
+      if (sy < 0 || sy >= v.h) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int sx = ox * 2 - a.pad_l[i] + kx;
+        if (sx < 0 || sx >= v.w) continue;
+        float t[8];
+        load8<T>(base + ((size_t)(n * v.h + sy) * v.w + sx) * v.ld + c0, t);
+        affine8(v, k, t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], t[e]);
+      }
+    }
+  }
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restrict__ out,
+                                                 const T* __restrict__ dout, T* __restrict__ ds,
+                                                 float* dwn) {
+  const int nvec = a.c / 8;
+  const int64_t total = (int64_t)a.n * a.oh * a.ow * nvec;
+  float wn[3] = {0.f, 0.f, 0.f};
+  for (int i = 0; i < a.nin; ++i) wn[i] = a.wn[i];
+  float dw_acc[3] = {0.f, 0.f, 0.f};
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(q % nvec) * 8;
+    int64_t pix = q / nvec;
+    const int ox = (int)(pix % a.ow);
+    pix /= a.ow;
+    const int oy = (int)(pix % a.oh);
+    const int n = (int)(pix / a.oh);
+    float s[8], xi[3][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    for (int i = 0; i < a.nin; ++i) {
+      ViewCoef k;
+      view_load_coef(a.in[i], c0, k);
+      sample_input<T>(a, i, k, n, oy, ox, c0, xi[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] = fmaf(wn[i], xi[i][e], s[e]);
+    }
+    const size_t off = ((size_t)(n * a.oh + oy) * a.ow + ox) * a.ldo + c0;
+    if (!BWD) {
+      if (a.act == EDET_ACT_SWISH) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = swishf_(s[e]);
+      }
+      store8<T>(out + off, s);
+    } else {
+      float d[8];
+      load8<T>(dout + off, d);
+      if (a.act == EDET_ACT_SWISH) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] *= swish_gradf_(s[e]);
+      }
+      store8<T>(ds + off, d);
+      for (int i = 0; i < a.nin; ++i) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dw_acc[i] = fmaf(d[e], xi[i][e], dw_acc[i]);
+      }
+    }
+  }
+  if (BWD && dwn) {
+    __shared__ float red[3];
+    if (threadIdx.x < 3) red[threadIdx.x] = 0.f;
+    __syncthreads();
+    for (int i = 0; i < a.nin; ++i) {
+      float v = dw_acc[i];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if ((threadIdx.x & 63) == 0) atomicAdd(&red[i], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < a.nin) atomicAdd(&dwn[threadIdx.x], red[threadIdx.x]);
+  }
+}
+
+// gradient w.r.t. the stored tensor of one fusion input (affine-only view => d(data) = scale * d(view);
+// the scale factor is applied later by the BN backward coefficients, so here g = d(view))
+struct FuseInArgs {
+  edet_tview_t in;
+  int mode, pad_t, pad_l;
+  const float* wn;
+  int idx;
+  int n, oh, ow, ldds;
+  int beta;
+};
+
+template <typename T>
+__global__ __launch_bounds__(THREADS) void k_fuse_bwd_input(const FuseInArgs a, const T* __restrict__ ds,
+                                                           T* __restrict__ gout) {
+  const edet_tview_t& v = a.in;
+  const int nvec = v.c / 8;
+  const int64_t total = (int64_t)v.n * v.h * v.w * nvec;
+  const float wn = a.wn[a.idx];
+  const T* base = reinterpret_cast<const T*>(v.data);
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(q % nvec) * 8;
+    int64_t pix = q / nvec;
+    const int sx = (int)(pix % v.w);
+    pix /= v.w;
+    const int sy = (int)(pix % v.h);
+    const int n = (int)(pix / v.h);
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = 0.f;
+    if (a.mode == EDET_RS_IDENTITY) {
+      load8<T>(ds + ((size_t)(n * a.oh + sy) * a.ow + sx) * a.ldds + c0, g);
+    } else if (a.mode == EDET_RS_UP2) {
+      // destination pixels whose nearest source is (sy, sx): oy with floor(oy*h/oh) == sy
+      const int oy_lo = (int)(((int64_t)sy * a.oh + v.h - 1) / v.h);
+      int oy_hi = (int)(((int64_t)(sy + 1) * a.oh + v.h - 1) / v.h);
+      const int ox_lo = (int)(((int64_t)sx * a.ow + v.w - 1) / v.w);
+      int ox_hi = (int)(((int64_t)(sx + 1) * a.ow + v.w - 1) / v.w);
+      if (sy == v.h - 1) oy_hi = a.oh;
+      if (sx == v.w - 1) ox_hi = a.ow;
+      for (int oy = oy_lo; oy < oy_hi; ++oy)
+        for (int ox = ox_lo; ox < ox_hi; ++ox) {
+          float t[8];
+          load8<T>(ds + ((size_t)(n * a.oh + oy) * a.ow + ox) * a.ldds + c0, t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] += t[e];
+        }
+    } else {
+      // max-pool: this pixel receives ds of every window in which it is the FIRST maximum
+      // (row-major scan), matching the argmax convention of the oracle.
+      ViewCoef k;
+      view_load_coef(v, c0, k);
+      float mine[8];
+      load8<T>(base + ((size_t)(n * v.h + sy) * v.w + sx) * v.ld + c0, mine);
+      affine8(v, k, mine);
+      for (int oy = (sy + a.pad_t - 2 + 1) / 2; oy <= (sy + a.pad_t) / 2; ++oy) {
+        if (oy < 0 || oy >= a.oh) continue;
+        for (int ox = (sx + a.pad_l - 2 + 1) / 2; ox <= (sx + a.pad_l) / 2; ++ox) {
+          if (ox < 0 || ox >= a.ow) continue;
+          bool win[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) win[e] = true;
+          for (int ky = 0; ky < 3; ++ky) {
+            const int yy = oy * 2 - a.pad_t + ky;
+            if (yy < 0 || yy >= v.h) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+              const int xx = ox * 2 - a.pad_l + kx;
+              if (xx < 0 || xx >= v.w) continue;
+              if (yy == sy && xx == sx) continue;
+              float t[8];
+              load8<T>(base + ((size_t)(n * v.h + yy) * v.w + xx) * v.ld + c0, t);
+              affine8(v, k, t);
+              const bool before = (yy < sy) || (yy == sy && xx < sx);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                // an earlier element wins ties, a later one only if strictly greater
+                if (before ? (t[e] >= mine[e]) : (t[e] > mine[e])) win[e] = false;
+              }
+            }
+          }
+          float t[8];
+          load8<T>(ds + ((size_t)(n * a.oh + oy) * a.ow + ox) * a.ldds + c0, t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (win[e]) g[e] += t[e];
+        }
+      }
+    }
+    const size_t off = ((size_t)(n * v.h + sy) * v.w + sx) * v.ld + c0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] *= wn;
+    if (a.beta) {
+      float old[8];
+      load8<T>(gout + off, old);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] += old[e];
+    }
+    store8<T>(gout + off, g);
+  }
+}
+
+__global__ void k_fuse_weights(const float* w0, const float* w1, const float* w2, int nin, int method,
+                               float* wn) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float* w[3] = {w0, w1, w2};
+  if (method == 1) {
+    for (int i = 0; i < nin; ++i) wn[i] = 1.f;
+    return;
+  }
+  float r[3], s = 0.f;
+  for (int i = 0; i < nin; ++i) { r[i] = fmaxf(w[i][0], 0.f); s += r[i]; }
+  for (int i = 0; i < nin; ++i) wn[i] = r[i] / (s + 0.0001f);
+}
+
+__global__ void k_fuse_weights_bwd(const float* w0, const float* w1, const float* w2, int nin, int method,
+                                   const float* dwn, float* dw0, float* dw1, float* dw2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0 || method == 1) return;
+  const float* w[3] = {w0, w1, w2};
+  float* dw[3] = {dw0, dw1, dw2};
+  float r[3], s = 0.0001f, dot = 0.f;
+  for (int i = 0; i < nin; ++i) { r[i] = fmaxf(w[i][0], 0.f); s += r[i]; }
+  for (int i = 0; i < nin; ++i) dot += dwn[i] * r[i];
+  for (int i = 0; i < nin; ++i) {
+    const float dr = dwn[i] / s - dot / (s * s);
+    if (w[i][0] > 0.f) dw[i][0] += dr;
+  }
+}
+
+inline int ew_grid(int64_t total) {
+  int64_t g = (total + THREADS - 1) / THREADS;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+int fill_args(FuseArgs& a, const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
+              const int* modes, int nin, const float* wn, int act, int oh, int ow, int ldo) {
+  EDET_CHECK(nin >= 1 && nin <= 3 && in0 && modes && wn, "edet_fuse: bad arguments");
+  const edet_tview_t* ins[3] = {in0, in1, in2};
+  memset(&a, 0, sizeof(a));
+  a.nin = nin; a.wn = wn; a.act = act; a.oh = oh; a.ow = ow; a.ldo = ldo;
+  for (int i = 0; i < nin; ++i) {
+    EDET_CHECK(ins[i] && ins[i]->data, "edet_fuse: null input %d", i);
+    a.in[i] = *ins[i];
+    a.mode[i] = modes[i];
+    EDET_CHECK(ins[i]->act == EDET_ACT_NONE && !ins[i]->gate, "edet_fuse: inputs must be affine-only views");
+    EDET_CHECK(ins[i]->c == in0->c && ins[i]->n == in0->n && ins[i]->c % 8 == 0 && ins[i]->ld % 8 == 0,
+               "edet_fuse: channel/batch mismatch");
+    if (modes[i] == EDET_RS_IDENTITY) {
+      EDET_CHECK(ins[i]->h == oh && ins[i]->w == ow, "edet_fuse: identity input %d has a different size", i);
+    } else if (modes[i] == EDET_RS_UP2) {
+      EDET_CHECK(ins[i]->h <= oh && ins[i]->w <= ow, "edet_fuse: upsample input %d is larger than the output", i);
+    } else if (modes[i] == EDET_RS_POOL) {
+      EDET_CHECK(same_out(ins[i]->h, 2) == oh && same_out(ins[i]->w, 2) == ow,
+                 "Incompatible Resampling : feat shape %dx%d target_shape: %dx%d", ins[i]->h, ins[i]->w, oh, ow);
+      a.pad_t[i] = same_pad_before(ins[i]->h, 3, 2);
+      a.pad_l[i] = same_pad_before(ins[i]->w, 3, 2);
+    } else {
+      EDET_CHECK(false, "edet_fuse: bad mode %d", modes[i]);
+    }
+  }
+  a.n = in0->n; a.c = in0->c;
+  EDET_CHECK(ldo % 8 == 0 && ldo >= a.c, "edet_fuse: bad ldo");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int edet_fuse_weights(const float* w0, const float* w1, const float* w2, int nin,
+                                 int method, float* wn, void* stream) {
+  EDET_CHECK(wn && (method == 1 || w0), "edet_fuse_weights: null pointer");
+  k_fuse_weights<<<1, 64, 0, to_stream(stream)>>>(w0, w1, w2, nin, method, wn);
+  EDET_LAUNCH_CHECK("edet_fuse_weights");
+  return 0;
+}
+
+extern "C" int edet_fuse_weights_bwd(const float* w0, const float* w1, const float* w2, int nin,
+                                     int method, const float* dwn, float* dw0, float* dw1, float* dw2,
+                                     void* stream) {
+  if (method == 1) return 0;
+  EDET_CHECK(w0 && dwn && dw0, "edet_fuse_weights_bwd: null pointer");
+  k_fuse_weights_bwd<<<1, 64, 0, to_stream(stream)>>>(w0, w1, w2, nin, method, dwn, dw0, dw1, dw2);
+  EDET_LAUNCH_CHECK("edet_fuse_weights_bwd");
+  return 0;
+}
+
+extern "C" int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
+                             const int* modes, int nin, const float* wn, int act,
+                             void* out, int oh, int ow, int ldo, int dtype, void* stream) {
+  FuseArgs a;
+  if (int rc = fill_args(a, in0, in1, in2, modes, nin, wn, act, oh, ow, ldo)) return rc;
+  EDET_CHECK(out, "edet_fuse_fwd: null output");
+  const int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8));
+  if (dtype == EDET_BF16) k_fuse<bf16_t, false><<<grid, THREADS, 0, to_stream(stream)>>>(a, (bf16_t*)out, nullptr, nullptr, nullptr);
+  else if (dtype == EDET_F32) k_fuse<float, false><<<grid, THREADS, 0, to_stream(stream)>>>(a, (float*)out, nullptr, nullptr, nullptr);
+  else EDET_CHECK(false, "edet_fuse_fwd: bad dtype %d", dtype);
+  EDET_LAUNCH_CHECK("edet_fuse_fwd");
+  return 0;
+}
+
+extern "C" int edet_fuse_bwd_pre(const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
+                                 const int* modes, int nin, const float* wn, int act,
+                                 const void* dout, int oh, int ow, int ldo,
+                                 void* ds, float* dwn, int dtype, void* stream) {
+  FuseArgs a;
+  if (int rc = fill_args(a, in0, in1, in2, modes, nin, wn, act, oh, ow, ldo)) return rc;
+  EDET_CHECK(dout && ds, "edet_fuse_bwd_pre: null pointer");
+  const int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8));
+  if (dtype == EDET_BF16) k_fuse<bf16_t, true><<<grid, THREADS, 0, to_stream(stream)>>>(a, nullptr, (const bf16_t*)dout, (bf16_t*)ds, dwn);
+  else if (dtype == EDET_F32) k_fuse<float, true><<<grid, THREADS, 0, to_stream(stream)>>>(a, nullptr, (const float*)dout, (float*)ds, dwn);
+  else EDET_CHECK(false, "edet_fuse_bwd_pre: bad dtype %d", dtype);
+  EDET_LAUNCH_CHECK("edet_fuse_bwd_pre");
+  return 0;
+}
+
+extern "C" int edet_fuse_bwd_input(const edet_tview_t* in, int mode, const float* wn, int idx,
+                                   const void* ds, int oh, int ow, int lds_,
+                                   void* gout, int beta, int dtype, void* stream) {
+  EDET_CHECK(in && in->data && wn && ds && gout && idx >= 0 && idx < 3, "edet_fuse_bwd_input: bad arguments");
+  EDET_CHECK(in->c % 8 == 0 && in->ld % 8 == 0 && lds_ % 8 == 0, "edet_fuse_bwd_input: c/ld % 8");
+  FuseInArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = *in; a.mode = mode; a.wn = wn; a.idx = idx; a.n = in->n; a.oh = oh; a.ow = ow; a.ldds = lds_;
+  a.beta = beta;
+  if (mode == EDET_RS_POOL) {
+    a.pad_t = same_pad_before(in->h, 3, 2);
+    a.pad_l = same_pad_before(in->w, 3, 2);
+  }
+  const int grid = ew_grid((int64_t)in->n * in->h * in->w * (in->c / 8));
+  if (dtype == EDET_BF16) k_fuse_bwd_input<bf16_t><<<grid, THREADS, 0, to_stream(stream)>>>(a, (const bf16_t*)ds, (bf16_t*)gout);
+  else if (dtype == EDET_F32) k_fuse_bwd_input<float><<<grid, THREADS, 0, to_stream(stream)>>>(a, (const float*)ds, (float*)gout);
+  else EDET_CHECK(false, "edet_fuse_bwd_input: bad dtype %d", dtype);
+  EDET_LAUNCH_CHECK("edet_fuse_bwd_input");
+  return 0;
+}

@@ -1,0 +1,301 @@
+// Detection loss (focal + Huber) forward and backward in one pass, and the fused optimizer
+// (L2 regularisation, per-tensor + global gradient clipping, SGD momentum, EMA) over a flat
+// fp32 parameter arena.
+//
+// Reference: efficientdet/tf2/train_lib.py:357-406 (FocalLoss), :409-437 (BoxLoss / Keras Huber),
+// :493-604 (_detection_loss), :486-491 (_reg_l2_loss), :675-683 (clip + apply), :176-199 (optimizer).
+#include "common.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+
+struct RowMap { int tpr, rpp; };
+inline RowMap row_map_ld(int ld) {
+  int nvec = ld / 8, tpr = 1;
+  while (tpr < nvec && tpr < THREADS) tpr <<= 1;
+  RowMap m; m.tpr = tpr; m.rpp = THREADS / tpr;
+  return m;
+}
+
+__device__ __forceinline__ float softplusf_(float u) {
+  // log(1 + exp(u)), stable
+  return fmaxf(u, 0.f) + log1pf(__expf(-fabsf(u)));
+}
+
+// logits [positions][ld], channel j = anchor * num_classes + class
+template <typename T>
+__global__ __launch_bounds__(THREADS) void k_focal(const T* __restrict__ logits, int ld,
+                                                  const int32_t* __restrict__ tgt, int64_t positions,
+                                                  int na, int nc, float alpha, float gamma, float inv_norm,
+                                                  T* __restrict__ dlogits, float* dbias, float* sums, RowMap m) {
+  const int tid = threadIdx.x;
+  const int cv = tid % m.tpr, rr = tid / m.tpr;
+  const int j0 = cv * 8;
+  const int nch = na * nc;
+  const bool ok = j0 < ld;
+  float loss_acc = 0.f, db[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) db[e] = 0.f;
+  if (ok) {
+    for (int64_t p = (int64_t)blockIdx.x * m.rpp + rr; p < positions; p += (int64_t)gridDim.x * m.rpp) {
+      float x[8], g[8];
+      load8<T>(logits + p * ld + j0, x);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = j0 + e;
+        g[e] = 0.f;
+        if (j < nch) {
+          const int a = j / nc, k = j - a * nc;
+          const int t = tgt[p * na + a];
+          if (t != -2) {
+            const bool pos = (t == k);
+            const float u = pos ? -x[e] : x[e];   // 1 - p_t = sigmoid(u), ce = softplus(u)
+            const float sg = sigmoidf_(u);
+            const float sp = softplusf_(u);
+            const float af = pos ? alpha : 1.f - alpha;
+            const float mod = __powf(sg, gamma);
+            loss_acc += af * mod * sp * inv_norm;
+            // d/du [sg^gamma * softplus(u)] = sg^gamma * (gamma*(1-sg)*sp + sg)
+            const float dldu = af * mod * (gamma * (1.f - sg) * sp + sg) * inv_norm;
+            g[e] = pos ? -dldu : dldu;
+          }
+        }
+        db[e] += g[e];
+      }
+      store8<T>(dlogits + p * ld + j0, g);
+    }
+  }
+  __shared__ float red_loss;
+  extern __shared__ float red[];  // [ld]
+  if (tid == 0) red_loss = 0.f;
+  for (int i = tid; i < ld; i += THREADS) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) loss_acc += __shfl_down(loss_acc, off, 64);
+  if ((tid & 63) == 0) atomicAdd(&red_loss, loss_acc);
+  if (ok && dbias) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(&red[j0 + e], db[e]);
+  }
+  __syncthreads();
+  if (tid == 0) atomicAdd(&sums[0], red_loss);
+  if (dbias)
+    for (int i = tid; i < nch; i += THREADS) atomicAdd(&dbias[i], red[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(THREADS) void k_box(const T* __restrict__ out, int ld,
+                                                const float* __restrict__ tgt, int64_t positions, int nch,
+                                                float delta, float inv_norm, float grad_scale,
+                                                T* __restrict__ dbox, float* dbias, float* sums, RowMap m) {
+  const int tid = threadIdx.x;
+  const int cv = tid % m.tpr, rr = tid / m.tpr;
+  const int j0 = cv * 8;
+  const bool ok = j0 < ld;
+  float loss_acc = 0.f, db[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) db[e] = 0.f;
+  if (ok) {
+    for (int64_t p = (int64_t)blockIdx.x * m.rpp + rr; p < positions; p += (int64_t)gridDim.x * m.rpp) {
+      float x[8], g[8];
+      load8<T>(out + p * ld + j0, x);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = j0 + e;
+        g[e] = 0.f;
+        if (j < nch) {
+          const float t = tgt[p * nch + j];
+          if (t != 0.f) {
+            const float err = x[e] - t;
+            const float ae = fabsf(err);
+            const bool quad = ae <= delta;
+            loss_acc += (quad ? 0.5f * err * err : delta * ae - 0.5f * delta * delta) * inv_norm;
+            g[e] = (quad ? err : (err > 0.f ? delta : -delta)) * inv_norm * grad_scale;
+          }
+        }
+        db[e] += g[e];
+      }
+      store8<T>(dbox + p * ld + j0, g);
+    }
+  }
+  __shared__ float red_loss;
+  extern __shared__ float red[];
+  if (tid == 0) red_loss = 0.f;
+  for (int i = tid; i < ld; i += THREADS) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) loss_acc += __shfl_down(loss_acc, off, 64);
+  if ((tid & 63) == 0) atomicAdd(&red_loss, loss_acc);
+  if (ok && dbias) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(&red[j0 + e], db[e]);
+  }
+  __syncthreads();
+  if (tid == 0) atomicAdd(&sums[1], red_loss);
+  if (dbias)
+    for (int i = tid; i < nch; i += THREADS) atomicAdd(&dbias[i], red[i]);
+}
+
+// ----------------------------------------------------------------------------------- optimizer
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < THREADS / 64; ++i) t += sh[i];
+  return t;
+}
+
+// one workgroup per tensor segment
+__global__ __launch_bounds__(THREADS) void k_l2_norms(float* grads, const float* params,
+                                                     const int64_t* seg_off, const int32_t* seg_flags,
+                                                     float wd, float* seg_sqnorm, float* l2_sum) {
+  __shared__ float sh[THREADS / 64];
+  const int s = blockIdx.x;
+  const int64_t b = seg_off[s], e = seg_off[s + 1];
+  const bool reg = (seg_flags[s] & 1) != 0;
+  float gsq = 0.f, wsq = 0.f;
+  for (int64_t i = b + threadIdx.x; i < e; i += THREADS) {
+    float g = grads[i];
+    if (reg) {
+      const float w = params[i];
+      g = fmaf(wd, w, g);
+      grads[i] = g;
+      wsq = fmaf(w, w, wsq);
+    }
+    gsq = fmaf(g, g, gsq);
+  }
+  const float tg = block_sum(gsq, sh);
+  const float tw = block_sum(wsq, sh);
+  if (threadIdx.x == 0) {
+    seg_sqnorm[s] = tg;
+    if (reg && l2_sum) atomicAdd(l2_sum, 0.5f * wd * tw);
+  }
+}
+
+// tf.clip_by_norm per tensor, then tf.clip_by_global_norm over the clipped tensors
+__global__ __launch_bounds__(THREADS) void k_clip_factors(const float* seg_sqnorm, int nseg, float clip,
+                                                         float* seg_factor, float* gnorm_out) {
+  __shared__ float sh[THREADS / 64];
+  float acc = 0.f;
+  for (int s = threadIdx.x; s < nseg; s += THREADS) {
+    const float nrm = sqrtf(seg_sqnorm[s]);
+    float f = 1.f;
+    if (clip > 0.f) f = clip / fmaxf(nrm, clip);
+    seg_factor[s] = f;
+    const float cn = nrm * f;
+    acc = fmaf(cn, cn, acc);
+  }
+  const float tot = block_sum(acc, sh);
+  const float gn = sqrtf(tot);
+  float f2 = 1.f;
+  if (clip > 0.f) f2 = clip / fmaxf(gn, clip);
+  __syncthreads();
+  for (int s = threadIdx.x; s < nseg; s += THREADS) seg_factor[s] *= f2;
+  if (threadIdx.x == 0 && gnorm_out) gnorm_out[0] = gn * f2;
+}
+
+__global__ __launch_bounds__(THREADS) void k_scale(float* grads, const int64_t* seg_off,
+                                                  const float* seg_factor) {
+  const int s = blockIdx.x;
+  const float f = seg_factor[s];
+  for (int64_t i = seg_off[s] + threadIdx.x; i < seg_off[s + 1]; i += THREADS) grads[i] *= f;
+}
+
+// Keras SGD: v = m*v - lr*g ; w += v.  TFA MovingAverage: ema -= (1-decay)*(ema - w)
+__global__ __launch_bounds__(THREADS) void k_sgd_ema(float* params, float* grads, float* vel, float* ema,
+                                                    const int64_t* seg_off, const float* seg_factor,
+                                                    const float* hyper, float momentum) {
+  const int s = blockIdx.x;
+  const float f = seg_factor ? seg_factor[s] : 1.f;
+  const float lr = hyper[0], decay = hyper[1];
+  for (int64_t i = seg_off[s] + threadIdx.x; i < seg_off[s + 1]; i += THREADS) {
+    const float g = grads[i] * f;
+    const float v = momentum * vel[i] - lr * g;
+    vel[i] = v;
+    const float w = params[i] + v;
+    params[i] = w;
+    if (ema) ema[i] -= (1.f - decay) * (ema[i] - w);
+  }
+}
+
+}  // namespace
+
+extern "C" int edet_focal_loss(const void* logits, int ld, const int32_t* cls_targets,
+                               int64_t positions, int num_anchors, int num_classes,
+                               float alpha, float gamma, float inv_normalizer,
+                               void* dlogits, float* dbias, float* sums, int dtype, void* stream) {
+  EDET_CHECK(logits && cls_targets && dlogits && sums, "edet_focal_loss: null pointer");
+  EDET_CHECK(ld % 8 == 0 && ld >= num_anchors * num_classes && ld <= 2048, "edet_focal_loss: bad ld %d", ld);
+  const RowMap m = row_map_ld(ld);
+  int64_t g = (positions + m.rpp - 1) / m.rpp;
+  g = (g + 3) / 4;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  const size_t lds = (size_t)ld * sizeof(float);
+  if (dtype == EDET_BF16)
+    k_focal<bf16_t><<<(int)g, THREADS, lds, to_stream(stream)>>>((const bf16_t*)logits, ld, cls_targets, positions, num_anchors, num_classes, alpha, gamma, inv_normalizer, (bf16_t*)dlogits, dbias, sums, m);
+  else if (dtype == EDET_F32)
+    k_focal<float><<<(int)g, THREADS, lds, to_stream(stream)>>>((const float*)logits, ld, cls_targets, positions, num_anchors, num_classes, alpha, gamma, inv_normalizer, (float*)dlogits, dbias, sums, m);
+  else EDET_CHECK(false, "edet_focal_loss: bad dtype %d", dtype);
+  EDET_LAUNCH_CHECK("edet_focal_loss");
+  return 0;
+}
+
+extern "C" int edet_box_loss(const void* box_out, int ld, const float* box_targets,
+                             int64_t positions, int nch, float delta, float inv_normalizer,
+                             float grad_scale, void* dbox, float* dbias, float* sums,
+                             int dtype, void* stream) {
+  EDET_CHECK(box_out && box_targets && dbox && sums, "edet_box_loss: null pointer");
+  EDET_CHECK(ld % 8 == 0 && ld >= nch && ld <= 2048, "edet_box_loss: bad ld %d", ld);
+  const RowMap m = row_map_ld(ld);
+  int64_t g = (positions + m.rpp - 1) / m.rpp;
+  g = (g + 3) / 4;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  const size_t lds = (size_t)ld * sizeof(float);
+  if (dtype == EDET_BF16)
+    k_box<bf16_t><<<(int)g, THREADS, lds, to_stream(stream)>>>((const bf16_t*)box_out, ld, box_targets, positions, nch, delta, inv_normalizer, grad_scale, (bf16_t*)dbox, dbias, sums, m);
+  else if (dtype == EDET_F32)
+    k_box<float><<<(int)g, THREADS, lds, to_stream(stream)>>>((const float*)box_out, ld, box_targets, positions, nch, delta, inv_normalizer, grad_scale, (float*)dbox, dbias, sums, m);
+  else EDET_CHECK(false, "edet_box_loss: bad dtype %d", dtype);
+  EDET_LAUNCH_CHECK("edet_box_loss");
+  return 0;
+}
+
+extern "C" int edet_opt_l2_norms(float* grads, const float* params, const int64_t* seg_offsets,
+                                 const int32_t* seg_flags, int nseg, float weight_decay,
+                                 float* seg_sqnorm, float* l2_sum, void* stream) {
+  EDET_CHECK(grads && params && seg_offsets && seg_flags && seg_sqnorm && nseg > 0, "edet_opt_l2_norms: bad arguments");
+  k_l2_norms<<<nseg, THREADS, 0, to_stream(stream)>>>(grads, params, seg_offsets, seg_flags, weight_decay, seg_sqnorm, l2_sum);
+  EDET_LAUNCH_CHECK("edet_opt_l2_norms");
+  return 0;
+}
+
+extern "C" int edet_opt_clip_factors(const float* seg_sqnorm, int nseg, float clip_norm,
+                                     float* seg_factor, float* global_norm_out, void* stream) {
+  EDET_CHECK(seg_sqnorm && seg_factor && nseg > 0, "edet_opt_clip_factors: bad arguments");
+  k_clip_factors<<<1, THREADS, 0, to_stream(stream)>>>(seg_sqnorm, nseg, clip_norm, seg_factor, global_norm_out);
+  EDET_LAUNCH_CHECK("edet_opt_clip_factors");
+  return 0;
+}
+
+extern "C" int edet_opt_scale(float* grads, const int64_t* seg_offsets, const float* seg_factor,
+                              int nseg, void* stream) {
+  EDET_CHECK(grads && seg_offsets && seg_factor && nseg > 0, "edet_opt_scale: bad arguments");
+  k_scale<<<nseg, THREADS, 0, to_stream(stream)>>>(grads, seg_offsets, seg_factor);
+  EDET_LAUNCH_CHECK("edet_opt_scale");
+  return 0;
+}
+
+extern "C" int edet_opt_sgd_ema(float* params, float* grads, float* velocity, float* ema,
+                                const int64_t* seg_offsets, const float* seg_factor, int nseg,
+                                const float* hyper_dev, float momentum, void* stream) {
+  EDET_CHECK(params && grads && velocity && seg_offsets && hyper_dev && nseg > 0, "edet_opt_sgd_ema: bad arguments");
+  k_sgd_ema<<<nseg, THREADS, 0, to_stream(stream)>>>(params, grads, velocity, ema, seg_offsets, seg_factor, hyper_dev, momentum);
+  EDET_LAUNCH_CHECK("edet_opt_sgd_ema");
+  return 0;
+}

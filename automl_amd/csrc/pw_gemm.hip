@@ -1,0 +1,689 @@
+// Pointwise (1x1) convolution on the gfx950 matrix cores.
+//
+//   forward : out[m, j]  = sum_k view(in)[m, k] * Wt[j, k] (+ bias[j])          (+ BN stat partials)
+//   dgrad   : d in[m, k] = sum_j dy[m, j] * W[k, j]  -> chained through the input view's
+//             activation / BatchNorm statistics / SE gate in the epilogue
+//   wgrad   : dW[k, j]  += sum_m view(in)[m, k] * dy[m, j]
+//
+// All three are HBM-bound "tall-skinny" GEMMs (M = N*H*W up to 13 M rows, K and J <= 1152), so
+// the design goal is: stream the big operand exactly once with 16-byte coalesced accesses, apply
+// BatchNorm/swish/SE-gate (forward) or the BatchNorm backward (gradient) on load, keep the small
+// operand in L2, and fuse the per-channel reductions into the epilogue.  MFMA 16x16x32 bf16
+// (16x16x4 f32 in the fp32 validation mode) does the contraction; MFMA utilisation is not the
+// limiter at these arithmetic intensities.
+//
+// Reference call sites: efficientdet/backbone/efficientnet_model.py:304-312,345-353;
+// efficientdet/tf2/efficientdet_keras.py:195-207,286-290,459-464,546-556.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128;  // rows per workgroup tile
+constexpr int BK = 32;   // reduction step
+constexpr int THREADS = 256;
+
+struct GemmArgs {
+  edet_tview_t tv;  // fwd: A source.  bwd: the conv's *input* view (epilogue chain target)
+  edet_gview_t gv;  // bwd: A source (dy)
+  const void* Bm;   // [J][ldb], reduction index contiguous
+  int ldb;
+  int M, R, J, Jp;  // rows, reduction length, output columns, J rounded up to 8
+  int hw;           // pixels per image
+  int tiles_per_wg;
+  const float* bias;  // fwd
+  void* out;
+  int ldo;
+  edet_bwd_epi_t epi;  // bwd
+  float* stat_partials;
+};
+
+template <typename T> struct Raw8;  // 8 raw elements in registers
+template <> struct Raw8<bf16_t> { uint4 v; };
+template <> struct Raw8<float> { float4 lo, hi; };
+
+template <typename T> __device__ __forceinline__ void raw_zero(Raw8<T>& r);
+template <> __device__ __forceinline__ void raw_zero<bf16_t>(Raw8<bf16_t>& r) { r.v = make_uint4(0, 0, 0, 0); }
+template <> __device__ __forceinline__ void raw_zero<float>(Raw8<float>& r) {
+  r.lo = make_float4(0, 0, 0, 0);
+  r.hi = r.lo;
+}
+template <typename T> __device__ __forceinline__ void raw_load(Raw8<T>& r, const T* p);
+template <> __device__ __forceinline__ void raw_load<bf16_t>(Raw8<bf16_t>& r, const bf16_t* p) {
+  r.v = *reinterpret_cast<const uint4*>(p);
+}
+template <> __device__ __forceinline__ void raw_load<float>(Raw8<float>& r, const float* p) {
+  r.lo = *reinterpret_cast<const float4*>(p);
+  r.hi = *reinterpret_cast<const float4*>(p + 4);
+}
+template <typename T> __device__ __forceinline__ void raw_unpack(const Raw8<T>& r, float x[8]);
+template <> __device__ __forceinline__ void raw_unpack<bf16_t>(const Raw8<bf16_t>& r, float x[8]) {
+  x[0] = __uint_as_float(r.v.x << 16); x[1] = __uint_as_float(r.v.x & 0xffff0000u);
+  x[2] = __uint_as_float(r.v.y << 16); x[3] = __uint_as_float(r.v.y & 0xffff0000u);
+  x[4] = __uint_as_float(r.v.z << 16); x[5] = __uint_as_float(r.v.z & 0xffff0000u);
+  x[6] = __uint_as_float(r.v.w << 16); x[7] = __uint_as_float(r.v.w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void raw_unpack<float>(const Raw8<float>& r, float x[8]) {
+  x[0] = r.lo.x; x[1] = r.lo.y; x[2] = r.lo.z; x[3] = r.lo.w;
+  x[4] = r.hi.x; x[5] = r.hi.y; x[6] = r.hi.z; x[7] = r.hi.w;
+}
+
+template <typename T, int NT> struct GemmCfg {
+  static constexpr int BN = NT * 16;
+  static constexpr int LDA = BK + 16 / (int)sizeof(T);
+  static constexpr int LDC = BN + 4;
+  static constexpr int HALF = BM / 2;
+  static constexpr int AB_BYTES = (BM + BN) * LDA * (int)sizeof(T);
+  static constexpr int C_BYTES = HALF * LDC * 4;
+  static constexpr int TILE_BYTES = ((AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES) + 15) / 16 * 16;
+};
+
+// ---- MFMA step over one BK slab held in LDS --------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void mma_slab(const bf16_t* As, const bf16_t* Bs, int lda, int wave,
+                                         int lane, f32x4 (&acc)[2][NT]) {
+  const int r16 = lane & 15, kq = (lane >> 4) * 8;
+  bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&As[(wave * 32 + r16) * lda + kq]);
+  bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[(wave * 32 + 16 + r16) * lda + kq]);
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) {
+    bf16x8 b = *reinterpret_cast<const bf16x8*>(&Bs[(ni * 16 + r16) * lda + kq]);
+    acc[0][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][ni], 0, 0, 0);
+    acc[1][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][ni], 0, 0, 0);
+  }
+}
+template <int NT>
+__device__ __forceinline__ void mma_slab(const float* As, const float* Bs, int lda, int wave,
+                                         int lane, f32x4 (&acc)[2][NT]) {
+  const int r16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < BK / 4; ++kk) {
+    float a0 = As[(wave * 32 + r16) * lda + kk * 4 + kq];
+    float a1 = As[(wave * 32 + 16 + r16) * lda + kk * 4 + kq];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+      float b = Bs[(ni * 16 + r16) * lda + kk * 4 + kq];
+      acc[0][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][ni], 0, 0, 0);
+      acc[1][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][ni], 0, 0, 0);
+    }
+  }
+}
+
+// ---- rows x small-matrix GEMM: forward (BWD=false) and data gradient (BWD=true) --------------
+template <typename T, int NT, bool BWD>
+__global__ __launch_bounds__(THREADS) void k_gemm(const GemmArgs a) {
+  using C = GemmCfg<T, NT>;
+  constexpr int BN = C::BN, LDA = C::LDA, LDC = C::LDC, HALF = C::HALF;
+  constexpr int CH = BN / 8;                   // 8-wide chunks per output row
+  constexpr int A_TASKS = BM * (BK / 8) / THREADS;  // = 2
+  constexpr int B_TASKS = (BN * (BK / 8) + THREADS - 1) / THREADS;
+
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* As = reinterpret_cast<T*>(smem);
+  T* Bs = As + BM * LDA;
+  float* Cs = reinterpret_cast<float*>(smem);
+  float* red = reinterpret_cast<float*>(smem + C::TILE_BYTES);  // [2][Jp] stat sums
+  float* gs = red + 2 * a.Jp;                                   // [2][Jp] dgate sums (bwd + gate)
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const bool want_stats = a.stat_partials != nullptr;
+  const bool want_gate = BWD && a.epi.dgate != nullptr;
+
+  for (int i = tid; i < 2 * a.Jp; i += THREADS) red[i] = 0.f;
+  if (want_gate)
+    for (int i = tid; i < 2 * a.Jp; i += THREADS) gs[i] = 0.f;
+  __syncthreads();
+
+  const int ntn = (a.J + BN - 1) / BN;
+  const int ntm = (a.M + BM - 1) / BM;
+  const int mt0 = blockIdx.x * a.tiles_per_wg;
+  const int mt1 = min(ntm, mt0 + a.tiles_per_wg);
+  int cur_img = -1;
+
+  const T* Bm = reinterpret_cast<const T*>(a.Bm);
+
+  for (int mt = mt0; mt < mt1; ++mt) {
+    if (want_gate) {
+      const int first_img = (int)(((int64_t)mt * BM) / a.hw);
+      if (first_img != cur_img) {
+        if (cur_img >= 0) {
+          __syncthreads();
+          for (int i = tid; i < 2 * a.Jp; i += THREADS) {
+            const int slot = i / a.Jp, col = i - slot * a.Jp;
+            const float v = gs[i];
+            if (v != 0.f && col < a.J && cur_img + slot < a.tv.n)
+              atomicAdd(&a.epi.dgate[(size_t)(cur_img + slot) * a.J + col], v);
+            gs[i] = 0.f;
+          }
+          __syncthreads();
+        }
+        cur_img = first_img;
+      }
+    }
+    // per-thread A staging geometry (fixed for the whole m-tile)
+    int a_row[A_TASKS], a_kc[A_TASKS], a_img[A_TASKS];
+    int64_t a_m[A_TASKS];
+#pragma unroll
+    for (int i = 0; i < A_TASKS; ++i) {
+      const int q = tid + i * THREADS;
+      a_row[i] = q >> 2;
+      a_kc[i] = (q & 3) * 8;
+      a_m[i] = (int64_t)mt * BM + a_row[i];
+      a_img[i] = (!BWD && a.tv.gate) ? (int)(a_m[i] / a.hw) : 0;
+    }
+
+    for (int nt = 0; nt < ntn; ++nt) {
+      f32x4 acc[2][NT];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+      // ---- software-pipelined K loop: raw loads for step k0+BK are issued before the MFMAs of k0
+      Raw8<T> ra[A_TASKS], ry[A_TASKS];
+      auto issue = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_TASKS; ++i) {
+          const int k = k0 + a_kc[i];
+          raw_zero<T>(ra[i]);
+          if (BWD) raw_zero<T>(ry[i]);
+          if (a_m[i] < a.M && k < a.R) {
+            if (!BWD) {
+              raw_load<T>(ra[i], reinterpret_cast<const T*>(a.tv.data) + a_m[i] * a.tv.ld + k);
+            } else {
+              raw_load<T>(ra[i], reinterpret_cast<const T*>(a.gv.dz) + a_m[i] * a.gv.ld + k);
+              if (a.gv.a) raw_load<T>(ry[i], reinterpret_cast<const T*>(a.gv.y) + a_m[i] * a.gv.ld + k);
+            }
+          }
+        }
+      };
+      auto commit = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_TASKS; ++i) {
+          const int k = k0 + a_kc[i];
+          float x[8];
+          raw_unpack<T>(ra[i], x);
+          const bool valid = a_m[i] < a.M && k < a.R;
+          if (valid) {
+            if (!BWD) {
+              ViewCoef vc;
+              view_load_coef(a.tv, k, vc);
+              view_apply(a.tv, vc, k, a_img[i], x);
+            } else if (a.gv.a) {
+              float y[8];
+              raw_unpack<T>(ry[i], y);
+              GradCoef gc;
+              grad_load_coef(a.gv, k, gc);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[e] = fmaf(gc.a[e], x[e], fmaf(gc.b[e], y[e], gc.cc[e]));
+            }
+            if (k + 8 > a.R) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                if (k + e >= a.R) x[e] = 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = 0.f;
+          }
+          store8<T>(&As[a_row[i] * LDA + a_kc[i]], x);
+        }
+        // weights: raw copy from the L2-resident compute copy
+#pragma unroll
+        for (int i = 0; i < B_TASKS; ++i) {
+          const int q = tid + i * THREADS;
+          if (q < BN * (BK / 8)) {
+            const int j = q >> 2, kc = (q & 3) * 8;
+            const int jj = nt * BN + j, k = k0 + kc;
+            float w[8];
+            if (jj < a.J && k < a.R) {
+              load8<T>(Bm + (size_t)jj * a.ldb + k, w);
+              if (k + 8 > a.R) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                  if (k + e >= a.R) w[e] = 0.f;
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) w[e] = 0.f;
+            }
+            store8<T>(&Bs[j * LDA + kc], w);
+          }
+        }
+      };
+
+      issue(0);
+      for (int k0 = 0; k0 < a.R; k0 += BK) {
+        commit(k0);
+        __syncthreads();
+        if (k0 + BK < a.R) issue(k0 + BK);
+        mma_slab<NT>(As, Bs, LDA, wave, lane, acc);
+        __syncthreads();
+      }
+
+      // ---- epilogue, two half tiles through LDS so that global I/O is row-major 16 B / lane
+      const int cc = (tid % CH) * 8;
+      const int j = nt * BN + cc;
+      const bool col_ok = j < a.J;
+      float s1[8], s2[8], gp[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s1[e] = s2[e] = gp[e] = 0.f;
+      int my_img = -1;
+      float bias8[8], sc8[8], sh8[8], mean8[8], rstd8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        bias8[e] = 0.f; sc8[e] = 1.f; sh8[e] = 0.f; mean8[e] = 0.f; rstd8[e] = 1.f;
+      }
+      if (col_ok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (j + e < a.J) {
+            if (!BWD && a.bias) bias8[e] = a.bias[j + e];
+            if (BWD && a.tv.scale) { sc8[e] = a.tv.scale[j + e]; sh8[e] = a.tv.shift[j + e]; }
+            if (BWD && want_stats) { mean8[e] = a.epi.mean[j + e]; rstd8[e] = a.epi.rstd[j + e]; }
+          }
+        }
+      }
+      auto flush_gate = [&]() {
+        if (my_img < 0) return;
+        const int slot = my_img - cur_img;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (j + e < a.J && gp[e] != 0.f) {
+            if (slot >= 0 && slot < 2) atomicAdd(&gs[slot * a.Jp + j + e], gp[e]);
+            else atomicAdd(&a.epi.dgate[(size_t)my_img * a.J + j + e], gp[e]);
+          }
+          gp[e] = 0.f;
+        }
+      };
+
+      for (int half = 0; half < 2; ++half) {
+        if ((wave >> 1) == half) {
+          const int wr = (wave & 1) * 32;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                Cs[(wr + mi * 16 + (lane >> 4) * 4 + r) * LDC + ni * 16 + (lane & 15)] = acc[mi][ni][r];
+        }
+        __syncthreads();
+        if (col_ok) {
+          for (int q = tid; q < HALF * CH; q += THREADS) {  // THREADS % CH == 0: cc fixed per thread
+            const int row = q / CH;
+            const int64_t m = (int64_t)mt * BM + half * HALF + row;
+            if (m >= a.M) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = Cs[row * LDC + cc + e];
+            if (!BWD) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = (j + e < a.J) ? v[e] + bias8[e] : 0.f;
+              store8<T>(reinterpret_cast<T*>(a.out) + m * a.ldo + j, v);
+              if (want_stats) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+              }
+            } else {
+              const size_t off = (size_t)m * a.tv.ld + j;
+              float x[8];
+              const bool need_x = a.tv.act != EDET_ACT_NONE || want_gate || want_stats;
+              if (need_x) load8<T>(reinterpret_cast<const T*>(a.tv.data) + off, x);
+              float g[8];
+              if (want_gate) {
+                const int img = (int)(m / a.hw);
+                if (img != my_img) { flush_gate(); my_img = img; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  const float z = fmaf(x[e], sc8[e], sh8[e]);
+                  const float av = a.tv.act == EDET_ACT_SWISH ? swishf_(z) : z;
+                  gp[e] += v[e] * av;
+                  g[e] = v[e];
+                }
+              } else if (a.tv.act == EDET_ACT_SWISH) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = v[e] * swish_gradf_(fmaf(x[e], sc8[e], sh8[e]));
+              } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = v[e];
+              }
+              if (a.epi.beta) {
+                float old[8];
+                load8<T>(reinterpret_cast<const T*>(a.epi.gout) + off, old);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] += old[e];
+              }
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                if (j + e >= a.J) g[e] = 0.f;
+              store8<T>(reinterpret_cast<T*>(a.epi.gout) + off, g);
+              if (want_stats) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  s1[e] += g[e];
+                  s2[e] += g[e] * (x[e] - mean8[e]) * rstd8[e];
+                }
+              }
+            }
+          }
+        }
+        __syncthreads();
+      }
+      if (col_ok && want_stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (j + e < a.J) {
+            atomicAdd(&red[j + e], s1[e]);
+            atomicAdd(&red[a.Jp + j + e], s2[e]);
+          }
+        }
+      }
+      if (want_gate && col_ok) flush_gate();
+    }  // nt
+  }    // mt
+
+  __syncthreads();
+  if (want_gate && cur_img >= 0) {
+    for (int i = tid; i < 2 * a.Jp; i += THREADS) {
+      const int slot = i / a.Jp, col = i - slot * a.Jp;
+      const float v = gs[i];
+      if (v != 0.f && col < a.J && cur_img + slot < a.tv.n)
+        atomicAdd(&a.epi.dgate[(size_t)(cur_img + slot) * a.J + col], v);
+    }
+  }
+  if (want_stats) {
+    float* dst = a.stat_partials + (size_t)blockIdx.x * 2 * a.J;
+    for (int i = tid; i < 2 * a.J; i += THREADS) {
+      const int which = i / a.J, col = i - which * a.J;
+      dst[i] = red[which * a.Jp + col];
+    }
+  }
+}
+
+template <typename T, bool BWD>
+int launch_gemm(GemmArgs& a, int* nparts_out, hipStream_t st) {
+  const int ntm = cdiv(a.M, BM);
+  a.tiles_per_wg = cdiv(ntm, EDET_MAX_PARTS);
+  const int grid = cdiv(ntm, a.tiles_per_wg);
+  a.Jp = (a.J + 7) / 8 * 8;
+  const bool gate = BWD && a.epi.dgate != nullptr;
+  const size_t extra = (size_t)(gate ? 4 : 2) * a.Jp * sizeof(float);
+  if (nparts_out) *nparts_out = grid;
+  if (a.J <= 32) {
+    k_gemm<T, 2, BWD><<<dim3(grid), dim3(THREADS), GemmCfg<T, 2>::TILE_BYTES + extra, st>>>(a);
+  } else if (a.J <= 64) {
+    k_gemm<T, 4, BWD><<<dim3(grid), dim3(THREADS), GemmCfg<T, 4>::TILE_BYTES + extra, st>>>(a);
+  } else {
+    k_gemm<T, 8, BWD><<<dim3(grid), dim3(THREADS), GemmCfg<T, 8>::TILE_BYTES + extra, st>>>(a);
+  }
+  EDET_LAUNCH_CHECK(BWD ? "edet_pw_bwd_data" : "edet_pw_fwd");
+  return 0;
+}
+
+// ---- weight gradient: P[i][j] = sum_m U[m][i] * V[m][j] -----------------------------------------
+// U is the operand with more channels (tiled 64 columns per workgroup, one 16-col MFMA tile per
+// wave), V the one with fewer (all NJ*16 columns held per workgroup).  Either may be the
+// activated input view or the gradient view; the big tensor is therefore read exactly once.
+struct WgradArgs {
+  edet_tview_t tv;  // conv input (activated view), K = tv.c channels
+  edet_gview_t gv;  // dy, N = gv.c channels
+  int u_is_grad;    // 1: U = dy (i -> n, j -> k); 0: U = in (i -> k, j -> n)
+  int M, CU, CV;    // rows, channels of U and V
+  int hw;
+  int rows_per_wg;
+  float* dw;        // [K][N] fp32
+  int N;            // = gv.c (row length of dw)
+};
+
+template <typename T> struct WgCfg;
+template <> struct WgCfg<bf16_t> { static constexpr int BMR = 64; };
+template <> struct WgCfg<float> { static constexpr int BMR = 32; };
+
+template <typename T>
+__device__ __forceinline__ void wg_load(const WgradArgs& a, bool is_grad, int64_t m, int c, float x[8]) {
+  if (is_grad) {
+    GradCoef gc;
+    grad_load_coef(a.gv, c, gc);
+    grad_load<T>(a.gv, gc, (size_t)m * a.gv.ld + c, x);
+  } else {
+    load8<T>(reinterpret_cast<const T*>(a.tv.data) + (size_t)m * a.tv.ld + c, x);
+    ViewCoef vc;
+    view_load_coef(a.tv, c, vc);
+    view_apply(a.tv, vc, c, a.tv.gate ? (int)(m / a.hw) : 0, x);
+  }
+}
+
+template <typename T, int NJ>
+__global__ __launch_bounds__(THREADS) void k_wgrad(const WgradArgs a) {
+  constexpr int BMR = WgCfg<T>::BMR;
+  constexpr int TI = 64, TJ = NJ * 16;
+  constexpr bool IS_BF = sizeof(T) == 2;
+  // bf16: transposed images Ut[TI][BMR+8], Vt[TJ][BMR+8]; fp32: row-major Us[BMR][TI+4], Vs[BMR][TJ+4]
+  constexpr int LDT = BMR + 8;
+  constexpr int LDU = TI + 4, LDV = TJ + 4;
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* Ub = reinterpret_cast<T*>(smem);
+  T* Vb = IS_BF ? Ub + TI * LDT : Ub + BMR * LDU;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nti = (a.CU + TI - 1) / TI;
+  const int it = blockIdx.x % nti;
+  const int split = blockIdx.x / nti;
+  const int i0 = it * TI;
+  const int64_t r0 = (int64_t)split * a.rows_per_wg;
+  const int64_t r1 = min((int64_t)a.M, r0 + a.rows_per_wg);
+  const bool u_grad = a.u_is_grad != 0;
+
+  f32x4 acc[NJ];
+#pragma unroll
+  for (int nj = 0; nj < NJ; ++nj) acc[nj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int64_t mb = r0; mb < r1; mb += BMR) {
+    if constexpr (IS_BF) {
+      // task = 8 rows x 8 channels, transposed in registers while packing to bf16
+      constexpr int UT = (BMR / 8) * (TI / 8), VT = (BMR / 8) * (TJ / 8);
+      for (int q = tid; q < UT + VT; q += THREADS) {
+        const bool isU = q < UT;
+        const int qq = isU ? q : q - UT;
+        const int ncol = isU ? TI / 8 : TJ / 8;
+        const int cb = (qq % ncol) * 8;      // channel offset within the tile
+        const int rb = (qq / ncol) * 8;      // row offset within the slab
+        const int cglob = (isU ? i0 : 0) + cb;
+        const int cmax = isU ? a.CU : a.CV;
+        float f[8][8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int64_t m = mb + rb + r;
+          if (m < r1 && cglob < cmax) {
+            wg_load<T>(a, isU ? u_grad : !u_grad, m, cglob, f[r]);
+            if (cglob + 8 > cmax) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                if (cglob + e >= cmax) f[r][e] = 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[r][e] = 0.f;
+          }
+        }
+        bf16_t* dst = reinterpret_cast<bf16_t*>(isU ? Ub : Vb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          uint4 o;
+          o.x = pack2bf(f[0][e], f[1][e]);
+          o.y = pack2bf(f[2][e], f[3][e]);
+          o.z = pack2bf(f[4][e], f[5][e]);
+          o.w = pack2bf(f[6][e], f[7][e]);
+          *reinterpret_cast<uint4*>(&dst[(cb + e) * LDT + rb]) = o;
+        }
+      }
+      __syncthreads();
+      const bf16_t* Ut = reinterpret_cast<const bf16_t*>(Ub);
+      const bf16_t* Vt = reinterpret_cast<const bf16_t*>(Vb);
+#pragma unroll
+      for (int ks = 0; ks < BMR / 32; ++ks) {
+        const int kq = ks * 32 + (lane >> 4) * 8;
+        bf16x8 af = *reinterpret_cast<const bf16x8*>(&Ut[(wave * 16 + (lane & 15)) * LDT + kq]);
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) {
+          bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&Vt[(nj * 16 + (lane & 15)) * LDT + kq]);
+          acc[nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[nj], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    } else {
+      constexpr int UT = BMR * (TI / 8), VT = BMR * (TJ / 8);
+      for (int q = tid; q < UT + VT; q += THREADS) {
+        const bool isU = q < UT;
+        const int qq = isU ? q : q - UT;
+        const int ncol = isU ? TI / 8 : TJ / 8;
+        const int cb = (qq % ncol) * 8;
+        const int row = qq / ncol;
+        const int cglob = (isU ? i0 : 0) + cb;
+        const int cmax = isU ? a.CU : a.CV;
+        const int64_t m = mb + row;
+        float f[8];
+        if (m < r1 && cglob < cmax) {
+          wg_load<T>(a, isU ? u_grad : !u_grad, m, cglob, f);
+          if (cglob + 8 > cmax) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (cglob + e >= cmax) f[e] = 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = 0.f;
+        }
+        float* dst = reinterpret_cast<float*>(isU ? Ub : Vb);
+        store8<float>(&dst[row * (isU ? LDU : LDV) + cb], f);
+      }
+      __syncthreads();
+      const float* Us = reinterpret_cast<const float*>(Ub);
+      const float* Vs = reinterpret_cast<const float*>(Vb);
+#pragma unroll
+      for (int ks = 0; ks < BMR / 4; ++ks) {
+        const int mrow = ks * 4 + (lane >> 4);
+        const float af = Us[mrow * LDU + wave * 16 + (lane & 15)];
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) {
+          const float bfr = Vs[mrow * LDV + nj * 16 + (lane & 15)];
+          acc[nj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bfr, acc[nj], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // D layout: row i = (lane>>4)*4 + r, col j = lane & 15
+#pragma unroll
+  for (int nj = 0; nj < NJ; ++nj) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + wave * 16 + (lane >> 4) * 4 + r;
+      const int j = nj * 16 + (lane & 15);
+      if (i < a.CU && j < a.CV) {
+        const int k = u_grad ? j : i;
+        const int n = u_grad ? i : j;
+        atomicAdd(&a.dw[(size_t)k * a.N + n], acc[nj][r]);
+      }
+    }
+  }
+}
+
+template <typename T, int NJ>
+void launch_wgrad_nj(const WgradArgs& a, int grid, hipStream_t st) {
+  constexpr int BMR = WgCfg<T>::BMR;
+  constexpr int TJ = NJ * 16;
+  const size_t lds = sizeof(T) == 2 ? (size_t)(64 + TJ) * (BMR + 8) * 2
+                                     : (size_t)BMR * ((64 + 4) + (TJ + 4)) * 4;
+  if (lds > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, NJ>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+  }
+  k_wgrad<T, NJ><<<dim3(grid), dim3(THREADS), lds, st>>>(a);
+}
+
+template <typename T>
+int launch_wgrad(WgradArgs& a, hipStream_t st) {
+  const int K = a.tv.c, N = a.gv.c;
+  a.N = N;
+  a.u_is_grad = N >= K ? 1 : 0;
+  a.CU = a.u_is_grad ? N : K;
+  a.CV = a.u_is_grad ? K : N;
+  EDET_CHECK(a.CV <= 640, "edet_pw_bwd_weight: min(cin, cout) = %d > 640 unsupported", a.CV);
+  const int nti = cdiv(a.CU, 64);
+  // ~1024 workgroups; each at least 512 rows
+  int split = 1024 / nti;
+  if (split < 1) split = 1;
+  int64_t rows = cdiv(a.M, split);
+  if (rows < 512) rows = 512;
+  rows = (rows + 63) / 64 * 64;
+  a.rows_per_wg = (int)rows;
+  split = cdiv(a.M, rows);
+  const int grid = nti * split;
+  if (a.CV <= 64) launch_wgrad_nj<T, 4>(a, grid, st);
+  else if (a.CV <= 128) launch_wgrad_nj<T, 8>(a, grid, st);
+  else if (a.CV <= 192) launch_wgrad_nj<T, 12>(a, grid, st);
+  else if (a.CV <= 320) launch_wgrad_nj<T, 20>(a, grid, st);
+  else launch_wgrad_nj<T, 40>(a, grid, st);
+  EDET_LAUNCH_CHECK("edet_pw_bwd_weight");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int edet_pw_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bias,
+                           void* out, int cout, int ldo, float* stat_partials, int* nparts_out,
+                           int dtype, void* stream) {
+  EDET_CHECK(in && in->data && wt && out, "edet_pw_fwd: null pointer");
+  EDET_CHECK(in->c % 8 == 0 && in->ld % 8 == 0 && ldo % 8 == 0 && ldw % 8 == 0 && ldw >= in->c,
+             "edet_pw_fwd: channel counts/strides must be multiples of 8 (c=%d ld=%d ldo=%d ldw=%d)",
+             in->c, in->ld, ldo, ldw);
+  EDET_CHECK(ldo >= cout && cout <= 1152 * 4, "edet_pw_fwd: bad cout/ldo");
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tv = *in;
+  a.Bm = wt; a.ldb = ldw;
+  a.M = in->n * in->h * in->w; a.R = in->c; a.J = cout; a.hw = in->h * in->w;
+  a.bias = bias; a.out = out; a.ldo = ldo; a.stat_partials = stat_partials;
+  if (dtype == EDET_BF16) return launch_gemm<bf16_t, false>(a, nparts_out, to_stream(stream));
+  if (dtype == EDET_F32) return launch_gemm<float, false>(a, nparts_out, to_stream(stream));
+  EDET_CHECK(false, "edet_pw_fwd: bad dtype %d", dtype);
+}
+
+extern "C" int edet_pw_bwd_data(const edet_gview_t* dy, const void* w, int ldw,
+                                const edet_tview_t* in, const edet_bwd_epi_t* epi, int* nparts_out,
+                                int dtype, void* stream) {
+  EDET_CHECK(dy && dy->dz && w && in && in->data && epi && epi->gout, "edet_pw_bwd_data: null pointer");
+  EDET_CHECK(in->c % 8 == 0 && in->ld % 8 == 0 && dy->ld % 8 == 0 && ldw % 8 == 0 && ldw >= dy->c,
+             "edet_pw_bwd_data: strides must be multiples of 8");
+  EDET_CHECK(!(epi->stat_partials && epi->beta), "edet_pw_bwd_data: fused stats need beta == 0");
+  EDET_CHECK(!(epi->dgate && !in->gate), "edet_pw_bwd_data: dgate given but input view has no gate");
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tv = *in; a.gv = *dy;
+  a.Bm = w; a.ldb = ldw;
+  a.M = in->n * in->h * in->w; a.R = dy->c; a.J = in->c; a.hw = in->h * in->w;
+  a.epi = *epi; a.stat_partials = epi->stat_partials;
+  if (dtype == EDET_BF16) return launch_gemm<bf16_t, true>(a, nparts_out, to_stream(stream));
+  if (dtype == EDET_F32) return launch_gemm<float, true>(a, nparts_out, to_stream(stream));
+  EDET_CHECK(false, "edet_pw_bwd_data: bad dtype %d", dtype);
+}
+
+extern "C" int edet_pw_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy, float* dweight,
+                                  int dtype, void* stream) {
+  EDET_CHECK(in && in->data && dy && dy->dz && dweight, "edet_pw_bwd_weight: null pointer");
+  EDET_CHECK(in->c % 8 == 0 && in->ld % 8 == 0 && dy->ld % 8 == 0, "edet_pw_bwd_weight: strides % 8");
+  WgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tv = *in; a.gv = *dy;
+  a.M = in->n * in->h * in->w; a.hw = in->h * in->w;
+  a.dw = dweight;
+  if (dtype == EDET_BF16) return launch_wgrad<bf16_t>(a, to_stream(stream));
+  if (dtype == EDET_F32) return launch_wgrad<float>(a, to_stream(stream));
+  EDET_CHECK(false, "edet_pw_bwd_weight: bad dtype %d", dtype);
+}

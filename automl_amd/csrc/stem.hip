@@ -1,0 +1,284 @@
+// Stem: dense 3x3 stride-2 convolution with Cin = 3 (TF 'SAME'), plus parameter cast kernels.
+//
+// Cin = 3 gives K = 27: too thin for the matrix cores and only ~3 % of the network's bytes, so
+// this is a direct VALU convolution: the input tile is staged in LDS (fp32), each thread owns one
+// output pixel and all Cout channels, weights are broadcast-read from LDS, the output row segment
+// written by a wave is contiguous (Cout * 2 B per lane).
+// Reference: efficientdet/backbone/efficientnet_model.py:506-527 (Stem), :511-519 (Conv2D).
+#include "common.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+constexpr int TH = 8, TW = 32;  // output tile, one pixel per thread
+constexpr int IH = (TH - 1) * 2 + 3, IW = (TW - 1) * 2 + 3;
+
+struct StemArgs {
+  const void* img;  // [n,h,w,3]
+  int n, h, w, oh, ow, pad_t, pad_l, cout;
+  const float* wgt;  // [3][3][3][cout]
+  void* out; int ldo;
+  float* stat_partials;
+  edet_gview_t gy;
+  float* dweight;
+  int tiles_y, tiles_x, nsp, P;
+};
+
+template <typename T>
+__device__ __forceinline__ void stage_image_tile(const StemArgs& a, int n, int iy0, int ix0, float* tile) {
+  // tile [IH][IW*3]; rows are contiguous runs of IW*3 elements in memory
+  for (int q = threadIdx.x; q < IH * IW * 3; q += THREADS) {
+    const int ly = q / (IW * 3), r = q - ly * (IW * 3);
+    const int lx = r / 3, ci = r - lx * 3;
+    const int gy = iy0 + ly, gx = ix0 + lx;
+    float v = 0.f;
+    if (gy >= 0 && gy < a.h && gx >= 0 && gx < a.w)
+      v = to_f<T>(reinterpret_cast<const T*>(a.img)[((size_t)(n * a.h + gy) * a.w + gx) * 3 + ci]);
+    tile[q] = v;
+  }
+}
+
+template <typename T, int CV>  // CV = cout / 8
+__global__ __launch_bounds__(THREADS) void k_stem_fwd(const StemArgs a) {
+  constexpr int CO = CV * 8;
+  __shared__ __align__(16) float tile[IH * IW * 3];
+  __shared__ __align__(16) float wl[27 * CO];
+  __shared__ float red[2 * CO];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 27 * CO; i += THREADS) wl[i] = a.wgt[i];
+  for (int i = tid; i < 2 * CO; i += THREADS) red[i] = 0.f;
+  const int ty = tid / TW, tx = tid % TW;
+  const bool want_stats = a.stat_partials != nullptr;
+  float s1[CO], s2[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) s1[c] = s2[c] = 0.f;
+
+  for (int sp = blockIdx.x; sp < a.nsp; sp += a.P) {
+    const int per_img = a.tiles_y * a.tiles_x;
+    const int n = sp / per_img, r = sp - n * per_img;
+    const int oy0 = (r / a.tiles_x) * TH, ox0 = (r % a.tiles_x) * TW;
+    __syncthreads();
+    stage_image_tile<T>(a, n, oy0 * 2 - a.pad_t, ox0 * 2 - a.pad_l, tile);
+    __syncthreads();
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy < a.oh && ox < a.ow) {
+      float acc[CO];
+#pragma unroll
+      for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int ci = 0; ci < 3; ++ci) {
+            const float x = tile[(ty * 2 + ky) * (IW * 3) + (tx * 2 + kx) * 3 + ci];
+            const float* wr = &wl[((ky * 3 + kx) * 3 + ci) * CO];
+#pragma unroll
+            for (int c = 0; c < CO; c += 4) {
+              const float4 w4 = *reinterpret_cast<const float4*>(wr + c);
+              acc[c] = fmaf(x, w4.x, acc[c]);
+              acc[c + 1] = fmaf(x, w4.y, acc[c + 1]);
+              acc[c + 2] = fmaf(x, w4.z, acc[c + 2]);
+              acc[c + 3] = fmaf(x, w4.w, acc[c + 3]);
+            }
+          }
+      T* dst = reinterpret_cast<T*>(a.out) + ((size_t)(n * a.oh + oy) * a.ow + ox) * a.ldo;
+#pragma unroll
+      for (int v = 0; v < CV; ++v) store8<T>(dst + v * 8, &acc[v * 8]);
+      if (want_stats) {
+#pragma unroll
+        for (int c = 0; c < CO; ++c) { s1[c] += acc[c]; s2[c] += acc[c] * acc[c]; }
+      }
+    }
+  }
+  if (want_stats) {
+    // wave-level reduction first (64 lanes), then LDS atomics from lane 0
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+      float u = s1[c], v = s2[c];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { u += __shfl_down(u, off, 64); v += __shfl_down(v, off, 64); }
+      if ((tid & 63) == 0) { atomicAdd(&red[c], u); atomicAdd(&red[CO + c], v); }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * CO; i += THREADS)
+      a.stat_partials[(size_t)blockIdx.x * 2 * CO + i] = red[i];
+  }
+}
+
+// dW[tap][co] = sum_pixels x[pixel, tap] * dy[pixel, co]; tap = (ky*3+kx)*3+ci
+template <typename T, int CV>
+__global__ __launch_bounds__(THREADS) void k_stem_bwd_weight(const StemArgs a) {
+  constexpr int CO = CV * 8;
+  constexpr int TG = THREADS / CO;            // tap groups
+  constexpr int TPT = (27 + TG - 1) / TG;     // taps per thread
+  __shared__ __align__(16) float tile[IH * IW * 3];
+  __shared__ __align__(16) float dyt[TH * TW / 2 * CO];
+  const int tid = threadIdx.x;
+  const int co = tid % CO, tg = tid / CO;
+  float acc[TPT];
+#pragma unroll
+  for (int t = 0; t < TPT; ++t) acc[t] = 0.f;
+  const bool active = tg < TG;
+
+  for (int sp = blockIdx.x; sp < a.nsp; sp += a.P) {
+    const int per_img = a.tiles_y * a.tiles_x;
+    const int n = sp / per_img, r = sp - n * per_img;
+    const int oy0 = (r / a.tiles_x) * TH, ox0 = (r % a.tiles_x) * TW;
+    __syncthreads();
+    stage_image_tile<T>(a, n, oy0 * 2 - a.pad_t, ox0 * 2 - a.pad_l, tile);
+    for (int half = 0; half < 2; ++half) {
+      constexpr int HP = TH * TW / 2;  // pixels per half tile
+      if (half) __syncthreads();
+      for (int q = tid; q < HP * CV; q += THREADS) {
+        const int v = q % CV, lp = q / CV, pix = half * HP + lp;
+        const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
+        float g[8];
+        if (oy < a.oh && ox < a.ow) {
+          GradCoef gc;
+          grad_load_coef(a.gy, v * 8, gc);
+          grad_load<T>(a.gy, gc, ((size_t)(n * a.oh + oy) * a.ow + ox) * a.gy.ld + v * 8, g);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] = 0.f;
+        }
+        store8<float>(&dyt[lp * CO + v * 8], g);
+      }
+      __syncthreads();
+      if (active) {
+        for (int lp = 0; lp < HP; ++lp) {
+          const float g = dyt[lp * CO + co];
+          const int pix = half * HP + lp;
+          const int ty = pix / TW, tx = pix % TW;
+#pragma unroll
+          for (int t = 0; t < TPT; ++t) {
+            const int tap = tg * TPT + t;
+            if (tap < 27) {
+              const int ky = tap / 9, kx = (tap / 3) % 3, ci = tap % 3;
+              acc[t] = fmaf(tile[(ty * 2 + ky) * (IW * 3) + (tx * 2 + kx) * 3 + ci], g, acc[t]);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < TPT; ++t) {
+      const int tap = tg * TPT + t;
+      if (tap < 27) atomicAdd(&a.dweight[tap * CO + co], acc[t]);
+    }
+  }
+}
+
+template <typename T>
+__global__ void k_cast(const float* __restrict__ src, T* __restrict__ dst, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = from_f<T>(src[i]);
+}
+
+// dst[r][c] (ld_out, zero padded) = src[r][c]            (transpose == 0, dst rows = rows)
+// dst[c][r] (ld_out, zero padded) = src[r][c]            (transpose == 1, dst rows = cols)
+template <typename T>
+__global__ void k_cast_matrix(const float* __restrict__ src, T* __restrict__ dst, int rows, int cols,
+                              int ld_out, int transpose) {
+  const int drows = transpose ? cols : rows;
+  const int dcols = transpose ? rows : cols;
+  const int64_t total = (int64_t)drows * ld_out;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ld_out), c = (int)(i - (int64_t)r * ld_out);
+    float v = 0.f;
+    if (c < dcols) v = transpose ? src[(size_t)c * cols + r] : src[(size_t)r * cols + c];
+    dst[i] = from_f<T>(v);
+  }
+}
+
+template <typename T>
+int stem_launch(bool fwd, StemArgs& a, hipStream_t st) {
+  a.tiles_y = cdiv(a.oh, TH);
+  a.tiles_x = cdiv(a.ow, TW);
+  a.nsp = a.n * a.tiles_y * a.tiles_x;
+  a.P = a.nsp < EDET_MAX_PARTS ? a.nsp : EDET_MAX_PARTS;
+  const dim3 grid(a.P), block(THREADS);
+#define STEM_CASE(CV)                                                   \
+  case CV:                                                              \
+    if (fwd) k_stem_fwd<T, CV><<<grid, block, 0, st>>>(a);              \
+    else k_stem_bwd_weight<T, CV><<<grid, block, 0, st>>>(a);           \
+    break;
+  switch (a.cout / 8) {
+    STEM_CASE(4) STEM_CASE(5) STEM_CASE(6) STEM_CASE(7) STEM_CASE(8)
+    default:
+      EDET_CHECK(false, "stem: cout %d unsupported (need 32,40,48,56,64)", a.cout);
+  }
+#undef STEM_CASE
+  EDET_LAUNCH_CHECK("edet_stem");
+  return 0;
+}
+
+void stem_geometry(StemArgs& a) {
+  a.oh = same_out(a.h, 2);
+  a.ow = same_out(a.w, 2);
+  a.pad_t = same_pad_before(a.h, 3, 2);
+  a.pad_l = same_pad_before(a.w, 3, 2);
+}
+
+}  // namespace
+
+extern "C" int edet_stem_fwd(const void* images, int n, int h, int w, const float* weight,
+                             void* out, int cout, int ldo, float* stat_partials, int* nparts_out,
+                             int dtype, void* stream) {
+  EDET_CHECK(images && weight && out, "edet_stem_fwd: null pointer");
+  EDET_CHECK(cout % 8 == 0 && ldo % 8 == 0 && ldo >= cout, "edet_stem_fwd: bad cout/ldo");
+  StemArgs a;
+  memset(&a, 0, sizeof(a));
+  a.img = images; a.n = n; a.h = h; a.w = w; a.cout = cout; a.wgt = weight;
+  a.out = out; a.ldo = ldo; a.stat_partials = stat_partials;
+  stem_geometry(a);
+  int rc = dtype == EDET_BF16 ? stem_launch<bf16_t>(true, a, to_stream(stream))
+         : dtype == EDET_F32 ? stem_launch<float>(true, a, to_stream(stream)) : -1;
+  if (rc == -1 && dtype != EDET_BF16 && dtype != EDET_F32) edet_set_error("edet_stem_fwd: bad dtype %d", dtype);
+  if (nparts_out) *nparts_out = a.P;
+  return rc;
+}
+
+extern "C" int edet_stem_bwd_weight(const void* images, int n, int h, int w,
+                                    const edet_gview_t* dy, float* dweight, int dtype, void* stream) {
+  EDET_CHECK(images && dy && dy->dz && dweight, "edet_stem_bwd_weight: null pointer");
+  EDET_CHECK(dy->c % 8 == 0 && dy->ld % 8 == 0, "edet_stem_bwd_weight: dy c/ld % 8");
+  StemArgs a;
+  memset(&a, 0, sizeof(a));
+  a.img = images; a.n = n; a.h = h; a.w = w; a.cout = dy->c; a.gy = *dy; a.dweight = dweight;
+  stem_geometry(a);
+  EDET_CHECK(a.oh == dy->h && a.ow == dy->w, "edet_stem_bwd_weight: dy geometry mismatch");
+  if (dtype == EDET_BF16) return stem_launch<bf16_t>(false, a, to_stream(stream));
+  if (dtype == EDET_F32) return stem_launch<float>(false, a, to_stream(stream));
+  EDET_CHECK(false, "edet_stem_bwd_weight: bad dtype %d", dtype);
+}
+
+extern "C" int edet_cast(const float* src, void* dst, int64_t count, int dtype, void* stream) {
+  EDET_CHECK(src && dst, "edet_cast: null pointer");
+  if (count <= 0) return 0;
+  const int grid = (int)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
+  if (dtype == EDET_BF16) k_cast<bf16_t><<<grid, 256, 0, to_stream(stream)>>>(src, (bf16_t*)dst, count);
+  else if (dtype == EDET_F32) k_cast<float><<<grid, 256, 0, to_stream(stream)>>>(src, (float*)dst, count);
+  else EDET_CHECK(false, "edet_cast: bad dtype %d", dtype);
+  EDET_LAUNCH_CHECK("edet_cast");
+  return 0;
+}
+
+extern "C" int edet_cast_matrix(const float* src, void* dst, int rows, int cols, int ld_out,
+                                int transpose, int dtype, void* stream) {
+  EDET_CHECK(src && dst, "edet_cast_matrix: null pointer");
+  EDET_CHECK(ld_out >= (transpose ? rows : cols), "edet_cast_matrix: ld_out too small");
+  const int64_t total = (int64_t)(transpose ? cols : rows) * ld_out;
+  const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  if (dtype == EDET_BF16)
+    k_cast_matrix<bf16_t><<<grid, 256, 0, to_stream(stream)>>>(src, (bf16_t*)dst, rows, cols, ld_out, transpose);
+  else if (dtype == EDET_F32)
+    k_cast_matrix<float><<<grid, 256, 0, to_stream(stream)>>>(src, (float*)dst, rows, cols, ld_out, transpose);
+  else EDET_CHECK(false, "edet_cast_matrix: bad dtype %d", dtype);
+  EDET_LAUNCH_CHECK("edet_cast_matrix");
+  return 0;
+}

@@ -1,0 +1,309 @@
+"""Hyper-parameter surface of the EfficientDet hot path (host side, pure Python).
+
+Mirrors the public names of the reference's ``efficientdet/hparams_config.py``
+(Config :35-167, default_detection_configs :170-298, model tables :301-467,
+get_efficientdet_config :470-487) so that a user of the reference finds the
+same model names (``efficientdet-d0`` .. ``efficientdet-d7x``) and the same
+``k=v,k2.sub=v`` override syntax.  No TensorFlow: yaml I/O uses plain ``open``.
+"""
+import ast
+import copy
+from collections import abc
+
+import yaml
+
+
+def eval_str_fn(val):
+  """'true'/'false' -> bool, python literals -> value, anything else stays str."""
+  if val in ('true', 'false'):
+    return val == 'true'
+  try:
+    return ast.literal_eval(val)
+  except (ValueError, SyntaxError):
+    return val
+
+
+class Config(object):
+  """Nested attribute dictionary with string / dict / yaml overrides."""
+
+  def __init__(self, config_dict=None):
+    self.update(config_dict)
+
+  def __setattr__(self, k, v):
+    self.__dict__[k] = Config(v) if isinstance(v, dict) else copy.deepcopy(v)
+
+  def __getattr__(self, k):
+    try:
+      return self.__dict__[k]
+    except KeyError:
+      raise AttributeError(k)
+
+  def __getitem__(self, k):
+    return self.__dict__[k]
+
+  def __contains__(self, k):
+    return k in self.__dict__
+
+  def __repr__(self):
+    return repr(self.as_dict())
+
+  def __deepcopy__(self, memodict):
+    return type(self)(self.as_dict())
+
+  def __str__(self):
+    try:
+      return yaml.dump(self.as_dict(), indent=4)
+    except TypeError:
+      return str(self.as_dict())
+
+  def _update(self, config_dict, allow_new_keys=True):
+    if not config_dict:
+      return
+    for k, v in config_dict.items():
+      if k not in self.__dict__:
+        if not allow_new_keys:
+          raise KeyError('Key `{}` does not exist for overriding. '.format(k))
+        self.__setattr__(k, v)
+      else:
+        cur = self.__dict__[k]
+        if isinstance(cur, Config) and isinstance(v, dict):
+          cur._update(v, allow_new_keys)
+        elif isinstance(cur, Config) and isinstance(v, Config):
+          cur._update(v.as_dict(), allow_new_keys)
+        else:
+          self.__setattr__(k, v)
+
+  def get(self, k, default_value=None):
+    return self.__dict__.get(k, default_value)
+
+  def update(self, config_dict):
+    """Update members, new keys allowed."""
+    self._update(config_dict, allow_new_keys=True)
+
+  def keys(self):
+    return self.__dict__.keys()
+
+  def override(self, config_dict_or_str, allow_new_keys=False):
+    """Update members; unknown keys raise KeyError unless allow_new_keys."""
+    if isinstance(config_dict_or_str, str):
+      if not config_dict_or_str:
+        return
+      if '=' in config_dict_or_str:
+        config_dict = self.parse_from_str(config_dict_or_str)
+      elif config_dict_or_str.endswith('.yaml'):
+        config_dict = self.parse_from_yaml(config_dict_or_str)
+      else:
+        raise ValueError(
+            'Invalid string {}, must end with .yaml or contains "=".'.format(
+                config_dict_or_str))
+    elif isinstance(config_dict_or_str, dict):
+      config_dict = config_dict_or_str
+    else:
+      raise ValueError('Unknown value type: {}'.format(config_dict_or_str))
+    self._update(config_dict, allow_new_keys)
+
+  def parse_from_yaml(self, yaml_file_path):
+    with open(yaml_file_path, 'r') as f:
+      return yaml.load(f, Loader=yaml.FullLoader)
+
+  def save_to_yaml(self, yaml_file_path):
+    with open(yaml_file_path, 'w') as f:
+      yaml.dump(self.as_dict(), f, default_flow_style=False)
+
+  def parse_from_str(self, config_str):
+    """'x.y=1,x.z=2' -> {x: {y: 1, z: 2}}; '*' splits lists; 'WxH' stays str."""
+    if not config_str:
+      return {}
+    out = {}
+
+    def nest(key, val):
+      if '.' not in key:
+        if '*' in val:
+          return {key: [eval_str_fn(v) for v in val.split('*')]}
+        return {key: eval_str_fn(val)}
+      head, rest = key.split('.', 1)
+      return {head: nest(rest, val)}
+
+    def merge(dst, src):
+      for k in src:
+        if k in dst and isinstance(dst[k], dict) and isinstance(src[k], abc.Mapping):
+          merge(dst[k], src[k])
+        else:
+          dst[k] = src[k]
+
+    try:
+      for pair in config_str.split(','):
+        if not pair:
+          continue
+        key, val = pair.split('=')
+        merge(out, nest(key.strip(), val))
+      return out
+    except ValueError:
+      raise ValueError('Invalid config_str: {}'.format(config_str))
+
+  def as_dict(self):
+    d = {}
+    for k, v in self.__dict__.items():
+      d[k] = v.as_dict() if isinstance(v, Config) else copy.deepcopy(v)
+    return d
+
+
+def default_detection_configs():
+  """Defaults of the detection path (reference hparams_config.py:170-298)."""
+  h = Config()
+  h.name = 'efficientdet-d1'
+  h.act_type = 'swish'
+  # input preprocessing (kept for interface completeness; data pipeline is out of scope)
+  h.image_size = 640
+  h.target_size = None
+  h.input_rand_hflip = True
+  h.jitter_min = 0.1
+  h.jitter_max = 2.0
+  h.autoaugment_policy = None
+  h.grid_mask = False
+  h.sample_image = None
+  h.map_freq = 5
+  # dataset
+  h.num_classes = 90
+  h.seg_num_classes = 3
+  h.heads = ['object_detection']
+  h.skip_crowd_during_training = True
+  h.label_map = None
+  h.max_instances_per_image = 100
+  h.regenerate_source_id = False
+  # architecture
+  h.min_level = 3
+  h.max_level = 7
+  h.num_scales = 3
+  h.aspect_ratios = [1.0, 2.0, 0.5]
+  h.anchor_scale = 4.0
+  h.is_training_bn = True
+  # optimisation
+  h.momentum = 0.9
+  h.optimizer = 'sgd'
+  h.learning_rate = 0.08
+  h.lr_warmup_init = 0.008
+  h.lr_warmup_epoch = 1.0
+  h.first_lr_drop_epoch = 200.0
+  h.second_lr_drop_epoch = 250.0
+  h.poly_lr_power = 0.9
+  h.clip_gradients_norm = 10.0
+  h.num_epochs = 300
+  h.data_format = 'channels_last'
+  h.mean_rgb = [0.485 * 255, 0.456 * 255, 0.406 * 255]
+  h.stddev_rgb = [0.229 * 255, 0.224 * 255, 0.225 * 255]
+  h.scale_range = False
+  # losses
+  h.label_smoothing = 0.0
+  h.alpha = 0.25
+  h.gamma = 1.5
+  h.delta = 0.1
+  h.box_loss_weight = 50.0
+  h.iou_loss_type = None
+  h.iou_loss_weight = 1.0
+  h.weight_decay = 4e-5
+  h.strategy = None
+  h.mixed_precision = False
+  h.loss_scale = None
+  # detection structure
+  h.box_class_repeats = 3
+  h.fpn_cell_repeats = 3
+  h.fpn_num_filters = 88
+  h.separable_conv = True
+  h.apply_bn_for_resampling = True
+  h.conv_after_downsample = False
+  h.conv_bn_act_pattern = False
+  h.drop_remainder = True
+  h.nms_configs = {
+      'method': 'gaussian',
+      'iou_thresh': None,
+      'score_thresh': 0.,
+      'sigma': None,
+      'pyfunc': False,
+      'max_nms_inputs': 0,
+      'max_output_size': 100,
+  }
+  h.tflite_max_detections = 100
+  h.fpn_name = None
+  h.fpn_weight_method = None
+  h.fpn_config = None
+  h.survival_prob = None
+  h.img_summary_steps = None
+  h.lr_decay_method = 'cosine'
+  h.moving_average_decay = 0.9998
+  h.ckpt_var_scope = None
+  h.skip_mismatch = True
+  h.backbone_name = 'efficientnet-b1'
+  h.backbone_config = None
+  h.var_freeze_expr = None
+  h.use_keras_model = True
+  h.dataset_type = None
+  h.positives_momentum = None
+  h.grad_checkpoint = False
+  h.verbose = 1
+  h.save_freq = 'epoch'
+  return h
+
+
+def _det(name, backbone, size, filters, cells, repeats, **extra):
+  d = dict(name=name, backbone_name=backbone, image_size=size,
+           fpn_num_filters=filters, fpn_cell_repeats=cells,
+           box_class_repeats=repeats)
+  d.update(extra)
+  return d
+
+
+# compound-scaling table (reference hparams_config.py:301-389)
+efficientdet_model_param_dict = {
+    'efficientdet-d0': _det('efficientdet-d0', 'efficientnet-b0', 512, 64, 3, 3),
+    'efficientdet-d1': _det('efficientdet-d1', 'efficientnet-b1', 640, 88, 4, 3),
+    'efficientdet-d2': _det('efficientdet-d2', 'efficientnet-b2', 768, 112, 5, 3),
+    'efficientdet-d3': _det('efficientdet-d3', 'efficientnet-b3', 896, 160, 6, 4),
+    'efficientdet-d4': _det('efficientdet-d4', 'efficientnet-b4', 1024, 224, 7, 4),
+    'efficientdet-d5': _det('efficientdet-d5', 'efficientnet-b5', 1280, 288, 7, 4),
+    'efficientdet-d6': _det('efficientdet-d6', 'efficientnet-b6', 1280, 384, 8, 5,
+                            fpn_weight_method='sum'),
+    'efficientdet-d7': _det('efficientdet-d7', 'efficientnet-b6', 1536, 384, 8, 5,
+                            anchor_scale=5.0, fpn_weight_method='sum'),
+    'efficientdet-d7x': _det('efficientdet-d7x', 'efficientnet-b7', 1536, 384, 8, 5,
+                             anchor_scale=4.0, max_level=8,
+                             fpn_weight_method='sum'),
+}
+
+# The lite family (relu6, efficientnet-lite backbones) is listed for name
+# completeness; the MI355X path does not build efficientnet-lite backbones
+# (out of scope per SURVEY.md section 8 row C2).
+_lite_common = dict(mean_rgb=127.0, stddev_rgb=128.0, act_type='relu6',
+                    fpn_weight_method='sum')
+efficientdet_lite_param_dict = {
+    'efficientdet-lite0': _det('efficientdet-lite0', 'efficientnet-lite0', 320, 64, 3, 3,
+                               anchor_scale=3.0, **_lite_common),
+    'efficientdet-lite1': _det('efficientdet-lite1', 'efficientnet-lite1', 384, 88, 4, 3,
+                               anchor_scale=3.0, **_lite_common),
+    'efficientdet-lite2': _det('efficientdet-lite2', 'efficientnet-lite2', 448, 112, 5, 3,
+                               anchor_scale=3.0, **_lite_common),
+    'efficientdet-lite3': _det('efficientdet-lite3', 'efficientnet-lite3', 512, 160, 6, 4,
+                               **_lite_common),
+    'efficientdet-lite3x': _det('efficientdet-lite3x', 'efficientnet-lite3', 640, 200, 6, 4,
+                                anchor_scale=3.0, **_lite_common),
+    'efficientdet-lite4': _det('efficientdet-lite4', 'efficientnet-lite4', 640, 224, 7, 4,
+                               **_lite_common),
+}
+
+
+def get_efficientdet_config(model_name='efficientdet-d1'):
+  """Default config of a named model (reference hparams_config.py:470-480)."""
+  h = default_detection_configs()
+  if model_name in efficientdet_model_param_dict:
+    h.override(efficientdet_model_param_dict[model_name])
+  elif model_name in efficientdet_lite_param_dict:
+    h.override(efficientdet_lite_param_dict[model_name])
+  else:
+    raise ValueError('Unknown model name: {}'.format(model_name))
+  return h
+
+
+def get_detection_config(model_name):
+  if model_name.startswith('efficientdet'):
+    return get_efficientdet_config(model_name)
+  raise ValueError('model name must start with efficientdet.')

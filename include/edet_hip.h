@@ -1,0 +1,259 @@
+/*
+ * edet_hip.h -- C ABI of the MI355X (gfx950) EfficientDet hot path.
+ *
+ * The reference (google/automl, efficientdet/) has no FFI boundary of its own:
+ * its hot path is Python calling un-vendored TensorFlow ops.  Each entry point
+ * below therefore replaces one *TensorFlow op call site* of the reference and
+ * cites it (paths relative to the reference root).  The caller is the Python
+ * host mirror in automl_amd/ (ctypes); see INTEGRATION.md for the binding a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative code on failure;
+ *     edet_last_error() returns a thread-local message.
+ *   - all tensors are NHWC in device memory (HBM), element type `dtype`
+ *     (EDET_F32 or EDET_BF16), channel stride `ld` >= c (ld % 8 == 0);
+ *     statistics, gates, scales, parameters' master copies and parameter
+ *     gradients are always fp32.
+ *   - the caller owns every buffer; the library allocates nothing and only
+ *     enqueues work on the HIP stream passed in (`stream` is a hipStream_t
+ *     passed as void*; NULL = default stream).  Nothing synchronises, so all
+ *     entry points are legal inside hipGraph stream capture.
+ *   - not thread-safe per stream; re-entrant across streams.
+ */
+#ifndef EDET_HIP_H_
+#define EDET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EDET_F32 0
+#define EDET_BF16 1
+
+#define EDET_ACT_NONE 0
+#define EDET_ACT_SWISH 1
+
+/* resample modes of one BiFPN fusion input */
+#define EDET_RS_IDENTITY 0
+#define EDET_RS_UP2 1   /* nearest-neighbour upsample, src = min(floor(dst*in/out), in-1) */
+#define EDET_RS_POOL 2  /* max-pool 3x3 stride 2, TF 'SAME', padding excluded from the max */
+
+/* number of per-workgroup statistic partial rows a kernel may write */
+#define EDET_MAX_PARTS 1024
+
+/*
+ * "Activated view" of a stored tensor: value(n,h,w,c) =
+ *     act(data * scale[c] + shift[c]) * gate[n,c]
+ * scale/shift NULL -> identity affine; gate NULL -> 1.  This is how BatchNorm
+ * (utils.py:166-266), swish (utils.py:36-39) and the SE gate
+ * (efficientnet_model.py:183-195) are applied on load by the consuming kernel
+ * instead of as separate HBM passes.
+ */
+typedef struct edet_tview {
+  const void* data;
+  const float* scale;
+  const float* shift;
+  const float* gate;
+  int act;
+  int n, h, w, c, ld;
+} edet_tview_t;
+
+/*
+ * Gradient view: dy(n,h,w,c) = a[c]*dz + b[c]*y + cc[c]  (a == NULL -> dy = dz).
+ * This is the BatchNorm backward applied on load: dz is the gradient w.r.t. the
+ * BN output, y the saved conv output, and (a,b,cc) come from
+ * edet_bn_bwd_finalize.
+ */
+typedef struct edet_gview {
+  const void* dz;
+  const void* y;
+  const float* a;
+  const float* b;
+  const float* cc;
+  int n, h, w, c, ld;
+} edet_gview_t;
+
+/*
+ * What a data-gradient kernel does with d(view) for its input view `in`:
+ *   plain        : g = d
+ *   act          : g = d * act'(z),  z = data*scale+shift
+ *   gate         : store D = d (the gated gradient) and accumulate
+ *                  dgate[n,c] += sum_hw D * act(z); edet_se_gate_bwd finishes.
+ *   beta != 0    : g += previous contents of gout.
+ *   stat_partials: per-workgroup partial sums of (g, g*xhat), xhat =
+ *                  (data-mean)*rstd, row p at stat_partials[p*2*c .. ]; the
+ *                  kernel writes exactly `*nparts_out` rows.
+ */
+typedef struct edet_bwd_epi {
+  void* gout;
+  int beta;
+  const float* mean;
+  const float* rstd;
+  float* stat_partials;
+  float* dgate;
+} edet_bwd_epi_t;
+
+const char* edet_last_error(void);
+int edet_version(void);
+
+/* ---- parameter preparation ------------------------------------------------
+ * fp32 master -> compute copy (dtype), optionally transposed [rows][cols] ->
+ * [cols][ld_out].  Replaces the Keras mixed-precision variable cast
+ * (utils.py:552-566).  */
+int edet_cast(const float* src, void* dst, int64_t count, int dtype, void* stream);
+int edet_cast_matrix(const float* src, void* dst, int rows, int cols, int ld_out,
+                     int transpose, int dtype, void* stream);
+
+/* ---- stem: Conv2D 3x3 stride 2 'SAME', Cin = 3, no bias --------------------
+ * efficientnet_model.py:511-519.  images [n,h,w,3] (ld 3), weight fp32 HWIO
+ * [3,3,3,cout].  Writes raw conv output and BN statistic partials.  */
+int edet_stem_fwd(const void* images, int n, int h, int w, const float* weight,
+                  void* out, int cout, int ldo, float* stat_partials, int* nparts_out,
+                  int dtype, void* stream);
+int edet_stem_bwd_weight(const void* images, int n, int h, int w,
+                         const edet_gview_t* dy, float* dweight, int dtype, void* stream);
+
+/* ---- pointwise (1x1) convolution = GEMM on the matrix cores ----------------
+ * Conv2D 1x1 call sites: efficientnet_model.py:304-312,345-353;
+ * efficientdet_keras.py:286-290 and the pointwise half of SeparableConv2D
+ * (:195-207,459-464,546-556).  wt is the compute copy [cout][ldw] (K contiguous),
+ * bias fp32 [cout] or NULL.  */
+int edet_pw_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bias,
+                void* out, int cout, int ldo, float* stat_partials, int* nparts_out,
+                int dtype, void* stream);
+/* d(in) from dy: w is the compute copy [cin][ldw] (Cout contiguous).  */
+int edet_pw_bwd_data(const edet_gview_t* dy, const void* w, int ldw,
+                     const edet_tview_t* in, const edet_bwd_epi_t* epi, int* nparts_out,
+                     int dtype, void* stream);
+/* dweight[cin][cout] (fp32, HWIO of a 1x1 kernel) += in^T dy (atomic adds). */
+int edet_pw_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy, float* dweight,
+                       int dtype, void* stream);
+
+/* ---- depthwise convolution k in {3,5}, stride in {1,2}, TF 'SAME' ----------
+ * DepthwiseConv2D call sites: efficientnet_model.py:320-327 and the depthwise
+ * half of SeparableConv2D.  weight fp32 [k,k,c] (HWIO with multiplier 1).  */
+int edet_dw_fwd(const edet_tview_t* in, const float* weight, int k, int stride,
+                void* out, int ldo, float* stat_partials, int* nparts_out,
+                int dtype, void* stream);
+int edet_dw_bwd_data(const edet_gview_t* dy, const float* weight, int k, int stride,
+                     const edet_tview_t* in, const edet_bwd_epi_t* epi, int* nparts_out,
+                     int dtype, void* stream);
+int edet_dw_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy, int k, int stride,
+                       float* dweight, int dtype, void* stream);
+
+/* ---- BatchNorm statistics --------------------------------------------------
+ * utils.py:244-266 / util_keras.py:29-66 (eps 1e-3, momentum 0.99).
+ * finalize: partial sums -> batch mean / biased variance -> scale, shift, mean,
+ * rstd; moving statistics updated in place when momentum >= 0.  */
+int edet_bn_finalize(const float* partials, int nparts, int c, double count,
+                     const float* gamma, const float* beta, float eps, float momentum,
+                     float* moving_mean, float* moving_var,
+                     float* scale, float* shift, float* mean, float* rstd, void* stream);
+/* inference: scale/shift from the moving statistics */
+int edet_bn_eval(int c, const float* gamma, const float* beta, float eps,
+                 const float* moving_mean, const float* moving_var,
+                 float* scale, float* shift, void* stream);
+/* partial sums of (dz, dz*xhat) over a stored gradient (multi-consumer case) */
+int edet_bn_bwd_reduce(const void* dz, const void* y, int64_t rows, int c, int ld,
+                       const float* mean, const float* rstd,
+                       float* stat_partials, int* nparts_out, int dtype, void* stream);
+/* partials -> dgamma, dbeta (accumulated) and the on-load coefficients a,b,cc.
+ * dbias is ignored (may be NULL): the gradient of a bias that feeds a BatchNorm is
+ * analytically zero because BN removes the per-channel mean.  */
+int edet_bn_bwd_finalize(const float* partials, int nparts, int c, double count,
+                         const float* gamma, const float* mean, const float* rstd,
+                         float* dgamma, float* dbeta, float* dbias,
+                         float* a, float* b, float* cc, void* stream);
+
+/* ---- block output: out = y*scale+shift (+ residual) ------------------------
+ * efficientnet_model.py:393-410 (project BN, identity skip).  */
+int edet_bn_res(const edet_tview_t* y, const void* residual, void* out, int ldo,
+                int dtype, void* stream);
+/* dst = (beta ? dst : 0) + src, elementwise on [rows][c] with ld */
+int edet_add(void* dst, const void* src, int64_t rows, int c, int ld, int beta,
+             int dtype, void* stream);
+
+/* ---- squeeze-and-excitation --------------------------------------------------
+ * efficientnet_model.py:153-195: mean over H,W -> 1x1 (+bias) -> swish -> 1x1
+ * (+bias) -> sigmoid.  pooled [n,c] must be zero before edet_se_pool (atomics).  */
+int edet_se_pool(const edet_tview_t* in, float* pooled_sum, int dtype, void* stream);
+int edet_se_fc(const float* pooled_sum, int n, int c, int se, float inv_hw,
+               const float* w1, const float* b1, const float* w2, const float* b2,
+               float* hidden_pre, float* gate, void* stream);
+/* dgate [n,c] -> dpool [n,c] (already divided by H*W), parameter gradients */
+int edet_se_fc_bwd(const float* pooled_sum, const float* hidden_pre, const float* gate,
+                   const float* dgate, int n, int c, int se, float inv_hw,
+                   const float* w1, const float* w2,
+                   float* dw1, float* db1, float* dw2, float* db2,
+                   float* dpool, float* scratch, void* stream);
+/* in place on g (holding the gated gradient D): dz = (D*gate + dpool)*act'(z);
+ * writes BN backward partials for `in`'s BatchNorm.  */
+int edet_se_gate_bwd(const edet_tview_t* in, void* g, const float* dpool,
+                     const float* mean, const float* rstd,
+                     float* stat_partials, int* nparts_out, int dtype, void* stream);
+
+/* ---- BiFPN weighted fusion ---------------------------------------------------
+ * efficientdet_keras.py:75-121 (fuse_features), :254-281 (max-pool / nearest
+ * resample), :214-217 (swish before the separable conv).
+ * out = act( sum_i wn_i * resample_i(view_i) ), wn = normalised weights (fp32[3]).  */
+int edet_fuse_weights(const float* w0, const float* w1, const float* w2, int nin,
+                      int method /*0 fastattn, 1 sum*/, float* wn, void* stream);
+int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
+                  const int* modes, int nin, const float* wn, int act,
+                  void* out, int oh, int ow, int ldo, int dtype, void* stream);
+/* ds = dout * act'(s) (s recomputed) written to `ds`; dwn[i] += sum ds * x_i */
+int edet_fuse_bwd_pre(const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
+                      const int* modes, int nin, const float* wn, int act,
+                      const void* dout, int oh, int ow, int ldo,
+                      void* ds, float* dwn, int dtype, void* stream);
+/* gradient of one fusion input: gout (+)= wn[i] * resample_i^T(ds) */
+int edet_fuse_bwd_input(const edet_tview_t* in, int mode, const float* wn, int idx,
+                        const void* ds, int oh, int ow, int lds_,
+                        void* gout, int beta, int dtype, void* stream);
+/* raw weight gradients from dwn (fast-attention normalisation backward) */
+int edet_fuse_weights_bwd(const float* w0, const float* w1, const float* w2, int nin,
+                          int method, const float* dwn, float* dw0, float* dw1, float* dw2,
+                          void* stream);
+
+/* ---- detection loss forward + backward --------------------------------------
+ * train_lib.py:357-437,493-604: focal loss (alpha, gamma) on class logits,
+ * Huber(delta) on box codes; writes d(loss)/d(logits) and accumulates
+ * sums[0] += cls_loss, sums[1] += box_loss (already normalised).
+ * cls_targets int32 [n,h,w,a] (-1 background, -2 ignore).  */
+int edet_focal_loss(const void* logits, int ld, const int32_t* cls_targets,
+                    int64_t positions, int num_anchors, int num_classes,
+                    float alpha, float gamma, float inv_normalizer,
+                    void* dlogits, float* dbias, float* sums, int dtype, void* stream);
+int edet_box_loss(const void* box_out, int ld, const float* box_targets,
+                  int64_t positions, int nch, float delta, float inv_normalizer,
+                  float grad_scale, void* dbox, float* dbias, float* sums,
+                  int dtype, void* stream);
+
+/* ---- optimizer -----------------------------------------------------------------
+ * train_lib.py:486-491 (L2), :675-682 (per-tensor clip_by_norm then
+ * clip_by_global_norm), Keras SGD momentum, TFA MovingAverage (:176-199).
+ * All parameters live in one flat fp32 arena; seg_offsets[nseg+1] delimits the
+ * tensors, seg_flags bit0 = L2-regularised (kernel/weight variables).  */
+int edet_opt_l2_norms(float* grads, const float* params, const int64_t* seg_offsets,
+                      const int32_t* seg_flags, int nseg, float weight_decay,
+                      float* seg_sqnorm, float* l2_sum, void* stream);
+/* seg_factor[s] = clip_by_norm factor * clip_by_global_norm factor; global_norm_out = norm after clipping */
+int edet_opt_clip_factors(const float* seg_sqnorm, int nseg, float clip_norm,
+                          float* seg_factor, float* global_norm_out, void* stream);
+/* grads[s] *= seg_factor[s]  (data-parallel path: clip locally, then all-reduce, train_lib.py:675-683) */
+int edet_opt_scale(float* grads, const int64_t* seg_offsets, const float* seg_factor,
+                   int nseg, void* stream);
+/* hyper_dev = device float[2] {learning_rate, ema_decay}; seg_factor may be NULL (already scaled);
+ * ema may be NULL.  v = momentum*v - lr*g; w += v; ema -= (1-decay)*(ema - w).  */
+int edet_opt_sgd_ema(float* params, float* grads, float* velocity, float* ema,
+                     const int64_t* seg_offsets, const float* seg_factor, int nseg,
+                     const float* hyper_dev, float momentum, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* EDET_HIP_H_ */
