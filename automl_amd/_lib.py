@@ -1,0 +1,161 @@
+"""ctypes binding of libedet_hip.so (C ABI declared in include/edet_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call
+fails this module raises, loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libedet_hip.so')
+
+EDET_F32, EDET_BF16 = 0, 1
+ACT_NONE, ACT_SWISH = 0, 1
+RS_IDENTITY, RS_UP2, RS_POOL = 0, 1, 2
+MAX_PARTS = 1024
+
+c_void_p, c_int, c_float, c_double, c_int64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
+                                               ctypes.c_double, ctypes.c_int64)
+
+
+class TView(ctypes.Structure):
+  _fields_ = [('data', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('gate', c_void_p),
+              ('act', c_int), ('n', c_int), ('h', c_int), ('w', c_int), ('c', c_int), ('ld', c_int)]
+
+
+class GView(ctypes.Structure):
+  _fields_ = [('dz', c_void_p), ('y', c_void_p), ('a', c_void_p), ('b', c_void_p), ('cc', c_void_p),
+              ('n', c_int), ('h', c_int), ('w', c_int), ('c', c_int), ('ld', c_int)]
+
+
+class BwdEpi(ctypes.Structure):
+  _fields_ = [('gout', c_void_p), ('beta', c_int), ('mean', c_void_p), ('rstd', c_void_p),
+              ('stat_partials', c_void_p), ('dgate', c_void_p)]
+
+
+PT, PG, PE, PI = (ctypes.POINTER(TView), ctypes.POINTER(GView), ctypes.POINTER(BwdEpi),
+                  ctypes.POINTER(c_int))
+
+# name -> argtypes; every function returns int.  Must list EVERY symbol of include/edet_hip.h
+# (tests/test_abi.py checks the header against this table and the built library).
+SIGNATURES = {
+    'edet_cast': [c_void_p, c_void_p, c_int64, c_int, c_void_p],
+    'edet_cast_matrix': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'edet_stem_fwd': [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, PI,
+                      c_int, c_void_p],
+    'edet_stem_bwd_weight': [c_void_p, c_int, c_int, c_int, PG, c_void_p, c_int, c_void_p],
+    'edet_pw_fwd': [PT, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, PI, c_int, c_void_p],
+    'edet_pw_bwd_data': [PG, c_void_p, c_int, PT, PE, PI, c_int, c_void_p],
+    'edet_pw_bwd_weight': [PT, PG, c_void_p, c_int, c_void_p],
+    'edet_dw_fwd': [PT, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, PI, c_int, c_void_p],
+    'edet_dw_bwd_data': [PG, c_void_p, c_int, c_int, PT, PE, PI, c_int, c_void_p],
+    'edet_dw_bwd_weight': [PT, PG, c_int, c_int, c_void_p, c_int, c_void_p],
+    'edet_bn_finalize': [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_float, c_float,
+                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    'edet_bn_eval': [c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    'edet_bn_bwd_reduce': [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, PI,
+                           c_int, c_void_p],
+    'edet_bn_bwd_finalize': [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    'edet_bn_res': [PT, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    'edet_add': [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
+    'edet_se_pool': [PT, c_void_p, c_int, c_void_p],
+    'edet_se_fc': [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                   c_void_p, c_void_p, c_void_p],
+    'edet_se_fc_bwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
+                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    'edet_se_gate_bwd': [PT, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, PI, c_int, c_void_p],
+    'edet_fuse_weights': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
+    'edet_fuse_fwd': [PT, PT, PT, PI, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                      c_void_p],
+    'edet_fuse_bwd_pre': [PT, PT, PT, PI, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                          c_void_p, c_void_p, c_int, c_void_p],
+    'edet_fuse_bwd_input': [PT, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
+                            c_int, c_void_p],
+    'edet_fuse_weights_bwd': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_void_p],
+    'edet_focal_loss': [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float,
+                        c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    'edet_box_loss': [c_void_p, c_int, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_void_p,
+                      c_void_p, c_void_p, c_int, c_void_p],
+    'edet_opt_l2_norms': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
+                          c_void_p],
+    'edet_opt_clip_factors': [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    'edet_opt_scale': [c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    'edet_opt_sgd_ema': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                         c_float, c_void_p],
+}
+
+_lib = None
+
+
+class EdetError(RuntimeError):
+  pass
+
+
+def load():
+  """Loads the shared library (once). Raises if it has not been built."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise EdetError(
+        'libedet_hip.so not found at %s: the gfx950 HIP library has not been built '
+        '(run `python -c "import __graft_entry__ as g; g.build()"`). There is no CPU fallback.' % LIB_PATH)
+  lib = ctypes.CDLL(LIB_PATH)
+  lib.edet_last_error.restype = ctypes.c_char_p
+  lib.edet_last_error.argtypes = []
+  lib.edet_version.restype = c_int
+  lib.edet_version.argtypes = []
+  for name, argtypes in SIGNATURES.items():
+    fn = getattr(lib, name)
+    fn.restype = c_int
+    fn.argtypes = argtypes
+  _lib = lib
+  return lib
+
+
+class Profiler(object):
+  """Per-launch HIP-event timing on the launch stream (bench.py's roofline leg).
+
+  names: None = every entry point, else a set of entry-point names to time.  Each record is
+  (name, algorithmic_bytes, start_event, end_event); events are recorded on torch's current
+  stream, which is the stream every kernel of this library is launched on.
+  """
+
+  def __init__(self, names=None):
+    self.names = names
+    self.records = []
+
+  def summary(self):
+    """name -> (launches, total_ms, total_bytes); call after torch.cuda.synchronize()."""
+    out = {}
+    for name, nbytes, s, e in self.records:
+      n, ms, b = out.get(name, (0, 0.0, 0))
+      out[name] = (n + 1, ms + s.elapsed_time(e), b + nbytes)
+    return out
+
+
+profiler = None
+
+
+def call(name, *args, nbytes=0):
+  """Calls lib.<name>(*args); raises EdetError with edet_last_error() on failure."""
+  lib = load()
+  p = profiler
+  if p is not None and (p.names is None or name in p.names):
+    import torch
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    rc = getattr(lib, name)(*args)
+    e.record()
+    p.records.append((name, nbytes, s, e))
+  else:
+    rc = getattr(lib, name)(*args)
+  if rc != 0:
+    raise EdetError('%s failed (%d): %s' % (name, rc, lib.edet_last_error().decode()))
+
+
+def ptr(t):
+  """Device/host pointer of a torch tensor (None -> NULL)."""
+  return None if t is None else t.data_ptr()

@@ -1,0 +1,76 @@
+"""EfficientDetNet: the reference's network interface on MI355X kernels.
+
+Mirror of ``efficientdet/tf2/efficientdet_keras.py:787-915``:
+``EfficientDetNet(model_name=None, config=None)(images[B,H,W,3], training) ->
+(cls_outputs, box_outputs)``, each a list over levels min_level..max_level of
+``[B,H_l,W_l,A*num_classes]`` / ``[B,H_l,W_l,A*4]``.  Buffers are sized at the first
+call for that batch / image size (static shapes), extra keyword arguments choose
+the storage dtype and device.
+"""
+import numpy as np
+import torch
+
+from automl_amd import engine as engine_lib
+from automl_amd import hparams_config
+from automl_amd import utils
+
+
+class EfficientDetNet(object):
+  """EfficientDet network without pre/post-processing."""
+
+  def __init__(self, model_name=None, config=None, name='', feature_only=False, dtype='bf16',
+               device='cuda:0', seed=0, params=None):
+    if feature_only:
+      raise ValueError('feature_only=True is out of scope')
+    config = config or hparams_config.get_efficientdet_config(model_name)
+    if 'object_detection' not in config.heads or len(config.heads) != 1:
+      raise ValueError('No valid head found: {}'.format(config.heads))
+    self.config = config
+    self.name = name
+    self._dtype, self._device, self._seed = dtype, device, seed
+    self._init_params = params
+    self.engine = None
+
+  def _ensure_engine(self, batch, height, width):
+    e = self.engine
+    if e is None or e.batch != batch or e.image_size != (height, width):
+      params = self._init_params
+      if e is not None:
+        params = e.get_params()      # keep the current weights when shapes change
+      self.engine = engine_lib.Engine(self.config, batch, (height, width), dtype=self._dtype,
+                                      device=self._device, seed=self._seed, params=params)
+    return self.engine
+
+  def _to_device_images(self, images, eng):
+    if isinstance(images, np.ndarray):
+      images = torch.from_numpy(images)
+    if images.dim() != 4 or images.shape[-1] != 3:
+      raise ValueError('images must be [batch, height, width, 3], got %s' % (tuple(images.shape),))
+    return images.to(device=eng.device, dtype=eng.tdtype).contiguous()
+
+  def __call__(self, inputs, training=False):
+    b, h, w = int(inputs.shape[0]), int(inputs.shape[1]), int(inputs.shape[2])
+    eng = self._ensure_engine(b, h, w)
+    eng.forward(self._to_device_images(inputs, eng), training=training)
+    return eng.outputs()
+
+  call = __call__
+
+  # ---- variables, addressed by the reference names ------------------------------------------
+  def set_weights(self, values):
+    if self.engine is None:
+      self._init_params = dict(values) if self._init_params is None else {**self._init_params, **values}
+    else:
+      self.engine.set_params(values)
+
+  def get_weights(self):
+    if self.engine is None:
+      raise RuntimeError('the network has not been built yet (call it once)')
+    return self.engine.get_params()
+
+  def anchors(self, image_size=None):
+    from automl_amd import anchors as anchors_lib
+    c = self.config
+    size = image_size if image_size is not None else c.image_size
+    return anchors_lib.Anchors(c.min_level, c.max_level, c.num_scales, c.aspect_ratios, c.anchor_scale,
+                               size)

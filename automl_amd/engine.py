@@ -1,0 +1,675 @@
+"""Executor of the EfficientDet hot path on one MI355X: launches the gfx950 kernels through the C ABI.
+
+Host side is plain Python (as BASELINE.json's north_star asks): it owns the layer graph, the HBM
+buffers (torch tensors are used only as device allocations) and the order of kernel launches.
+Design:
+  * every conv output is stored ONCE, raw (pre-BatchNorm); BatchNorm + swish + SE gate are applied
+    on load by the consumer ("activated view"), BatchNorm statistics come out of the producing
+    kernel's epilogue as deterministic per-workgroup partials;
+  * backward mirrors it: a data-gradient kernel chains through the consumer-side activation and
+    emits the BatchNorm-backward sums; the BatchNorm backward itself is applied on load
+    (dy = a*dz + b*y + c) by the producer's wgrad / dgrad kernels;
+  * forward records a tape of closures, backward replays it in reverse.
+Reference structure followed: efficientdet/tf2/efficientdet_keras.py:787-915 (EfficientDetNet),
+efficientdet/backbone/efficientnet_model.py:360-416,710-779, efficientdet/tf2/train_lib.py:493-684.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from automl_amd import _lib
+from automl_amd import netspec as netspec_lib
+from automl_amd import utils
+from automl_amd._lib import (ACT_NONE, ACT_SWISH, EDET_BF16, EDET_F32, RS_IDENTITY, RS_POOL, RS_UP2,
+                             BwdEpi, GView, TView, call, ptr)
+
+
+def _pad8(c):
+  return (c + 7) // 8 * 8
+
+
+class Raw(object):
+  """A stored NHWC tensor and (lazily) its gradient buffer."""
+
+  def __init__(self, eng, key, n, h, w, c, ld=None, needs_grad=True):
+    self.eng, self.key = eng, key
+    self.n, self.h, self.w, self.c = n, h, w, c
+    self.ld = ld or _pad8(c)
+    self.data = eng.buf(key, (n, h, w, self.ld), eng.tdtype)
+    self.needs_grad = needs_grad
+    self.grad = None
+    self.grad_written = False
+
+  def ensure_grad(self):
+    if self.grad is None:
+      self.grad = self.eng.buf(self.key + '#grad', (self.n, self.h, self.w, self.ld), self.eng.tdtype)
+    return self.grad
+
+  @property
+  def rows(self):
+    return self.n * self.h * self.w
+
+
+class BN(object):
+  """BatchNorm layer state: parameter slices + per-step derived vectors (fp32 [c])."""
+
+  def __init__(self, eng, name, c):
+    self.name, self.c = name, c
+    self.gamma = eng.param(name + '/gamma')
+    self.beta = eng.param(name + '/beta')
+    self.mm = eng.param(name + '/moving_mean')
+    self.mv = eng.param(name + '/moving_variance')
+    self.dgamma = eng.grad(name + '/gamma')
+    self.dbeta = eng.grad(name + '/beta')
+    v = eng.buf('bn:' + name, (7, c), torch.float32)
+    self.scale, self.shift, self.mean, self.rstd, self.a, self.b, self.cc = (v[i] for i in range(7))
+    self.count = 0
+    self.bwd_ready = False
+    self.eval_done = False
+
+
+class View(object):
+  """act(bn(raw)) * gate -- what a consumer kernel sees (edet_tview_t)."""
+
+  def __init__(self, raw, bn=None, act=ACT_NONE, gate=None):
+    self.raw, self.bn, self.act, self.gate = raw, bn, act, gate
+    self.consumers = 0
+
+  def tview(self):
+    r = self.raw
+    return TView(ptr(r.data), ptr(self.bn.scale) if self.bn else None,
+                 ptr(self.bn.shift) if self.bn else None, ptr(self.gate), self.act,
+                 r.n, r.h, r.w, r.c, r.ld)
+
+
+class Engine(object):
+  """Builds buffers for (config, batch, image size, dtype) and runs forward / backward / update."""
+
+  def __init__(self, config, batch_size, image_size=None, dtype='bf16', device='cuda:0', seed=0,
+               params=None):
+    if not torch.cuda.is_available():
+      raise _lib.EdetError('no HIP device visible: the EfficientDet engine has no CPU path')
+    _lib.load()
+    self.config = config
+    self.spec = netspec_lib.NetSpec(config)
+    self.device = torch.device(device)
+    torch.cuda.set_device(self.device)
+    self.dtype = EDET_BF16 if dtype in ('bf16', EDET_BF16) else EDET_F32
+    self.tdtype = torch.bfloat16 if self.dtype == EDET_BF16 else torch.float32
+    self.batch = batch_size
+    self.image_size = utils.parse_image_size(image_size if image_size is not None else config.image_size)
+    self._bufs = {}
+    self._zero_list = []
+    self.tape = []
+    self.training = False
+    self.step_count = 0
+    self._nparts = ctypes.c_int(0)
+    self._build_params(params, seed)
+    cmax = max([p.shape[0] for p in self.spec.params if len(p.shape) == 1] + [64])
+    self.partials = torch.empty(_lib.MAX_PARTS * 2 * cmax, dtype=torch.float32, device=self.device)
+    self.bns = {}
+    self._cast_plan = None
+    self.loss_sums = self.zbuf('loss_sums', (4,))
+    self.hyper = torch.zeros(2, dtype=torch.float32, device=self.device)
+    self.gnorm = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+  @property
+  def esize(self):
+    return 2 if self.dtype == EDET_BF16 else 4
+
+  # ------------------------------------------------------------------ memory
+  @property
+  def stream(self):
+    return torch.cuda.current_stream(self.device).cuda_stream
+
+  def buf(self, key, shape, dtype):
+    t = self._bufs.get(key)
+    if t is None:
+      t = torch.empty(shape, dtype=dtype, device=self.device)
+      self._bufs[key] = t
+    assert tuple(t.shape) == tuple(shape), (key, tuple(t.shape), tuple(shape))
+    return t
+
+  def zbuf(self, key, shape):
+    """fp32 buffer that is zeroed at the start of every step (atomic accumulation targets)."""
+    t = self._bufs.get(key)
+    if t is None:
+      t = torch.zeros(shape, dtype=torch.float32, device=self.device)
+      self._bufs[key] = t
+      self._zero_list.append(t)
+    return t
+
+  def _build_params(self, params, seed):
+    spec = self.spec
+    values = params if params is not None else netspec_lib.init_params(spec, seed)
+    train = [p for p in spec.params if p.trainable]
+    state = [p for p in spec.params if not p.trainable]
+    self.offsets = {}
+    off = 0
+    seg = [0]
+    flags = []
+    for p in train:
+      n = int(np.prod(p.shape)) if p.shape else 1
+      self.offsets[p.name] = (off, n, p.shape, True)
+      off += n
+      off_al = (off + 3) // 4 * 4  # keep every tensor 16-byte aligned
+      seg.append(off)
+      flags.append(1 if netspec_lib.is_l2_regularised(p.name) else 0)
+      if off_al != off:
+        seg.append(off_al)  # padding segment (zeros, never regularised)
+        flags.append(0)
+        off = off_al
+    self.n_train_elems = off
+    self.seg_names = [p.name for p in train]
+    soff = 0
+    for p in state:
+      n = int(np.prod(p.shape))
+      self.offsets[p.name] = (soff, n, p.shape, False)
+      soff = (soff + n + 3) // 4 * 4
+    dev = self.device
+    self.params_flat = torch.zeros(off, dtype=torch.float32, device=dev)
+    self.grads_flat = torch.zeros(off, dtype=torch.float32, device=dev)
+    self.velocity = torch.zeros(off, dtype=torch.float32, device=dev)
+    self.ema = torch.zeros(off, dtype=torch.float32, device=dev)
+    self.state_flat = torch.zeros(max(soff, 4), dtype=torch.float32, device=dev)
+    self.seg_offsets = torch.tensor(seg, dtype=torch.int64, device=dev)
+    self.seg_flags = torch.tensor(flags, dtype=torch.int32, device=dev)
+    self.nseg = len(flags)
+    self.seg_sqnorm = torch.zeros(self.nseg, dtype=torch.float32, device=dev)
+    self.seg_factor = torch.ones(self.nseg, dtype=torch.float32, device=dev)
+    self.set_params(values)
+    self.ema.copy_(self.params_flat)
+
+  def param(self, name):
+    off, n, shape, tr = self.offsets[name]
+    base = self.params_flat if tr else self.state_flat
+    return base[off:off + n]
+
+  def grad(self, name):
+    off, n, shape, tr = self.offsets[name]
+    assert tr, name
+    return self.grads_flat[off:off + n]
+
+  def set_params(self, values):
+    """values: name -> array-like in reference layouts."""
+    for name, v in values.items():
+      if name not in self.offsets:
+        raise KeyError('unknown variable %s' % name)
+      off, n, shape, tr = self.offsets[name]
+      t = torch.as_tensor(np.asarray(v, dtype=np.float32)).reshape(-1)
+      if t.numel() != n:
+        raise ValueError('variable %s: expected %d elements, got %d' % (name, n, t.numel()))
+      self.param(name).copy_(t)
+    self._cast_dirty = True
+
+  def get_params(self, names=None):
+    out = {}
+    for name in (names or self.offsets.keys()):
+      off, n, shape, tr = self.offsets[name]
+      out[name] = self.param(name).detach().cpu().numpy().reshape(shape)
+    return out
+
+  def get_grads(self):
+    return {name: self.grad(name).detach().cpu().numpy().reshape(self.offsets[name][2])
+            for name in self.seg_names}
+
+  # ------------------------------------------------------------------ compute copies of 1x1 kernels
+  def _pw_copies(self, name, cin, cout):
+    """(Wt [cout][ldk], ldk, W [cin][ldn], ldn) compute-dtype copies of an HWIO 1x1 kernel."""
+    ldk, ldn = _pad8(cin), _pad8(cout)
+    wt = self.buf('wt:' + name, (cout, ldk), self.tdtype)
+    w = self.buf('w:' + name, (cin, ldn), self.tdtype)
+    if name not in self._cast_done:
+      src = ptr(self.param(name))
+      call('edet_cast_matrix', src, ptr(wt), cin, cout, ldk, 1, self.dtype, self.stream)
+      call('edet_cast_matrix', src, ptr(w), cin, cout, ldn, 0, self.dtype, self.stream)
+      self._cast_done.add(name)
+    return wt, ldk, w, ldn
+
+  # ------------------------------------------------------------------ BatchNorm plumbing
+  def get_bn(self, name, c):
+    bn = self.bns.get(name)
+    if bn is None:
+      bn = BN(self, name, c)
+      self.bns[name] = bn
+    return bn
+
+  def _bn_forward(self, bn, count, nparts):
+    if self.training:
+      bn.count = count
+      call('edet_bn_finalize', ptr(self.partials), nparts, bn.c, float(count), ptr(bn.gamma), ptr(bn.beta),
+           netspec_lib.BN_EPSILON, netspec_lib.BN_MOMENTUM if self.update_moving else -1.0,
+           ptr(bn.mm), ptr(bn.mv), ptr(bn.scale), ptr(bn.shift), ptr(bn.mean), ptr(bn.rstd), self.stream)
+      bn.bwd_ready = False
+    else:
+      call('edet_bn_eval', bn.c, ptr(bn.gamma), ptr(bn.beta), netspec_lib.BN_EPSILON, ptr(bn.mm), ptr(bn.mv),
+           ptr(bn.scale), ptr(bn.shift), self.stream)
+
+  def _bn_bwd_finalize(self, bn, nparts):
+    call('edet_bn_bwd_finalize', ptr(self.partials), nparts, bn.c, float(bn.count), ptr(bn.gamma),
+         ptr(bn.mean), ptr(bn.rstd), ptr(bn.dgamma), ptr(bn.dbeta), None, ptr(bn.a), ptr(bn.b), ptr(bn.cc),
+         self.stream)
+    bn.bwd_ready = True
+
+  def _ensure_bn_bwd(self, v):
+    """Make the on-load BatchNorm-backward coefficients of view v available (multi-consumer case)."""
+    if v.bn is None or v.bn.bwd_ready:
+      return
+    r = v.raw
+    call('edet_bn_bwd_reduce', ptr(r.grad), ptr(r.data), r.rows, r.c, r.ld, ptr(v.bn.mean), ptr(v.bn.rstd),
+         ptr(self.partials), ctypes.byref(self._nparts), self.dtype, self.stream)
+    self._bn_bwd_finalize(v.bn, self._nparts.value)
+
+  def _gview(self, v):
+    """dy of the conv that produced v.raw, as an on-load gradient view."""
+    self._ensure_bn_bwd(v)
+    r = v.raw
+    if v.bn is not None:
+      return GView(ptr(r.grad), ptr(r.data), ptr(v.bn.a), ptr(v.bn.b), ptr(v.bn.cc), r.n, r.h, r.w, r.c, r.ld)
+    return GView(ptr(r.grad), None, None, None, None, r.n, r.h, r.w, r.c, r.ld)
+
+  def _epi(self, vin, dgate=None):
+    """Epilogue descriptor for writing d(vin) into vin.raw.grad; returns (epi, fused_stats)."""
+    r = vin.raw
+    g = r.ensure_grad()
+    beta = 1 if r.grad_written else 0
+    fused = (vin.bn is not None and vin.consumers == 1 and vin.gate is None and beta == 0)
+    epi = BwdEpi(ptr(g), beta,
+                 ptr(vin.bn.mean) if fused else None, ptr(vin.bn.rstd) if fused else None,
+                 ptr(self.partials) if fused else None, ptr(dgate))
+    return epi, fused
+
+  # ------------------------------------------------------------------ layers
+  def pw(self, key, vin, wname, cout, bias=None, bn=None, act=ACT_NONE, ld=None):
+    """1x1 conv (+bias) [-> BN -> act as a view]."""
+    r = vin.raw
+    cin = r.c
+    wt, ldk, w, ldn = self._pw_copies(wname, cin, cout)
+    out = Raw(self, key, r.n, r.h, r.w, cout, ld)
+    bnl = self.get_bn(bn, cout) if bn else None
+    stats = ptr(self.partials) if (bnl and self.training) else None
+    call('edet_pw_fwd', ctypes.byref(vin.tview()), ptr(wt), ldk, ptr(self.param(bias)) if bias else None,
+         ptr(out.data), cout, out.ld, stats, ctypes.byref(self._nparts), self.dtype, self.stream,
+         nbytes=r.rows * (cin + cout) * self.esize)
+    if bnl:
+      self._bn_forward(bnl, out.rows, self._nparts.value)
+    vout = View(out, bnl, act)
+    vin.consumers += 1
+    if self.training:
+      self.tape.append(lambda: self._pw_bwd(vin, vout, wname, w, ldn))
+    return vout
+
+  def _pw_bwd(self, vin, vout, wname, w, ldn):
+    g = self._gview(vout)
+    nb = vin.raw.rows * (vin.raw.c + vout.raw.c) * self.esize
+    call('edet_pw_bwd_weight', ctypes.byref(vin.tview()), ctypes.byref(g), ptr(self.grad(wname)),
+         self.dtype, self.stream, nbytes=nb)
+    if vin.raw.needs_grad:
+      dgate = vin.dgate if vin.gate is not None else None
+      epi, fused = self._epi(vin, dgate)
+      call('edet_pw_bwd_data', ctypes.byref(g), ptr(w), ldn, ctypes.byref(vin.tview()), ctypes.byref(epi),
+           ctypes.byref(self._nparts), self.dtype, self.stream, nbytes=nb)
+      vin.raw.grad_written = True
+      if fused:
+        self._bn_bwd_finalize(vin.bn, self._nparts.value)
+
+  def dw(self, key, vin, wname, k, stride, bn=None, act=ACT_NONE):
+    r = vin.raw
+    oh, _, _ = utils.same_padding(r.h, k, stride)
+    ow, _, _ = utils.same_padding(r.w, k, stride)
+    out = Raw(self, key, r.n, oh, ow, r.c)
+    bnl = self.get_bn(bn, r.c) if bn else None
+    stats = ptr(self.partials) if (bnl and self.training) else None
+    wp = ptr(self.param(wname))
+    call('edet_dw_fwd', ctypes.byref(vin.tview()), wp, k, stride, ptr(out.data), out.ld, stats,
+         ctypes.byref(self._nparts), self.dtype, self.stream, nbytes=(r.rows + out.rows) * r.c * self.esize)
+    if bnl:
+      self._bn_forward(bnl, out.rows, self._nparts.value)
+    vout = View(out, bnl, act)
+    vin.consumers += 1
+    if self.training:
+      self.tape.append(lambda: self._dw_bwd(vin, vout, wname, k, stride))
+    return vout
+
+  def _dw_bwd(self, vin, vout, wname, k, stride):
+    g = self._gview(vout)
+    nb = (vin.raw.rows + vout.raw.rows) * vin.raw.c * self.esize
+    call('edet_dw_bwd_weight', ctypes.byref(vin.tview()), ctypes.byref(g), k, stride, ptr(self.grad(wname)),
+         self.dtype, self.stream, nbytes=nb)
+    if vin.raw.needs_grad:
+      epi, fused = self._epi(vin)
+      call('edet_dw_bwd_data', ctypes.byref(g), ptr(self.param(wname)), k, stride, ctypes.byref(vin.tview()),
+           ctypes.byref(epi), ctypes.byref(self._nparts), self.dtype, self.stream, nbytes=nb)
+      vin.raw.grad_written = True
+      if fused:
+        self._bn_bwd_finalize(vin.bn, self._nparts.value)
+
+  def se(self, key, v, scope, se_filters):
+    """Squeeze-and-excitation: returns the gated view of v (efficientnet_model.py:183-195)."""
+    r = v.raw
+    n, c = r.n, r.c
+    inv_hw = 1.0 / (r.h * r.w)
+    pooled = self.zbuf(key + ':pool', (n, c))
+    hidden = self.buf(key + ':hid', (n, se_filters), torch.float32)
+    gate = self.buf(key + ':gate', (n, c), torch.float32)
+    w1, b1 = scope + '/se/conv2d/kernel', scope + '/se/conv2d/bias'
+    w2, b2 = scope + '/se/conv2d_1/kernel', scope + '/se/conv2d_1/bias'
+    call('edet_se_pool', ctypes.byref(v.tview()), ptr(pooled), self.dtype, self.stream,
+         nbytes=r.rows * c * self.esize)
+    call('edet_se_fc', ptr(pooled), n, c, se_filters, inv_hw, ptr(self.param(w1)), ptr(self.param(b1)),
+         ptr(self.param(w2)), ptr(self.param(b2)), ptr(hidden), ptr(gate), self.stream)
+    vg = View(r, v.bn, v.act, gate)
+    vg.dgate = self.zbuf(key + ':dgate', (n, c)) if self.training else None
+    v.consumers += 1
+    if self.training:
+      dpool = self.buf(key + ':dpool', (n, c), torch.float32)
+      scratch = self.buf(key + ':scr', (n * (c + se_filters),), torch.float32)
+
+      def bwd():
+        call('edet_se_fc_bwd', ptr(pooled), ptr(hidden), ptr(gate), ptr(vg.dgate), n, c, se_filters, inv_hw,
+             ptr(self.param(w1)), ptr(self.param(w2)), ptr(self.grad(w1)), ptr(self.grad(b1)),
+             ptr(self.grad(w2)), ptr(self.grad(b2)), ptr(dpool), ptr(scratch), self.stream)
+        call('edet_se_gate_bwd', ctypes.byref(vg.tview()), ptr(r.grad), ptr(dpool), ptr(v.bn.mean),
+             ptr(v.bn.rstd), ptr(self.partials), ctypes.byref(self._nparts), self.dtype, self.stream,
+             nbytes=2 * r.rows * c * self.esize)
+        self._bn_bwd_finalize(v.bn, self._nparts.value)
+
+      self.tape.append(bwd)
+    return vg
+
+  def bn_res(self, key, vy, residual):
+    """Materialise a block output: bn(y) (+ residual)."""
+    r = vy.raw
+    out = Raw(self, key, r.n, r.h, r.w, r.c)
+    call('edet_bn_res', ctypes.byref(vy.tview()), ptr(residual.raw.data) if residual else None, ptr(out.data),
+         out.ld, self.dtype, self.stream, nbytes=(3 if residual else 2) * r.rows * r.c * self.esize)
+    vout = View(out)
+    vy.consumers += 1
+    if residual is not None:
+      residual.consumers += 1
+    if self.training:
+      def bwd():
+        assert out.grad_written, key
+        r.grad = out.grad           # d(bn output) aliases d(block output)
+        r.grad_written = True
+        if residual is not None and residual.raw.needs_grad:
+          rr = residual.raw
+          call('edet_add', ptr(rr.ensure_grad()), ptr(out.grad), rr.rows, rr.c, rr.ld,
+               1 if rr.grad_written else 0, self.dtype, self.stream)
+          rr.grad_written = True
+      self.tape.append(bwd)
+    return vout
+
+  def fuse(self, key, inputs, modes, wnames, oh, ow, act=ACT_SWISH):
+    """BiFPN node fusion: act(sum_i wn_i * resample_i(input_i))."""
+    c = inputs[0].raw.c
+    n = inputs[0].raw.n
+    nin = len(inputs)
+    out = Raw(self, key, n, oh, ow, c)
+    wn = self.buf(key + ':wn', (4,), torch.float32)
+    method = 0 if wnames else 1
+    wp = [ptr(self.param(w)) for w in wnames] + [None] * (3 - len(wnames)) if wnames else [None] * 3
+    call('edet_fuse_weights', wp[0], wp[1], wp[2], nin, method, ptr(wn), self.stream)
+    tv = [v.tview() for v in inputs]
+    tvp = [ctypes.byref(t) for t in tv] + [None] * (3 - nin)
+    marr = (ctypes.c_int * 3)(*(list(modes) + [0] * (3 - nin)))
+    fbytes = (sum(v.raw.rows for v in inputs) + out.rows) * c * self.esize
+    call('edet_fuse_fwd', tvp[0], tvp[1], tvp[2], marr, nin, ptr(wn), act, ptr(out.data), oh, ow, out.ld,
+         self.dtype, self.stream, nbytes=fbytes)
+    vout = View(out)
+    for v in inputs:
+      v.consumers += 1
+    if self.training:
+      ds = self.buf(key + ':ds', (n, oh, ow, out.ld), self.tdtype)
+      dwn = self.zbuf(key + ':dwn', (4,))
+
+      def bwd():
+        assert out.grad_written, key
+        tv2 = [v.tview() for v in inputs]
+        tvp2 = [ctypes.byref(t) for t in tv2] + [None] * (3 - nin)
+        call('edet_fuse_bwd_pre', tvp2[0], tvp2[1], tvp2[2], marr, nin, ptr(wn), act, ptr(out.grad), oh, ow,
+             out.ld, ptr(ds), ptr(dwn), self.dtype, self.stream)
+        for i, v in enumerate(inputs):
+          if not v.raw.needs_grad:
+            continue
+          g = v.raw.ensure_grad()
+          call('edet_fuse_bwd_input', ctypes.byref(tv2[i]), modes[i], ptr(wn), i, ptr(ds), oh, ow, out.ld,
+               ptr(g), 1 if v.raw.grad_written else 0, self.dtype, self.stream)
+          v.raw.grad_written = True
+        if wnames:
+          gp = [ptr(self.grad(w)) for w in wnames] + [None] * (3 - len(wnames))
+          call('edet_fuse_weights_bwd', wp[0], wp[1], wp[2], nin, method, ptr(dwn), gp[0], gp[1], gp[2],
+               self.stream)
+
+      self.tape.append(bwd)
+    return vout
+
+  # ------------------------------------------------------------------ network
+  def _begin(self, training, update_moving=True):
+    self.training = training
+    self.update_moving = update_moving
+    self.tape = []
+    self._cast_done = set()
+    for bn in self.bns.values():
+      bn.bwd_ready = False
+    if training:
+      for t in self._zero_list:
+        t.zero_()
+      self.grads_flat.zero_()
+
+  def forward(self, images, training=False, update_moving=True):
+    """images: device tensor [B,H,W,3] in the engine dtype. Returns (cls_views, box_views)."""
+    c = self.config
+    spec = self.spec
+    assert tuple(images.shape) == (self.batch, self.image_size[0], self.image_size[1], 3), images.shape
+    assert images.dtype == self.tdtype and images.is_contiguous()
+    self._begin(training, update_moving)
+    self.images = images
+    n, h, w = self.batch, self.image_size[0], self.image_size[1]
+    bb = c.backbone_name
+    # ---- stem
+    oh, _, _ = utils.same_padding(h, 3, 2)
+    ow, _, _ = utils.same_padding(w, 3, 2)
+    y0 = Raw(self, 'stem', n, oh, ow, spec.stem_filters)
+    bn0 = self.get_bn(bb + '/stem/tpu_batch_normalization', spec.stem_filters)
+    wstem = bb + '/stem/conv2d/kernel'
+    call('edet_stem_fwd', ptr(images), n, h, w, ptr(self.param(wstem)), ptr(y0.data), spec.stem_filters, y0.ld,
+         ptr(self.partials) if training else None, ctypes.byref(self._nparts), self.dtype, self.stream,
+         nbytes=(n * h * w * 3 + y0.rows * y0.c) * self.esize)
+    self._bn_forward(bn0, y0.rows, self._nparts.value)
+    x = View(y0, bn0, ACT_SWISH)
+    if training:
+      v0 = x
+
+      def stem_bwd():
+        g = self._gview(v0)
+        call('edet_stem_bwd_weight', ptr(images), n, h, w, ctypes.byref(g), ptr(self.grad(wstem)), self.dtype,
+             self.stream, nbytes=(n * h * w * 3 + y0.rows * y0.c) * self.esize)
+      self.tape.append(stem_bwd)
+    # ---- MBConv blocks
+    reds = []
+    for b in spec.blocks:
+      x = self._mbconv(x, b, '%s/blocks_%d' % (bb, b.index))
+      if b.index in spec.reductions:
+        reds.append(x)
+    all_feats = [None] + reds
+    feats = list(all_feats[c.min_level:c.max_level + 1])
+    wf = c.fpn_num_filters
+    # ---- extra levels P6.. (efficientdet_keras.py:823-836,900-901)
+    for level in range(6, c.max_level + 1):
+      f = feats[-1]
+      th, tw = (f.raw.h + 1) // 2, (f.raw.w + 1) // 2
+      s = 'resample_p%d' % level
+      if f.raw.c != wf:
+        f = self.pw(s, f, s + '/conv2d/kernel', wf, bias=s + '/conv2d/bias', bn=s + '/bn')
+      feats.append(self.fuse(s + ':pool', [f], [RS_POOL], [], th, tw, act=ACT_NONE))
+    # ---- BiFPN
+    for rep in range(c.fpn_cell_repeats):
+      feats = self._fpn_cell(feats, 'fpn_cells/cell_%d' % rep)
+    self.fpn_feats = feats
+    # ---- heads
+    na = spec.num_anchors
+    cls = self._head(feats, 'class_net', 'class', c.num_classes * na)
+    box = self._head(feats, 'box_net', 'box', 4 * na)
+    self.cls_views, self.box_views = cls, box
+    return cls, box
+
+  def _mbconv(self, xin, b, scope):
+    cexp = b.input_filters * b.expand_ratio
+    bn_names = ['tpu_batch_normalization', 'tpu_batch_normalization_1', 'tpu_batch_normalization_2']
+    conv_names = ['conv2d', 'conv2d_1']
+    bi = ci = 0
+    x = xin
+    if b.expand_ratio != 1:
+      x = self.pw(scope + ':exp', x, '%s/%s/kernel' % (scope, conv_names[ci]), cexp,
+                  bn='%s/%s' % (scope, bn_names[bi]), act=ACT_SWISH)
+      ci += 1
+      bi += 1
+    x = self.dw(scope + ':dw', x, scope + '/depthwise_conv2d/depthwise_kernel', b.kernel_size, b.stride,
+                bn='%s/%s' % (scope, bn_names[bi]), act=ACT_SWISH)
+    bi += 1
+    if b.se_filters:
+      x = self.se(scope + ':se', x, scope, b.se_filters)
+    y = self.pw(scope + ':proj', x, '%s/%s/kernel' % (scope, conv_names[ci]), b.output_filters,
+                bn='%s/%s' % (scope, bn_names[bi]), act=ACT_NONE)
+    return self.bn_res(scope + ':out', y, xin if b.has_residual else None)
+
+  def _fpn_cell(self, feats, cell_scope):
+    c = self.config
+    wf = c.fpn_num_filters
+    fpn = self.spec.fpn
+    feats = list(feats)
+    num_in = len(feats)
+    for n, node in enumerate(fpn.nodes):
+      scope = '%s/fnode%d' % (cell_scope, n)
+      lvl = node['feat_level'] - c.min_level
+      th, tw = feats[lvl].raw.h, feats[lvl].raw.w
+      ins, modes = [], []
+      for i, off in enumerate(node['inputs_offsets']):
+        f = feats[off]
+        if f.raw.c != wf:
+          rs = '%s/resample_%d_%d_%d' % (scope, i, off, len(feats))
+          f = self.pw(rs, f, rs + '/conv2d/kernel', wf, bias=rs + '/conv2d/bias', bn=rs + '/bn')
+        fh, fw = f.raw.h, f.raw.w
+        if fh > th and fw > tw:
+          if (fh - 1) // th + 1 != 2 or (fw - 1) // tw + 1 != 2:
+            raise ValueError('only 2x down-sampling between pyramid levels is supported')
+          modes.append(RS_POOL)
+        elif fh <= th and fw <= tw:
+          modes.append(RS_IDENTITY if (fh == th and fw == tw) else RS_UP2)
+        else:
+          raise ValueError('Incompatible Resampling : feat shape {}x{} target_shape: {}x{}'.format(
+              fh, fw, th, tw))
+        ins.append(f)
+      wnames = []
+      if fpn.weight_method == 'fastattn':
+        wnames = [scope + '/WSM' + ('' if i == 0 else '_%d' % i) for i in range(len(ins))]
+      x = self.fuse(scope + ':fuse', ins, modes, wnames, th, tw, act=ACT_SWISH)
+      oc = '%s/op_after_combine%d' % (scope, len(feats))
+      d = self.dw(oc + ':dw', x, oc + '/conv/depthwise_kernel', 3, 1)
+      y = self.pw(oc + ':pw', d, oc + '/conv/pointwise_kernel', wf, bias=oc + '/conv/bias', bn=oc + '/bn')
+      feats.append(y)
+    out = []
+    for level in range(c.min_level, c.max_level + 1):
+      for i, node in enumerate(reversed(fpn.nodes)):
+        if node['feat_level'] == level:
+          out.append(feats[-1 - i])
+          break
+    assert len(out) == num_in
+    return out
+
+  def _head(self, feats, net, prefix, out_ch):
+    c = self.config
+    wf = c.fpn_num_filters
+    outs = []
+    for li, feat in enumerate(feats):
+      level = c.min_level + li
+      x = feat
+      for i in range(c.box_class_repeats):
+        s = '%s/%s-%d' % (net, prefix, i)
+        key = '%s:l%d' % (s, level)
+        d = self.dw(key + ':dw', x, s + '/depthwise_kernel', 3, 1)
+        x = self.pw(key + ':pw', d, s + '/pointwise_kernel', wf, bias=s + '/bias',
+                    bn='%s/%s-%d-bn-%d' % (net, prefix, i, level), act=ACT_SWISH)
+      s = '%s/%s-predict' % (net, prefix)
+      key = '%s:l%d' % (s, level)
+      d = self.dw(key + ':dw', x, s + '/depthwise_kernel', 3, 1)
+      outs.append(self.pw(key + ':pw', d, s + '/pointwise_kernel', out_ch, bias=s + '/bias'))
+    return outs
+
+  # ------------------------------------------------------------------ outputs
+  def outputs(self):
+    """(list of [B,h,w,A*classes], list of [B,h,w,A*4]) strided torch views of the logits buffers."""
+    cls = [v.raw.data[..., :v.raw.c] for v in self.cls_views]
+    box = [v.raw.data[..., :v.raw.c] for v in self.box_views]
+    return cls, box
+
+  # ------------------------------------------------------------------ loss + backward + update
+  def loss_backward(self, labels):
+    """Detection loss forward+backward (train_lib.py:493-604) then the tape in reverse.
+
+    labels: dict with device tensors cls_targets_L int32 [B,h,w,A], box_targets_L fp32 [B,h,w,4A],
+    mean_num_positives fp32 [B] (or [B,1]).
+    """
+    c = self.config
+    assert self.training
+    if 'normalizer' in labels:   # host float supplied by the caller: no device sync
+      normalizer = float(labels['normalizer'])
+    else:
+      normalizer = float(labels['mean_num_positives'].sum().item()) + 1.0
+    na = self.spec.num_anchors
+    for li, (cv, bv) in enumerate(zip(self.cls_views, self.box_views)):
+      level = c.min_level + li
+      ct = labels['cls_targets_%d' % level]
+      bt = labels['box_targets_%d' % level]
+      assert ct.dtype == torch.int32 and ct.is_contiguous() and bt.dtype == torch.float32 and bt.is_contiguous()
+      r = cv.raw
+      call('edet_focal_loss', ptr(r.data), r.ld, ptr(ct), r.rows, na, c.num_classes, c.alpha, c.gamma,
+           1.0 / normalizer, ptr(r.ensure_grad()), ptr(self.grad('class_net/class-predict/bias')),
+           ptr(self.loss_sums), self.dtype, self.stream, nbytes=2 * r.rows * r.c * self.esize)
+      r.grad_written = True
+      rb = bv.raw
+      call('edet_box_loss', ptr(rb.data), rb.ld, ptr(bt), rb.rows, 4 * na, c.delta, 1.0 / (normalizer * 4.0),
+           float(c.box_loss_weight), ptr(rb.ensure_grad()), ptr(self.grad('box_net/box-predict/bias')),
+           ptr(self.loss_sums), self.dtype, self.stream)
+      rb.grad_written = True
+    self.backward()
+
+  def backward(self):
+    for fn in reversed(self.tape):
+      fn()
+    self.tape = []
+
+  def optimizer_step(self, lr, ema_decay=None, all_reduce=None):
+    """L2 + clip (local, before the reduce) + [all-reduce SUM] + SGD momentum + EMA."""
+    c = self.config
+    st = self.stream
+    call('edet_opt_l2_norms', ptr(self.grads_flat), ptr(self.params_flat), ptr(self.seg_offsets),
+         ptr(self.seg_flags), self.nseg, float(c.weight_decay), ptr(self.seg_sqnorm),
+         ptr(self.loss_sums[2:]), st)
+    clip = abs(c.clip_gradients_norm) if c.clip_gradients_norm else 0.0
+    call('edet_opt_clip_factors', ptr(self.seg_sqnorm), self.nseg, float(clip), ptr(self.seg_factor),
+         ptr(self.gnorm), st)
+    if ema_decay is None:
+      ema_decay = 0.0
+      ema_ptr = None
+    else:
+      ema_ptr = ptr(self.ema)
+    self.hyper.copy_(torch.tensor([lr, ema_decay], dtype=torch.float32), non_blocking=True)
+    factor = ptr(self.seg_factor)
+    if all_reduce is not None:
+      call('edet_opt_scale', ptr(self.grads_flat), ptr(self.seg_offsets), ptr(self.seg_factor), self.nseg, st)
+      all_reduce(self.grads_flat)
+      factor = None
+    call('edet_opt_sgd_ema', ptr(self.params_flat), ptr(self.grads_flat), ptr(self.velocity), ema_ptr,
+         ptr(self.seg_offsets), factor, self.nseg, ptr(self.hyper), float(c.momentum), st)
+    self.step_count += 1
+
+  def loss_values(self):
+    s = self.loss_sums.detach().cpu().numpy()
+    c = self.config
+    det = float(s[0] + c.box_loss_weight * s[1])
+    return {'cls_loss': float(s[0]), 'box_loss': float(s[1]), 'det_loss': det, 'reg_l2_loss': float(s[2]),
+            'loss': det + float(s[2]), 'gradient_norm': float(self.gnorm.item())}

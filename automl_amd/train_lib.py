@@ -1,0 +1,172 @@
+"""Training step of the detection path on MI355X (mirror of efficientdet/tf2/train_lib.py).
+
+``EfficientDetNetTrain.train_step((images, labels))`` follows train_lib.py:606-684: forward with
+training BatchNorm, focal + Huber detection loss (:493-604), L2 on kernels (:486-491), per-tensor
+clip_by_norm then clip_by_global_norm (:675-682, on the LOCAL gradient), gradient all-reduce SUM
+across data-parallel replicas (implicit in optimizer.apply_gradients, :683), SGD momentum and the
+TFA MovingAverage EMA (:176-199).  LR schedules restate :37-173.
+"""
+import math
+
+import torch
+
+from automl_amd import efficientdet_net
+
+
+def update_learning_rate_schedule_parameters(params):
+  """train_lib.py:37-49 (params: dict-like with batch_size and steps_per_epoch)."""
+  params['adjusted_learning_rate'] = params['learning_rate'] * params['batch_size'] / 64
+  spe = params['steps_per_epoch']
+  params['lr_warmup_step'] = int(params['lr_warmup_epoch'] * spe)
+  params['first_lr_drop_step'] = int(params['first_lr_drop_epoch'] * spe)
+  params['second_lr_drop_step'] = int(params['second_lr_drop_epoch'] * spe)
+  params['total_steps'] = int(params['num_epochs'] * spe)
+
+
+def _warmup(step, lr_warmup_init, lr_warmup_step, adjusted_lr):
+  return lr_warmup_init + (float(step) / lr_warmup_step * (adjusted_lr - lr_warmup_init))
+
+
+class StepwiseLrSchedule(object):
+  def __init__(self, adjusted_lr, lr_warmup_init, lr_warmup_step, first_lr_drop_step, second_lr_drop_step):
+    self.adjusted_lr, self.lr_warmup_init, self.lr_warmup_step = adjusted_lr, lr_warmup_init, lr_warmup_step
+    self.first_lr_drop_step, self.second_lr_drop_step = first_lr_drop_step, second_lr_drop_step
+
+  def __call__(self, step):
+    lr = _warmup(step, self.lr_warmup_init, self.lr_warmup_step, self.adjusted_lr) \
+        if step < self.lr_warmup_step else self.adjusted_lr
+    for mult, start in ((1.0, self.lr_warmup_step), (0.1, self.first_lr_drop_step),
+                        (0.01, self.second_lr_drop_step)):
+      if step >= start:
+        lr = self.adjusted_lr * mult
+    return lr
+
+
+class CosineLrSchedule(object):
+  def __init__(self, adjusted_lr, lr_warmup_init, lr_warmup_step, total_steps):
+    self.adjusted_lr, self.lr_warmup_init, self.lr_warmup_step = adjusted_lr, lr_warmup_init, lr_warmup_step
+    self.decay_steps = float(total_steps - lr_warmup_step)
+
+  def __call__(self, step):
+    if step < self.lr_warmup_step:
+      return _warmup(step, self.lr_warmup_init, self.lr_warmup_step, self.adjusted_lr)
+    return 0.5 * self.adjusted_lr * (1 + math.cos(math.pi * float(step) / self.decay_steps))
+
+
+class PolynomialLrSchedule(object):
+  def __init__(self, adjusted_lr, lr_warmup_init, lr_warmup_step, power, total_steps):
+    self.adjusted_lr, self.lr_warmup_init, self.lr_warmup_step = adjusted_lr, lr_warmup_init, lr_warmup_step
+    self.power, self.total_steps = power, total_steps
+
+  def __call__(self, step):
+    if step < self.lr_warmup_step:
+      return _warmup(step, self.lr_warmup_init, self.lr_warmup_step, self.adjusted_lr)
+    return self.adjusted_lr * (1 - float(step) / self.total_steps)**self.power
+
+
+def learning_rate_schedule(params):
+  update_learning_rate_schedule_parameters(params)
+  m = params['lr_decay_method']
+  if m == 'stepwise':
+    return StepwiseLrSchedule(params['adjusted_learning_rate'], params['lr_warmup_init'],
+                              params['lr_warmup_step'], params['first_lr_drop_step'],
+                              params['second_lr_drop_step'])
+  if m == 'cosine':
+    return CosineLrSchedule(params['adjusted_learning_rate'], params['lr_warmup_init'],
+                            params['lr_warmup_step'], params['total_steps'])
+  if m == 'polynomial':
+    return PolynomialLrSchedule(params['adjusted_learning_rate'], params['lr_warmup_init'],
+                                params['lr_warmup_step'], params['poly_lr_power'], params['total_steps'])
+  raise ValueError('unknown lr_decay_method: {}'.format(m))
+
+
+def split_global_batch(global_batch_size, world_size, rank):
+  """Per-replica slice [begin, end) of the global batch; the reference requires divisibility
+  (tf2/train.py:186-189: 'batch size must be divisible by number of replicas')."""
+  if global_batch_size % world_size != 0:
+    raise ValueError('batch size {} must be divisible by the number of replicas {}'.format(
+        global_batch_size, world_size))
+  per = global_batch_size // world_size
+  return rank * per, (rank + 1) * per
+
+
+def make_grad_all_reduce(process_group=None):
+  """SUM all-reduce of the flat gradient arena (one RCCL call per step; 15.5 MB fp32 for D0).
+
+  The reference clips the LOCAL gradient (per tensor, then global norm) before apply_gradients
+  reduces it (train_lib.py:675-683), and the global-norm clip needs every local gradient, so the
+  reduce cannot start before the backward pass has finished; see DESIGN.md section multi-GPU.
+  """
+  import torch.distributed as dist
+
+  def reduce_fn(flat):
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)
+    return flat
+  return reduce_fn
+
+
+def ema_decay_dynamic(average_decay, num_updates):
+  """TFA MovingAverage(dynamic_decay=True): min(decay, (1 + n) / (10 + n))."""
+  return min(average_decay, (1.0 + num_updates) / (10.0 + num_updates))
+
+
+class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
+  """EfficientDetNet plus the reference train_step.
+
+  Data parallel: one process per GPU; pass ``process_group`` (torch.distributed, backend 'nccl'
+  == RCCL over xGMI) and every replica's locally-clipped gradient is SUM all-reduced before the
+  update, exactly the reference's MirroredStrategy semantics.
+  """
+
+  def __init__(self, *args, steps_per_epoch=1000, global_batch_size=None, process_group=None,
+               use_dist=False, **kwargs):
+    super().__init__(*args, **kwargs)
+    self.steps_per_epoch = steps_per_epoch
+    self.global_batch_size = global_batch_size
+    self.process_group = process_group
+    self.use_dist = use_dist or process_group is not None
+    self._lr_fn = None
+    self.iterations = 0
+
+  def _lr(self, batch):
+    if self._lr_fn is None:
+      p = self.config.as_dict()
+      p['batch_size'] = self.global_batch_size or batch
+      p['steps_per_epoch'] = self.steps_per_epoch
+      self._lr_fn = learning_rate_schedule(p)
+    return self._lr_fn(self.iterations)
+
+  def _labels_to_device(self, labels, eng):
+    out = {}
+    for k, v in labels.items():
+      if k == 'normalizer':
+        out[k] = float(v)
+        continue
+      t = torch.as_tensor(v)
+      if k.startswith('cls_targets'):
+        t = t.to(device=eng.device, dtype=torch.int32)
+      else:
+        t = t.to(device=eng.device, dtype=torch.float32)
+      out[k] = t.contiguous()
+    return out
+
+  def train_step(self, data, sync_loss=True):
+    images, labels = data
+    b, h, w = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
+    eng = self._ensure_engine(b, h, w)
+    lr = self._lr(b)
+    eng.forward(self._to_device_images(images, eng), training=True)
+    eng.loss_backward(self._labels_to_device(labels, eng))
+    decay = None
+    if self.config.moving_average_decay:
+      decay = ema_decay_dynamic(self.config.moving_average_decay, self.iterations)
+    reduce_fn = None
+    if self.use_dist:
+      reduce_fn = make_grad_all_reduce(self.process_group)
+    eng.optimizer_step(lr, decay, reduce_fn)
+    self.iterations += 1
+    if not sync_loss:
+      return {'learning_rate': lr}
+    vals = eng.loss_values()
+    vals['learning_rate'] = lr
+    return vals

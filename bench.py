@@ -1,0 +1,195 @@
+"""Headline benchmark: EfficientDet-D0 640x640 forward+backward (one full train_step) images/sec.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = forward (training BatchNorm), focal+Huber loss, backward, L2, clip, [gradient all-reduce
+SUM over RCCL], SGD-momentum + EMA update on a synthetic COCO-shaped batch already resident in HBM
+(BASELINE.json configs[2]; weak scaling: 128 images per GPU).  Rank 0 prints ONE JSON line with
+`roofline` (dominant kernel family, HIP-event timed inside the timed region, algorithmic bytes per
+SURVEY.md section 8d) and `cpu_baseline` (the fp32 CPU oracle -- a port, not the reference's
+TensorFlow binary, which cannot be installed here -- on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+from automl_amd import _lib, hparams_config, netspec, train_lib  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
+# algorithmic work per image, D0 640x640 fwd+bwd
+ALG_GFLOP_PER_IMG = 23.36
+ALG_MB_PER_IMG = 925.0
+
+
+def synth_batch(config, batch, size, seed, device, tdtype):
+  """Images N(0,1); ~100 positive anchors / image, ~50 ignored."""
+  rng = np.random.default_rng(seed)
+  spec = netspec.NetSpec(config)
+  fs = spec.feat_sizes(size)
+  na = spec.num_anchors
+  images = torch.from_numpy(rng.standard_normal((batch, size, size, 3)).astype(np.float32))
+  images = images.to(device=device, dtype=tdtype).contiguous()
+  labels = {}
+  total = sum(fs[l]['height'] * fs[l]['width'] * na for l in range(config.min_level, config.max_level + 1))
+  for level in range(config.min_level, config.max_level + 1):
+    h, w = fs[level]['height'], fs[level]['width']
+    cnt = h * w * na
+    ct = np.full((batch, cnt), -1, np.int32)
+    bt = np.zeros((batch, cnt, 4), np.float32)
+    npos = max(1, int(round(100.0 * cnt / total)))
+    nign = max(0, int(round(50.0 * cnt / total)))
+    for b in range(batch):
+      idx = rng.choice(cnt, npos + nign, replace=False)
+      ct[b, idx[:npos]] = rng.integers(0, config.num_classes, npos)
+      ct[b, idx[npos:]] = -2
+      bt[b, idx[:npos]] = rng.standard_normal((npos, 4)).astype(np.float32) * 0.2
+    labels['cls_targets_%d' % level] = torch.from_numpy(ct.reshape(batch, h, w, na)).to(device)
+    labels['box_targets_%d' % level] = torch.from_numpy(bt.reshape(batch, h, w, na * 4)).to(device)
+  labels['mean_num_positives'] = torch.full((batch,), 100.0, device=device)
+  labels['normalizer'] = 100.0 * batch + 1.0     # host copy of sum(mean_num_positives)+1: no device sync
+  return images, labels
+
+
+def cpu_baseline(config, size, seconds_budget=25.0):
+  """fp32 CPU oracle train step (forward+backward+update) on a bounded sample of the same workload."""
+  from oracle import efficientdet_oracle as orc
+  threads = torch.get_num_threads()
+  batch = 2
+  spec = netspec.NetSpec(config)
+  vals = netspec.init_params(spec, 0)
+  oracle = orc.Oracle(config=config, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
+  images, labels = synth_batch(config, batch, size, 3, 'cpu', torch.float32)
+  labels = {k: v for k, v in labels.items() if k != 'normalizer'}
+  with torch.no_grad():
+    oracle.forward(images[:1, :64, :64], False)       # registers the variable list
+  state = {}
+  t0 = time.perf_counter()
+  orc.train_step(oracle, images, labels, state, 0.01, 0.9)     # warm-up
+  warm = time.perf_counter() - t0
+  iters = max(1, min(4, int(seconds_budget / max(warm, 1e-3)) - 1))
+  t0 = time.perf_counter()
+  for _ in range(iters):
+    orc.train_step(oracle, images, labels, state, 0.01, 0.9)
+  dt = (time.perf_counter() - t0) / iters
+  return {'value': batch / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+          'sample': 'fp32 PyTorch-CPU oracle (restatement of the reference graph; the reference TF binary '
+                    'is not installable), efficientdet-d0 %dx%d batch %d train_step, 1 warm-up + %d timed'
+                    % (size, size, batch, iters)}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=10)
+  ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--batch', type=int, default=128, help='images per GPU')
+  ap.add_argument('--image_size', type=int, default=640)
+  ap.add_argument('--model', default='efficientdet-d0')
+  ap.add_argument('--dtype', default='bf16')
+  ap.add_argument('--no_cpu_baseline', action='store_true')
+  args = ap.parse_args()
+
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  if args.gpus > 1 and world != args.gpus:
+    raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+  device = 'cuda:%d' % local_rank
+  torch.cuda.set_device(device)
+  dist = None
+  if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device))
+
+  config = hparams_config.get_efficientdet_config(args.model)
+  config.override('image_size=%d' % args.image_size)
+  net = train_lib.EfficientDetNetTrain(config=config, dtype=args.dtype, device=device, seed=0,
+                                       global_batch_size=args.batch * world, use_dist=world > 1,
+                                       steps_per_epoch=1000)
+  eng = net._ensure_engine(args.batch, args.image_size, args.image_size)
+  images, labels = synth_batch(config, args.batch, args.image_size, 3 + rank, device, eng.tdtype)
+
+  def step():
+    net.train_step((images, labels), sync_loss=False)
+
+  # ---- warm-up; the last warm-up step is fully profiled to find the dominant kernel family
+  for i in range(args.warmup):
+    step()
+  torch.cuda.synchronize()
+  _lib.profiler = _lib.Profiler(None)
+  step()
+  torch.cuda.synchronize()
+  full = _lib.profiler.summary()
+  _lib.profiler = None
+  dominant = max(full.items(), key=lambda kv: kv[1][1])[0]
+  kernel_ms_total = sum(v[1] for v in full.values())
+
+  # ---- timed region: exactly K steps between barrier + synchronize
+  _lib.profiler = _lib.Profiler({dominant})
+  if dist is not None:
+    dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    step()
+  torch.cuda.synchronize()
+  if dist is not None:
+    dist.barrier()
+  elapsed = time.perf_counter() - t0
+  prof = _lib.profiler.summary()
+  _lib.profiler = None
+  if dist is not None:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+  losses = eng.loss_values()
+
+  if rank == 0:
+    ms_per_step = elapsed / args.steps * 1e3
+    value = args.batch * world * args.steps / elapsed
+    n_l, ms_l, bytes_l = prof[dominant]
+    achieved = bytes_l / (ms_l * 1e-3) / 1e9
+    out = {
+        'metric': 'images/sec EfficientDet-D0 640x640 fwd+bwd (whole job; per-GPU = value / n_gpus)',
+        'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': '%s %dx%d batch %d/GPU forward+backward+SGD/EMA update (BASELINE configs[2]; '
+                               'DP replicas of it for n_gpus>1)' % (args.model, args.image_size,
+                                                                   args.image_size, args.batch),
+                   'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
+                   'loss': losses.get('loss')},
+        'roofline': {
+            'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+            'launches_per_step': n_l / args.steps, 'avg_launch_ms': ms_l / n_l,
+            'algorithmic_bytes_per_launch': bytes_l / n_l,
+            'kernel_time_share': full[dominant][1] / kernel_ms_total,
+            'whole_step_hbm_frac': (ALG_MB_PER_IMG * 1e6 * args.batch / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS
+            if (args.model == 'efficientdet-d0' and args.image_size == 640) else None,
+            'whole_step_mfma_frac': (ALG_GFLOP_PER_IMG * 1e9 * args.batch / (ms_per_step * 1e-3) / 2.5e15)
+            if (args.model == 'efficientdet-d0' and args.image_size == 640) else None,
+            'per_kernel_ms': {k: round(v[1], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1][1])[:12]},
+        },
+    }
+    if not args.no_cpu_baseline:
+      out['cpu_baseline'] = cpu_baseline(config, args.image_size)
+    print(json.dumps(out))
+  if dist is not None:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

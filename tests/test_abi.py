@@ -1,0 +1,65 @@
+"""The C-ABI shared library loads and exports every symbol include/edet_hip.h declares; the ctypes
+table mirrors the header (no compute calls: this runs without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from automl_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'edet_hip.h')
+
+
+def header_functions():
+  src = open(HEADER).read()
+  src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+  out = {}
+  for m in re.finditer(r'\b(?:int|const char\*)\s+(edet_\w+)\s*\(([^;]*?)\)\s*;', src, flags=re.S):
+    args = [a.strip() for a in m.group(2).split(',') if a.strip() and a.strip() != 'void']
+    out[m.group(1)] = args
+  return out
+
+
+def test_header_declares_what_ctypes_binds():
+  fns = header_functions()
+  assert 'edet_last_error' in fns and 'edet_version' in fns
+  declared = set(fns) - {'edet_last_error', 'edet_version'}
+  assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+  for name, argtypes in _lib.SIGNATURES.items():
+    assert len(argtypes) == len(fns[name]), (name, len(argtypes), fns[name])
+
+
+def test_library_exports_every_symbol():
+  if not os.path.exists(_lib.LIB_PATH):
+    import __graft_entry__
+    __graft_entry__.build()
+  lib = ctypes.CDLL(_lib.LIB_PATH)
+  for name in list(header_functions()):
+    assert hasattr(lib, name), 'libedet_hip.so does not export %s' % name
+  lib.edet_version.restype = ctypes.c_int
+  assert lib.edet_version() >= 1
+
+
+def test_struct_layouts_match_header():
+  assert ctypes.sizeof(_lib.TView) == 4 * 8 + 6 * 4
+  assert ctypes.sizeof(_lib.GView) == 5 * 8 + 5 * 4 + 4      # padded to 8
+  assert ctypes.sizeof(_lib.BwdEpi) == 6 * 8                  # int beta padded
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+  monkeypatch.setattr(_lib, '_lib', None)
+  monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libedet_hip.so')
+  with pytest.raises(_lib.EdetError):
+    _lib.load()
+
+
+def test_engine_refuses_to_run_without_gpu():
+  import torch
+  if torch.cuda.is_available():
+    pytest.skip('GPU present')
+  from automl_amd import efficientdet_net
+  net = efficientdet_net.EfficientDetNet('efficientdet-d0')
+  with pytest.raises(_lib.EdetError):
+    net(torch.zeros(1, 64, 64, 3))

@@ -1,0 +1,632 @@
+"""-m gpu: every HIP kernel, called through the C ABI, against the CPU oracle's ops (+ autograd)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from automl_amd import _lib
+from automl_amd._lib import ACT_NONE, ACT_SWISH, BwdEpi, call, ptr
+from oracle import efficientdet_oracle as orc
+from tests import gpu_util as gu
+
+pytestmark = pytest.mark.gpu
+
+NP = ctypes.c_int
+
+
+def nhwc_to_nchw(t):
+  return t.permute(0, 3, 1, 2)
+
+
+def nchw_to_nhwc(t):
+  return t.permute(0, 2, 3, 1).contiguous()
+
+
+def apply_view(x, scale, shift, act, gate):
+  """oracle version of the activated view; x [n,h,w,c]."""
+  z = x
+  if scale is not None:
+    z = z * scale + shift
+  if act == ACT_SWISH:
+    z = orc.swish(z)
+  if gate is not None:
+    z = z * gate[:, None, None, :]
+  return z
+
+
+def partial_buf(c):
+  return torch.zeros(_lib.MAX_PARTS * 2 * c, dtype=torch.float32, device=gu.DEV)
+
+
+# ------------------------------------------------------------------------------------ pointwise fwd
+@pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
+@pytest.mark.parametrize('shape', [(2, 9, 7, 24, 40), (1, 16, 16, 16, 96), (2, 5, 5, 64, 810),
+                                   (3, 13, 11, 144, 24), (1, 20, 20, 1152, 192), (2, 8, 8, 64, 36)])
+@pytest.mark.parametrize('mode', ['plain', 'bn_swish', 'bn_swish_gate'])
+def test_pw_fwd(dt, shape, mode):
+  name, edt, tdt = dt
+  n, h, w, cin, cout = shape
+  rng = np.random.default_rng(gu.seed_of((shape, mode)))
+  x = gu.rnd(rng, (n, h, w, cin), tdt)
+  wk = gu.rnd(rng, (cin, cout), tdt, 1.0 / np.sqrt(cin))
+  bias = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+  scale = shift = gate = None
+  act = ACT_NONE
+  if mode != 'plain':
+    scale = torch.from_numpy((1 + 0.3 * rng.standard_normal(cin)).astype(np.float32))
+    shift = torch.from_numpy((0.3 * rng.standard_normal(cin)).astype(np.float32))
+    act = ACT_SWISH
+  if mode == 'bn_swish_gate':
+    gate = torch.from_numpy(rng.uniform(0.2, 1.0, (n, cin)).astype(np.float32))
+  a = apply_view(x, scale, shift, act, gate)
+  if name == 'bf16':
+    a = a.to(torch.bfloat16).float()   # the kernel feeds bf16 operands to the MFMA
+  want = a.reshape(-1, cin) @ wk + bias
+  want = want.reshape(n, h, w, cout)
+
+  xd = gu.to_dev(x, tdt)
+  ldk = gu.pad8(cin)
+  wt = torch.zeros(cout, ldk, dtype=tdt, device=gu.DEV)
+  call('edet_cast_matrix', ptr(gu.fdev(wk)), ptr(wt), cin, cout, ldk, 1, edt, gu.stream())
+  ldo = gu.pad8(cout)
+  out = torch.full((n, h, w, ldo), float('nan'), dtype=tdt, device=gu.DEV)
+  parts = partial_buf(cout)
+  npart = NP(0)
+  sc, sh, gt, bd = gu.fdev(scale), gu.fdev(shift), gu.fdev(gate), gu.fdev(bias)
+  tv = gu.tview(xd, cin, sc, sh, gt, act)
+  call('edet_pw_fwd', ctypes.byref(tv), ptr(wt), ldk, ptr(bd), ptr(out), cout, ldo, ptr(parts),
+       ctypes.byref(npart), edt, gu.stream())
+  torch.cuda.synchronize()
+  gu.check(out[..., :cout], want, name, 'pw_fwd out %s %s' % (shape, mode))
+  s1, s2 = gu.sum_partials(parts, npart.value, cout)
+  gu.check(s1, want.sum((0, 1, 2)), name, 'pw_fwd sum', rtol=3e-2 if name == 'bf16' else 1e-3,
+           atol=1e-2 * n * h * w if name == 'bf16' else 1e-4 * n * h * w, scale_by_max=False)
+  gu.check(s2, (want * want).sum((0, 1, 2)), name, 'pw_fwd sumsq', rtol=3e-2 if name == 'bf16' else 1e-3)
+
+
+# ------------------------------------------------------------------------------------ pointwise bwd
+def make_grad_view(rng, n, h, w, c, tdt, with_bn):
+  dz = gu.rnd(rng, (n, h, w, c), tdt)
+  if not with_bn:
+    return dz, None, None, None, None, dz
+  y = gu.rnd(rng, (n, h, w, c), tdt)
+  a = torch.from_numpy((1 + 0.2 * rng.standard_normal(c)).astype(np.float32))
+  b = torch.from_numpy((0.2 * rng.standard_normal(c)).astype(np.float32))
+  cc = torch.from_numpy((0.2 * rng.standard_normal(c)).astype(np.float32))
+  return dz, y, a, b, cc, a * dz + b * y + cc
+
+
+@pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
+@pytest.mark.parametrize('shape', [(2, 9, 7, 24, 40), (2, 5, 5, 64, 810), (3, 13, 11, 144, 24),
+                                   (2, 12, 12, 96, 16), (1, 20, 20, 1152, 192)])
+@pytest.mark.parametrize('mode', ['plain', 'plain_beta', 'bn', 'bn_swish_stats', 'gate'])
+@pytest.mark.parametrize('gbn', [False, True])
+def test_pw_bwd_data(dt, shape, mode, gbn):
+  name, edt, tdt = dt
+  n, h, w, cin, cout = shape
+  rng = np.random.default_rng(gu.seed_of((shape, mode, gbn)))
+  dz, y, ga, gb, gcc, dy = make_grad_view(rng, n, h, w, cout, tdt, gbn)
+  wk = gu.rnd(rng, (cin, cout), tdt, 1.0 / np.sqrt(cout))
+  x = gu.rnd(rng, (n, h, w, cin), tdt)
+  dyk = dy.to(torch.bfloat16).float() if name == 'bf16' else dy
+  d = (dyk.reshape(-1, cout) @ wk.t()).reshape(n, h, w, cin)   # gradient w.r.t. the view value
+  scale = shift = gate = mean = rstd = None
+  act = ACT_NONE
+  old = None
+  if mode in ('bn', 'bn_swish_stats', 'gate'):
+    scale = torch.from_numpy((1 + 0.3 * rng.standard_normal(cin)).astype(np.float32))
+    shift = torch.from_numpy((0.3 * rng.standard_normal(cin)).astype(np.float32))
+    mean = torch.from_numpy((0.2 * rng.standard_normal(cin)).astype(np.float32))
+    rstd = torch.from_numpy(rng.uniform(0.5, 2.0, cin).astype(np.float32))
+  if mode in ('bn_swish_stats', 'gate'):
+    act = ACT_SWISH
+  z = x * scale + shift if scale is not None else x
+  if mode == 'gate':
+    gate = torch.from_numpy(rng.uniform(0.2, 1.0, (n, cin)).astype(np.float32))
+    want_g = d
+    want_dgate = (d * orc.swish(z)).sum((1, 2))
+  else:
+    zz = z.clone().requires_grad_(True)
+    (orc.swish(zz) if act == ACT_SWISH else zz).backward(d)
+    want_g = zz.grad
+  if mode == 'plain_beta':
+    old = gu.rnd(rng, (n, h, w, cin), tdt)
+    want_g = want_g + old
+
+  xd = gu.to_dev(x, tdt)
+  ldn = gu.pad8(cout)
+  wd = torch.zeros(cin, ldn, dtype=tdt, device=gu.DEV)
+  call('edet_cast_matrix', ptr(gu.fdev(wk)), ptr(wd), cin, cout, ldn, 0, edt, gu.stream())
+  dzd = gu.to_dev(dz, tdt)
+  if name == 'bf16':
+    dzd[..., cout:] = float('nan')     # padding columns must never leak into the result
+  yd = gu.to_dev(y, tdt) if y is not None else None
+  gv = gu.gview(dzd, cout, yd, ga, gb, gcc)
+  sc, sh, gt = gu.fdev(scale), gu.fdev(shift), gu.fdev(gate)
+  tv = gu.tview(xd, cin, sc, sh, gt, act)
+  gout = gu.to_dev(old, tdt) if old is not None else torch.full((n, h, w, gu.pad8(cin)), float('nan'),
+                                                                 dtype=tdt, device=gu.DEV)
+  parts = partial_buf(cin)
+  dgate = torch.zeros(n, cin, dtype=torch.float32, device=gu.DEV)
+  stats = mode == 'bn_swish_stats'
+  md, rd = gu.fdev(mean), gu.fdev(rstd)
+  epi = BwdEpi(ptr(gout), 1 if old is not None else 0, ptr(md) if stats else None, ptr(rd) if stats else None,
+               ptr(parts) if stats else None, ptr(dgate) if mode == 'gate' else None)
+  npart = NP(0)
+  call('edet_pw_bwd_data', ctypes.byref(gv), ptr(wd), ldn, ctypes.byref(tv), ctypes.byref(epi),
+       ctypes.byref(npart), edt, gu.stream())
+  torch.cuda.synchronize()
+  gu.check(gout[..., :cin], want_g, name, 'pw_bwd_data g %s %s' % (shape, mode))
+  if mode == 'gate':
+    gu.check(dgate, want_dgate, name, 'pw_bwd_data dgate', rtol=3e-2 if name == 'bf16' else 1e-3)
+  if stats:
+    s1, s2 = gu.sum_partials(parts, npart.value, cin)
+    xh = (x - mean) * rstd
+    gq = want_g.to(tdt).float() if name == 'bf16' else want_g
+    gu.check(s1, want_g.sum((0, 1, 2)), name, 'pw_bwd_data S1', rtol=3e-2 if name == 'bf16' else 1e-3)
+    gu.check(s2, (gq * xh).sum((0, 1, 2)), name, 'pw_bwd_data S2', rtol=3e-2 if name == 'bf16' else 1e-3)
+
+
+@pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
+@pytest.mark.parametrize('shape', [(2, 9, 7, 24, 40), (2, 5, 5, 64, 810), (3, 13, 11, 144, 24),
+                                   (2, 12, 12, 96, 16), (1, 20, 20, 1152, 192), (2, 8, 8, 64, 36),
+                                   (4, 33, 31, 16, 96), (1, 10, 10, 320, 64)])
+@pytest.mark.parametrize('mode', ['plain', 'bn_swish_gate'])
+def test_pw_bwd_weight(dt, shape, mode):
+  name, edt, tdt = dt
+  n, h, w, cin, cout = shape
+  rng = np.random.default_rng(gu.seed_of((shape, mode, 3)))
+  dz, y, ga, gb, gcc, dy = make_grad_view(rng, n, h, w, cout, tdt, mode != 'plain')
+  x = gu.rnd(rng, (n, h, w, cin), tdt)
+  scale = shift = gate = None
+  act = ACT_NONE
+  if mode != 'plain':
+    scale = torch.from_numpy((1 + 0.3 * rng.standard_normal(cin)).astype(np.float32))
+    shift = torch.from_numpy((0.3 * rng.standard_normal(cin)).astype(np.float32))
+    gate = torch.from_numpy(rng.uniform(0.2, 1.0, (n, cin)).astype(np.float32))
+    act = ACT_SWISH
+  a = apply_view(x, scale, shift, act, gate)
+  if name == 'bf16':
+    a, dyq = a.to(torch.bfloat16).float(), dy.to(torch.bfloat16).float()
+  else:
+    dyq = dy
+  want = a.reshape(-1, cin).t() @ dyq.reshape(-1, cout)
+  xd, dzd = gu.to_dev(x, tdt), gu.to_dev(dz, tdt)
+  yd = gu.to_dev(y, tdt) if y is not None else None
+  gv = gu.gview(dzd, cout, yd, ga, gb, gcc)
+  sc, sh, gt = gu.fdev(scale), gu.fdev(shift), gu.fdev(gate)
+  tv = gu.tview(xd, cin, sc, sh, gt, act)
+  dw = torch.zeros(cin, cout, dtype=torch.float32, device=gu.DEV)
+  call('edet_pw_bwd_weight', ctypes.byref(tv), ctypes.byref(gv), ptr(dw), edt, gu.stream())
+  torch.cuda.synchronize()
+  gu.check(dw, want, name, 'pw_bwd_weight %s %s' % (shape, mode), rtol=2e-2 if name == 'bf16' else 1e-3)
+
+
+# ------------------------------------------------------------------------------------ depthwise
+DW_SHAPES = [(2, 9, 11, 16), (1, 16, 16, 40), (2, 7, 5, 144), (1, 20, 20, 96), (2, 33, 17, 32)]
+
+
+def dw_oracle(x_nhwc, wk, k, s):
+  return nchw_to_nhwc(orc.depthwise_same(nhwc_to_nchw(x_nhwc), wk.reshape(k, k, -1, 1), s))
+
+
+@pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
+@pytest.mark.parametrize('shape', DW_SHAPES)
+@pytest.mark.parametrize('ks', [(3, 1), (3, 2), (5, 1), (5, 2)])
+@pytest.mark.parametrize('mode', ['plain', 'bn_swish'])
+def test_dw_fwd(dt, shape, ks, mode):
+  name, edt, tdt = dt
+  n, h, w, c = shape
+  k, s = ks
+  rng = np.random.default_rng(gu.seed_of((shape, ks, mode)))
+  x = gu.rnd(rng, (n, h, w, c), tdt)
+  wk = torch.from_numpy((rng.standard_normal((k, k, c)) / k).astype(np.float32))
+  scale = shift = None
+  act = ACT_NONE
+  if mode != 'plain':
+    scale = torch.from_numpy((1 + 0.3 * rng.standard_normal(c)).astype(np.float32))
+    shift = torch.from_numpy((0.3 * rng.standard_normal(c)).astype(np.float32))
+    act = ACT_SWISH
+  want = dw_oracle(apply_view(x, scale, shift, act, None), wk, k, s)
+  xd = gu.to_dev(x, tdt)
+  oh, ow = want.shape[1], want.shape[2]
+  out = torch.full((n, oh, ow, c), float('nan'), dtype=tdt, device=gu.DEV)
+  parts = partial_buf(c)
+  npart = NP(0)
+  sc, sh, wd = gu.fdev(scale), gu.fdev(shift), gu.fdev(wk)
+  tv = gu.tview(xd, c, sc, sh, None, act)
+  call('edet_dw_fwd', ctypes.byref(tv), ptr(wd), k, s, ptr(out), c, ptr(parts), ctypes.byref(npart), edt,
+       gu.stream())
+  torch.cuda.synchronize()
+  gu.check(out, want, name, 'dw_fwd %s k%d s%d %s' % (shape, k, s, mode))
+  s1, s2 = gu.sum_partials(parts, npart.value, c)
+  gu.check(s1, want.sum((0, 1, 2)), name, 'dw_fwd sum', rtol=1e-3, atol=1e-3 * n * oh * ow, scale_by_max=False)
+  gu.check(s2, (want * want).sum((0, 1, 2)), name, 'dw_fwd sumsq', rtol=1e-3)
+
+
+@pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
+@pytest.mark.parametrize('shape', DW_SHAPES)
+@pytest.mark.parametrize('ks', [(3, 1), (3, 2), (5, 1), (5, 2)])
+@pytest.mark.parametrize('mode', ['plain_beta', 'bn_swish_stats'])
+def test_dw_bwd(dt, shape, ks, mode):
+  """data gradient (with epilogue chain) and weight gradient against autograd."""
+  name, edt, tdt = dt
+  n, h, w, c = shape
+  k, s = ks
+  rng = np.random.default_rng(gu.seed_of((shape, ks, mode, 7)))
+  x = gu.rnd(rng, (n, h, w, c), tdt)
+  wk = torch.from_numpy((rng.standard_normal((k, k, c)) / k).astype(np.float32))
+  oh, _, _ = __import__('automl_amd.utils', fromlist=['x']).same_padding(h, k, s)
+  ow, _, _ = __import__('automl_amd.utils', fromlist=['x']).same_padding(w, k, s)
+  dz, y, ga, gb, gcc, dy = make_grad_view(rng, n, oh, ow, c, tdt, True)
+  scale = shift = mean = rstd = None
+  act = ACT_NONE
+  old = None
+  if mode == 'bn_swish_stats':
+    scale = torch.from_numpy((1 + 0.3 * rng.standard_normal(c)).astype(np.float32))
+    shift = torch.from_numpy((0.3 * rng.standard_normal(c)).astype(np.float32))
+    mean = torch.from_numpy((0.2 * rng.standard_normal(c)).astype(np.float32))
+    rstd = torch.from_numpy(rng.uniform(0.5, 2.0, c).astype(np.float32))
+    act = ACT_SWISH
+  else:
+    old = gu.rnd(rng, (n, h, w, c), tdt)
+  zz = (x * scale + shift if scale is not None else x).clone().requires_grad_(True)
+  wq = wk.clone().requires_grad_(True)
+  a = orc.swish(zz) if act == ACT_SWISH else zz
+  dw_oracle(a, wq, k, s).backward(dy)
+  want_g = zz.grad + (old if old is not None else 0)
+  want_dw = wq.grad
+
+  xd, dzd, yd = gu.to_dev(x, tdt), gu.to_dev(dz, tdt), gu.to_dev(y, tdt)
+  gv = gu.gview(dzd, c, yd, ga, gb, gcc)
+  sc, sh, wd = gu.fdev(scale), gu.fdev(shift), gu.fdev(wk)
+  tv = gu.tview(xd, c, sc, sh, None, act)
+  gout = gu.to_dev(old, tdt) if old is not None else torch.full((n, h, w, c), float('nan'), dtype=tdt,
+                                                                 device=gu.DEV)
+  parts = partial_buf(c)
+  stats = mode == 'bn_swish_stats'
+  md, rd = gu.fdev(mean), gu.fdev(rstd)
+  epi = BwdEpi(ptr(gout), 0 if stats else 1, ptr(md) if stats else None, ptr(rd) if stats else None,
+               ptr(parts) if stats else None, None)
+  npart = NP(0)
+  call('edet_dw_bwd_data', ctypes.byref(gv), ptr(wd), k, s, ctypes.byref(tv), ctypes.byref(epi),
+       ctypes.byref(npart), edt, gu.stream())
+  dwd = torch.zeros(k, k, c, dtype=torch.float32, device=gu.DEV)
+  call('edet_dw_bwd_weight', ctypes.byref(tv), ctypes.byref(gv), k, s, ptr(dwd), edt, gu.stream())
+  torch.cuda.synchronize()
+  gu.check(gout, want_g, name, 'dw_bwd_data %s k%d s%d %s' % (shape, k, s, mode))
+  gu.check(dwd, want_dw, name, 'dw_bwd_weight %s k%d s%d' % (shape, k, s), rtol=1e-3, atol=1e-3)
+  if stats:
+    s1, s2 = gu.sum_partials(parts, npart.value, c)
+    gq = want_g.to(tdt).float() if name == 'bf16' else want_g
+    gu.check(s1, want_g.sum((0, 1, 2)), name, 'dw_bwd S1', rtol=2e-2 if name == 'bf16' else 1e-3)
+    gu.check(s2, (gq * (x - mean) * rstd).sum((0, 1, 2)), name, 'dw_bwd S2', rtol=2e-2 if name == 'bf16' else 1e-3)
+
+
+# ------------------------------------------------------------------------------------ stem
+@pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
+@pytest.mark.parametrize('shape', [(2, 64, 64, 32), (1, 37, 51, 32), (2, 40, 72, 64), (1, 33, 33, 40)])
+def test_stem(dt, shape):
+  name, edt, tdt = dt
+  n, h, w, co = shape
+  rng = np.random.default_rng(gu.seed_of(shape))
+  img = gu.rnd(rng, (n, h, w, 3), tdt)
+  wk = torch.from_numpy((rng.standard_normal((3, 3, 3, co)) / 5).astype(np.float32))
+  wq = wk.clone().requires_grad_(True)
+  out = nchw_to_nhwc(orc.conv2d_same(nhwc_to_nchw(img), wq, 2))
+  oh, ow = out.shape[1], out.shape[2]
+  dz, y, ga, gb, gcc, dy = make_grad_view(rng, n, oh, ow, co, tdt, True)
+  out.backward(dy)
+  imgd = img.to(device=gu.DEV, dtype=tdt).contiguous()
+  od = torch.full((n, oh, ow, co), float('nan'), dtype=tdt, device=gu.DEV)
+  parts = partial_buf(co)
+  npart = NP(0)
+  wd = gu.fdev(wk)
+  call('edet_stem_fwd', ptr(imgd), n, h, w, ptr(wd), ptr(od), co, co, ptr(parts), ctypes.byref(npart), edt,
+       gu.stream())
+  torch.cuda.synchronize()
+  gu.check(od, out, name, 'stem_fwd %s' % (shape,))
+  s1, s2 = gu.sum_partials(parts, npart.value, co)
+  gu.check(s2, (out * out).sum((0, 1, 2)), name, 'stem sumsq', rtol=1e-3)
+  gu.check(s1, out.sum((0, 1, 2)), name, 'stem sum', rtol=1e-3, atol=1e-3 * n * oh * ow, scale_by_max=False)
+  dzd, yd = gu.to_dev(dz, tdt), gu.to_dev(y, tdt)
+  gv = gu.gview(dzd, co, yd, ga, gb, gcc)
+  dwd = torch.zeros(3, 3, 3, co, dtype=torch.float32, device=gu.DEV)
+  call('edet_stem_bwd_weight', ptr(imgd), n, h, w, ctypes.byref(gv), ptr(dwd), edt, gu.stream())
+  torch.cuda.synchronize()
+  gu.check(dwd, wq.grad, name, 'stem_bwd_weight %s' % (shape,), rtol=1e-3, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------ BatchNorm
+@pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
+@pytest.mark.parametrize('shape', [(2, 9, 7, 24), (3, 5, 5, 144), (1, 16, 16, 1152)])
+def test_batchnorm_train_fwd_bwd(dt, shape):
+  """stats from a reduce over y -> finalize -> bn_res forward; backward reduce/finalize -> dy == autograd."""
+  name, edt, tdt = dt
+  n, h, w, c = shape
+  rng = np.random.default_rng(gu.seed_of(shape))
+  y = gu.rnd(rng, (n, h, w, c), tdt, 2.0) + 0.5
+  y = y.to(tdt).float()
+  gamma = torch.from_numpy((1 + 0.3 * rng.standard_normal(c)).astype(np.float32))
+  beta = torch.from_numpy((0.3 * rng.standard_normal(c)).astype(np.float32))
+  res = gu.rnd(rng, (n, h, w, c), tdt)
+  dz = gu.rnd(rng, (n, h, w, c), tdt)
+  yq = y.clone().requires_grad_(True)
+  gq, bq = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+  mean = yq.mean((0, 1, 2))
+  var = yq.var((0, 1, 2), unbiased=False)
+  out = (yq - mean) * torch.rsqrt(var + 1e-3) * gq + bq
+  out.backward(dz)
+  cnt = n * h * w
+  # forward statistics: use sums computed on the host in fp64 as the "partials" (1 part)
+  parts = torch.stack([y.double().sum((0, 1, 2)), (y.double()**2).sum((0, 1, 2))]).float().to(gu.DEV).reshape(-1).contiguous()
+  vec = torch.zeros(7, c, dtype=torch.float32, device=gu.DEV)
+  mm = torch.zeros(c, dtype=torch.float32, device=gu.DEV)
+  mv = torch.ones(c, dtype=torch.float32, device=gu.DEV)
+  gd, bd = gu.fdev(gamma), gu.fdev(beta)
+  call('edet_bn_finalize', ptr(parts), 1, c, float(cnt), ptr(gd), ptr(bd), 1e-3, 0.99, ptr(mm), ptr(mv),
+       ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), gu.stream())
+  yd, rd = gu.to_dev(y, tdt), gu.to_dev(res, tdt)
+  od = torch.empty_like(yd)
+  tv = gu.tview(yd, c, vec[0], vec[1])
+  call('edet_bn_res', ctypes.byref(tv), ptr(rd), ptr(od), c, edt, gu.stream())
+  torch.cuda.synchronize()
+  gu.check(od, out.detach() + res, name, 'bn_res %s' % (shape,))
+  gu.check(mm, 0.01 * mean.detach(), 'f32', 'moving_mean', rtol=1e-4, atol=1e-6)
+  gu.check(mv, 0.99 + 0.01 * var.detach() * cnt / (cnt - 1), 'f32', 'moving_var', rtol=1e-4, atol=1e-6)
+  # backward
+  dzd = gu.to_dev(dz, tdt)
+  p2 = partial_buf(c)
+  npart = NP(0)
+  call('edet_bn_bwd_reduce', ptr(dzd), ptr(yd), cnt, c, c, ptr(vec[2]), ptr(vec[3]), ptr(p2),
+       ctypes.byref(npart), edt, gu.stream())
+  dg = torch.zeros(c, dtype=torch.float32, device=gu.DEV)
+  db = torch.zeros(c, dtype=torch.float32, device=gu.DEV)
+  call('edet_bn_bwd_finalize', ptr(p2), npart.value, c, float(cnt), ptr(gd), ptr(vec[2]), ptr(vec[3]), ptr(dg),
+       ptr(db), None, ptr(vec[4]), ptr(vec[5]), ptr(vec[6]), gu.stream())
+  torch.cuda.synchronize()
+  gu.check(dg, gq.grad, 'f32', 'dgamma', rtol=1e-3, atol=1e-3)
+  gu.check(db, bq.grad, 'f32', 'dbeta', rtol=1e-3, atol=1e-3)
+  dy = vec[4].cpu() * dz + vec[5].cpu() * y + vec[6].cpu()
+  gu.check(dy, yq.grad, 'f32', 'bn on-load backward', rtol=1e-3, atol=1e-4)
+  # edet_add
+  acc = gu.to_dev(res, tdt)
+  call('edet_add', ptr(acc), ptr(dzd), cnt, c, c, 1, edt, gu.stream())
+  torch.cuda.synchronize()
+  gu.check(acc, res + dz, name, 'edet_add')
+
+
+# ------------------------------------------------------------------------------------ SE
+@pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
+@pytest.mark.parametrize('shape', [(2, 9, 7, 32, 8), (3, 20, 20, 144, 6), (2, 5, 5, 1152, 48)])
+def test_squeeze_excite(dt, shape):
+  name, edt, tdt = dt
+  n, h, w, c, se = shape
+  rng = np.random.default_rng(gu.seed_of(shape))
+  x = gu.rnd(rng, (n, h, w, c), tdt)
+  scale = torch.from_numpy((1 + 0.3 * rng.standard_normal(c)).astype(np.float32))
+  shift = torch.from_numpy((0.3 * rng.standard_normal(c)).astype(np.float32))
+  mean = torch.from_numpy((0.2 * rng.standard_normal(c)).astype(np.float32))
+  rstd = torch.from_numpy(rng.uniform(0.5, 2.0, c).astype(np.float32))
+  w1 = torch.from_numpy((rng.standard_normal((c, se)) / np.sqrt(c)).astype(np.float32))
+  b1 = torch.from_numpy((0.1 * rng.standard_normal(se)).astype(np.float32))
+  w2 = torch.from_numpy((rng.standard_normal((se, c)) / np.sqrt(se)).astype(np.float32))
+  b2 = torch.from_numpy((0.1 * rng.standard_normal(c)).astype(np.float32))
+  dout = gu.rnd(rng, (n, h, w, c), tdt)    # gradient w.r.t. the gated activation
+  zz = (x * scale + shift).clone().requires_grad_(True)
+  ps = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+  a = orc.swish(zz)
+  pooled = a.mean((1, 2))
+  hid = pooled @ ps[0] + ps[1]
+  gate = torch.sigmoid(orc.swish(hid) @ ps[2] + ps[3])
+  (a * gate[:, None, None, :]).backward(dout)
+
+  xd = gu.to_dev(x, tdt)
+  sc, sh, md, rd = gu.fdev(scale), gu.fdev(shift), gu.fdev(mean), gu.fdev(rstd)
+  pd = torch.zeros(n, c, dtype=torch.float32, device=gu.DEV)
+  hd = torch.zeros(n, se, dtype=torch.float32, device=gu.DEV)
+  gd = torch.zeros(n, c, dtype=torch.float32, device=gu.DEV)
+  tv = gu.tview(xd, c, sc, sh, None, ACT_SWISH)
+  w1d, b1d, w2d, b2d = (gu.fdev(t) for t in (w1, b1, w2, b2))
+  call('edet_se_pool', ctypes.byref(tv), ptr(pd), edt, gu.stream())
+  call('edet_se_fc', ptr(pd), n, c, se, 1.0 / (h * w), ptr(w1d), ptr(b1d), ptr(w2d), ptr(b2d), ptr(hd), ptr(gd),
+       gu.stream())
+  torch.cuda.synchronize()
+  gu.check(pd / (h * w), pooled.detach(), 'f32', 'se pooled', rtol=1e-3, atol=1e-4)
+  gu.check(gd, gate.detach(), 'f32', 'se gate', rtol=1e-3, atol=1e-4)
+  # backward: D = dout (what the project dgrad would store), dgate = sum D * act(z)
+  D = gu.to_dev(dout, tdt)
+  dgate = gu.fdev((dout * a.detach()).sum((1, 2)))
+  grads = [torch.zeros_like(t) for t in (w1d, b1d, w2d, b2d)]
+  dpool = torch.zeros(n, c, dtype=torch.float32, device=gu.DEV)
+  scratch = torch.zeros(n * (c + se), dtype=torch.float32, device=gu.DEV)
+  call('edet_se_fc_bwd', ptr(pd), ptr(hd), ptr(gd), ptr(dgate), n, c, se, 1.0 / (h * w), ptr(w1d), ptr(w2d),
+       ptr(grads[0]), ptr(grads[1]), ptr(grads[2]), ptr(grads[3]), ptr(dpool), ptr(scratch), gu.stream())
+  parts = partial_buf(c)
+  npart = NP(0)
+  tvg = gu.tview(xd, c, sc, sh, gd, ACT_SWISH)
+  call('edet_se_gate_bwd', ctypes.byref(tvg), ptr(D), ptr(dpool), ptr(md), ptr(rd), ptr(parts),
+       ctypes.byref(npart), edt, gu.stream())
+  torch.cuda.synchronize()
+  for g, p, nm in zip(grads, ps, ('dw1', 'db1', 'dw2', 'db2')):
+    gu.check(g, p.grad, 'f32', 'se ' + nm, rtol=2e-3, atol=1e-4)
+  gu.check(D, zz.grad, name, 'se dz %s' % (shape,))
+  s1, s2 = gu.sum_partials(parts, npart.value, c)
+  gu.check(s1, zz.grad.sum((0, 1, 2)), name, 'se S1', rtol=2e-2 if name == 'bf16' else 1e-3)
+  gu.check(s2, (zz.grad * (x - mean) * rstd).sum((0, 1, 2)), name, 'se S2', rtol=2e-2 if name == 'bf16' else 1e-3)
+
+
+# ------------------------------------------------------------------------------------ BiFPN fusion
+def resample_oracle(x_nhwc, mode, oh, ow):
+  x = nhwc_to_nchw(x_nhwc)
+  if mode == _lib.RS_UP2:
+    x = orc.resize_nearest(x, oh, ow)
+  elif mode == _lib.RS_POOL:
+    x = orc.max_pool_same_3x3_s2(x)
+  return nchw_to_nhwc(x)
+
+
+@pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
+@pytest.mark.parametrize('case', [
+    ((2, 10, 10, 64), [(_lib.RS_IDENTITY, 10, 10), (_lib.RS_UP2, 5, 5)], 'fastattn'),
+    ((2, 5, 5, 64), [(_lib.RS_IDENTITY, 5, 5), (_lib.RS_IDENTITY, 5, 5), (_lib.RS_POOL, 10, 10)], 'fastattn'),
+    ((1, 4, 3, 16), [(_lib.RS_IDENTITY, 4, 3), (_lib.RS_POOL, 7, 5)], 'sum'),
+    ((2, 7, 9, 24), [(_lib.RS_UP2, 4, 5), (_lib.RS_IDENTITY, 7, 9), (_lib.RS_UP2, 4, 5)], 'fastattn'),
+    ((2, 5, 5, 64), [(_lib.RS_POOL, 10, 10)], 'none'),
+])
+def test_fuse(dt, case):
+  name, edt, tdt = dt
+  (n, oh, ow, c), ins, method = case
+  rng = np.random.default_rng(gu.seed_of(str(case)))
+  nin = len(ins)
+  xs, scs, shs = [], [], []
+  for (mode, ih, iw) in ins:
+    xs.append(gu.rnd(rng, (n, ih, iw, c), tdt))
+    scs.append(torch.from_numpy((1 + 0.3 * rng.standard_normal(c)).astype(np.float32)))
+    shs.append(torch.from_numpy((0.3 * rng.standard_normal(c)).astype(np.float32)))
+  ws = [torch.tensor(float(v)) for v in rng.uniform(0.3, 1.5, nin)]
+  if method == 'fastattn':
+    ws[-1] = torch.tensor(-0.3) if nin == 3 else ws[-1]   # exercise the relu
+  act = ACT_NONE if method == 'none' else ACT_SWISH
+  dout = gu.rnd(rng, (n, oh, ow, c), tdt)
+  xq = [x.clone().requires_grad_(True) for x in xs]
+  wq = [w.clone().requires_grad_(True) for w in ws]
+  vals = [resample_oracle(x * sc + sh, m[0], oh, ow) for x, sc, sh, m in zip(xq, scs, shs, ins)]
+  if method == 'fastattn':
+    r = [torch.relu(w) for w in wq]
+    tot = sum(r) + 0.0001
+    s = sum(v * ri / tot for v, ri in zip(vals, r))
+  else:
+    s = sum(vals)
+  out = orc.swish(s) if act == ACT_SWISH else s
+  out.backward(dout)
+
+  xd = [gu.to_dev(x, tdt) for x in xs]
+  scd, shd = [gu.fdev(t) for t in scs], [gu.fdev(t) for t in shs]
+  tvs = [gu.tview(x, c, sc, sh) for x, sc, sh in zip(xd, scd, shd)]
+  tvp = [ctypes.byref(t) for t in tvs] + [None] * (3 - nin)
+  modes = (ctypes.c_int * 3)(*([m[0] for m in ins] + [0] * (3 - nin)))
+  wd = [gu.fdev(w.reshape(1)) for w in ws] + [None] * (3 - nin)
+  wn = torch.zeros(4, dtype=torch.float32, device=gu.DEV)
+  meth = 0 if method == 'fastattn' else 1
+  call('edet_fuse_weights', ptr(wd[0]), ptr(wd[1]), ptr(wd[2]), nin, meth, ptr(wn), gu.stream())
+  od = torch.full((n, oh, ow, c), float('nan'), dtype=tdt, device=gu.DEV)
+  call('edet_fuse_fwd', tvp[0], tvp[1], tvp[2], modes, nin, ptr(wn), act, ptr(od), oh, ow, c, edt, gu.stream())
+  torch.cuda.synchronize()
+  gu.check(od, out.detach(), name, 'fuse_fwd %s' % (case,))
+  dd = gu.to_dev(dout, tdt)
+  ds = torch.empty_like(dd)
+  dwn = torch.zeros(4, dtype=torch.float32, device=gu.DEV)
+  call('edet_fuse_bwd_pre', tvp[0], tvp[1], tvp[2], modes, nin, ptr(wn), act, ptr(dd), oh, ow, c, ptr(ds),
+       ptr(dwn), edt, gu.stream())
+  for i in range(nin):
+    g = torch.full_like(xd[i], float('nan'))
+    call('edet_fuse_bwd_input', ctypes.byref(tvs[i]), ins[i][0], ptr(wn), i, ptr(ds), oh, ow, c, ptr(g), 0, edt,
+         gu.stream())
+    torch.cuda.synchronize()
+    # engine convention: gradient w.r.t. the BN *output* (scale is applied by the BN-backward coefficients)
+    gu.check(g, xq[i].grad / scs[i], name, 'fuse_bwd_input %d %s' % (i, case,))
+  if method == 'fastattn':
+    dws = [torch.zeros(1, dtype=torch.float32, device=gu.DEV) for _ in range(3)]
+    call('edet_fuse_weights_bwd', ptr(wd[0]), ptr(wd[1]), ptr(wd[2]), nin, meth, ptr(dwn), ptr(dws[0]),
+         ptr(dws[1]), ptr(dws[2]), gu.stream())
+    torch.cuda.synchronize()
+    for i in range(nin):
+      gu.check(dws[i].reshape(()), wq[i].grad, 'f32', 'fuse dW%d' % i, rtol=2e-2 if name == 'bf16' else 2e-3,
+               atol=2e-2 if name == 'bf16' else 1e-3, scale_by_max=False)
+
+
+# ------------------------------------------------------------------------------------ losses
+@pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
+def test_detection_loss(dt):
+  name, edt, tdt = dt
+  rng = np.random.default_rng(5)
+  n, h, w, na, nc = 2, 5, 4, 9, 90
+  logits = gu.rnd(rng, (n, h, w, na * nc), tdt, 2.0)
+  box = gu.rnd(rng, (n, h, w, 4 * na), tdt, 0.3)
+  ct = torch.from_numpy(rng.integers(-2, nc, (n, h, w, na)).astype(np.int32))
+  ct[rng.random((n, h, w, na)) < 0.7] = -1
+  bt = torch.from_numpy((rng.standard_normal((n, h, w, 4 * na)) * 0.2).astype(np.float32))
+  bt[torch.from_numpy(rng.random((n, h, w, 4 * na)) < 0.6)] = 0.0
+  norm = 37.0
+  lq, bq = logits.clone().requires_grad_(True), box.clone().requires_grad_(True)
+  onehot = torch.nn.functional.one_hot(torch.clamp(ct, min=0).long(), nc).float() * (ct >= 0).unsqueeze(-1)
+  fl = orc.focal_loss(lq, onehot.reshape(n, h, w, -1), 0.25, 1.5, norm).reshape(n, h, w, na, nc)
+  cls_loss = (fl * (ct != -2).unsqueeze(-1)).sum()
+  box_loss = (orc.huber(bq - bt, 0.1) * (bt != 0).float()).sum() / (norm * 4)
+  (cls_loss + 50.0 * box_loss).backward()
+  ld, bd = gu.to_dev(logits, tdt), gu.to_dev(box, tdt)
+  dl, db = torch.full_like(ld, float('nan')), torch.full_like(bd, float('nan'))
+  ctd, btd = ct.to(gu.DEV), bt.to(gu.DEV)
+  sums = torch.zeros(4, dtype=torch.float32, device=gu.DEV)
+  dbias_c = torch.zeros(na * nc, dtype=torch.float32, device=gu.DEV)
+  dbias_b = torch.zeros(4 * na, dtype=torch.float32, device=gu.DEV)
+  call('edet_focal_loss', ptr(ld), ld.shape[-1], ptr(ctd), n * h * w, na, nc, 0.25, 1.5, 1.0 / norm, ptr(dl),
+       ptr(dbias_c), ptr(sums), edt, gu.stream())
+  call('edet_box_loss', ptr(bd), bd.shape[-1], ptr(btd), n * h * w, 4 * na, 0.1, 1.0 / (norm * 4), 50.0, ptr(db),
+       ptr(dbias_b), ptr(sums), edt, gu.stream())
+  torch.cuda.synchronize()
+  s = sums.cpu()
+  assert abs(float(s[0]) - float(cls_loss)) <= 1e-3 * abs(float(cls_loss)) + 1e-5, (float(s[0]), float(cls_loss))
+  assert abs(float(s[1]) - float(box_loss)) <= 1e-3 * abs(float(box_loss)) + 1e-6, (float(s[1]), float(box_loss))
+  gu.check(dl[..., :na * nc], lq.grad, name, 'dlogits', rtol=1e-2 if name == 'bf16' else 1e-4)
+  gu.check(db[..., :4 * na], bq.grad, name, 'dbox', rtol=1e-2 if name == 'bf16' else 1e-4)
+  assert float(dl[..., na * nc:].abs().max()) == 0.0 and float(db[..., 4 * na:].abs().max()) == 0.0
+  gu.check(dbias_c, lq.grad.sum((0, 1, 2)), name, 'class bias grad', rtol=2e-2 if name == 'bf16' else 1e-3)
+  gu.check(dbias_b, bq.grad.sum((0, 1, 2)), name, 'box bias grad', rtol=2e-2 if name == 'bf16' else 1e-3)
+
+
+# ------------------------------------------------------------------------------------ optimizer
+def test_optimizer():
+  rng = np.random.default_rng(11)
+  sizes = [7, 64, 1, 1000, 33, 4096]
+  flags = [1, 0, 0, 1, 1, 0]
+  offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+  tot = int(offs[-1])
+  p = torch.from_numpy(rng.standard_normal(tot).astype(np.float32))
+  g = torch.from_numpy((rng.standard_normal(tot) * 3).astype(np.float32))
+  v = torch.from_numpy((rng.standard_normal(tot) * 0.1).astype(np.float32))
+  ema = torch.from_numpy(rng.standard_normal(tot).astype(np.float32))
+  wd, clip, lr, mom, decay = 4e-5, 10.0, 0.05, 0.9, 0.95
+  # oracle
+  g2 = g.clone()
+  l2 = 0.0
+  for i in range(len(sizes)):
+    sl = slice(int(offs[i]), int(offs[i + 1]))
+    if flags[i]:
+      g2[sl] += wd * p[sl]
+      l2 += 0.5 * wd * float((p[sl]**2).sum())
+  for i in range(len(sizes)):
+    sl = slice(int(offs[i]), int(offs[i + 1]))
+    g2[sl] = g2[sl] * clip / max(float(g2[sl].norm()), clip)
+  gn = float(g2.norm())
+  g2 = g2 * clip / max(gn, clip)
+  v2 = mom * v - lr * g2
+  p2 = p + v2
+  e2 = ema - (1 - decay) * (ema - p2)
+  pd, gd, vd, ed = (t.to(gu.DEV) for t in (p, g, v, ema))
+  od = torch.from_numpy(offs).to(gu.DEV)
+  fd = torch.tensor(flags, dtype=torch.int32, device=gu.DEV)
+  sq = torch.zeros(len(sizes), dtype=torch.float32, device=gu.DEV)
+  fac = torch.zeros(len(sizes), dtype=torch.float32, device=gu.DEV)
+  l2d = torch.zeros(1, dtype=torch.float32, device=gu.DEV)
+  gnd = torch.zeros(1, dtype=torch.float32, device=gu.DEV)
+  hyper = torch.tensor([lr, decay], dtype=torch.float32, device=gu.DEV)
+  call('edet_opt_l2_norms', ptr(gd), ptr(pd), ptr(od), ptr(fd), len(sizes), wd, ptr(sq), ptr(l2d), gu.stream())
+  call('edet_opt_clip_factors', ptr(sq), len(sizes), clip, ptr(fac), ptr(gnd), gu.stream())
+  call('edet_opt_sgd_ema', ptr(pd), ptr(gd), ptr(vd), ptr(ed), ptr(od), ptr(fac), len(sizes), ptr(hyper), mom,
+       gu.stream())
+  torch.cuda.synchronize()
+  assert abs(float(l2d) - l2) <= 1e-4 * l2
+  assert abs(float(gnd) - float(g2.norm())) <= 1e-4 * float(g2.norm())
+  gu.check(pd, p2, 'f32', 'sgd params', rtol=1e-5, atol=1e-6)
+  gu.check(vd, v2, 'f32', 'sgd velocity', rtol=1e-5, atol=1e-6)
+  gu.check(ed, e2, 'f32', 'ema', rtol=1e-5, atol=1e-6)
+  # data-parallel path: scale first, then update with factor == NULL
+  gd2 = g.to(gu.DEV)
+  call('edet_opt_l2_norms', ptr(gd2), ptr(p.to(gu.DEV)), ptr(od), ptr(fd), len(sizes), wd, ptr(sq), None, gu.stream())
+  call('edet_opt_clip_factors', ptr(sq), len(sizes), clip, ptr(fac), None, gu.stream())
+  call('edet_opt_scale', ptr(gd2), ptr(od), ptr(fac), len(sizes), gu.stream())
+  torch.cuda.synchronize()
+  gu.check(gd2, g2, 'f32', 'scaled grads', rtol=1e-5, atol=1e-6)

@@ -1,0 +1,91 @@
+"""Config parser behaviour, mirroring the reference's hparams_config_test.py:27-83, plus golden
+tables generated from the reference's own module (tests/golden/make_golden.py)."""
+import json
+import os
+import tempfile
+
+import pytest
+import yaml
+
+from automl_amd import hparams_config
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden', 'reference_tables.json')
+
+
+def test_config_override():
+  c = hparams_config.Config({'a': 1, 'b': 2})
+  assert c.as_dict() == {'a': 1, 'b': 2}
+  c.update({'a': 10})
+  assert c.as_dict() == {'a': 10, 'b': 2}
+  c.b = 20
+  assert c.as_dict() == {'a': 10, 'b': 20}
+  c.override('a=true,b=ss')
+  assert c.as_dict() == {'a': True, 'b': 'ss'}
+  c.override('a=100,,,b=2.3,')  # extra ',' is fine.
+  assert c.as_dict() == {'a': 100, 'b': 2.3}
+  c.override('a=2x3,b=50')  # special format for image size.
+  assert c.as_dict() == {'a': '2x3', 'b': 50}
+  with pytest.raises(ValueError):
+    c.override('a=true,invalid_string')
+
+
+def test_config_yaml():
+  tmpdir = tempfile.gettempdir()
+  p1 = os.path.join(tmpdir, 'edet_x.yaml')
+  with open(p1, 'w') as f:
+    f.write("""
+        x: 2
+        y:
+          z: 'test'
+      """)
+  c = hparams_config.Config(dict(x=234, y=2342))
+  c.override(p1)
+  assert c.as_dict() == {'x': 2, 'y': {'z': 'test'}}
+  p2 = os.path.join(tmpdir, 'edet_y.yaml')
+  c.save_to_yaml(p2)
+  with open(p2, 'r') as f:
+    assert yaml.load(f, Loader=yaml.FullLoader) == {'x': 2, 'y': {'z': 'test'}}
+
+
+def test_config_override_recursive():
+  c = hparams_config.Config({'x': 1})
+  c.override('y.y0=2,y.y1=3', allow_new_keys=True)
+  assert c.as_dict() == {'x': 1, 'y': {'y0': 2, 'y1': 3}}
+  c.update({'y': {'y0': 5, 'y1': {'y11': 100}}})
+  assert c.as_dict() == {'x': 1, 'y': {'y0': 5, 'y1': {'y11': 100}}}
+  assert c.y.y1.y11 == 100
+
+
+def test_config_override_list():
+  c = hparams_config.Config({'x': [1.0, 2.0]})
+  c.override('x=3.0*4.0*5.0')
+  assert c.as_dict() == {'x': [3.0, 4.0, 5.0]}
+
+
+def test_unknown_key_rejected():
+  c = hparams_config.get_efficientdet_config('efficientdet-d0')
+  with pytest.raises(KeyError):
+    c.override('no_such_key=1')
+  with pytest.raises(ValueError):
+    hparams_config.get_efficientdet_config('efficientdet-d9')
+  with pytest.raises(ValueError):
+    hparams_config.get_detection_config('retinanet')
+
+
+def test_model_tables_equal_reference():
+  """Every named model's full config dict equals the dict produced by the reference module."""
+  with open(GOLDEN) as f:
+    gold = json.load(f)
+  assert len(gold['models']) == 15
+  for name, want in gold['models'].items():
+    got = json.loads(json.dumps(hparams_config.get_efficientdet_config(name).as_dict()))
+    assert got == want, name
+
+
+def test_override_strings_equal_reference():
+  with open(GOLDEN) as f:
+    gold = json.load(f)
+  for case in gold['override_cases']:
+    c = hparams_config.get_efficientdet_config('efficientdet-d0')
+    c.override(case['str'])
+    assert json.loads(json.dumps(c.as_dict())) == case['result'], case['str']

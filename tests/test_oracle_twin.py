@@ -1,0 +1,74 @@
+"""The torch oracle's ops equal an independent direct-loop numpy implementation on small shapes
+(the oracle's own validation)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import direct_loops as dl
+from oracle import efficientdet_oracle as orc
+
+
+def nchw(x):
+  return torch.from_numpy(x).permute(0, 3, 1, 2)
+
+
+def nhwc(t):
+  return t.permute(0, 2, 3, 1).numpy()
+
+
+@pytest.mark.parametrize('h,w', [(8, 8), (7, 9), (5, 4), (1, 1)])
+@pytest.mark.parametrize('k,s', [(3, 1), (3, 2), (5, 1), (5, 2), (1, 1)])
+def test_conv_and_depthwise(h, w, k, s):
+  rng = np.random.default_rng(h * 100 + w * 10 + k + s)
+  x = rng.standard_normal((2, h, w, 6)).astype(np.float32)
+  wk = rng.standard_normal((k, k, 6, 5)).astype(np.float32)
+  got = nhwc(orc.conv2d_same(nchw(x), torch.from_numpy(wk), s))
+  np.testing.assert_allclose(got, dl.conv2d_same(x, wk, s), rtol=1e-4, atol=1e-5)
+  wd = rng.standard_normal((k, k, 6)).astype(np.float32)
+  got = nhwc(orc.depthwise_same(nchw(x), torch.from_numpy(wd.reshape(k, k, 6, 1)), s))
+  np.testing.assert_allclose(got, dl.depthwise_same(x, wd, s), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('h,w', [(8, 8), (7, 9), (5, 4), (2, 3), (1, 1)])
+def test_pool_and_resize(h, w):
+  rng = np.random.default_rng(h * 10 + w)
+  x = rng.standard_normal((2, h, w, 3)).astype(np.float32) - 2.0   # negative values: padding must not win
+  np.testing.assert_array_equal(nhwc(orc.max_pool_same_3x3_s2(nchw(x))), dl.max_pool_3x3_s2_same(x))
+  for oh, ow in ((2 * h, 2 * w), (2 * h - 1, 2 * w + 1), (h, w)):
+    np.testing.assert_array_equal(nhwc(orc.resize_nearest(nchw(x), oh, ow)), dl.resize_nearest(x, oh, ow))
+
+
+def test_batchnorm_training_and_moving_stats():
+  rng = np.random.default_rng(1)
+  x = (rng.standard_normal((3, 5, 4, 8)) * 2 + 1).astype(np.float32)
+  g = rng.standard_normal(8).astype(np.float32)
+  b = rng.standard_normal(8).astype(np.float32)
+  o = orc.Oracle('efficientdet-d0', params={
+      'bn/gamma': torch.from_numpy(g), 'bn/beta': torch.from_numpy(b),
+      'bn/moving_mean': torch.zeros(8), 'bn/moving_variance': torch.ones(8)})
+  got = nhwc(o.bn(nchw(x), 'bn', True))
+  want, mean, var = dl.batch_norm_train(x, g, b)
+  np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+  n = 3 * 5 * 4
+  np.testing.assert_allclose(o.new_moving['bn/moving_mean'].numpy(), 0.01 * mean, rtol=1e-4, atol=1e-6)
+  np.testing.assert_allclose(o.new_moving['bn/moving_variance'].numpy(), 0.99 + 0.01 * var * n / (n - 1), rtol=1e-4)
+
+
+def test_swish_and_fusion():
+  x = np.linspace(-4, 4, 9)
+  np.testing.assert_allclose(orc.swish(torch.from_numpy(x)).numpy(), dl.swish(x), rtol=1e-6)
+  np.testing.assert_allclose(dl.fast_attention([np.array([1.0, 3.0])] * 2, [1.0, 1.0]), [0.99995, 2.99985],
+                             rtol=1e-6)
+
+
+def test_losses_against_closed_forms():
+  logits = torch.tensor([[0.3, -1.2, 2.0]])
+  t = torch.tensor([[1.0, 0.0, 0.0]])
+  got = orc.focal_loss(logits, t, 0.25, 1.5, 2.0).numpy()[0]
+  p = 1 / (1 + np.exp(-logits.numpy()[0]))
+  want = [0.25 * (1 - p[0])**1.5 * -np.log(p[0]) / 2, 0.75 * p[1]**1.5 * -np.log(1 - p[1]) / 2,
+          0.75 * p[2]**1.5 * -np.log(1 - p[2]) / 2]
+  np.testing.assert_allclose(got, want, rtol=1e-5)
+  e = torch.tensor([0.05, -0.1, 0.3, -2.0])
+  np.testing.assert_allclose(orc.huber(e, 0.1).numpy(), [0.00125, 0.005, 0.1 * 0.3 - 0.005, 0.1 * 2 - 0.005],
+                             rtol=1e-6)
