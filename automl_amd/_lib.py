@@ -98,6 +98,10 @@ def load():
   global _lib
   if _lib is not None:
     return _lib
+  # torch bundles its own libamdhip64.so (soname libamdhip64.so.7, the soname this library needs): it
+  # must be in the process BEFORE libedet_hip.so is dlopen'ed, otherwise the system HIP runtime gets
+  # loaded next to torch's, and the second runtime to initialise sees no device.
+  import torch  # noqa: F401
   if not os.path.exists(LIB_PATH):
     raise EdetError(
         'libedet_hip.so not found at %s: the gfx950 HIP library has not been built '
