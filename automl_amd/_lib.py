@@ -123,7 +123,7 @@ class Profiler(object):
   """Per-launch HIP-event timing on the launch stream (bench.py's roofline leg).
 
   names: None = every entry point, else a set of entry-point names to time.  Each record is
-  (name, algorithmic_bytes, start_event, end_event); events are recorded on torch's current
+  (name, algorithmic_bytes, start_event, end_event, shape_tag); events are recorded on torch's current
   stream, which is the stream every kernel of this library is launched on.
   """
 
@@ -134,16 +134,24 @@ class Profiler(object):
   def summary(self):
     """name -> (launches, total_ms, total_bytes); call after torch.cuda.synchronize()."""
     out = {}
-    for name, nbytes, s, e in self.records:
+    for name, nbytes, s, e, _ in self.records:
       n, ms, b = out.get(name, (0, 0.0, 0))
       out[name] = (n + 1, ms + s.elapsed_time(e), b + nbytes)
+    return out
+
+  def by_shape(self):
+    """(name, tag) -> (launches, total_ms, total_bytes), for the per-layer launch table."""
+    out = {}
+    for name, nbytes, s, e, tag in self.records:
+      n, ms, b = out.get((name, tag), (0, 0.0, 0))
+      out[(name, tag)] = (n + 1, ms + s.elapsed_time(e), b + nbytes)
     return out
 
 
 profiler = None
 
 
-def call(name, *args, nbytes=0):
+def call(name, *args, nbytes=0, tag=''):
   """Calls lib.<name>(*args); raises EdetError with edet_last_error() on failure."""
   lib = load()
   p = profiler
@@ -153,7 +161,7 @@ def call(name, *args, nbytes=0):
     s.record()
     rc = getattr(lib, name)(*args)
     e.record()
-    p.records.append((name, nbytes, s, e))
+    p.records.append((name, nbytes, s, e, tag))
   else:
     rc = getattr(lib, name)(*args)
   if rc != 0:

@@ -32,17 +32,47 @@ inline int persistent_grid(int64_t rows, int rpp, int max_wg) {
 }
 
 // ------------------------------------------------------------------ forward statistics finalize
-__global__ void k_bn_finalize(const float* __restrict__ partials, int nparts, int c, double count,
-                              const float* gamma, const float* beta, float eps, float momentum,
-                              float* moving_mean, float* moving_var, float* scale, float* shift,
-                              float* mean_out, float* rstd_out) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
-  double s = 0.0, s2 = 0.0;
-  for (int p = 0; p < nparts; ++p) {
-    s += (double)partials[((size_t)p * 2) * c + ch];
-    s2 += (double)partials[((size_t)p * 2 + 1) * c + ch];
+// Column sums of the [nparts][2][c] partial rows: one workgroup per 32 channels, 8 row slices per
+// channel (4 independent loads in flight per thread), fp64 accumulation, LDS tree at the end.
+constexpr int FIN_CH = 32, FIN_SL = 8;
+
+__device__ __forceinline__ void partial_colsum(const float* __restrict__ partials, int nparts, int c, int ch,
+                                               int slice, double& s, double& s2) {
+  double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+  if (ch < c) {
+    int p = slice;
+    for (; p + FIN_SL < nparts; p += 2 * FIN_SL) {
+      const float u0 = partials[((size_t)p * 2) * c + ch], v0 = partials[((size_t)p * 2 + 1) * c + ch];
+      const float u1 = partials[((size_t)(p + FIN_SL) * 2) * c + ch];
+      const float v1 = partials[((size_t)(p + FIN_SL) * 2 + 1) * c + ch];
+      a0 += (double)u0; b0 += (double)v0; a1 += (double)u1; b1 += (double)v1;
+    }
+    if (p < nparts) {
+      a0 += (double)partials[((size_t)p * 2) * c + ch];
+      b0 += (double)partials[((size_t)p * 2 + 1) * c + ch];
+    }
   }
+  __shared__ double red[2][FIN_SL][FIN_CH];
+  const int cl = threadIdx.x & (FIN_CH - 1);
+  red[0][slice][cl] = a0 + a1;
+  red[1][slice][cl] = b0 + b1;
+  __syncthreads();
+  s = 0.0; s2 = 0.0;
+  if (slice == 0) {
+#pragma unroll
+    for (int i = 0; i < FIN_SL; ++i) { s += red[0][i][cl]; s2 += red[1][i][cl]; }
+  }
+}
+
+__global__ __launch_bounds__(FIN_CH * FIN_SL) void k_bn_finalize(
+    const float* __restrict__ partials, int nparts, int c, double count, const float* gamma, const float* beta,
+    float eps, float momentum, float* moving_mean, float* moving_var, float* scale, float* shift,
+    float* mean_out, float* rstd_out) {
+  const int ch = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
+  const int slice = threadIdx.x / FIN_CH;
+  double s, s2;
+  partial_colsum(partials, nparts, c, ch, slice, s, s2);
+  if (slice != 0 || ch >= c) return;
   const double mean = s / count;
   double var = s2 / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -101,16 +131,14 @@ __global__ __launch_bounds__(THREADS) void k_bn_bwd_reduce(const T* __restrict__
   for (int i = tid; i < 2 * c; i += THREADS) partials[(size_t)blockIdx.x * 2 * c + i] = red[i];
 }
 
-__global__ void k_bn_bwd_finalize(const float* __restrict__ partials, int nparts, int c, double count,
-                                  const float* gamma, const float* mean, const float* rstd,
-                                  float* dgamma, float* dbeta, float* a, float* b, float* cc) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int p = 0; p < nparts; ++p) {
-    s1 += (double)partials[((size_t)p * 2) * c + ch];
-    s2 += (double)partials[((size_t)p * 2 + 1) * c + ch];
-  }
+__global__ __launch_bounds__(FIN_CH * FIN_SL) void k_bn_bwd_finalize(
+    const float* __restrict__ partials, int nparts, int c, double count, const float* gamma, const float* mean,
+    const float* rstd, float* dgamma, float* dbeta, float* a, float* b, float* cc) {
+  const int ch = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
+  const int slice = threadIdx.x / FIN_CH;
+  double s1, s2;
+  partial_colsum(partials, nparts, c, ch, slice, s1, s2);
+  if (slice != 0 || ch >= c) return;
   if (dbeta) dbeta[ch] += (float)s1;
   if (dgamma) dgamma[ch] += (float)s2;
   const double m1 = s1 / count, m2 = s2 / count;
@@ -229,7 +257,8 @@ __global__ __launch_bounds__(THREADS) void k_se_fc(const float* __restrict__ poo
   }
 }
 
-// per image: dgate -> dpre2, dh, dpre1, dpool.  scratch: dpre2 [n][c] then dpre1 [n][se]
+// per image: dgate -> dpre2, dh, dpre1, dpool.
+// scratch: dpre2 [n][c], dpre1 [n][se], hact = swish(hidden_pre) [n][se]
 __global__ __launch_bounds__(THREADS) void k_se_fc_bwd_img(const float* __restrict__ hidden_pre,
                                                           const float* __restrict__ gate,
                                                           const float* __restrict__ dgate, int nimg, int c,
@@ -241,6 +270,7 @@ __global__ __launch_bounds__(THREADS) void k_se_fc_bwd_img(const float* __restri
   const int n = blockIdx.x, tid = threadIdx.x;
   float* dpre2_g = scratch + (size_t)n * c;
   float* dpre1_g = scratch + (size_t)nimg * c + (size_t)n * se;
+  float* hact_g = scratch + (size_t)nimg * (c + se) + (size_t)n * se;
   for (int i = tid; i < c; i += THREADS) {
     const float g = gate[(size_t)n * c + i];
     const float v = dgate[(size_t)n * c + i] * g * (1.f - g);
@@ -248,12 +278,20 @@ __global__ __launch_bounds__(THREADS) void k_se_fc_bwd_img(const float* __restri
     dpre2_g[i] = v;
   }
   __syncthreads();
-  for (int j = tid; j < se; j += THREADS) {
+  // dh[j] = sum_i dpre2[i] * w2[j][i]: one wave per j (coalesced along i), shuffle reduction
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int j = wave; j < se; j += THREADS / 64) {
     float acc = 0.f;
-    for (int i = 0; i < c; ++i) acc = fmaf(d2[i], w2[(size_t)j * c + i], acc);
-    const float v = acc * swish_gradf_(hidden_pre[(size_t)n * se + j]);
-    d1[j] = v;
-    dpre1_g[j] = v;
+    for (int i = lane; i < c; i += 64) acc = fmaf(d2[i], w2[(size_t)j * c + i], acc);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) {
+      const float hp = hidden_pre[(size_t)n * se + j];
+      const float v = acc * swish_gradf_(hp);
+      d1[j] = v;
+      dpre1_g[j] = v;
+      hact_g[j] = swishf_(hp);
+    }
   }
   __syncthreads();
   for (int i = tid; i < c; i += THREADS) {
@@ -263,31 +301,64 @@ __global__ __launch_bounds__(THREADS) void k_se_fc_bwd_img(const float* __restri
   }
 }
 
-// parameter gradients: one thread per channel i (and per hidden unit j for db1)
-__global__ void k_se_fc_bwd_par(const float* __restrict__ pooled, const float* __restrict__ hidden_pre,
-                                const float* __restrict__ scratch, int nimg, int c, int se, float inv_hw,
-                                float* dw1, float* db1, float* dw2, float* db2) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// parameter gradients.  Workgroup = 64 channels i x 4 hidden-unit groups; thread (i, jg) owns the
+// (i, j) pairs with j % 4 == jg and sums over the images (loads coalesced along i).
+//   dw1[i][j] += sum_n pooled[n][i]*inv_hw * dpre1[n][j];  dw2[j][i] += sum_n hact[n][j] * dpre2[n][i]
+constexpr int SE_MAX_JPT = 12;  // hidden units per thread: se <= 48
+constexpr int SE_NB = 64;       // images per LDS chunk
+__global__ __launch_bounds__(THREADS) void k_se_fc_bwd_par(const float* __restrict__ pooled,
+                                                          const float* __restrict__ scratch, int nimg, int c,
+                                                          int se, float inv_hw, float* dw1, float* db1,
+                                                          float* dw2, float* db2) {
+  extern __shared__ float sm[];  // dpre1 [NB][se], hact [NB][se] for the current chunk of images
   const float* dpre2 = scratch;
-  const float* dpre1 = scratch + (size_t)nimg * c;
-  if (i < c) {
-    float sb2 = 0.f;
-    for (int n = 0; n < nimg; ++n) sb2 += dpre2[(size_t)n * c + i];
-    db2[i] += sb2;
-    for (int j = 0; j < se; ++j) {
-      float a1 = 0.f, a2 = 0.f;
-      for (int n = 0; n < nimg; ++n) {
-        a1 = fmaf(pooled[(size_t)n * c + i] * inv_hw, dpre1[(size_t)n * se + j], a1);
-        a2 = fmaf(swishf_(hidden_pre[(size_t)n * se + j]), dpre2[(size_t)n * c + i], a2);
-      }
-      dw1[(size_t)i * se + j] += a1;
-      dw2[(size_t)j * c + i] += a2;
+  const float* dpre1_g = scratch + (size_t)nimg * c;
+  const float* hact_g = scratch + (size_t)nimg * (c + se);
+  float* d1 = sm;
+  float* ha = sm + (size_t)SE_NB * se;
+  const int tid = threadIdx.x;
+  const int i = blockIdx.x * 64 + (tid & 63), jg = tid >> 6;
+  float a1[SE_MAX_JPT], a2[SE_MAX_JPT];
+#pragma unroll
+  for (int t = 0; t < SE_MAX_JPT; ++t) a1[t] = a2[t] = 0.f;
+  float sb2 = 0.f, sb1 = 0.f;
+  for (int n0 = 0; n0 < nimg; n0 += SE_NB) {
+    const int nb = min(SE_NB, nimg - n0);
+    __syncthreads();
+    for (int q = tid; q < nb * se; q += THREADS) {
+      d1[q] = dpre1_g[(size_t)n0 * se + q];
+      ha[q] = hact_g[(size_t)n0 * se + q];
     }
+    __syncthreads();
+    if (i < c) {
+      for (int n = 0; n < nb; ++n) {
+        const float pl = pooled[(size_t)(n0 + n) * c + i] * inv_hw;
+        const float d2 = dpre2[(size_t)(n0 + n) * c + i];
+        sb2 += d2;
+#pragma unroll
+        for (int t = 0; t < SE_MAX_JPT; ++t) {
+          const int j = jg + 4 * t;
+          if (j < se) {
+            a1[t] = fmaf(pl, d1[n * se + j], a1[t]);
+            a2[t] = fmaf(ha[n * se + j], d2, a2[t]);
+          }
+        }
+      }
+    }
+    if (blockIdx.x == 0 && tid < se)
+      for (int n = 0; n < nb; ++n) sb1 += d1[n * se + tid];
   }
-  if (i < se) {
-    float sb1 = 0.f;
-    for (int n = 0; n < nimg; ++n) sb1 += dpre1[(size_t)n * se + i];
-    db1[i] += sb1;
+  if (blockIdx.x == 0 && tid < se) db1[tid] += sb1;
+  if (i < c) {
+    if (jg == 0) db2[i] += sb2;
+#pragma unroll
+    for (int t = 0; t < SE_MAX_JPT; ++t) {
+      const int j = jg + 4 * t;
+      if (j < se) {
+        dw1[(size_t)i * se + j] += a1[t];
+        dw2[(size_t)j * c + i] += a2[t];
+      }
+    }
   }
 }
 
@@ -353,7 +424,7 @@ extern "C" int edet_bn_finalize(const float* partials, int nparts, int c, double
                                 float* moving_mean, float* moving_var, float* scale, float* shift,
                                 float* mean, float* rstd, void* stream) {
   EDET_CHECK(partials && gamma && beta && scale && shift && mean && rstd, "edet_bn_finalize: null pointer");
-  k_bn_finalize<<<cdiv(c, 128), 128, 0, to_stream(stream)>>>(partials, nparts, c, count, gamma, beta, eps,
+  k_bn_finalize<<<cdiv(c, FIN_CH), FIN_CH * FIN_SL, 0, to_stream(stream)>>>(partials, nparts, c, count, gamma, beta, eps,
                                                             momentum, moving_mean, moving_var, scale, shift,
                                                             mean, rstd);
   EDET_LAUNCH_CHECK("edet_bn_finalize");
@@ -393,7 +464,7 @@ extern "C" int edet_bn_bwd_finalize(const float* partials, int nparts, int c, do
                                     float* a, float* b, float* cc, void* stream) {
   EDET_CHECK(partials && gamma && mean && rstd && a && b && cc, "edet_bn_bwd_finalize: null pointer");
   (void)dbias;  // d(bias before BatchNorm) is analytically zero: BN removes the mean
-  k_bn_bwd_finalize<<<cdiv(c, 128), 128, 0, to_stream(stream)>>>(partials, nparts, c, count, gamma, mean, rstd,
+  k_bn_bwd_finalize<<<cdiv(c, FIN_CH), FIN_CH * FIN_SL, 0, to_stream(stream)>>>(partials, nparts, c, count, gamma, mean, rstd,
                                                                 dgamma, dbeta, a, b, cc);
   EDET_LAUNCH_CHECK("edet_bn_bwd_finalize");
   return 0;
@@ -462,9 +533,9 @@ extern "C" int edet_se_fc_bwd(const float* pooled_sum, const float* hidden_pre, 
                               float* dpool, float* scratch, void* stream) {
   EDET_CHECK(pooled_sum && hidden_pre && gate && dgate && w1 && w2 && dw1 && db1 && dw2 && db2 && dpool && scratch,
              "edet_se_fc_bwd: null pointer");
+  EDET_CHECK(se <= 4 * SE_MAX_JPT, "edet_se_fc_bwd: se %d > %d unsupported", se, 4 * SE_MAX_JPT);
   k_se_fc_bwd_img<<<n, THREADS, (size_t)(c + se) * sizeof(float), to_stream(stream)>>>(hidden_pre, gate, dgate, n, c, se, inv_hw, w1, w2, dpool, scratch);
-  const int tot = c > se ? c : se;
-  k_se_fc_bwd_par<<<cdiv(tot, 64), 64, 0, to_stream(stream)>>>(pooled_sum, hidden_pre, scratch, n, c, se, inv_hw, dw1, db1, dw2, db2);
+  k_se_fc_bwd_par<<<cdiv(c, 64), THREADS, (size_t)2 * SE_NB * se * sizeof(float), to_stream(stream)>>>(pooled_sum, scratch, n, c, se, inv_hw, dw1, db1, dw2, db2);
   EDET_LAUNCH_CHECK("edet_se_fc_bwd");
   return 0;
 }

@@ -409,9 +409,10 @@ size_t plan(DwArgs& a, int which, int k, int s, int n, int space_h, int space_w,
   a.tiles_x = cdiv(space_w, a.tw);
   a.nchunks = cdiv(C, a.cc);
   a.nsp = n * a.tiles_y * a.tiles_x;
-  int P = MAXP;
-  const int cap = 2048 / a.nchunks > 0 ? 2048 / a.nchunks : 1;
-  if (P > cap) P = cap;
+  // ~4096 workgroups in flight per launch (256 CUs x several per CU); P <= EDET_MAX_PARTS partial rows
+  int P = 4096 / a.nchunks;
+  if (P < MAXP) P = MAXP;
+  if (P > EDET_MAX_PARTS) P = EDET_MAX_PARTS;
   if (P > a.nsp) P = a.nsp;
   a.P = P;
   size_t elems;

@@ -18,13 +18,12 @@ inline RowMap row_map_ld(int ld) {
   return m;
 }
 
-__device__ __forceinline__ float softplusf_(float u) {
-  // log(1 + exp(u)), stable
-  return fmaxf(u, 0.f) + log1pf(__expf(-fabsf(u)));
-}
-
-// logits [positions][ld], channel j = anchor * num_classes + class
-template <typename T>
+// logits [positions][ld], channel j = anchor * num_classes + class.
+// Per element (train_lib.py:357-406 with label_smoothing 0): u = +-x, 1 - p_t = sigmoid(u),
+// ce = softplus(u); loss = alpha_t * sigmoid(u)^gamma * softplus(u) / normalizer.  One exp, one rcp,
+// one log and one sqrt (gamma = 1.5) or exp2/log2 pair (general gamma) per logit; the anchor index is
+// advanced incrementally along the 8-wide chunk, so there is one integer division per 16 bytes.
+template <typename T, bool G15>
 __global__ __launch_bounds__(THREADS) void k_focal(const T* __restrict__ logits, int ld,
                                                   const int32_t* __restrict__ tgt, int64_t positions,
                                                   int na, int nc, float alpha, float gamma, float inv_norm,
@@ -34,6 +33,7 @@ __global__ __launch_bounds__(THREADS) void k_focal(const T* __restrict__ logits,
   const int j0 = cv * 8;
   const int nch = na * nc;
   const bool ok = j0 < ld;
+  const int a0 = j0 / nc, k0 = j0 - a0 * nc;
   float loss_acc = 0.f, db[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) db[e] = 0.f;
@@ -41,27 +41,31 @@ __global__ __launch_bounds__(THREADS) void k_focal(const T* __restrict__ logits,
     for (int64_t p = (int64_t)blockIdx.x * m.rpp + rr; p < positions; p += (int64_t)gridDim.x * m.rpp) {
       float x[8], g[8];
       load8<T>(logits + p * ld + j0, x);
+      int a = a0, k = k0;
+      int t = a < na ? tgt[p * na + a] : -2;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int j = j0 + e;
         g[e] = 0.f;
-        if (j < nch) {
-          const int a = j / nc, k = j - a * nc;
-          const int t = tgt[p * na + a];
-          if (t != -2) {
-            const bool pos = (t == k);
-            const float u = pos ? -x[e] : x[e];   // 1 - p_t = sigmoid(u), ce = softplus(u)
-            const float sg = sigmoidf_(u);
-            const float sp = softplusf_(u);
-            const float af = pos ? alpha : 1.f - alpha;
-            const float mod = __powf(sg, gamma);
-            loss_acc += af * mod * sp * inv_norm;
-            // d/du [sg^gamma * softplus(u)] = sg^gamma * (gamma*(1-sg)*sp + sg)
-            const float dldu = af * mod * (gamma * (1.f - sg) * sp + sg) * inv_norm;
-            g[e] = pos ? -dldu : dldu;
-          }
+        if (j0 + e < nch && t != -2) {
+          const bool pos = (t == k);
+          const float u = pos ? -x[e] : x[e];
+          const float ex = __expf(-fabsf(u));
+          const float inv = __frcp_rn(1.f + ex);
+          const float sg = u >= 0.f ? inv : ex * inv;          // sigmoid(u) = 1 - p_t
+          const float sp = fmaxf(u, 0.f) + __logf(1.f + ex);   // softplus(u) = cross entropy
+          const float af = pos ? alpha : 1.f - alpha;
+          const float mod = G15 ? sg * __fsqrt_rn(sg) : __powf(sg, gamma);
+          loss_acc = fmaf(af * mod, sp * inv_norm, loss_acc);
+          // d/du [sg^gamma * softplus(u)] = sg^gamma * (gamma*(1-sg)*sp + sg)
+          const float dldu = af * mod * fmaf(gamma * (1.f - sg), sp, sg) * inv_norm;
+          g[e] = pos ? -dldu : dldu;
         }
         db[e] += g[e];
+        if (++k == nc) {
+          k = 0;
+          ++a;
+          t = a < na ? tgt[p * na + a] : -2;
+        }
       }
       store8<T>(dlogits + p * ld + j0, g);
     }
@@ -230,16 +234,20 @@ extern "C" int edet_focal_loss(const void* logits, int ld, const int32_t* cls_ta
                                void* dlogits, float* dbias, float* sums, int dtype, void* stream) {
   EDET_CHECK(logits && cls_targets && dlogits && sums, "edet_focal_loss: null pointer");
   EDET_CHECK(ld % 8 == 0 && ld >= num_anchors * num_classes && ld <= 2048, "edet_focal_loss: bad ld %d", ld);
+  EDET_CHECK(num_classes >= 1, "edet_focal_loss: num_classes must be positive");
   const RowMap m = row_map_ld(ld);
   int64_t g = (positions + m.rpp - 1) / m.rpp;
   g = (g + 3) / 4;
-  if (g > 2048) g = 2048;
+  if (g > 4096) g = 4096;
   if (g < 1) g = 1;
   const size_t lds = (size_t)ld * sizeof(float);
-  if (dtype == EDET_BF16)
-    k_focal<bf16_t><<<(int)g, THREADS, lds, to_stream(stream)>>>((const bf16_t*)logits, ld, cls_targets, positions, num_anchors, num_classes, alpha, gamma, inv_normalizer, (bf16_t*)dlogits, dbias, sums, m);
-  else if (dtype == EDET_F32)
-    k_focal<float><<<(int)g, THREADS, lds, to_stream(stream)>>>((const float*)logits, ld, cls_targets, positions, num_anchors, num_classes, alpha, gamma, inv_normalizer, (float*)dlogits, dbias, sums, m);
+  const bool g15 = gamma == 1.5f;
+#define FOCAL_LAUNCH(T, G)                                                                            \
+  k_focal<T, G><<<(int)g, THREADS, lds, to_stream(stream)>>>((const T*)logits, ld, cls_targets, positions, \
+      num_anchors, num_classes, alpha, gamma, inv_normalizer, (T*)dlogits, dbias, sums, m)
+  if (dtype == EDET_BF16) { if (g15) FOCAL_LAUNCH(bf16_t, true); else FOCAL_LAUNCH(bf16_t, false); }
+  else if (dtype == EDET_F32) { if (g15) FOCAL_LAUNCH(float, true); else FOCAL_LAUNCH(float, false); }
+#undef FOCAL_LAUNCH
   else EDET_CHECK(false, "edet_focal_loss: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_focal_loss");
   return 0;

@@ -38,6 +38,150 @@ __device__ __forceinline__ void stage_image_tile(const StemArgs& a, int n, int i
   }
 }
 
+// ---- bf16 forward on the matrix cores ------------------------------------------------------------
+// im2col GEMM with K = 27 (padded to 32), computed transposed so that every lane ends up with
+// contiguous channels of ONE pixel:  D'[channel][pixel] = sum_k W[k][channel] * patch[pixel][k].
+//   A' fragment (weights):  lane l -> channel (l & 31), k = 8*(l>>5) + 16*ks + e      (registers, loaded once)
+//   B' fragment (im2col):   lane l -> pixel   (l & 31), same k; k = ky*9 + r indexes 9 contiguous
+//                           input elements (3 pixels x 3 channels) of input row 2*oy + ky.
+// Workgroup tile = 2 output rows x 64 pixels (wave w: row w>>1, pixels (w&1)*32..+32); the 5 x 129
+// pixel input patch is staged once in LDS as raw bf16.  HBM traffic = image read once + output written
+// once (16-byte chunks per lane); BatchNorm statistic partials come from the rounded stored values.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+constexpr int MPX = 64;                      // pixels per tile row
+constexpr int MROWS = 2;                     // output rows per tile
+constexpr int MIW = (MPX - 1) * 2 + 3;       // 129 input pixels
+constexpr int MIH = (MROWS - 1) * 2 + 3;     // 5 input rows
+constexpr int MROWP = MIW * 3 + 5;           // 392 elements per LDS row
+constexpr int MZERO = MIH * MROWP;           // index of an always-zero element
+
+template <int NCT>  // channel tiles of 32
+__global__ __launch_bounds__(THREADS) void k_stem_fwd_mfma(const StemArgs a) {
+  __shared__ __align__(16) bf16_t tile[MIH * MROWP + 8];
+  __shared__ float red[2 * 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const int cout = a.cout;
+  const bool want_stats = a.stat_partials != nullptr;
+  const bf16_t* img = reinterpret_cast<const bf16_t*>(a.img);
+  bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
+
+  // weight fragments and the 16 LDS gather offsets of this lane
+  bf16x8 wf[NCT][2];
+  int goff[2][8];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 8 * h + 16 * ks + e;
+      const int ky = k / 9, r = k - ky * 9;
+      goff[ks][e] = k < 27 ? ky * MROWP + r : -1;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const int ch = ct * 32 + j;
+        const float w = (k < 27 && ch < cout) ? a.wgt[k * cout + ch] : 0.f;
+        wf[ct][ks][e] = (__bf16)w;
+      }
+    }
+  float s1[NCT][16], s2[NCT][16];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s1[ct][t] = s2[ct][t] = 0.f;
+  for (int i = tid; i < 2 * 64; i += THREADS) red[i] = 0.f;
+  if (tid < 8) tile[MZERO + tid] = 0;
+
+  const int wr = wave >> 1, wx = (wave & 1) * 32 + j;   // this lane's pixel inside the tile
+  for (int sp = blockIdx.x; sp < a.nsp; sp += a.P) {
+    const int per_img = a.tiles_y * a.tiles_x;
+    const int n = sp / per_img, rr = sp - n * per_img;
+    const int oy0 = (rr / a.tiles_x) * MROWS, ox0 = (rr % a.tiles_x) * MPX;
+    const int iy0 = oy0 * 2 - a.pad_t, ix3 = (ox0 * 2 - a.pad_l) * 3;
+    __syncthreads();
+    for (int q = tid; q < MIH * MIW * 3; q += THREADS) {
+      const int ly = q / (MIW * 3), r = q - ly * (MIW * 3);
+      const int gy = iy0 + ly, gx3 = ix3 + r;
+      bf16_t v = 0;
+      if (gy >= 0 && gy < a.h && gx3 >= 0 && gx3 < a.w * 3) v = img[(size_t)(n * a.h + gy) * a.w * 3 + gx3];
+      tile[ly * MROWP + r] = v;
+    }
+    __syncthreads();
+    const int base = (2 * wr) * MROWP + wx * 6;
+    bf16x8 bfrag[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      s16x8 raw;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) raw[e] = (short)tile[goff[ks][e] >= 0 ? base + goff[ks][e] : MZERO];
+      bfrag[ks] = __builtin_bit_cast(bf16x8, raw);
+    }
+    const int oy = oy0 + wr, ox = ox0 + wx;
+    const bool pix_ok = oy < a.oh && ox < a.ow;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      f32x16 acc;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ct][0], bfrag[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ct][1], bfrag[1], acc, 0, 0, 0);
+      // lane (pixel j, half h) holds channels (t&3) + 8*(t>>2) + 4*h.  Exchange 4-channel groups with the
+      // other half so that each lane owns two runs of 8 contiguous channels:
+      //   h = 0: ch 0-7 and 16-23;  h = 1: ch 8-15 and 24-31   (relative to ct*32)
+      float v[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) v[t] = acc[t];
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int lo_reg = half * 8 + 4 + i, hi_reg = half * 8 + i;
+          const float give = h == 0 ? v[lo_reg] : v[hi_reg];
+          const float got = __shfl_xor(give, 32, 64);
+          if (h == 0) v[lo_reg] = got; else v[hi_reg] = got;
+        }
+#pragma unroll
+      for (int run = 0; run < 2; ++run) {
+        const int ch0 = ct * 32 + run * 16 + h * 8;
+        if (pix_ok && ch0 < cout) {
+          uint4 pk;
+          pk.x = pack2bf(v[run * 8 + 0], v[run * 8 + 1]);
+          pk.y = pack2bf(v[run * 8 + 2], v[run * 8 + 3]);
+          pk.z = pack2bf(v[run * 8 + 4], v[run * 8 + 5]);
+          pk.w = pack2bf(v[run * 8 + 6], v[run * 8 + 7]);
+          *reinterpret_cast<uint4*>(out + ((size_t)(n * a.oh + oy) * a.ow + ox) * a.ldo + ch0) = pk;
+          if (want_stats) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float r = bf2f(f2bf(v[run * 8 + e]));
+              s1[ct][run * 8 + e] += r;
+              s2[ct][run * 8 + e] += r * r;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (want_stats) {
+    // reduce over the 32 pixel lanes of each half, then over the 4 waves through LDS
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        float u = s1[ct][t], w = s2[ct][t];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) { u += __shfl_down(u, off, 64); w += __shfl_down(w, off, 64); }
+        const int ch = ct * 32 + (t >> 3) * 16 + h * 8 + (t & 7);
+        if (j == 0 && ch < cout) { atomicAdd(&red[ch], u); atomicAdd(&red[64 + ch], w); }
+      }
+    __syncthreads();
+    for (int i = tid; i < 2 * cout; i += THREADS) {
+      const int which = i / cout, c = i - which * cout;
+      a.stat_partials[(size_t)blockIdx.x * 2 * cout + i] = red[which * 64 + c];
+    }
+  }
+}
+
+// ---- fp32 (validation) forward: one output pixel per thread, direct VALU convolution --------------
 template <typename T, int CV>  // CV = cout / 8
 __global__ __launch_bounds__(THREADS) void k_stem_fwd(const StemArgs a) {
   constexpr int CO = CV * 8;
@@ -92,7 +236,6 @@ __global__ __launch_bounds__(THREADS) void k_stem_fwd(const StemArgs a) {
     }
   }
   if (want_stats) {
-    // wave-level reduction first (64 lanes), then LDS atomics from lane 0
 #pragma unroll
     for (int c = 0; c < CO; ++c) {
       float u = s1[c], v = s2[c];
@@ -197,6 +340,17 @@ __global__ void k_cast_matrix(const float* __restrict__ src, T* __restrict__ dst
 
 template <typename T>
 int stem_launch(bool fwd, StemArgs& a, hipStream_t st) {
+  if (fwd && sizeof(T) == 2) {
+    a.tiles_y = cdiv(a.oh, MROWS);
+    a.tiles_x = cdiv(a.ow, MPX);
+    a.nsp = a.n * a.tiles_y * a.tiles_x;
+    a.P = a.nsp < EDET_MAX_PARTS ? a.nsp : EDET_MAX_PARTS;
+    EDET_CHECK(a.cout <= 64, "stem: cout %d unsupported (need <= 64)", a.cout);
+    if (a.cout <= 32) k_stem_fwd_mfma<1><<<dim3(a.P), dim3(THREADS), 0, st>>>(a);
+    else k_stem_fwd_mfma<2><<<dim3(a.P), dim3(THREADS), 0, st>>>(a);
+    EDET_LAUNCH_CHECK("edet_stem_fwd");
+    return 0;
+  }
   a.tiles_y = cdiv(a.oh, TH);
   a.tiles_x = cdiv(a.ow, TW);
   a.nsp = a.n * a.tiles_y * a.tiles_x;
@@ -204,8 +358,11 @@ int stem_launch(bool fwd, StemArgs& a, hipStream_t st) {
   const dim3 grid(a.P), block(THREADS);
 #define STEM_CASE(CV)                                                   \
   case CV:                                                              \
-    if (fwd) k_stem_fwd<T, CV><<<grid, block, 0, st>>>(a);              \
-    else k_stem_bwd_weight<T, CV><<<grid, block, 0, st>>>(a);           \
+    if (fwd) {                                                          \
+      if constexpr (sizeof(T) == 4) k_stem_fwd<T, CV><<<grid, block, 0, st>>>(a); \
+    } else {                                                            \
+      k_stem_bwd_weight<T, CV><<<grid, block, 0, st>>>(a);              \
+    }                                                                   \
     break;
   switch (a.cout / 8) {
     STEM_CASE(4) STEM_CASE(5) STEM_CASE(6) STEM_CASE(7) STEM_CASE(8)

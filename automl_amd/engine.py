@@ -292,7 +292,7 @@ class Engine(object):
     stats = ptr(self.partials) if (bnl and self.training) else None
     call('edet_pw_fwd', ctypes.byref(vin.tview()), ptr(wt), ldk, ptr(self.param(bias)) if bias else None,
          ptr(out.data), cout, out.ld, stats, ctypes.byref(self._nparts), self.dtype, self.stream,
-         nbytes=r.rows * (cin + cout) * self.esize)
+         nbytes=r.rows * (cin + cout) * self.esize, tag='%dx%dx%d->%d' % (r.h, r.w, cin, cout))
     if bnl:
       self._bn_forward(bnl, out.rows, self._nparts.value)
     vout = View(out, bnl, act)
@@ -304,13 +304,14 @@ class Engine(object):
   def _pw_bwd(self, vin, vout, wname, w, ldn):
     g = self._gview(vout)
     nb = vin.raw.rows * (vin.raw.c + vout.raw.c) * self.esize
+    tag = '%dx%dx%d->%d' % (vin.raw.h, vin.raw.w, vin.raw.c, vout.raw.c)
     call('edet_pw_bwd_weight', ctypes.byref(vin.tview()), ctypes.byref(g), ptr(self.grad(wname)),
-         self.dtype, self.stream, nbytes=nb)
+         self.dtype, self.stream, nbytes=nb, tag=tag)
     if vin.raw.needs_grad:
       dgate = vin.dgate if vin.gate is not None else None
       epi, fused = self._epi(vin, dgate)
       call('edet_pw_bwd_data', ctypes.byref(g), ptr(w), ldn, ctypes.byref(vin.tview()), ctypes.byref(epi),
-           ctypes.byref(self._nparts), self.dtype, self.stream, nbytes=nb)
+           ctypes.byref(self._nparts), self.dtype, self.stream, nbytes=nb, tag=tag)
       vin.raw.grad_written = True
       if fused:
         self._bn_bwd_finalize(vin.bn, self._nparts.value)
@@ -324,7 +325,8 @@ class Engine(object):
     stats = ptr(self.partials) if (bnl and self.training) else None
     wp = ptr(self.param(wname))
     call('edet_dw_fwd', ctypes.byref(vin.tview()), wp, k, stride, ptr(out.data), out.ld, stats,
-         ctypes.byref(self._nparts), self.dtype, self.stream, nbytes=(r.rows + out.rows) * r.c * self.esize)
+         ctypes.byref(self._nparts), self.dtype, self.stream, nbytes=(r.rows + out.rows) * r.c * self.esize,
+         tag='%dx%dx%d k%ds%d' % (r.h, r.w, r.c, k, stride))
     if bnl:
       self._bn_forward(bnl, out.rows, self._nparts.value)
     vout = View(out, bnl, act)
@@ -336,12 +338,13 @@ class Engine(object):
   def _dw_bwd(self, vin, vout, wname, k, stride):
     g = self._gview(vout)
     nb = (vin.raw.rows + vout.raw.rows) * vin.raw.c * self.esize
+    tag = '%dx%dx%d k%ds%d' % (vin.raw.h, vin.raw.w, vin.raw.c, k, stride)
     call('edet_dw_bwd_weight', ctypes.byref(vin.tview()), ctypes.byref(g), k, stride, ptr(self.grad(wname)),
-         self.dtype, self.stream, nbytes=nb)
+         self.dtype, self.stream, nbytes=nb, tag=tag)
     if vin.raw.needs_grad:
       epi, fused = self._epi(vin)
       call('edet_dw_bwd_data', ctypes.byref(g), ptr(self.param(wname)), k, stride, ctypes.byref(vin.tview()),
-           ctypes.byref(epi), ctypes.byref(self._nparts), self.dtype, self.stream, nbytes=nb)
+           ctypes.byref(epi), ctypes.byref(self._nparts), self.dtype, self.stream, nbytes=nb, tag=tag)
       vin.raw.grad_written = True
       if fused:
         self._bn_bwd_finalize(vin.bn, self._nparts.value)
@@ -365,7 +368,7 @@ class Engine(object):
     v.consumers += 1
     if self.training:
       dpool = self.buf(key + ':dpool', (n, c), torch.float32)
-      scratch = self.buf(key + ':scr', (n * (c + se_filters),), torch.float32)
+      scratch = self.buf(key + ':scr', (n * (c + 2 * se_filters),), torch.float32)
 
       def bwd():
         call('edet_se_fc_bwd', ptr(pooled), ptr(hidden), ptr(gate), ptr(vg.dgate), n, c, se_filters, inv_hw,

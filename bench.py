@@ -97,6 +97,7 @@ def main():
   ap.add_argument('--model', default='efficientdet-d0')
   ap.add_argument('--dtype', default='bf16')
   ap.add_argument('--no_cpu_baseline', action='store_true')
+  ap.add_argument('--dump_launches', default='', help='write the per-(kernel, shape) launch table of one step here')
   args = ap.parse_args()
 
   rank = int(os.environ.get('RANK', '0'))
@@ -131,6 +132,14 @@ def main():
   step()
   torch.cuda.synchronize()
   full = _lib.profiler.summary()
+  if args.dump_launches and rank == 0:
+    rows = sorted(_lib.profiler.by_shape().items(), key=lambda kv: -kv[1][1])
+    with open(args.dump_launches, 'w') as f:
+      f.write('%-22s %-22s %5s %10s %10s %9s\n' % ('entry point', 'shape', 'calls', 'total_ms', 'MB/call', 'GB/s'))
+      for (name, tag), (n, ms, b) in rows:
+        f.write('%-22s %-22s %5d %10.3f %10.1f %9.1f\n' % (name, tag, n, ms, b / n / 1e6,
+                                                            b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0))
+      f.write('TOTAL kernel ms %.3f\n' % sum(v[1] for v in full.values()))
   _lib.profiler = None
   dominant = max(full.items(), key=lambda kv: kv[1][1])[0]
   kernel_ms_total = sum(v[1] for v in full.values())

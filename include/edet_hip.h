@@ -184,7 +184,8 @@ int edet_se_pool(const edet_tview_t* in, float* pooled_sum, int dtype, void* str
 int edet_se_fc(const float* pooled_sum, int n, int c, int se, float inv_hw,
                const float* w1, const float* b1, const float* w2, const float* b2,
                float* hidden_pre, float* gate, void* stream);
-/* dgate [n,c] -> dpool [n,c] (already divided by H*W), parameter gradients */
+/* dgate [n,c] -> dpool [n,c] (already divided by H*W), parameter gradients.
+ * scratch: caller-owned fp32 workspace of n*(c + 2*se) elements; se <= 48.  */
 int edet_se_fc_bwd(const float* pooled_sum, const float* hidden_pre, const float* gate,
                    const float* dgate, int n, int c, int se, float inv_hw,
                    const float* w1, const float* w2,

@@ -328,8 +328,15 @@ def test_stem(dt, shape):
   torch.cuda.synchronize()
   gu.check(od, out, name, 'stem_fwd %s' % (shape,))
   s1, s2 = gu.sum_partials(parts, npart.value, co)
-  gu.check(s2, (out * out).sum((0, 1, 2)), name, 'stem sumsq', rtol=1e-3)
-  gu.check(s1, out.sum((0, 1, 2)), name, 'stem sum', rtol=1e-3, atol=1e-3 * n * oh * ow, scale_by_max=False)
+  # the statistics must describe the tensor that was actually stored (what the consumers will read) ...
+  odf = od.float().cpu()
+  gu.check(s2, (odf * odf).sum((0, 1, 2)), name, 'stem sumsq vs stored output', rtol=1e-3)
+  gu.check(s1, odf.sum((0, 1, 2)), name, 'stem sum vs stored output', rtol=1e-3, atol=1e-3 * n * oh * ow,
+           scale_by_max=False)
+  # ... and agree with the oracle up to the compute dtype (the bf16 path rounds the weights to bf16)
+  srt = 1e-3 if name == 'f32' else 1e-2
+  gu.check(s2, (out * out).sum((0, 1, 2)), name, 'stem sumsq', rtol=srt)
+  gu.check(s1, out.sum((0, 1, 2)), name, 'stem sum', rtol=srt, atol=srt * n * oh * ow, scale_by_max=False)
   dzd, yd = gu.to_dev(dz, tdt), gu.to_dev(y, tdt)
   gv = gu.gview(dzd, co, yd, ga, gb, gcc)
   dwd = torch.zeros(3, 3, 3, co, dtype=torch.float32, device=gu.DEV)
@@ -440,7 +447,7 @@ def test_squeeze_excite(dt, shape):
   dgate = gu.fdev((dout * a.detach()).sum((1, 2)))
   grads = [torch.zeros_like(t) for t in (w1d, b1d, w2d, b2d)]
   dpool = torch.zeros(n, c, dtype=torch.float32, device=gu.DEV)
-  scratch = torch.zeros(n * (c + se), dtype=torch.float32, device=gu.DEV)
+  scratch = torch.zeros(n * (c + 2 * se), dtype=torch.float32, device=gu.DEV)
   call('edet_se_fc_bwd', ptr(pd), ptr(hd), ptr(gd), ptr(dgate), n, c, se, 1.0 / (h * w), ptr(w1d), ptr(w2d),
        ptr(grads[0]), ptr(grads[1]), ptr(grads[2]), ptr(grads[3]), ptr(dpool), ptr(scratch), gu.stream())
   parts = partial_buf(c)
