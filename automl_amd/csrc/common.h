@@ -32,15 +32,15 @@ void edet_set_error(const char* fmt, ...);
 
 // ---------------------------------------------------------------- scalar conversions
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even fp32 -> bf16 (NaN stays NaN)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even fp32 -> bf16: gfx950 has v_cvt_pk_bf16_f32, which the compiler selects for a
+// plain float -> __bf16 conversion (one instruction per two elements)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  bf16x2_t v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(uint32_t, v);
 }
 
 template <typename T> __device__ __forceinline__ float to_f(T v);
@@ -102,7 +102,8 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const floa
 }
 
 // ---------------------------------------------------------------- activations
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each); a full-precision divide would cost ~10 more VALU instructions
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
 // d/dx x*sigmoid(x) = s * (1 + x * (1 - s))
 __device__ __forceinline__ float swish_gradf_(float x) {

@@ -636,6 +636,13 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// streaming bf16 kernels (pw_stream.hip); return 1 = handled, 0 = shape outside their envelope
+int pws_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bias, void* out, int cout,
+                int ldo, float* stat_partials, int* nparts_out, hipStream_t st);
+
+int pws_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tview_t* in,
+                  const edet_bwd_epi_t* epi, int* nparts_out, hipStream_t st);
+
 extern "C" int edet_pw_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bias,
                            void* out, int cout, int ldo, float* stat_partials, int* nparts_out,
                            int dtype, void* stream) {
@@ -650,7 +657,11 @@ extern "C" int edet_pw_fwd(const edet_tview_t* in, const void* wt, int ldw, cons
   a.Bm = wt; a.ldb = ldw;
   a.M = in->n * in->h * in->w; a.R = in->c; a.J = cout; a.hw = in->h * in->w;
   a.bias = bias; a.out = out; a.ldo = ldo; a.stat_partials = stat_partials;
-  if (dtype == EDET_BF16) return launch_gemm<bf16_t, false>(a, nparts_out, to_stream(stream));
+  if (dtype == EDET_BF16) {
+    const int rc = pws_try_fwd(in, wt, ldw, bias, out, cout, ldo, stat_partials, nparts_out, to_stream(stream));
+    if (rc != 0) return rc < 0 ? rc : 0;
+    return launch_gemm<bf16_t, false>(a, nparts_out, to_stream(stream));
+  }
   if (dtype == EDET_F32) return launch_gemm<float, false>(a, nparts_out, to_stream(stream));
   EDET_CHECK(false, "edet_pw_fwd: bad dtype %d", dtype);
 }
@@ -669,13 +680,20 @@ extern "C" int edet_pw_bwd_data(const edet_gview_t* dy, const void* w, int ldw,
   a.Bm = w; a.ldb = ldw;
   a.M = in->n * in->h * in->w; a.R = dy->c; a.J = in->c; a.hw = in->h * in->w;
   a.epi = *epi; a.stat_partials = epi->stat_partials;
-  if (dtype == EDET_BF16) return launch_gemm<bf16_t, true>(a, nparts_out, to_stream(stream));
+  if (dtype == EDET_BF16) {
+    const int rc = pws_try_dgrad(dy, w, ldw, in, epi, nparts_out, to_stream(stream));
+    if (rc != 0) return rc < 0 ? rc : 0;
+    return launch_gemm<bf16_t, true>(a, nparts_out, to_stream(stream));
+  }
   if (dtype == EDET_F32) return launch_gemm<float, true>(a, nparts_out, to_stream(stream));
   EDET_CHECK(false, "edet_pw_bwd_data: bad dtype %d", dtype);
 }
 
+int pws_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight, void* workspace,
+                  size_t workspace_bytes, hipStream_t st);
+
 extern "C" int edet_pw_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy, float* dweight,
-                                  int dtype, void* stream) {
+                                  void* workspace, size_t workspace_bytes, int dtype, void* stream) {
   EDET_CHECK(in && in->data && dy && dy->dz && dweight, "edet_pw_bwd_weight: null pointer");
   EDET_CHECK(in->c % 8 == 0 && in->ld % 8 == 0 && dy->ld % 8 == 0, "edet_pw_bwd_weight: strides % 8");
   WgradArgs a;
@@ -683,7 +701,11 @@ extern "C" int edet_pw_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy
   a.tv = *in; a.gv = *dy;
   a.M = in->n * in->h * in->w; a.hw = in->h * in->w;
   a.dw = dweight;
-  if (dtype == EDET_BF16) return launch_wgrad<bf16_t>(a, to_stream(stream));
+  if (dtype == EDET_BF16) {
+    const int rc = pws_try_wgrad(in, dy, dweight, workspace, workspace_bytes, to_stream(stream));
+    if (rc != 0) return rc < 0 ? rc : 0;
+    return launch_wgrad<bf16_t>(a, to_stream(stream));
+  }
   if (dtype == EDET_F32) return launch_wgrad<float>(a, to_stream(stream));
   EDET_CHECK(false, "edet_pw_bwd_weight: bad dtype %d", dtype);
 }

@@ -1,0 +1,1000 @@
+// Streaming pointwise (1x1) convolution kernels for the bf16 path on gfx950 (wave64, MFMA 32x32x16).
+//
+// The pointwise convolutions of EfficientDet are tall-skinny GEMMs (M = N*H*W rows up to 13.1 M,
+// K, N <= a few hundred channels): 25-100 FLOP/B, i.e. HBM-bound on MI355X.  The structure below is
+// therefore built around the memory stream, not around the matrix cores:
+//
+//   * one wave owns a CONTIGUOUS range of 32-row tiles and never synchronises with the other waves of
+//     its workgroup inside the main loop (no __syncthreads between loads and MFMAs): 16 waves per CU
+//     with independent load -> transform -> MFMA -> store chains hide HBM latency by themselves;
+//   * the big operand is read once, in whole rows, 16 bytes per lane ("fixed-column" mapping: lane ->
+//     (row r0 + lane / chunks_per_row, channel chunk lane % chunks_per_row), so the per-channel
+//     BatchNorm / swish coefficients of the producing layer live in registers), transformed to the
+//     activated bf16 value and staged in a wave-private LDS tile; the MFMA B' fragments (8 consecutive
+//     k of one row) are ds_read_b128 from there;
+//   * the small operand (weights, <= ~100 KB) sits in workgroup-shared LDS for the whole kernel;
+//   * the product is computed transposed, D'[out channel][row], so that after the accumulator ->
+//     LDS round trip every lane stores 16 contiguous bytes of one row (fully coalesced writes);
+//   * BatchNorm statistic partials (sum, sum of squares) are taken from the ROUNDED values that were
+//     stored, column-wise from the LDS tile, one partial row per workgroup.
+//
+// Reference call sites replaced: tf.keras.layers.Conv2D 1x1 in efficientdet/backbone/efficientnet_model.py
+// :304-312 (expand), :345-353 (project); efficientdet/tf2/efficientdet_keras.py:286-290 (resample 1x1)
+// and the pointwise half of SeparableConv2D (:195-207, :459-464, :546-556).
+#include "common.h"
+
+namespace pws {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int THREADS = 256;
+constexpr int WAVES = 4;
+constexpr int TR = 32;        // rows per wave tile
+constexpr int NCC = 64;       // output channels per LDS C tile (2 MFMA tiles)
+constexpr int PB = 8;         // row passes whose loads are issued back to back
+
+// Fixed-column mapping of a [32 rows][nvec 16-byte chunks] tile onto the 64 lanes of a wave.
+struct ColMap {
+  int nvec;   // chunks per row
+  int rp;     // rows per pass = 64 / nvec   (nvec <= 64)
+  int npass;  // ceil(32 / rp)
+};
+
+inline ColMap make_colmap(int channels) {
+  ColMap m;
+  m.nvec = (channels + 7) / 8;
+  m.rp = 64 / m.nvec;
+  m.npass = (TR + m.rp - 1) / m.rp;
+  return m;
+}
+
+// LDS row stride (bytes) of a bf16 tile whose rows are read as MFMA fragments (lane = row, 16 B per lane).
+// `need_zero_tail` reserves 16 zero bytes after the row for the k-step that overhangs K (K % 16 == 8).
+// Rows are kept dense (no bank padding): the fragment reads are a small part of the per-tile work and the
+// LDS bytes saved buy an extra resident workgroup per CU.
+inline int frag_stride(int cols, bool need_zero_tail) {
+  int b = (cols * 2 + 15) / 16 * 16;
+  if (need_zero_tail) b += 16;
+  return b;
+}
+// stride of the C tile (written 8 B per lane by rows, read 16 B per lane): one 16-B slot of padding
+inline int ctile_stride(int cols) { return cols * 2 + 16; }
+
+struct FwdArgs {
+  edet_tview_t tv;
+  const bf16_t* Wt;   // [N][ldw], k contiguous
+  int ldw;
+  const float* bias;  // [N] or null
+  bf16_t* out;
+  int ldo;
+  int M, K, N, hw;
+  float* stat_partials;
+  ColMap ck;
+  int G;              // 32-row tiles per super-tile (one super-tile = the loads kept in flight per wave)
+  int pst;            // load passes per super-tile (<= NS)
+  int SA, SC, SW;     // LDS row strides in bytes
+  int Npad;           // N rounded up to 32
+  int NWC, nwc;       // weight chunk rows (multiple of 32), number of chunks
+  int spw;            // super-tiles per wave (contiguous range)
+  int ksteps;         // ceil(K / 16)
+  int nvec_out;       // valid 16-byte chunks per output row = ceil(N / 8)
+};
+
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return pack2bf(lo, hi); }
+
+__device__ __forceinline__ void unpack8(const uint4 raw, float x[8]) {
+  x[0] = __uint_as_float(raw.x << 16); x[1] = __uint_as_float(raw.x & 0xffff0000u);
+  x[2] = __uint_as_float(raw.y << 16); x[3] = __uint_as_float(raw.y & 0xffff0000u);
+  x[4] = __uint_as_float(raw.z << 16); x[5] = __uint_as_float(raw.z & 0xffff0000u);
+  x[6] = __uint_as_float(raw.w << 16); x[7] = __uint_as_float(raw.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float x[8]) {
+  uint4 o;
+  o.x = pack_bf2(x[0], x[1]); o.y = pack_bf2(x[2], x[3]);
+  o.z = pack_bf2(x[4], x[5]); o.w = pack_bf2(x[6], x[7]);
+  return o;
+}
+
+// activated value of 8 raw bf16 elements -> 8 bf16 packed
+__device__ __forceinline__ uint4 transform8(const uint4 raw, const float sc[8], const float sh[8],
+                                            const float gt[8], bool affine, bool swish, bool gate) {
+  float x[8];
+  unpack8(raw, x);
+  if (affine) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], sc[e], sh[e]);
+  }
+  if (swish) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = swishf_(x[e]);
+  }
+  if (gate) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] *= gt[e];
+  }
+  return pack8(x);
+}
+
+// D'[out channel][row] for one 32-row tile and one 32-channel slice: A' = weight rows (LDS), B' = staged rows (LDS)
+__device__ __forceinline__ f32x16 mma_tile(const unsigned char* wrow, const unsigned char* arow, int ksteps) {
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + ks * 32);
+    const bf16x8 bf = *reinterpret_cast<const bf16x8*>(arow + ks * 32);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, bf, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// column sums of a [rows][.] bf16 LDS tile: lane = column `c`
+__device__ __forceinline__ void column_stats(const unsigned char* Ct, int SC, int c, int rows_valid, float& s,
+                                             float& s2) {
+  const bf16_t* colp = reinterpret_cast<const bf16_t*>(Ct) + c;
+  const int ld = SC / 2;
+  float u0 = 0.f, u1 = 0.f, v0 = 0.f, v1 = 0.f;
+  if (rows_valid == TR) {
+#pragma unroll 4
+    for (int r = 0; r < TR; r += 2) {
+      const float x0 = bf2f(colp[r * ld]), x1 = bf2f(colp[(r + 1) * ld]);
+      u0 += x0; u1 += x1;
+      v0 = fmaf(x0, x0, v0); v1 = fmaf(x1, x1, v1);
+    }
+  } else {
+    for (int r = 0; r < rows_valid; ++r) {
+      const float x0 = bf2f(colp[r * ld]);
+      u0 += x0;
+      v0 = fmaf(x0, x0, v0);
+    }
+  }
+  s = u0 + u1;
+  s2 = v0 + v1;
+}
+
+// ------------------------------------------------------------------------------------ forward
+template <int NS>
+__global__ __launch_bounds__(THREADS, NS == 8 ? 3 : 2) void k_pw_fwd(const FwdArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int j = lane & 31, h = lane >> 5;
+  // LDS carve-up
+  unsigned char* Wl = smem;                                        // [NWC][SW]
+  float* biasL = reinterpret_cast<float*>(Wl + (size_t)a.NWC * a.SW);   // [Npad]
+  float* red = biasL + a.Npad;                                     // [2][Npad]
+  const int a_rows = TR * a.G;                                     // rows per super-tile
+  const int a_alloc = a.pst * a.ck.rp;                             // >= a_rows: every load pass lands in-bounds
+  const size_t wave_bytes = (size_t)a_alloc * a.SA + (size_t)TR * a.SC + (size_t)2 * a.NWC * 4;
+  unsigned char* wbase = reinterpret_cast<unsigned char*>(red + 2 * a.Npad) + (size_t)wave * wave_bytes;
+  unsigned char* At = wbase;                                       // [32*G][SA]
+  unsigned char* Ct = wbase + (size_t)a_alloc * a.SA;              // [32][SC]
+  float* wst = reinterpret_cast<float*>(Ct + TR * a.SC);           // [2][NWC] this wave's column sums
+  const bool want_stats = a.stat_partials != nullptr;
+
+  for (int i = tid; i < a.Npad; i += THREADS) biasL[i] = (a.bias && i < a.N) ? a.bias[i] : 0.f;
+  for (int i = tid; i < 2 * a.Npad; i += THREADS) red[i] = 0.f;
+  // zero this wave's A buffer once: the bytes after column K stay zero (k-step overhang)
+  for (int i = lane; i < a_alloc * a.SA / 16; i += 64) reinterpret_cast<uint4*>(At)[i] = make_uint4(0, 0, 0, 0);
+
+  // K-side mapping and coefficients
+  // lanes beyond nvec*rp duplicate the work of lane % (nvec*rp): no divergence, no extra traffic
+  const int lane_k = lane % (a.ck.nvec * a.ck.rp);
+  const int colK = lane_k % a.ck.nvec, rsub = lane_k / a.ck.nvec;
+  const bool activeK = true;
+  const bool affine = a.tv.scale != nullptr, swish = a.tv.act == EDET_ACT_SWISH, gated = a.tv.gate != nullptr;
+  float sc[8], sh[8], gt[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; gt[e] = 1.f; }
+  if (affine && activeK) { loadf8(a.tv.scale + colK * 8, sc); loadf8(a.tv.shift + colK * 8, sh); }
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(a.tv.data);
+
+  const int nst = (a.M + a_rows - 1) / a_rows;                     // super-tiles
+  const int gw = blockIdx.x * WAVES + wave;
+  const int st0 = min(nst, gw * a.spw), st1 = min(nst, st0 + a.spw);
+
+  uint4 raw[NS];
+  // address = (uniform 64-bit base of the pass) + (32-bit lane offset): one VGPR of addressing for all passes
+  const uint32_t lane_off = (uint32_t)(rsub * a.tv.ld + colK * 8) * 2u;
+  const size_t pass_bytes = (size_t)a.ck.rp * a.tv.ld * 2;
+  auto issue = [&](int st) {
+    const int row0 = st * a_rows;
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(A) + (size_t)row0 * a.tv.ld * 2;
+    const bool full = row0 + a_alloc <= a.M;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      if (i < a.pst) {
+        if (full) {
+          raw[i] = *reinterpret_cast<const uint4*>(base + (size_t)i * pass_bytes + lane_off);
+        } else {  // tail: rows past M re-read row M-1 (finite values, never stored)
+          const int r = min(row0 + i * a.ck.rp + rsub, a.M - 1);
+          raw[i] = *reinterpret_cast<const uint4*>(A + (size_t)r * a.tv.ld + colK * 8);
+        }
+      }
+    }
+  };
+
+  for (int wc = 0; wc < a.nwc; ++wc) {
+    const int n0 = wc * a.NWC;                       // first output channel of this weight chunk
+    const int nrows = min(a.NWC, a.Npad - n0);       // multiple of 32
+    __syncthreads();
+    {  // weight chunk -> LDS (zero-filled beyond N and beyond K)
+      const int slots = a.SW / 16;
+      for (int q = tid; q < nrows * slots; q += THREADS) {
+        const int r = q / slots, s = q - r * slots;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (n0 + r < a.N && s * 8 < a.K) v = *reinterpret_cast<const uint4*>(a.Wt + (size_t)(n0 + r) * a.ldw + s * 8);
+        *reinterpret_cast<uint4*>(Wl + (size_t)r * a.SW + s * 16) = v;
+      }
+    }
+    __syncthreads();
+    for (int i = lane; i < 2 * a.NWC; i += 64) wst[i] = 0.f;
+
+    int gate_img = -1;
+    if (st0 < st1) issue(st0);
+    for (int st = st0; st < st1; ++st) {
+      const int row0 = st * a_rows;
+      const int rows_in_st = min(a_rows, a.M - row0);
+      // ---- transform the loaded rows into the activated A super-tile
+      bool per_row_gate = false;
+      if (gated) {
+        const int img0 = row0 / a.hw, img1 = (row0 + rows_in_st - 1) / a.hw;
+        per_row_gate = img0 != img1;
+        if (!per_row_gate && img0 != gate_img && activeK) {
+          loadf8(a.tv.gate + (size_t)img0 * a.K + colK * 8, gt);
+          gate_img = img0;
+        }
+        if (per_row_gate) gate_img = -1;
+      }
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        if (i < a.pst) {
+          const int r = i * a.ck.rp + rsub;
+          if (per_row_gate) {
+            const uint32_t rr = (uint32_t)min(row0 + r, a.M - 1);
+            loadf8(a.tv.gate + (size_t)(rr / (uint32_t)a.hw) * a.K + colK * 8, gt);
+          }
+          *reinterpret_cast<uint4*>(At + r * a.SA + colK * 16) = transform8(raw[i], sc, sh, gt, affine, swish, gated);
+        }
+      }
+      if (st + 1 < st1) issue(st + 1);               // next super-tile's loads fly during the MFMA phase
+      __builtin_amdgcn_wave_barrier();
+
+      for (int sub = 0; sub * TR < rows_in_st; ++sub) {
+        const int trow0 = row0 + sub * TR;
+        const int rows_valid = min(TR, rows_in_st - sub * TR);
+        const unsigned char* arow = At + (size_t)(sub * TR + j) * a.SA + h * 16;
+        // ---- MFMA over the output channels of this weight chunk, one C sub-tile (<= 128 channels) at a time
+        for (int c0 = 0; c0 < nrows; c0 += NCC) {
+          const int ccols = min(NCC, nrows - c0);    // multiple of 32
+          for (int nt = 0; nt < ccols / 32; ++nt) {
+            const f32x16 acc = mma_tile(Wl + (size_t)(c0 + nt * 32 + j) * a.SW + h * 16, arow, a.ksteps);
+            // lane (row j, half h) holds channels nt*32 + (e&3) + 8*(e>>2) + 4*h
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int ch = c0 + nt * 32 + 8 * g + 4 * h;
+              const float4 b4 = *reinterpret_cast<const float4*>(biasL + n0 + ch);
+              uint2 pk;
+              pk.x = pack_bf2(acc[4 * g + 0] + b4.x, acc[4 * g + 1] + b4.y);
+              pk.y = pack_bf2(acc[4 * g + 2] + b4.z, acc[4 * g + 3] + b4.w);
+              *reinterpret_cast<uint2*>(Ct + j * a.SC + (nt * 32 + 8 * g + 4 * h) * 2) = pk;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          // ---- C sub-tile -> global, 16 bytes per lane in row-major order
+          {
+            const int nvc_tile = ccols / 8;                                  // chunks per LDS row
+            const int nvc = min(nvc_tile, a.nvec_out - (n0 + c0) / 8);       // valid chunks per row
+            const int total = rows_valid * nvc;
+            int row = lane / nvc, col = lane - row * nvc;
+            const int drow = 64 / nvc, dcol = 64 - drow * nvc;
+            bf16_t* obase = a.out + (size_t)trow0 * a.ldo + n0 + c0;
+#pragma unroll 2
+            for (int q = lane; q < total; q += 64) {
+              const uint4 v = *reinterpret_cast<const uint4*>(Ct + row * a.SC + col * 16);
+              *reinterpret_cast<uint4*>(obase + (size_t)row * a.ldo + col * 8) = v;
+              row += drow; col += dcol;
+              if (col >= nvc) { col -= nvc; ++row; }
+            }
+          }
+          // ---- statistics of the stored values: lane = column
+          if (want_stats) {
+            if (lane < ccols) {
+              float s, s2;
+              column_stats(Ct, a.SC, lane, rows_valid, s, s2);
+              wst[c0 + lane] += s;                 // wave-private LDS accumulators
+              wst[a.NWC + c0 + lane] += s2;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+    if (want_stats) {
+      __builtin_amdgcn_wave_barrier();
+      for (int c = lane; c < nrows; c += 64) {
+        if (n0 + c < a.N) {
+          atomicAdd(&red[n0 + c], wst[c]);
+          atomicAdd(&red[a.Npad + n0 + c], wst[a.NWC + c]);
+        }
+      }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    float* dst = a.stat_partials + (size_t)blockIdx.x * 2 * a.N;
+    for (int i = tid; i < 2 * a.N; i += THREADS) {
+      const int which = i / a.N, col = i - which * a.N;
+      dst[i] = red[which * a.Npad + col];
+    }
+  }
+}
+
+// Chooses the weight chunking so that the workgroup's LDS stays under `cap` bytes; returns total bytes
+// or 0 when even one 32-row chunk does not fit.
+inline size_t plan_lds(int Npad, int a_rows, int SA, int SW, size_t cap, int* NWC_out, int* SC_out) {
+  for (int nwcr = Npad; nwcr >= 32; nwcr -= 32) {
+    const int ccols = nwcr < NCC ? nwcr : NCC;
+    const int SC = ctile_stride(ccols);
+    const size_t total = (size_t)nwcr * SW + (size_t)3 * Npad * 4 +
+                         (size_t)WAVES * ((size_t)a_rows * SA + (size_t)TR * SC + (size_t)2 * nwcr * 4);
+    if (total <= cap) {
+      *NWC_out = nwcr;
+      *SC_out = SC;
+      return total;
+    }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ data gradient
+// d(in)[m][k] = sum_n dy[m][n] * W[k][n], chained through the input view's activation in the epilogue.
+// Same skeleton as the forward kernel with dy as the streamed operand (BatchNorm backward applied on load:
+// dy = a*dz + b*y + c, two tensors per row) and an fp32 C tile; the epilogue works on 64-channel chunks with
+// a fixed 8-channel column per lane (col = lane & 7, 8 rows per pass), reads the saved conv input x, applies
+// act'(z), optionally accumulates into the existing gradient, stores 16 B per lane and keeps the BatchNorm
+// backward sums (sum g, sum g*xhat) / the SE dgate sums (sum D*act(z)) in registers across the sub-tiles.
+struct BwdArgs {
+  edet_gview_t gv;    // dy (contraction length R = gv.c)
+  edet_tview_t tv;    // conv input view: raw x, scale, shift, gate, act; KO = tv.c output columns
+  const bf16_t* W;    // [KO][ldw], n contiguous
+  int ldw;
+  edet_bwd_epi_t epi;
+  int M, R, KO, hw;
+  ColMap cr;
+  int G, pst;
+  int SA, SC, SW;     // SC: fp32 C tile stride in bytes
+  int KOpad;          // KO rounded up to 32
+  int spw, ksteps;
+  int nvec_out;       // ceil(KO / 8)
+};
+
+constexpr int ECC = 64;   // epilogue chunk: channels per C tile
+
+template <int NS, bool GBN>
+__global__ __launch_bounds__(THREADS, 2) void k_pw_dgrad(const BwdArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int j = lane & 31, h = lane >> 5;
+  unsigned char* Wl = smem;                                             // [KOpad][SW]
+  float* red = reinterpret_cast<float*>(Wl + (size_t)a.KOpad * a.SW);   // [2][KOpad] stats, then [KOpad] gate
+  const int a_rows = TR * a.G;
+  const int a_alloc = a.pst * a.cr.rp;
+  const size_t wave_bytes = (size_t)a_alloc * a.SA + (size_t)TR * a.SC + (size_t)3 * a.KOpad * 4;
+  unsigned char* wbase = reinterpret_cast<unsigned char*>(red + 2 * a.KOpad) + (size_t)wave * wave_bytes;
+  unsigned char* At = wbase;                                            // [a_alloc][SA] bf16 dy
+  unsigned char* Ct = wbase + (size_t)a_alloc * a.SA;                   // [32][SC] fp32
+  float* wst = reinterpret_cast<float*>(Ct + TR * a.SC);                // [2][KOpad] stat sums of this wave
+  float* wgt = wst + 2 * a.KOpad;                                       // [KOpad] dgate sums of the current image
+  const bool want_stats = a.epi.stat_partials != nullptr;
+  const bool want_gate = a.epi.dgate != nullptr;
+  const bool swish = a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr;
+
+  for (int i = tid; i < 2 * a.KOpad; i += THREADS) red[i] = 0.f;
+  for (int i = lane; i < 3 * a.KOpad; i += 64) wst[i] = 0.f;
+  for (int i = lane; i < a_alloc * a.SA / 16; i += 64) reinterpret_cast<uint4*>(At)[i] = make_uint4(0, 0, 0, 0);
+  {  // weights -> LDS (zero-filled beyond KO and beyond R)
+    const int slots = a.SW / 16;
+    for (int q = tid; q < a.KOpad * slots; q += THREADS) {
+      const int r = q / slots, sl = q - r * slots;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (r < a.KO && sl * 8 < a.R) v = *reinterpret_cast<const uint4*>(a.W + (size_t)r * a.ldw + sl * 8);
+      *reinterpret_cast<uint4*>(Wl + (size_t)r * a.SW + sl * 16) = v;
+    }
+  }
+  __syncthreads();
+
+  // dy-side mapping
+  const int lane_k = lane % (a.cr.nvec * a.cr.rp);
+  const int colR = lane_k % a.cr.nvec, rsub = lane_k / a.cr.nvec;
+  const int kvalid = min(8, a.R - colR * 8);                           // elements of this chunk inside R
+  const bf16_t* DZ = reinterpret_cast<const bf16_t*>(a.gv.dz);
+  const bf16_t* Y = reinterpret_cast<const bf16_t*>(a.gv.y);
+  const bf16_t* X = reinterpret_cast<const bf16_t*>(a.tv.data);
+  bf16_t* GO = reinterpret_cast<bf16_t*>(a.epi.gout);
+  const uint32_t lane_off = (uint32_t)(rsub * a.gv.ld + colR * 8) * 2u;
+  const size_t pass_bytes = (size_t)a.cr.rp * a.gv.ld * 2;
+
+  const int nst = (a.M + a_rows - 1) / a_rows;
+  const int gw = blockIdx.x * WAVES + wave;
+  const int st0 = min(nst, gw * a.spw), st1 = min(nst, st0 + a.spw);
+
+  uint4 rz[NS], ry[GBN ? NS : 1];
+  auto issue = [&](int st) {
+    const int row0 = st * a_rows;
+    const bool full = row0 + a_alloc <= a.M;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      if (i < a.pst) {
+        size_t off;
+        if (full) off = (size_t)row0 * a.gv.ld * 2 + (size_t)i * pass_bytes + lane_off;
+        else off = ((size_t)min(row0 + i * a.cr.rp + rsub, a.M - 1) * a.gv.ld + colR * 8) * 2;
+        rz[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(DZ) + off);
+        if (GBN) ry[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(Y) + off);
+      }
+    }
+  };
+
+  // epilogue mapping: 64-channel chunk, 8 lanes per row
+  const int ecol = lane & 7, erow = lane >> 3;
+  int gate_img = -1;                       // image whose dgate sums are in wgt
+  if (st0 < st1) issue(st0);
+  for (int st = st0; st < st1; ++st) {
+    const int row0 = st * a_rows;
+    const int rows_in_st = min(a_rows, a.M - row0);
+    {  // dy = a*dz + b*y + c, masked to the R valid columns, as bf16 into the A super-tile
+      float ga[8], gb[8], gc[8];
+      if (GBN) {
+        loadf8(a.gv.a + colR * 8, ga); loadf8(a.gv.b + colR * 8, gb); loadf8(a.gv.cc + colR * 8, gc);
+      }
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        if (i < a.pst) {
+          float x[8];
+          unpack8(rz[i], x);
+          if (GBN) {
+            float y[8];
+            unpack8(ry[i], y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = fmaf(ga[e], x[e], fmaf(gb[e], y[e], gc[e]));
+          }
+          if (kvalid < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e >= kvalid) x[e] = 0.f;
+          }
+          *reinterpret_cast<uint4*>(At + (i * a.cr.rp + rsub) * a.SA + colR * 16) = pack8(x);
+        }
+      }
+    }
+    if (st + 1 < st1) issue(st + 1);
+    __builtin_amdgcn_wave_barrier();
+
+    // dgate bookkeeping: sums in wgt belong to one image; a super-tile that straddles two images goes
+    // straight to global atomics
+    bool gate_direct = false;
+    if (want_gate) {
+      const int img0 = row0 / a.hw, img1 = (row0 + rows_in_st - 1) / a.hw;
+      gate_direct = img0 != img1;
+      if (gate_img >= 0 && (gate_direct || img0 != gate_img)) {
+        for (int c = lane; c < a.KO; c += 64) {
+          const float v = wgt[c];
+          if (v != 0.f) atomicAdd(&a.epi.dgate[(size_t)gate_img * a.KO + c], v);
+          wgt[c] = 0.f;
+        }
+        gate_img = -1;
+      }
+      if (!gate_direct) gate_img = img0;
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    for (int c0 = 0; c0 < a.KOpad; c0 += ECC) {
+      const int ccols = min(ECC, a.KOpad - c0);                // 32 or 64
+      const int ch0 = c0 + ecol * 8;                           // this lane's 8 output channels
+      const bool col_ok = ch0 < a.KO && ecol * 8 < ccols;
+      // s1: sum g (stats) or sum D*act(z) (gate); s2: sum g*x, turned into sum g*xhat when it is flushed
+      float sc[8], sh[8], s1[8], s2[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; s1[e] = s2[e] = 0.f; }
+      if (col_ok && affine) { loadf8(a.tv.scale + ch0, sc); loadf8(a.tv.shift + ch0, sh); }
+      const bool need_x = swish || want_gate || want_stats;
+      for (int sub = 0; sub * TR < rows_in_st; ++sub) {
+        const int trow0 = row0 + sub * TR;
+        const int rows_valid = min(TR, rows_in_st - sub * TR);
+        // saved conv input for this (sub-tile, chunk): 4 passes of 8 rows, in flight during the MFMAs
+        uint4 xr[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          xr[p] = make_uint4(0, 0, 0, 0);
+          const int r = p * 8 + erow;
+          if (need_x && col_ok && r < rows_valid)
+            xr[p] = *reinterpret_cast<const uint4*>(X + (size_t)(trow0 + r) * a.tv.ld + ch0);
+        }
+        const unsigned char* arow = At + (size_t)(sub * TR + j) * a.SA + h * 16;
+        for (int nt = 0; nt < ccols / 32; ++nt) {
+          const f32x16 acc = mma_tile(Wl + (size_t)(c0 + nt * 32 + j) * a.SW + h * 16, arow, a.ksteps);
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(Ct + j * a.SC + (nt * 32 + 8 * g + 4 * h) * 4) =
+                make_float4(acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int r = p * 8 + erow;
+          if (col_ok && r < rows_valid) {
+            const float4 d0 = *reinterpret_cast<const float4*>(Ct + r * a.SC + ecol * 32);
+            const float4 d1 = *reinterpret_cast<const float4*>(Ct + r * a.SC + ecol * 32 + 16);
+            float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            float x[8], g[8];
+            unpack8(xr[p], x);
+            const size_t off = (size_t)(trow0 + r) * a.tv.ld + ch0;
+            if (want_gate) {
+              float gsum[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float z = fmaf(x[e], sc[e], sh[e]);
+                gsum[e] = d[e] * (swish ? swishf_(z) : z);
+                g[e] = d[e];
+              }
+              if (gate_direct) {
+                const int img = (trow0 + r) / a.hw;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                  if (ch0 + e < a.KO) atomicAdd(&a.epi.dgate[(size_t)img * a.KO + ch0 + e], gsum[e]);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s1[e] += gsum[e];
+              }
+            } else if (swish) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) g[e] = d[e] * swish_gradf_(fmaf(x[e], sc[e], sh[e]));
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) g[e] = d[e];
+            }
+            if (a.epi.beta) {
+              float old[8];
+              unpack8(*reinterpret_cast<const uint4*>(GO + off), old);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) g[e] += old[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (ch0 + e >= a.KO) g[e] = 0.f;
+            *reinterpret_cast<uint4*>(GO + off) = pack8(g);
+            if (want_stats) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                s1[e] += g[e];
+                s2[e] = fmaf(g[e], x[e], s2[e]);
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      // chunk sums -> wave LDS accumulators (8 lanes share a column: LDS atomics)
+      if (col_ok) {
+        if (want_stats) {
+          float mu[8], rs[8];
+          loadf8(a.epi.mean + ch0, mu);
+          loadf8(a.epi.rstd + ch0, rs);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (ch0 + e < a.KO) {
+              atomicAdd(&wst[ch0 + e], s1[e]);
+              atomicAdd(&wst[a.KOpad + ch0 + e], rs[e] * (s2[e] - mu[e] * s1[e]));   // sum g*(x-mean)*rstd
+            }
+          }
+        }
+        if (want_gate && !gate_direct) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (ch0 + e < a.KO) atomicAdd(&wgt[ch0 + e], s1[e]);
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (want_gate && gate_img >= 0) {
+    for (int c = lane; c < a.KO; c += 64) {
+      const float v = wgt[c];
+      if (v != 0.f) atomicAdd(&a.epi.dgate[(size_t)gate_img * a.KO + c], v);
+    }
+  }
+  if (want_stats) {
+    for (int c = lane; c < a.KO; c += 64) {
+      atomicAdd(&red[c], wst[c]);
+      atomicAdd(&red[a.KOpad + c], wst[a.KOpad + c]);
+    }
+    __syncthreads();
+    float* dst = a.epi.stat_partials + (size_t)blockIdx.x * 2 * a.KO;
+    for (int i = tid; i < 2 * a.KO; i += THREADS) {
+      const int which = i / a.KO, col = i - which * a.KO;
+      dst[i] = red[which * a.KOpad + col];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------- weight gradient
+// dW[k][n] = sum_m view(in)[m][k] * dy[m][n]: the contraction runs over the rows, so both operands are
+// needed "transposed" (8 consecutive rows of one channel per lane).  Each wave owns a 64 x CV block of dW
+// (U = the operand with more channels, sliced 64 wide; V = the other one, CV <= 64) over a contiguous row
+// range: per 32-row step it loads its U slice and V in whole 16-byte chunks (fixed column per lane, so the
+// BatchNorm / swish / BatchNorm-backward coefficients stay in registers), stages the transformed bf16 rows in
+// wave-private LDS and gathers the MFMA fragments column-wise with ds_read_u16 (64 B/clk/CU, six times the
+// HBM feed rate).  Partial blocks go to a workspace [split][K][N] that a second kernel sums into dW:
+// deterministic, no atomics.
+struct WgArgs {
+  edet_tview_t tv;    // conv input view, K = tv.c
+  edet_gview_t gv;    // dy, N = gv.c
+  float* ws;          // [S][K][N]
+  int M, K, N, hw;
+  int CU, CV;         // channels of U and V
+  int nus;            // 64-wide slices of U
+  int S;              // row splits
+  int rows_per_split; // multiple of 32
+  int cpwV;           // V-side lanes per row (power of two >= CV/8, <= 8)
+};
+
+template <bool IS_G, bool GBN>
+struct OperandRegs {
+  uint4 r[4];
+  uint4 y[(IS_G && GBN) ? 4 : 1];
+};
+
+// loads pass p (rows rbase + p*rpp + rowl) of one operand
+template <bool IS_G, bool GBN>
+__device__ __forceinline__ void wg_issue(const WgArgs& a, OperandRegs<IS_G, GBN>& o, int npass, int rpp, int rowl,
+                                         int ch, bool col_ok, int m0, int m_end) {
+  const bf16_t* P = reinterpret_cast<const bf16_t*>(IS_G ? a.gv.dz : a.tv.data);
+  const bf16_t* Y = reinterpret_cast<const bf16_t*>(a.gv.y);
+  const int ld = IS_G ? a.gv.ld : a.tv.ld;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    if (p < npass) {
+      const int m = m0 + p * rpp + rowl;
+      o.r[p] = make_uint4(0, 0, 0, 0);
+      if (IS_G && GBN) o.y[p] = make_uint4(0, 0, 0, 0);
+      if (col_ok && m < m_end) {
+        o.r[p] = *reinterpret_cast<const uint4*>(P + (size_t)m * ld + ch);
+        if (IS_G && GBN) o.y[p] = *reinterpret_cast<const uint4*>(Y + (size_t)m * ld + ch);
+      }
+    }
+  }
+}
+
+// transforms the loaded passes and writes them (bf16) into the operand's LDS tile [32][stride]
+template <bool IS_G, bool GBN>
+__device__ __forceinline__ void wg_stage(const WgArgs& a, const OperandRegs<IS_G, GBN>& o, int npass, int rpp,
+                                         int rowl, int coll, int ch, int cmax, bool col_ok, int m0, int m_end,
+                                         unsigned char* tile, int stride) {
+  if (!col_ok) return;
+  float c0[8], c1[8], c2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { c0[e] = 1.f; c1[e] = 0.f; c2[e] = 0.f; }
+  if (IS_G) {
+    if (GBN) { loadf8(a.gv.a + ch, c0); loadf8(a.gv.b + ch, c1); loadf8(a.gv.cc + ch, c2); }
+  } else if (a.tv.scale) {
+    loadf8(a.tv.scale + ch, c0);
+    loadf8(a.tv.shift + ch, c1);
+  }
+  const int valid = min(8, cmax - ch);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    if (p < npass) {
+      const int r = p * rpp + rowl;
+      const int m = m0 + r;
+      float x[8];
+      unpack8(o.r[p], x);
+      if (m < m_end) {
+        if (IS_G) {
+          if (GBN) {
+            float y[8];
+            unpack8(o.y[p], y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = fmaf(c0[e], x[e], fmaf(c1[e], y[e], c2[e]));
+          }
+        } else {
+          if (a.tv.scale) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], c0[e], c1[e]);
+          }
+          if (a.tv.act == EDET_ACT_SWISH) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = swishf_(x[e]);
+          }
+          if (a.tv.gate) {
+            float gt[8];
+            loadf8(a.tv.gate + (size_t)(m / a.hw) * a.K + ch, gt);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] *= gt[e];
+          }
+        }
+        if (valid < 8) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (e >= valid) x[e] = 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = 0.f;
+      }
+      if (r < TR) *reinterpret_cast<uint4*>(tile + r * stride + coll * 16) = pack8(x);
+    }
+  }
+}
+
+// 8 consecutive rows (8*h + 16*ks ...) of column `col` of a [32][stride] bf16 tile
+__device__ __forceinline__ bf16x8 column_frag(const unsigned char* tile, int stride, int row0, int col) {
+  const bf16_t* p = reinterpret_cast<const bf16_t*>(tile + row0 * stride) + col;
+  const int ld = stride / 2;
+  s16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (short)p[e * ld];
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+constexpr int WG_SU = 64 * 2 + 16;   // U tile stride (64 channels)
+constexpr int WG_SV = 64 * 2 + 16;   // V tile stride (up to 64 channels)
+
+template <bool UG, bool GBN>   // UG: U is the gradient operand (N >= K)
+__global__ __launch_bounds__(THREADS, 2) void k_pw_wgrad(const WgArgs a) {
+  __shared__ __align__(16) unsigned char smem[WAVES * TR * (WG_SU + WG_SV)];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  unsigned char* Ut = smem + wave * TR * (WG_SU + WG_SV);
+  unsigned char* Vt = Ut + TR * WG_SU;
+  // wave -> (U slice, row split)
+  int us, rs;
+  if (a.nus >= 3) {
+    const int nus4 = (a.nus + 3) / 4;
+    us = (blockIdx.x % nus4) * 4 + wave;
+    rs = blockIdx.x / nus4;
+  } else {
+    us = wave % a.nus;
+    rs = blockIdx.x * (WAVES / a.nus) + wave / a.nus;
+  }
+  if (us >= a.nus || rs >= a.S) return;
+  const int m_begin = rs * a.rows_per_split;
+  const int m_end = min(a.M, m_begin + a.rows_per_split);
+
+  // U side: 8 chunks per row, 8 rows per pass, 4 passes; V side: cpwV chunks per row
+  const int ucol = lane & 7, urow = lane >> 3;
+  const int uch = us * 64 + ucol * 8;
+  const bool u_ok = uch < a.CU;
+  const int vcol = lane & (a.cpwV - 1), vrow = lane / a.cpwV;
+  const int rppV = 64 / a.cpwV;
+  const int npassV = rppV >= TR ? 1 : TR / rppV;
+  const int vch = vcol * 8;
+  const bool v_ok = vch < a.CV && vrow < TR;
+  const int nvt = (a.CV + 31) / 32;                 // 1 or 2 V tiles
+
+  // zero both tiles once (columns never written stay zero)
+  for (int i = lane; i < TR * (WG_SU + WG_SV) / 16; i += 64) reinterpret_cast<uint4*>(Ut)[i] = make_uint4(0, 0, 0, 0);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+    for (int vt = 0; vt < 2; ++vt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[ut][vt][e] = 0.f;
+
+  OperandRegs<UG, GBN> ou;
+  OperandRegs<!UG, GBN> ov;
+  if (m_begin < m_end) {
+    wg_issue<UG, GBN>(a, ou, 4, 8, urow, uch, u_ok, m_begin, m_end);
+    wg_issue<!UG, GBN>(a, ov, npassV, rppV, vrow, vch, v_ok, m_begin, m_end);
+  }
+  const int j = lane & 31, h = lane >> 5;
+  for (int m0 = m_begin; m0 < m_end; m0 += TR) {
+    wg_stage<UG, GBN>(a, ou, 4, 8, urow, ucol, uch, a.CU, u_ok, m0, m_end, Ut, WG_SU);
+    wg_stage<!UG, GBN>(a, ov, npassV, rppV, vrow, vcol, vch, a.CV, v_ok, m0, m_end, Vt, WG_SV);
+    if (m0 + TR < m_end) {
+      wg_issue<UG, GBN>(a, ou, 4, 8, urow, uch, u_ok, m0 + TR, m_end);
+      wg_issue<!UG, GBN>(a, ov, npassV, rppV, vrow, vch, v_ok, m0 + TR, m_end);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int r0 = ks * 16 + h * 8;
+      const bf16x8 u0 = column_frag(Ut, WG_SU, r0, j);
+      const bf16x8 u1 = column_frag(Ut, WG_SU, r0, 32 + j);
+      const bf16x8 v0 = column_frag(Vt, WG_SV, r0, j);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u0, v0, acc[0][0], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u1, v0, acc[1][0], 0, 0, 0);
+      if (nvt > 1) {
+        const bf16x8 v1 = column_frag(Vt, WG_SV, r0, 32 + j);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u0, v1, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u1, v1, acc[1][1], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // D[i = U channel][j = V channel]: lane holds V channel j (+32*vt), U channels (e&3)+8*(e>>2)+4*h (+32*ut)
+  float* dst = a.ws + (size_t)rs * a.K * a.N;
+#pragma unroll
+  for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+    for (int vt = 0; vt < 2; ++vt) {
+      if (vt < nvt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int iu = us * 64 + ut * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int jv = vt * 32 + j;
+          if (iu < a.CU && jv < a.CV) {
+            const int k = UG ? jv : iu, n = UG ? iu : jv;
+            dst[(size_t)k * a.N + n] = acc[ut][vt][e];
+          }
+        }
+      }
+    }
+}
+
+__global__ void k_wgrad_reduce(const float* __restrict__ ws, int S, int64_t kn, float* __restrict__ dw) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= kn) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int s = 0;
+  for (; s + 3 < S; s += 4) {
+    s0 += ws[(size_t)s * kn + i];
+    s1 += ws[(size_t)(s + 1) * kn + i];
+    s2 += ws[(size_t)(s + 2) * kn + i];
+    s3 += ws[(size_t)(s + 3) * kn + i];
+  }
+  for (; s < S; ++s) s0 += ws[(size_t)s * kn + i];
+  dw[i] += (s0 + s1) + (s2 + s3);
+}
+
+template <typename KernelT>
+inline bool allow_big_lds(KernelT kern, size_t lds) {
+  if (lds <= 64 * 1024) return true;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             160 * 1024) == hipSuccess;
+}
+
+}  // namespace pws
+
+// Returns 1 when the streaming kernel handled the call, 0 when the shape is outside its envelope
+// (the caller then falls back to the tiled kernel in pw_gemm.hip), negative on error.
+int pws_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bias, void* out, int cout,
+                int ldo, float* stat_partials, int* nparts_out, hipStream_t st) {
+  using namespace pws;
+  const int K = in->c, N = cout;
+  if (K > 256 || K % 8 != 0) return 0;
+  FwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tv = *in;
+  a.Wt = reinterpret_cast<const bf16_t*>(wt); a.ldw = ldw; a.bias = bias;
+  a.out = reinterpret_cast<bf16_t*>(out); a.ldo = ldo;
+  a.M = in->n * in->h * in->w; a.K = K; a.N = N; a.hw = in->h * in->w;
+  a.stat_partials = stat_partials;
+  a.ck = make_colmap(K);
+  const int NS = K > 128 ? 16 : 8;
+  a.ksteps = (K + 15) / 16;
+  a.SA = frag_stride(K, K % 16 != 0);
+  a.SW = a.SA;
+  a.Npad = (N + 31) / 32 * 32;
+  a.nvec_out = (N + 7) / 8;
+  if (ldo < a.nvec_out * 8) return 0;
+  // rows kept in flight per wave: as many 32-row tiles as NS load passes cover, shrunk until three
+  // workgroups fit in a CU's LDS (53 KB each); the weight chunk may take it to one workgroup per CU
+  size_t lds = 0;
+  for (a.G = NS * a.ck.rp / TR > 4 ? 4 : NS * a.ck.rp / TR; ; --a.G) {
+    if (a.G < 1) a.G = 1;
+    a.pst = (TR * a.G + a.ck.rp - 1) / a.ck.rp;
+    if (a.pst > NS) return 0;
+    lds = plan_lds(a.Npad, a.pst * a.ck.rp, a.SA, a.SW, 53 * 1024, &a.NWC, &a.SC);
+    if ((lds != 0 && a.NWC == a.Npad) || a.G == 1) break;
+  }
+  if (lds == 0 || a.NWC != a.Npad) {
+    lds = plan_lds(a.Npad, a.pst * a.ck.rp, a.SA, a.SW, 80 * 1024, &a.NWC, &a.SC);
+    if (lds == 0 || a.NWC != a.Npad) lds = plan_lds(a.Npad, a.pst * a.ck.rp, a.SA, a.SW, 150 * 1024, &a.NWC, &a.SC);
+    if (lds == 0) return 0;
+  }
+  a.nwc = (a.Npad + a.NWC - 1) / a.NWC;
+  if (a.nwc > 2) return 0;   // the big operand would be re-read too often: leave it to the tiled kernel
+  const int nst = (a.M + TR * a.G - 1) / (TR * a.G);
+  int grid = (nst + WAVES * 2 - 1) / (WAVES * 2);      // >= 2 super-tiles per wave
+  if (grid > EDET_MAX_PARTS) grid = EDET_MAX_PARTS;
+  if (grid < 1) grid = 1;
+  a.spw = (nst + grid * WAVES - 1) / (grid * WAVES);
+  grid = (nst + a.spw * WAVES - 1) / (a.spw * WAVES);
+  if (nparts_out) *nparts_out = grid;
+  if (NS == 8) {
+    if (!allow_big_lds(&k_pw_fwd<8>, lds)) return 0;
+    k_pw_fwd<8><<<dim3(grid), dim3(THREADS), lds, st>>>(a);
+  } else {
+    if (!allow_big_lds(&k_pw_fwd<16>, lds)) return 0;
+    k_pw_fwd<16><<<dim3(grid), dim3(THREADS), lds, st>>>(a);
+  }
+  EDET_LAUNCH_CHECK("edet_pw_fwd(stream)");
+  return 1;
+}
+
+int pws_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tview_t* in,
+                  const edet_bwd_epi_t* epi, int* nparts_out, hipStream_t st) {
+  using namespace pws;
+  const int R = dy->c, KO = in->c;
+  if (R > 128 || KO > 512 || KO % 8 != 0 || dy->ld % 8 != 0) return 0;
+  BwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.gv = *dy; a.tv = *in; a.W = reinterpret_cast<const bf16_t*>(w); a.ldw = ldw; a.epi = *epi;
+  a.M = in->n * in->h * in->w; a.R = R; a.KO = KO; a.hw = in->h * in->w;
+  a.cr = make_colmap(R);
+  const bool gbn = dy->a != nullptr;
+  const int NS = 8;
+  a.ksteps = (R + 15) / 16;
+  a.SA = frag_stride((R + 7) / 8 * 8, ((R + 7) / 8 * 8) % 16 != 0);
+  a.SW = a.SA;
+  a.KOpad = (KO + 31) / 32 * 32;
+  a.SC = ECC * 4 + 16;
+  a.nvec_out = KO / 8;
+  size_t lds = 0;
+  int g0 = NS * a.cr.rp / TR;
+  if (gbn) g0 /= 2;                    // two tensors per row: half the rows for the same bytes in flight
+  if (g0 > 4) g0 = 4;
+  for (a.G = g0;; --a.G) {
+    if (a.G < 1) a.G = 1;
+    a.pst = (TR * a.G + a.cr.rp - 1) / a.cr.rp;
+    if (a.pst > NS) return 0;
+    lds = (size_t)a.KOpad * a.SW + (size_t)2 * a.KOpad * 4 +
+          (size_t)WAVES * ((size_t)a.pst * a.cr.rp * a.SA + (size_t)TR * a.SC + (size_t)3 * a.KOpad * 4);
+    if (lds <= 53 * 1024 || a.G == 1) break;
+  }
+  if (lds > 150 * 1024) return 0;
+  const int nst = (a.M + TR * a.G - 1) / (TR * a.G);
+  int grid = (nst + WAVES * 2 - 1) / (WAVES * 2);
+  if (grid > EDET_MAX_PARTS) grid = EDET_MAX_PARTS;
+  if (grid < 1) grid = 1;
+  a.spw = (nst + grid * WAVES - 1) / (grid * WAVES);
+  grid = (nst + a.spw * WAVES - 1) / (a.spw * WAVES);
+  if (nparts_out) *nparts_out = grid;
+#define PWS_DGRAD(NS_, GBN_)                                                    \
+  do {                                                                          \
+    if (!allow_big_lds(&k_pw_dgrad<NS_, GBN_>, lds)) return 0;                  \
+    k_pw_dgrad<NS_, GBN_><<<dim3(grid), dim3(THREADS), lds, st>>>(a);           \
+  } while (0)
+  if (gbn) PWS_DGRAD(8, true); else PWS_DGRAD(8, false);
+#undef PWS_DGRAD
+  EDET_LAUNCH_CHECK("edet_pw_bwd_data(stream)");
+  return 1;
+}
+
+int pws_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight, void* workspace,
+                  size_t workspace_bytes, hipStream_t st) {
+  using namespace pws;
+  const int K = in->c, N = dy->c;
+  if (!workspace || K % 8 != 0 || dy->ld % 8 != 0 || in->ld % 8 != 0) return 0;
+  const bool ug = N >= K;
+  WgArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tv = *in; a.gv = *dy; a.ws = reinterpret_cast<float*>(workspace);
+  a.M = in->n * in->h * in->w; a.K = K; a.N = N; a.hw = in->h * in->w;
+  a.CU = ug ? N : K; a.CV = ug ? K : N;
+  if (a.CV > 64) return 0;
+  const bool gbn = dy->a != nullptr;
+  if (gbn && N % 8 != 0) return 0;
+  a.nus = (a.CU + 63) / 64;
+  const int nvecV = (a.CV + 7) / 8;
+  a.cpwV = 1;
+  while (a.cpwV < nvecV) a.cpwV <<= 1;
+  // row splits: ~2048 waves in total, at least 8 steps of 32 rows each, bounded by the workspace
+  const int64_t kn = (int64_t)K * N;
+  int S = 2048 / a.nus;
+  const int max_by_rows = (a.M + 8 * TR - 1) / (8 * TR);
+  if (S > max_by_rows) S = max_by_rows;
+  const int64_t max_by_ws = (int64_t)(workspace_bytes / sizeof(float)) / kn;
+  if (S > max_by_ws) S = (int)max_by_ws;
+  if (S < 1) return 0;
+  a.rows_per_split = ((a.M + S - 1) / S + TR - 1) / TR * TR;
+  a.S = (a.M + a.rows_per_split - 1) / a.rows_per_split;
+  int grid;
+  if (a.nus >= 3) grid = ((a.nus + 3) / 4) * a.S;
+  else grid = (a.S + WAVES / a.nus - 1) / (WAVES / a.nus);
+#define PWS_WG(UG_, GBN_) k_pw_wgrad<UG_, GBN_><<<dim3(grid), dim3(THREADS), 0, st>>>(a)
+  if (ug) { if (gbn) PWS_WG(true, true); else PWS_WG(true, false); }
+  else { if (gbn) PWS_WG(false, true); else PWS_WG(false, false); }
+#undef PWS_WG
+  EDET_LAUNCH_CHECK("edet_pw_bwd_weight(stream)");
+  k_wgrad_reduce<<<dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, st>>>(a.ws, a.S, kn, dweight);
+  EDET_LAUNCH_CHECK("edet_pw_bwd_weight(reduce)");
+  return 1;
+}

@@ -109,6 +109,7 @@ class Engine(object):
     self._build_params(params, seed)
     cmax = max([p.shape[0] for p in self.spec.params if len(p.shape) == 1] + [64])
     self.partials = torch.empty(_lib.MAX_PARTS * 2 * cmax, dtype=torch.float32, device=self.device)
+    self.workspace = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=self.device)  # 64 MiB scratch
     self.bns = {}
     self._cast_plan = None
     self.loss_sums = self.zbuf('loss_sums', (4,))
@@ -306,7 +307,7 @@ class Engine(object):
     nb = vin.raw.rows * (vin.raw.c + vout.raw.c) * self.esize
     tag = '%dx%dx%d->%d' % (vin.raw.h, vin.raw.w, vin.raw.c, vout.raw.c)
     call('edet_pw_bwd_weight', ctypes.byref(vin.tview()), ctypes.byref(g), ptr(self.grad(wname)),
-         self.dtype, self.stream, nbytes=nb, tag=tag)
+         ptr(self.workspace), self.workspace.numel() * 4, self.dtype, self.stream, nbytes=nb, tag=tag)
     if vin.raw.needs_grad:
       dgate = vin.dgate if vin.gate is not None else None
       epi, fused = self._epi(vin, dgate)

@@ -129,9 +129,12 @@ int edet_pw_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
 int edet_pw_bwd_data(const edet_gview_t* dy, const void* w, int ldw,
                      const edet_tview_t* in, const edet_bwd_epi_t* epi, int* nparts_out,
                      int dtype, void* stream);
-/* dweight[cin][cout] (fp32, HWIO of a 1x1 kernel) += in^T dy (atomic adds). */
+/* dweight[cin][cout] (fp32, HWIO of a 1x1 kernel) += in^T dy.
+ * workspace: caller-owned device scratch (fp32 partial sums [splits][cin][cout], deterministic
+ * two-pass reduction); may be NULL, then partials are combined with atomic adds.  64 MiB covers
+ * every EfficientDet-D0..D7x layer at full speed.  */
 int edet_pw_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy, float* dweight,
-                       int dtype, void* stream);
+                       void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
 /* ---- depthwise convolution k in {3,5}, stride in {1,2}, TF 'SAME' ----------
  * DepthwiseConv2D call sites: efficientnet_model.py:320-327 and the depthwise

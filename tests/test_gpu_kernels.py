@@ -173,7 +173,8 @@ def test_pw_bwd_data(dt, shape, mode, gbn):
                                    (2, 12, 12, 96, 16), (1, 20, 20, 1152, 192), (2, 8, 8, 64, 36),
                                    (4, 33, 31, 16, 96), (1, 10, 10, 320, 64)])
 @pytest.mark.parametrize('mode', ['plain', 'bn_swish_gate'])
-def test_pw_bwd_weight(dt, shape, mode):
+@pytest.mark.parametrize('use_ws', [True, False], ids=['workspace', 'atomics'])
+def test_pw_bwd_weight(dt, shape, mode, use_ws):
   name, edt, tdt = dt
   n, h, w, cin, cout = shape
   rng = np.random.default_rng(gu.seed_of((shape, mode, 3)))
@@ -197,8 +198,12 @@ def test_pw_bwd_weight(dt, shape, mode):
   gv = gu.gview(dzd, cout, yd, ga, gb, gcc)
   sc, sh, gt = gu.fdev(scale), gu.fdev(shift), gu.fdev(gate)
   tv = gu.tview(xd, cin, sc, sh, gt, act)
-  dw = torch.zeros(cin, cout, dtype=torch.float32, device=gu.DEV)
-  call('edet_pw_bwd_weight', ctypes.byref(tv), ctypes.byref(gv), ptr(dw), edt, gu.stream())
+  dw0 = torch.from_numpy(rng.standard_normal((cin, cout)).astype(np.float32))   # dweight is accumulated into
+  want = want + dw0
+  dw = dw0.to(gu.DEV)
+  wsp = torch.empty(4 * 1024 * 1024, dtype=torch.float32, device=gu.DEV) if use_ws else None
+  call('edet_pw_bwd_weight', ctypes.byref(tv), ctypes.byref(gv), ptr(dw), ptr(wsp), 16 * 1024 * 1024 if use_ws else 0,
+       edt, gu.stream())
   torch.cuda.synchronize()
   gu.check(dw, want, name, 'pw_bwd_weight %s %s' % (shape, mode), rtol=2e-2 if name == 'bf16' else 1e-3)
 
