@@ -1,0 +1,623 @@
+// Depthwise k x k convolution (k in {3,5}, stride in {1,2}, TF 'SAME') for the bf16 path: row-marching
+// kernels without LDS staging.
+//
+// A depthwise conv moves ~4 bytes per output element and does k*k FMAs on it: pure HBM streaming.  Each
+// thread owns one output column and CPT consecutive channels and marches DOWN the image: per input row it
+// loads the k horizontally adjacent pixels it needs (the neighbouring threads read the same cache lines, so
+// every byte comes from HBM once and k times from L1), applies the producer's BatchNorm + swish on load and
+// accumulates into a rotating set of ceil(k/stride) output-row accumulators held in registers; a finished
+// output row is written once.  The k*k weights of the thread's channels stay in registers (fp32) for the whole
+// kernel; CPT = 4 (k = 3) or 2 (k = 5) keeps the kernel near 100 VGPRs = 4-5 waves per SIMD, which is what
+// hides the HBM latency here (there is no barrier anywhere in the main loop).
+//
+// The same marching structure gives the weight gradient (accumulate in[r][x+kx] * dy[oy][x] into k*k
+// register sums per thread, reduced per workgroup into a workspace slab, summed by a second kernel) and
+// the data gradient (march over dy rows, scatter into the in-flight input-row accumulators, then chain
+// through act'(z), the optional accumulate and the BatchNorm backward sums in the row epilogue).
+//
+// Reference call sites: efficientdet/backbone/efficientnet_model.py:320-327 (MBConv DepthwiseConv2D),
+// efficientdet/tf2/efficientdet_keras.py:195-207,459-464,546-556 (depthwise half of SeparableConv2D).
+#include "common.h"
+
+namespace dwm {
+
+constexpr int THREADS = 256;
+
+template <int CPT> struct Raw;
+template <> struct Raw<8> { uint4 v; };
+template <> struct Raw<4> { uint2 v; };
+template <> struct Raw<2> { uint32_t v; };
+
+template <int CPT> __device__ __forceinline__ Raw<CPT> raw_zero();
+template <> __device__ __forceinline__ Raw<8> raw_zero<8>() { Raw<8> r; r.v = make_uint4(0, 0, 0, 0); return r; }
+template <> __device__ __forceinline__ Raw<4> raw_zero<4>() { Raw<4> r; r.v = make_uint2(0, 0); return r; }
+template <> __device__ __forceinline__ Raw<2> raw_zero<2>() { Raw<2> r; r.v = 0; return r; }
+
+template <int CPT> __device__ __forceinline__ Raw<CPT> raw_load(const bf16_t* p);
+template <> __device__ __forceinline__ Raw<8> raw_load<8>(const bf16_t* p) { Raw<8> r; r.v = *reinterpret_cast<const uint4*>(p); return r; }
+template <> __device__ __forceinline__ Raw<4> raw_load<4>(const bf16_t* p) { Raw<4> r; r.v = *reinterpret_cast<const uint2*>(p); return r; }
+template <> __device__ __forceinline__ Raw<2> raw_load<2>(const bf16_t* p) { Raw<2> r; r.v = *reinterpret_cast<const uint32_t*>(p); return r; }
+
+__device__ __forceinline__ void up2(uint32_t u, float& lo, float& hi) {
+  lo = __uint_as_float(u << 16);
+  hi = __uint_as_float(u & 0xffff0000u);
+}
+template <int CPT> __device__ __forceinline__ void raw_unpack(const Raw<CPT>& r, float x[CPT]);
+template <> __device__ __forceinline__ void raw_unpack<8>(const Raw<8>& r, float x[8]) {
+  up2(r.v.x, x[0], x[1]); up2(r.v.y, x[2], x[3]); up2(r.v.z, x[4], x[5]); up2(r.v.w, x[6], x[7]);
+}
+template <> __device__ __forceinline__ void raw_unpack<4>(const Raw<4>& r, float x[4]) {
+  up2(r.v.x, x[0], x[1]); up2(r.v.y, x[2], x[3]);
+}
+template <> __device__ __forceinline__ void raw_unpack<2>(const Raw<2>& r, float x[2]) { up2(r.v, x[0], x[1]); }
+
+template <int CPT> __device__ __forceinline__ void store_bf(bf16_t* p, const float x[CPT]);
+template <> __device__ __forceinline__ void store_bf<8>(bf16_t* p, const float x[8]) {
+  uint4 o;
+  o.x = pack2bf(x[0], x[1]); o.y = pack2bf(x[2], x[3]); o.z = pack2bf(x[4], x[5]); o.w = pack2bf(x[6], x[7]);
+  *reinterpret_cast<uint4*>(p) = o;
+}
+template <> __device__ __forceinline__ void store_bf<4>(bf16_t* p, const float x[4]) {
+  uint2 o;
+  o.x = pack2bf(x[0], x[1]); o.y = pack2bf(x[2], x[3]);
+  *reinterpret_cast<uint2*>(p) = o;
+}
+template <> __device__ __forceinline__ void store_bf<2>(bf16_t* p, const float x[2]) {
+  *reinterpret_cast<uint32_t*>(p) = pack2bf(x[0], x[1]);
+}
+
+template <int CPT> __device__ __forceinline__ void loadf(const float* p, float x[CPT]) {
+#pragma unroll
+  for (int e = 0; e < CPT; ++e) x[e] = p[e];
+}
+
+// static slot of a (possibly negative) relative output row
+__host__ __device__ constexpr int slot_of(int rel, int n) { return ((rel % n) + n) % n; }
+
+struct Args {
+  edet_tview_t in;      // fwd / wgrad: activated input view; dgrad: the conv input view (chain target)
+  edet_gview_t gy;      // dy (wgrad, dgrad)
+  const float* w;       // [K][K][C] fp32
+  bf16_t* out; int ldo; // fwd
+  float* stat_partials; // fwd
+  edet_bwd_epi_t epi;   // dgrad
+  float* ws;            // wgrad workspace [P][K*K][C]
+  int oh, ow, pad_t, pad_l;
+  int nch, ngroups;     // channel chunks (of CPT) per workgroup, channel groups
+  int TX, TY;           // tile: TX columns (one per thread) x TY rows of the marched space
+  int tiles_x, tiles_y, ntiles, P;
+};
+
+struct Lane {
+  int chunk, px, g, p, c;
+  bool active;
+};
+template <int CPT>
+__device__ __forceinline__ Lane lane_setup(const Args& a, int C) {
+  Lane l;
+  l.chunk = threadIdx.x % a.nch;
+  l.px = threadIdx.x / a.nch;
+  l.g = blockIdx.x % a.ngroups;
+  l.p = blockIdx.x / a.ngroups;
+  l.c = (l.g * a.nch + l.chunk) * CPT;
+  l.active = l.px < a.TX && l.c < C;
+  return l;
+}
+
+template <int CPT>
+__device__ __forceinline__ void view_act(const edet_tview_t& v, const float sc[CPT], const float sh[CPT],
+                                         float x[CPT]) {
+  if (v.scale) {
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) x[e] = fmaf(x[e], sc[e], sh[e]);
+  }
+  if (v.act == EDET_ACT_SWISH) {
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) x[e] = swishf_(x[e]);
+  }
+}
+
+// workgroup reduction of per-thread channel sums into one partial row: partials[(p*nrow + row)*C + c]
+template <int CPT, int NROW>
+__device__ __forceinline__ void block_channel_sums(const Args& a, const Lane& l, int C, const float (&s)[NROW][CPT],
+                                                   float* dst_rows, float* red /* LDS [NROW][nch*CPT] */) {
+  const int width = a.nch * CPT;
+  for (int i = threadIdx.x; i < NROW * width; i += THREADS) red[i] = 0.f;
+  __syncthreads();
+  if (l.active) {
+#pragma unroll
+    for (int r = 0; r < NROW; ++r)
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) atomicAdd(&red[r * width + l.chunk * CPT + e], s[r][e]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NROW * width; i += THREADS) {
+    const int r = i / width, cl = i - r * width;
+    const int c = l.g * width + cl;
+    if (c < C) dst_rows[((size_t)l.p * NROW + r) * C + c] = red[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------ forward
+template <int K, int S, int CPT>
+__global__ __launch_bounds__(THREADS) void k_fwd(const Args a) {
+  constexpr int NSL = (K + S - 1) / S;   // output rows in flight
+  constexpr int U = S * NSL;             // static unroll of the row loop
+  extern __shared__ float red[];
+  const int C = a.in.c, H = a.in.h, W = a.in.w;
+  const Lane l = lane_setup<CPT>(a, C);
+  const bf16_t* IN = reinterpret_cast<const bf16_t*>(a.in.data);
+  float w[K * K][CPT], sc[CPT], sh[CPT];
+  float st[2][CPT];
+#pragma unroll
+  for (int e = 0; e < CPT; ++e) { sc[e] = 1.f; sh[e] = 0.f; st[0][e] = st[1][e] = 0.f; }
+#pragma unroll
+  for (int t = 0; t < K * K; ++t)
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) w[t][e] = l.active ? a.w[(size_t)t * C + l.c + e] : 0.f;
+  if (l.active && a.in.scale) { loadf<CPT>(a.in.scale + l.c, sc); loadf<CPT>(a.in.shift + l.c, sh); }
+  const bool want_stats = a.stat_partials != nullptr;
+
+  for (int tile = l.p; tile < a.ntiles; tile += a.P) {
+    const int per_img = a.tiles_y * a.tiles_x;
+    const int n = tile / per_img, rr = tile - n * per_img;
+    const int ty = rr / a.tiles_x, tx = rr - ty * a.tiles_x;
+    const int oy0 = ty * a.TY, oy1 = min(a.oh, oy0 + a.TY);
+    const int ox = tx * a.TX + l.px;
+    const bool xok = l.active && ox < a.ow;
+    const int ix0 = ox * S - a.pad_l;
+    unsigned xmask = 0;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx)
+      if (xok && ix0 + kx >= 0 && ix0 + kx < W) xmask |= 1u << kx;
+    const bf16_t* ibase = IN + (((int64_t)n * H * W + ix0) * a.in.ld + l.c);   // ix0 may be -pad
+    bf16_t* obase = a.out + ((size_t)n * a.oh * a.ow + ox) * a.ldo + l.c;
+    float acc[NSL][CPT];
+#pragma unroll
+    for (int s = 0; s < NSL; ++s)
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) acc[s][e] = 0.f;
+
+    const int t0 = (oy0 * S / U) * U, t_last = (oy1 - 1) * S + K - 1;   // t = input row + pad_t
+    Raw<CPT> cur[K], nxt[K];
+    auto load_row = [&](int t, Raw<CPT> (&dst)[K]) {
+      const int r = t - a.pad_t;
+      if (r >= 0 && r < H) {
+        const bf16_t* rp = ibase + (int64_t)r * W * a.in.ld;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx)
+          dst[kx] = (xmask >> kx) & 1u ? raw_load<CPT>(rp + (int64_t)kx * a.in.ld) : raw_zero<CPT>();
+      }
+    };
+    load_row(t0, cur);
+    for (int tb = t0; tb <= t_last; tb += U) {
+#pragma unroll
+      for (int tt = 0; tt < U; ++tt) {
+        const int t = tb + tt;
+        if (t + 1 <= t_last) load_row(t + 1, nxt);
+        const int r = t - a.pad_t;
+        if (t <= t_last && r >= 0 && r < H) {
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) {
+            float x[CPT];
+            raw_unpack<CPT>(cur[kx], x);
+            view_act<CPT>(a.in, sc, sh, x);
+            if (!((xmask >> kx) & 1u)) {
+#pragma unroll
+              for (int e = 0; e < CPT; ++e) x[e] = 0.f;   // 'SAME' padding is zero in the activated domain
+            }
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+              if ((tt - ky) % S == 0) {                    // static: this input row feeds output (t - ky) / S
+                const int sl = slot_of((tt - ky) / S, NSL);
+#pragma unroll
+                for (int e = 0; e < CPT; ++e) acc[sl][e] = fmaf(w[ky * K + kx][e], x[e], acc[sl][e]);
+              }
+            }
+          }
+        }
+        if ((tt - (K - 1)) % S == 0) {                     // static: output row (t - K + 1) / S is complete
+          const int sl = slot_of((tt - (K - 1)) / S, NSL);
+          const int oy = (t - (K - 1)) / S;
+          if (t <= t_last && t >= K - 1 && oy >= oy0 && oy < oy1 && xok) {
+            store_bf<CPT>(obase + (size_t)oy * a.ow * a.ldo, acc[sl]);
+            if (want_stats) {
+#pragma unroll
+              for (int e = 0; e < CPT; ++e) {
+                const float v = bf2f(f2bf(acc[sl][e]));
+                st[0][e] += v;
+                st[1][e] = fmaf(v, v, st[1][e]);
+              }
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < CPT; ++e) acc[sl][e] = 0.f;
+        }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) cur[kx] = nxt[kx];
+      }
+    }
+  }
+  if (want_stats) block_channel_sums<CPT, 2>(a, l, C, st, a.stat_partials, red);
+}
+
+// ---------------------------------------------------------------------------- weight gradient
+// dW[ky][kx][c] = sum over (n, oy, ox) of act(in)[oy*S+ky-pt][ox*S+kx-pl][c] * dy[oy][ox][c].
+// Marches over the input rows; the dy rows an input row pairs with are kept in a rotating register window.
+template <int K, int S, int CPT, bool GBN>
+__global__ __launch_bounds__(THREADS) void k_wgrad(const Args a) {
+  constexpr int NSL = (K + S - 1) / S;
+  constexpr int U = S * NSL;
+  extern __shared__ float red[];
+  const int C = a.in.c, H = a.in.h, W = a.in.w;
+  const Lane l = lane_setup<CPT>(a, C);
+  const bf16_t* IN = reinterpret_cast<const bf16_t*>(a.in.data);
+  const bf16_t* DZ = reinterpret_cast<const bf16_t*>(a.gy.dz);
+  const bf16_t* YY = reinterpret_cast<const bf16_t*>(a.gy.y);
+  float wacc[K * K][CPT], sc[CPT], sh[CPT], ga[CPT], gb[CPT], gc[CPT];
+#pragma unroll
+  for (int e = 0; e < CPT; ++e) { sc[e] = 1.f; sh[e] = 0.f; ga[e] = 1.f; gb[e] = 0.f; gc[e] = 0.f; }
+#pragma unroll
+  for (int t = 0; t < K * K; ++t)
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) wacc[t][e] = 0.f;
+  if (l.active) {
+    if (a.in.scale) { loadf<CPT>(a.in.scale + l.c, sc); loadf<CPT>(a.in.shift + l.c, sh); }
+    if (GBN) { loadf<CPT>(a.gy.a + l.c, ga); loadf<CPT>(a.gy.b + l.c, gb); loadf<CPT>(a.gy.cc + l.c, gc); }
+  }
+
+  for (int tile = l.p; tile < a.ntiles; tile += a.P) {
+    const int per_img = a.tiles_y * a.tiles_x;
+    const int n = tile / per_img, rr = tile - n * per_img;
+    const int ty = rr / a.tiles_x, tx = rr - ty * a.tiles_x;
+    const int oy0 = ty * a.TY, oy1 = min(a.oh, oy0 + a.TY);
+    const int ox = tx * a.TX + l.px;
+    const bool xok = l.active && ox < a.ow;
+    const int ix0 = ox * S - a.pad_l;
+    unsigned xmask = 0;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx)
+      if (xok && ix0 + kx >= 0 && ix0 + kx < W) xmask |= 1u << kx;
+    const bf16_t* ibase = IN + (((int64_t)n * H * W + ix0) * a.in.ld + l.c);   // ix0 may be -pad
+    const size_t gbase = ((size_t)n * a.oh * a.ow + ox) * a.gy.ld + l.c;
+    float dyw[NSL][CPT];                       // dy rows in flight, slot = oy mod NSL
+#pragma unroll
+    for (int s = 0; s < NSL; ++s)
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) dyw[s][e] = 0.f;
+
+    const int t0 = (oy0 * S / U) * U, t_last = (oy1 - 1) * S + K - 1;
+    for (int tb = t0; tb <= t_last; tb += U) {
+#pragma unroll
+      for (int tt = 0; tt < U; ++tt) {
+        const int t = tb + tt;
+        if (tt % S == 0) {                     // static: a new dy row oy = t / S enters the window at ky = 0
+          const int sl = slot_of(tt / S, NSL);
+          const int oy = t / S;
+          float g[CPT];
+#pragma unroll
+          for (int e = 0; e < CPT; ++e) g[e] = 0.f;
+          if (t <= t_last && oy >= oy0 && oy < oy1 && xok) {
+            const size_t off = gbase + (size_t)oy * a.ow * a.gy.ld;
+            raw_unpack<CPT>(raw_load<CPT>(DZ + off), g);
+            if (GBN) {
+              float y[CPT];
+              raw_unpack<CPT>(raw_load<CPT>(YY + off), y);
+#pragma unroll
+              for (int e = 0; e < CPT; ++e) g[e] = fmaf(ga[e], g[e], fmaf(gb[e], y[e], gc[e]));
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < CPT; ++e) dyw[sl][e] = g[e];
+        }
+        const int r = t - a.pad_t;
+        if (t <= t_last && r >= 0 && r < H) {
+          const bf16_t* rp = ibase + (int64_t)r * W * a.in.ld;
+          Raw<CPT> raw[K];
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx)
+            raw[kx] = (xmask >> kx) & 1u ? raw_load<CPT>(rp + (int64_t)kx * a.in.ld) : raw_zero<CPT>();
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) {
+            float x[CPT];
+            raw_unpack<CPT>(raw[kx], x);
+            view_act<CPT>(a.in, sc, sh, x);
+            if (!((xmask >> kx) & 1u)) {
+#pragma unroll
+              for (int e = 0; e < CPT; ++e) x[e] = 0.f;
+            }
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+              if ((tt - ky) % S == 0) {
+                const int sl = slot_of((tt - ky) / S, NSL);
+#pragma unroll
+                for (int e = 0; e < CPT; ++e) wacc[ky * K + kx][e] = fmaf(x[e], dyw[sl][e], wacc[ky * K + kx][e]);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  block_channel_sums<CPT, K * K>(a, l, C, wacc, a.ws, red);
+}
+
+// dweight[t][c] += sum_p ws[p][t][c]
+__global__ void k_wgrad_reduce(const float* __restrict__ ws, int P, int64_t kkc, float* __restrict__ dw) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= kkc) return;
+  float s0 = 0.f, s1 = 0.f;
+  int p = 0;
+  for (; p + 1 < P; p += 2) {
+    s0 += ws[(size_t)p * kkc + i];
+    s1 += ws[(size_t)(p + 1) * kkc + i];
+  }
+  if (p < P) s0 += ws[(size_t)p * kkc + i];
+  dw[i] += s0 + s1;
+}
+
+// ------------------------------------------------------------------------------ data gradient
+// d in[iy][ix] = sum over (ky, kx) with (iy+pt-ky) % S == 0, (ix+pl-kx) % S == 0 of
+//                w[ky][kx] * dy[(iy+pt-ky)/S][(ix+pl-kx)/S].
+// With ty = iy + pt and tx = ix + pl, thread q owns the S columns tx = S*q + u (u < S) and marches over the
+// dy rows: row oy feeds ty = oy*S + ky, so K (+S-1) input rows are in flight; after dy row oy the rows
+// ty = oy*S .. oy*S + S-1 are complete and go through the epilogue (act', accumulate, BN backward sums).
+template <int K, int S, int CPT, bool GBN>
+__global__ __launch_bounds__(THREADS) void k_dgrad(const Args a) {
+  constexpr int D = (K + S - 1) / S;          // dy columns / rows a thread needs per step
+  constexpr int RS = S * D;                   // ring of in-flight ty rows (>= K), divisible by S
+  extern __shared__ float red[];
+  const int C = a.in.c, H = a.in.h, W = a.in.w;
+  const Lane l = lane_setup<CPT>(a, C);
+  const bf16_t* X = reinterpret_cast<const bf16_t*>(a.in.data);
+  const bf16_t* DZ = reinterpret_cast<const bf16_t*>(a.gy.dz);
+  const bf16_t* YY = reinterpret_cast<const bf16_t*>(a.gy.y);
+  bf16_t* GO = reinterpret_cast<bf16_t*>(a.epi.gout);
+  float w[K * K][CPT], sc[CPT], sh[CPT], ga[CPT], gb[CPT], gc[CPT], mu[CPT], rs[CPT];
+  float st[2][CPT];
+#pragma unroll
+  for (int e = 0; e < CPT; ++e) {
+    sc[e] = 1.f; sh[e] = 0.f; ga[e] = 1.f; gb[e] = 0.f; gc[e] = 0.f; mu[e] = 0.f; rs[e] = 1.f;
+    st[0][e] = st[1][e] = 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < K * K; ++t)
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) w[t][e] = l.active ? a.w[(size_t)t * C + l.c + e] : 0.f;
+  const bool want_stats = a.epi.stat_partials != nullptr;
+  const bool swish = a.in.act == EDET_ACT_SWISH;
+  if (l.active) {
+    if (a.in.scale) { loadf<CPT>(a.in.scale + l.c, sc); loadf<CPT>(a.in.shift + l.c, sh); }
+    if (GBN) { loadf<CPT>(a.gy.a + l.c, ga); loadf<CPT>(a.gy.b + l.c, gb); loadf<CPT>(a.gy.cc + l.c, gc); }
+    if (want_stats) { loadf<CPT>(a.epi.mean + l.c, mu); loadf<CPT>(a.epi.rstd + l.c, rs); }
+  }
+
+  // tiles are over (q, oy): q in [0, QW), QW = ceil((W + pad_l) / S); oy-space rows [qy0, qy1) with
+  // QH = ceil((H + pad_t) / S): step oy completes ty = oy*S + u
+  const int QW = (W + a.pad_l + S - 1) / S, QH = (H + a.pad_t + S - 1) / S;
+  for (int tile = l.p; tile < a.ntiles; tile += a.P) {
+    const int per_img = a.tiles_y * a.tiles_x;
+    const int n = tile / per_img, rr = tile - n * per_img;
+    const int ty_ = rr / a.tiles_x, tx_ = rr - ty_ * a.tiles_x;
+    const int q = tx_ * a.TX + l.px;
+    const bool qok = l.active && q < QW;
+    const int qy0 = ty_ * a.TY, qy1 = min(QH, qy0 + a.TY);
+    // dy column q - d (d < D) valid?
+    unsigned dmask = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (qok && q - d >= 0 && q - d < a.ow) dmask |= 1u << d;
+    float acc[RS][S][CPT];
+#pragma unroll
+    for (int s = 0; s < RS; ++s)
+#pragma unroll
+      for (int u = 0; u < S; ++u)
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) acc[s][u][e] = 0.f;
+    const size_t gimg = (size_t)n * a.oh * a.ow;
+    // dy rows needed for ty rows [qy0*S, qy1*S): oy from qy0 - (D-1) to qy1 - 1; start aligned to D steps
+    const int o_begin = ((qy0 - (D - 1)) >= 0 ? (qy0 - (D - 1)) / D : -((D - 1 - (qy0 - (D - 1))) / D)) * D;
+    for (int ob = o_begin; ob < qy1; ob += D) {
+#pragma unroll
+      for (int oo = 0; oo < D; ++oo) {
+        const int oy = ob + oo;
+        if (oy < qy1 && oy >= 0 && oy < a.oh) {            // uniform
+          const size_t rowoff = (gimg + (size_t)oy * a.ow) * a.gy.ld + l.c;
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            float g[CPT];
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) g[e] = 0.f;
+            if ((dmask >> d) & 1u) {
+              const size_t off = rowoff + (size_t)(q - d) * a.gy.ld;
+              raw_unpack<CPT>(raw_load<CPT>(DZ + off), g);
+              if (GBN) {
+                float y[CPT];
+                raw_unpack<CPT>(raw_load<CPT>(YY + off), y);
+#pragma unroll
+                for (int e = 0; e < CPT; ++e) g[e] = fmaf(ga[e], g[e], fmaf(gb[e], y[e], gc[e]));
+              }
+            }
+            // dy[oy][q-d] feeds tx = S*q + u with kx = u + S*d, and ty = oy*S + ky
+#pragma unroll
+            for (int u = 0; u < S; ++u) {
+              if (u + S * d < K) {
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky) {
+                  const int sl = slot_of(oo * S + ky, RS);     // (oy*S + ky) mod RS, ob*S = 0 mod RS
+#pragma unroll
+                  for (int e = 0; e < CPT; ++e)
+                    acc[sl][u][e] = fmaf(w[ky * K + u + S * d][e], g[e], acc[sl][u][e]);
+                }
+              }
+            }
+          }
+        }
+        // rows ty = oy*S + v (v < S) are complete
+#pragma unroll
+        for (int v = 0; v < S; ++v) {
+          const int sl = slot_of(oo * S + v, RS);
+          const int iy = oy * S + v - a.pad_t;
+          if (oy >= qy0 && oy < qy1 && iy >= 0 && iy < H) {   // uniform
+#pragma unroll
+            for (int u = 0; u < S; ++u) {
+              const int ix = q * S + u - a.pad_l;
+              if (qok && ix >= 0 && ix < W) {
+                const size_t off = ((size_t)(n * H + iy) * W + ix) * a.in.ld + l.c;
+                float g[CPT], x[CPT];
+#pragma unroll
+                for (int e = 0; e < CPT; ++e) { g[e] = acc[sl][u][e]; x[e] = 0.f; }
+                if (swish || want_stats) raw_unpack<CPT>(raw_load<CPT>(X + off), x);
+                if (swish) {
+#pragma unroll
+                  for (int e = 0; e < CPT; ++e) g[e] *= swish_gradf_(fmaf(x[e], sc[e], sh[e]));
+                }
+                if (a.epi.beta) {
+                  float old[CPT];
+                  raw_unpack<CPT>(raw_load<CPT>(GO + off), old);
+#pragma unroll
+                  for (int e = 0; e < CPT; ++e) g[e] += old[e];
+                }
+                store_bf<CPT>(GO + off, g);
+                if (want_stats) {
+#pragma unroll
+                  for (int e = 0; e < CPT; ++e) {
+                    st[0][e] += g[e];
+                    st[1][e] = fmaf(g[e], (x[e] - mu[e]) * rs[e], st[1][e]);
+                  }
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < S; ++u)
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) acc[sl][u][e] = 0.f;
+        }
+      }
+    }
+  }
+  if (want_stats) block_channel_sums<CPT, 2>(a, l, C, st, a.epi.stat_partials, red);
+}
+
+// ------------------------------------------------------------------------------------- host
+inline int pick_nch(int nvec, int maxch) {
+  if (nvec <= maxch) return nvec;
+  int best = maxch;
+  double best_u = 0.0;
+  for (int n = maxch; n >= maxch / 2; --n) {
+    const int groups = (nvec + n - 1) / n;
+    const double u = (double)nvec / (groups * n) * ((THREADS / n) * n) / THREADS;
+    if (u > best_u + 1e-9) { best_u = u; best = n; }
+  }
+  return best;
+}
+
+// space_w / space_h: extent of the marched tile space (output pixels; for dgrad the q / oy step space)
+template <int CPT>
+inline void plan(Args& a, int C, int n, int space_w, int space_h, int max_p) {
+  const int nvec = (C + CPT - 1) / CPT;
+  a.nch = pick_nch(nvec, 128 / (CPT * 2));      // <= 128 contiguous bytes per pixel and workgroup
+  a.ngroups = (nvec + a.nch - 1) / a.nch;
+  a.TX = THREADS / a.nch;
+  a.TY = 32;
+  if (a.TY > space_h) a.TY = space_h;
+  a.tiles_x = (space_w + a.TX - 1) / a.TX;
+  a.tiles_y = (space_h + a.TY - 1) / a.TY;
+  a.ntiles = n * a.tiles_x * a.tiles_y;
+  int P = 4096 / a.ngroups;
+  if (P < 64) P = 64;
+  if (P > max_p) P = max_p;
+  if (P > a.ntiles) P = a.ntiles;
+  a.P = P;
+}
+
+}  // namespace dwm
+
+// return 1 = handled, 0 = not applicable (caller falls back), < 0 = error
+int dwm_try_fwd(const edet_tview_t* in, const float* weight, int k, int s, void* out, int ldo,
+                float* stat_partials, int* nparts_out, hipStream_t st) {
+  using namespace dwm;
+  if (in->gate || in->c % 8 != 0) return 0;
+  Args a;
+  memset(&a, 0, sizeof(a));
+  a.in = *in; a.w = weight; a.out = reinterpret_cast<bf16_t*>(out); a.ldo = ldo; a.stat_partials = stat_partials;
+  a.oh = same_out(in->h, s); a.ow = same_out(in->w, s);
+  a.pad_t = same_pad_before(in->h, k, s); a.pad_l = same_pad_before(in->w, k, s);
+#define DWM_FWD(K_, S_, CPT_)                                                             \
+  do {                                                                                    \
+    plan<CPT_>(a, in->c, in->n, a.ow, a.oh, EDET_MAX_PARTS);                              \
+    k_fwd<K_, S_, CPT_><<<dim3(a.P * a.ngroups), dim3(THREADS), 2 * a.nch * CPT_ * sizeof(float), st>>>(a); \
+  } while (0)
+  if (k == 3 && s == 1) DWM_FWD(3, 1, 4);
+  else if (k == 3 && s == 2) DWM_FWD(3, 2, 4);
+  else if (k == 5 && s == 1) DWM_FWD(5, 1, 2);
+  else if (k == 5 && s == 2) DWM_FWD(5, 2, 2);
+  else return 0;
+#undef DWM_FWD
+  if (nparts_out) *nparts_out = a.P;
+  EDET_LAUNCH_CHECK("edet_dw_fwd(march)");
+  return 1;
+}
+
+int dwm_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, float* dweight, void* workspace,
+                  size_t workspace_bytes, hipStream_t st) {
+  using namespace dwm;
+  if (in->gate || in->c % 8 != 0 || !workspace) return 0;
+  Args a;
+  memset(&a, 0, sizeof(a));
+  a.in = *in; a.gy = *dy; a.ws = reinterpret_cast<float*>(workspace);
+  a.oh = same_out(in->h, s); a.ow = same_out(in->w, s);
+  a.pad_t = same_pad_before(in->h, k, s); a.pad_l = same_pad_before(in->w, k, s);
+  const int64_t kkc = (int64_t)k * k * in->c;
+  int max_p = (int)((int64_t)(workspace_bytes / sizeof(float)) / kkc);
+  if (max_p < 1) return 0;
+  if (max_p > 1024) max_p = 1024;
+  const bool gbn = dy->a != nullptr;
+#define DWM_WG(K_, S_, CPT_)                                                              \
+  do {                                                                                    \
+    plan<CPT_>(a, in->c, in->n, a.ow, a.oh, max_p);                                       \
+    const size_t lds = (size_t)K_ * K_ * a.nch * CPT_ * sizeof(float);                    \
+    if (gbn) k_wgrad<K_, S_, CPT_, true><<<dim3(a.P * a.ngroups), dim3(THREADS), lds, st>>>(a);   \
+    else k_wgrad<K_, S_, CPT_, false><<<dim3(a.P * a.ngroups), dim3(THREADS), lds, st>>>(a);      \
+  } while (0)
+  if (k == 3 && s == 1) DWM_WG(3, 1, 4);
+  else if (k == 3 && s == 2) DWM_WG(3, 2, 4);
+  else if (k == 5 && s == 1) DWM_WG(5, 1, 2);
+  else if (k == 5 && s == 2) DWM_WG(5, 2, 2);
+  else return 0;
+#undef DWM_WG
+  EDET_LAUNCH_CHECK("edet_dw_bwd_weight(march)");
+  k_wgrad_reduce<<<dim3((unsigned)((kkc + 255) / 256)), dim3(256), 0, st>>>(a.ws, a.P, kkc, dweight);
+  EDET_LAUNCH_CHECK("edet_dw_bwd_weight(reduce)");
+  return 1;
+}
+
+int dwm_try_dgrad(const edet_gview_t* dy, const float* weight, int k, int s, const edet_tview_t* in,
+                  const edet_bwd_epi_t* epi, int* nparts_out, hipStream_t st) {
+  using namespace dwm;
+  if (in->gate || epi->dgate || in->c % 8 != 0) return 0;
+  Args a;
+  memset(&a, 0, sizeof(a));
+  a.in = *in; a.gy = *dy; a.w = weight; a.epi = *epi;
+  a.oh = same_out(in->h, s); a.ow = same_out(in->w, s);
+  a.pad_t = same_pad_before(in->h, k, s); a.pad_l = same_pad_before(in->w, k, s);
+  const int QW = (in->w + a.pad_l + s - 1) / s, QH = (in->h + a.pad_t + s - 1) / s;
+  const bool gbn = dy->a != nullptr;
+#define DWM_DG(K_, S_, CPT_)                                                              \
+  do {                                                                                    \
+    plan<CPT_>(a, in->c, in->n, QW, QH, EDET_MAX_PARTS);                                  \
+    const size_t lds = (size_t)2 * a.nch * CPT_ * sizeof(float);                          \
+    if (gbn) k_dgrad<K_, S_, CPT_, true><<<dim3(a.P * a.ngroups), dim3(THREADS), lds, st>>>(a);   \
+    else k_dgrad<K_, S_, CPT_, false><<<dim3(a.P * a.ngroups), dim3(THREADS), lds, st>>>(a);      \
+  } while (0)
+  if (k == 3 && s == 1) DWM_DG(3, 1, 4);
+  else if (k == 3 && s == 2) DWM_DG(3, 2, 4);
+  else if (k == 5 && s == 1) DWM_DG(5, 1, 2);
+  else if (k == 5 && s == 2) DWM_DG(5, 2, 2);
+  else return 0;
+#undef DWM_DG
+  if (nparts_out) *nparts_out = a.P;
+  EDET_LAUNCH_CHECK("edet_dw_bwd_data(march)");
+  return 1;
+}

@@ -463,6 +463,14 @@ int run(int which, int k, int s, DwArgs& a, int dtype, void* stream, int* nparts
 
 }  // namespace
 
+// bf16 row-marching kernels (dw_march.hip): 1 = handled, 0 = not applicable
+int dwm_try_fwd(const edet_tview_t* in, const float* weight, int k, int s, void* out, int ldo,
+                float* stat_partials, int* nparts_out, hipStream_t st);
+int dwm_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, float* dweight, void* workspace,
+                  size_t workspace_bytes, hipStream_t st);
+int dwm_try_dgrad(const edet_gview_t* dy, const float* weight, int k, int s, const edet_tview_t* in,
+                  const edet_bwd_epi_t* epi, int* nparts_out, hipStream_t st);
+
 extern "C" int edet_dw_fwd(const edet_tview_t* in, const float* weight, int k, int stride,
                            void* out, int ldo, float* stat_partials, int* nparts_out,
                            int dtype, void* stream) {
@@ -471,6 +479,10 @@ extern "C" int edet_dw_fwd(const edet_tview_t* in, const float* weight, int k, i
   DwArgs a;
   memset(&a, 0, sizeof(a));
   a.in = *in; a.w = weight; a.out = out; a.ldo = ldo; a.stat_partials = stat_partials;
+  if (dtype == EDET_BF16 && ldo % 8 == 0) {
+    const int rc = dwm_try_fwd(in, weight, k, stride, out, ldo, stat_partials, nparts_out, to_stream(stream));
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
   return run(DW_FWD, k, stride, a, dtype, stream, nparts_out);
 }
 
@@ -484,15 +496,24 @@ extern "C" int edet_dw_bwd_data(const edet_gview_t* dy, const float* weight, int
   DwArgs a;
   memset(&a, 0, sizeof(a));
   a.in = *in; a.gy = *dy; a.w = weight; a.epi = *epi;
+  if (dtype == EDET_BF16) {
+    const int rc = dwm_try_dgrad(dy, weight, k, stride, in, epi, nparts_out, to_stream(stream));
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
   return run(DW_BWD_DATA, k, stride, a, dtype, stream, nparts_out);
 }
 
 extern "C" int edet_dw_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy, int k, int stride,
-                                  float* dweight, int dtype, void* stream) {
+                                  float* dweight, void* workspace, size_t workspace_bytes, int dtype,
+                                  void* stream) {
   EDET_CHECK(in && in->data && dy && dy->dz && dweight, "edet_dw_bwd_weight: null pointer");
   EDET_CHECK(dy->ld % 4 == 0, "edet_dw_bwd_weight: dy ld % 4");
   DwArgs a;
   memset(&a, 0, sizeof(a));
   a.in = *in; a.gy = *dy; a.dweight = dweight;
+  if (dtype == EDET_BF16 && dy->ld % 8 == 0) {
+    const int rc = dwm_try_wgrad(in, dy, k, stride, dweight, workspace, workspace_bytes, to_stream(stream));
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
   return run(DW_BWD_WEIGHT, k, stride, a, dtype, stream, nullptr);
 }

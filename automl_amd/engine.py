@@ -341,7 +341,7 @@ class Engine(object):
     nb = (vin.raw.rows + vout.raw.rows) * vin.raw.c * self.esize
     tag = '%dx%dx%d k%ds%d' % (vin.raw.h, vin.raw.w, vin.raw.c, k, stride)
     call('edet_dw_bwd_weight', ctypes.byref(vin.tview()), ctypes.byref(g), k, stride, ptr(self.grad(wname)),
-         self.dtype, self.stream, nbytes=nb, tag=tag)
+         ptr(self.workspace), self.workspace.numel() * 4, self.dtype, self.stream, nbytes=nb, tag=tag)
     if vin.raw.needs_grad:
       epi, fused = self._epi(vin)
       call('edet_dw_bwd_data', ctypes.byref(g), ptr(self.param(wname)), k, stride, ctypes.byref(vin.tview()),

@@ -145,8 +145,9 @@ int edet_dw_fwd(const edet_tview_t* in, const float* weight, int k, int stride,
 int edet_dw_bwd_data(const edet_gview_t* dy, const float* weight, int k, int stride,
                      const edet_tview_t* in, const edet_bwd_epi_t* epi, int* nparts_out,
                      int dtype, void* stream);
+/* dweight [k,k,c] fp32 is accumulated into; workspace as for edet_pw_bwd_weight (may be NULL). */
 int edet_dw_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy, int k, int stride,
-                       float* dweight, int dtype, void* stream);
+                       float* dweight, void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
 /* ---- BatchNorm statistics --------------------------------------------------
  * utils.py:244-266 / util_keras.py:29-66 (eps 1e-3, momentum 0.99).

@@ -246,8 +246,15 @@ def test_dw_fwd(dt, shape, ks, mode):
   torch.cuda.synchronize()
   gu.check(out, want, name, 'dw_fwd %s k%d s%d %s' % (shape, k, s, mode))
   s1, s2 = gu.sum_partials(parts, npart.value, c)
-  gu.check(s1, want.sum((0, 1, 2)), name, 'dw_fwd sum', rtol=1e-3, atol=1e-3 * n * oh * ow, scale_by_max=False)
-  gu.check(s2, (want * want).sum((0, 1, 2)), name, 'dw_fwd sumsq', rtol=1e-3)
+  # BatchNorm statistics describe the tensor that was STORED (rounded to the storage dtype): tight against
+  # the kernel's own output, storage-dtype tolerance against the unrounded oracle
+  of = out.float().cpu()
+  gu.check(s1, of.sum((0, 1, 2)), name, 'dw_fwd sum vs stored', rtol=1e-3, atol=1e-3 * n * oh * ow,
+           scale_by_max=False)
+  gu.check(s2, (of * of).sum((0, 1, 2)), name, 'dw_fwd sumsq vs stored', rtol=1e-3)
+  srt = 1e-3 if name == 'f32' else 1e-2
+  gu.check(s1, want.sum((0, 1, 2)), name, 'dw_fwd sum', rtol=srt, atol=srt * n * oh * ow, scale_by_max=False)
+  gu.check(s2, (want * want).sum((0, 1, 2)), name, 'dw_fwd sumsq', rtol=srt)
 
 
 @pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
@@ -298,7 +305,9 @@ def test_dw_bwd(dt, shape, ks, mode):
   call('edet_dw_bwd_data', ctypes.byref(gv), ptr(wd), k, s, ctypes.byref(tv), ctypes.byref(epi),
        ctypes.byref(npart), edt, gu.stream())
   dwd = torch.zeros(k, k, c, dtype=torch.float32, device=gu.DEV)
-  call('edet_dw_bwd_weight', ctypes.byref(tv), ctypes.byref(gv), k, s, ptr(dwd), edt, gu.stream())
+  wsp = torch.empty(4 * 1024 * 1024, dtype=torch.float32, device=gu.DEV)
+  call('edet_dw_bwd_weight', ctypes.byref(tv), ctypes.byref(gv), k, s, ptr(dwd), ptr(wsp), 16 * 1024 * 1024, edt,
+       gu.stream())
   torch.cuda.synchronize()
   gu.check(gout, want_g, name, 'dw_bwd_data %s k%d s%d %s' % (shape, k, s, mode))
   gu.check(dwd, want_dw, name, 'dw_bwd_weight %s k%d s%d' % (shape, k, s), rtol=1e-3, atol=1e-3)
