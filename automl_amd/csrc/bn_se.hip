@@ -410,6 +410,34 @@ __global__ __launch_bounds__(THREADS) void k_se_gate_bwd(const edet_tview_t in, 
   for (int i = tid; i < 2 * in.c; i += THREADS) partials[(size_t)blockIdx.x * 2 * in.c + i] = red[i];
 }
 
+// dst[i] += sum over the P partial rows: thread (element e = tid & 15, slice sl = tid >> 4) sums rows
+// sl, sl+16, ... with four independent loads in flight, the 16 slices are combined through LDS.
+__global__ __launch_bounds__(THREADS) void k_reduce_partials(const float* __restrict__ ws, int P, int64_t n,
+                                                            float* __restrict__ dst) {
+  __shared__ float red[16][17];
+  const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blockIdx.x * 16 + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int p = sl;
+    for (; p + 48 < P; p += 64) {
+      s0 += ws[(size_t)p * n + i];
+      s1 += ws[(size_t)(p + 16) * n + i];
+      s2 += ws[(size_t)(p + 32) * n + i];
+      s3 += ws[(size_t)(p + 48) * n + i];
+    }
+    for (; p < P; p += 16) s0 += ws[(size_t)p * n + i];
+  }
+  red[sl][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][e];
+    dst[i] += t;
+  }
+}
+
 inline int ew_grid(int64_t total) {
   int64_t g = (total + THREADS - 1) / THREADS;
   if (g > 4096) g = 4096;
@@ -418,6 +446,12 @@ inline int ew_grid(int64_t total) {
 }
 
 }  // namespace
+
+int edet_reduce_partials(const float* ws, int P, int64_t n, float* dst, hipStream_t st) {
+  k_reduce_partials<<<dim3((unsigned)((n + 15) / 16)), dim3(THREADS), 0, st>>>(ws, P, n, dst);
+  EDET_LAUNCH_CHECK("edet_reduce_partials");
+  return 0;
+}
 
 extern "C" int edet_bn_finalize(const float* partials, int nparts, int c, double count,
                                 const float* gamma, const float* beta, float eps, float momentum,

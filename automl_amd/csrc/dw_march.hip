@@ -117,24 +117,35 @@ __device__ __forceinline__ void view_act(const edet_tview_t& v, const float sc[C
   }
 }
 
-// workgroup reduction of per-thread channel sums into one partial row: partials[(p*nrow + row)*C + c]
+// workgroup reduction of per-thread channel sums into one partial row: partials[(p*nrow + row)*C + c].
+// One round per row: every thread parks its CPT values in LDS ([px][chunk][e] = thread-major), then
+// thread (col, slice) sums the pixels px = slice, slice + nsl, ... of column col and the few slices of a
+// column are combined with LDS atomics (nsl-way only).
 template <int CPT, int NROW>
 __device__ __forceinline__ void block_channel_sums(const Args& a, const Lane& l, int C, const float (&s)[NROW][CPT],
-                                                   float* dst_rows, float* red /* LDS [NROW][nch*CPT] */) {
+                                                   float* dst_rows, float* red /* LDS [THREADS*CPT + width] */) {
   const int width = a.nch * CPT;
-  for (int i = threadIdx.x; i < NROW * width; i += THREADS) red[i] = 0.f;
-  __syncthreads();
-  if (l.active) {
+  const int nthr = a.TX * a.nch;                 // threads that own a (pixel, chunk)
+  const int nsl = THREADS / width;               // pixel slices per column
+  const int col = threadIdx.x % width, slice = threadIdx.x / width;
+  float* out = red + THREADS * CPT;
 #pragma unroll
-    for (int r = 0; r < NROW; ++r)
+  for (int r = 0; r < NROW; ++r) {
+    __syncthreads();
 #pragma unroll
-      for (int e = 0; e < CPT; ++e) atomicAdd(&red[r * width + l.chunk * CPT + e], s[r][e]);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < NROW * width; i += THREADS) {
-    const int r = i / width, cl = i - r * width;
-    const int c = l.g * width + cl;
-    if (c < C) dst_rows[((size_t)l.p * NROW + r) * C + c] = red[i];
+    for (int e = 0; e < CPT; ++e) red[threadIdx.x * CPT + e] = (l.active && threadIdx.x < nthr) ? s[r][e] : 0.f;
+    if (threadIdx.x < width) out[threadIdx.x] = 0.f;
+    __syncthreads();
+    if (slice < nsl) {
+      float t = 0.f;
+      for (int px = slice; px < a.TX; px += nsl) t += red[px * width + col];
+      atomicAdd(&out[col], t);
+    }
+    __syncthreads();
+    if (threadIdx.x < width) {
+      const int c = l.g * width + threadIdx.x;
+      if (c < C) dst_rows[((size_t)l.p * NROW + r) * C + c] = out[threadIdx.x];
+    }
   }
 }
 
@@ -179,10 +190,10 @@ __global__ __launch_bounds__(THREADS) void k_fwd(const Args a) {
       for (int e = 0; e < CPT; ++e) acc[s][e] = 0.f;
 
     const int t0 = (oy0 * S / U) * U, t_last = (oy1 - 1) * S + K - 1;   // t = input row + pad_t
-    Raw<CPT> cur[K], nxt[K];
+    Raw<CPT> cur[K], n1[K], n2[K];
     auto load_row = [&](int t, Raw<CPT> (&dst)[K]) {
       const int r = t - a.pad_t;
-      if (r >= 0 && r < H) {
+      if (t <= t_last && r >= 0 && r < H) {
         const bf16_t* rp = ibase + (int64_t)r * W * a.in.ld;
 #pragma unroll
         for (int kx = 0; kx < K; ++kx)
@@ -190,11 +201,12 @@ __global__ __launch_bounds__(THREADS) void k_fwd(const Args a) {
       }
     };
     load_row(t0, cur);
+    load_row(t0 + 1, n1);
     for (int tb = t0; tb <= t_last; tb += U) {
 #pragma unroll
       for (int tt = 0; tt < U; ++tt) {
         const int t = tb + tt;
-        if (t + 1 <= t_last) load_row(t + 1, nxt);
+        load_row(t + 2, n2);                               // two input rows in flight per thread
         const int r = t - a.pad_t;
         if (t <= t_last && r >= 0 && r < H) {
 #pragma unroll
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(THREADS) void k_fwd(const Args a) {
           for (int e = 0; e < CPT; ++e) acc[sl][e] = 0.f;
         }
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) cur[kx] = nxt[kx];
+        for (int kx = 0; kx < K; ++kx) { cur[kx] = n1[kx]; n1[kx] = n2[kx]; }
       }
     }
   }
@@ -287,40 +299,55 @@ __global__ __launch_bounds__(THREADS) void k_wgrad(const Args a) {
       for (int e = 0; e < CPT; ++e) dyw[s][e] = 0.f;
 
     const int t0 = (oy0 * S / U) * U, t_last = (oy1 - 1) * S + K - 1;
+    Raw<CPT> cur[K], n1[K], n2[K], gz, gyr;
+    auto load_row = [&](int t, Raw<CPT> (&dst)[K]) {
+      const int r = t - a.pad_t;
+      if (t <= t_last && r >= 0 && r < H) {
+        const bf16_t* rp = ibase + (int64_t)r * W * a.in.ld;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx)
+          dst[kx] = (xmask >> kx) & 1u ? raw_load<CPT>(rp + (int64_t)kx * a.in.ld) : raw_zero<CPT>();
+      }
+    };
+    auto load_dy = [&](int oy) {                       // raw dy row oy (zero outside the tile / image)
+      gz = raw_zero<CPT>();
+      gyr = raw_zero<CPT>();
+      if (oy >= oy0 && oy < oy1 && xok) {
+        const size_t off = gbase + (size_t)oy * a.ow * a.gy.ld;
+        gz = raw_load<CPT>(DZ + off);
+        if (GBN) gyr = raw_load<CPT>(YY + off);
+      }
+    };
+    load_row(t0, cur);
+    load_row(t0 + 1, n1);
+    load_dy(t0 / S);
     for (int tb = t0; tb <= t_last; tb += U) {
 #pragma unroll
       for (int tt = 0; tt < U; ++tt) {
         const int t = tb + tt;
-        if (tt % S == 0) {                     // static: a new dy row oy = t / S enters the window at ky = 0
+        load_row(t + 2, n2);
+        if (tt % S == 0) {                     // static: dy row oy = t / S enters the window at ky = 0
           const int sl = slot_of(tt / S, NSL);
           const int oy = t / S;
           float g[CPT];
+          raw_unpack<CPT>(gz, g);
+          if (GBN) {
+            float y[CPT];
+            raw_unpack<CPT>(gyr, y);
+            const bool in_tile = oy >= oy0 && oy < oy1 && xok;
 #pragma unroll
-          for (int e = 0; e < CPT; ++e) g[e] = 0.f;
-          if (t <= t_last && oy >= oy0 && oy < oy1 && xok) {
-            const size_t off = gbase + (size_t)oy * a.ow * a.gy.ld;
-            raw_unpack<CPT>(raw_load<CPT>(DZ + off), g);
-            if (GBN) {
-              float y[CPT];
-              raw_unpack<CPT>(raw_load<CPT>(YY + off), y);
-#pragma unroll
-              for (int e = 0; e < CPT; ++e) g[e] = fmaf(ga[e], g[e], fmaf(gb[e], y[e], gc[e]));
-            }
+            for (int e = 0; e < CPT; ++e) g[e] = in_tile ? fmaf(ga[e], g[e], fmaf(gb[e], y[e], gc[e])) : 0.f;
           }
 #pragma unroll
           for (int e = 0; e < CPT; ++e) dyw[sl][e] = g[e];
+          load_dy(oy + 1);                     // next dy row flies while this input row is processed
         }
         const int r = t - a.pad_t;
         if (t <= t_last && r >= 0 && r < H) {
-          const bf16_t* rp = ibase + (int64_t)r * W * a.in.ld;
-          Raw<CPT> raw[K];
-#pragma unroll
-          for (int kx = 0; kx < K; ++kx)
-            raw[kx] = (xmask >> kx) & 1u ? raw_load<CPT>(rp + (int64_t)kx * a.in.ld) : raw_zero<CPT>();
 #pragma unroll
           for (int kx = 0; kx < K; ++kx) {
             float x[CPT];
-            raw_unpack<CPT>(raw[kx], x);
+            raw_unpack<CPT>(cur[kx], x);
             view_act<CPT>(a.in, sc, sh, x);
             if (!((xmask >> kx) & 1u)) {
 #pragma unroll
@@ -336,24 +363,12 @@ __global__ __launch_bounds__(THREADS) void k_wgrad(const Args a) {
             }
           }
         }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) { cur[kx] = n1[kx]; n1[kx] = n2[kx]; }
       }
     }
   }
   block_channel_sums<CPT, K * K>(a, l, C, wacc, a.ws, red);
-}
-
-// dweight[t][c] += sum_p ws[p][t][c]
-__global__ void k_wgrad_reduce(const float* __restrict__ ws, int P, int64_t kkc, float* __restrict__ dw) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= kkc) return;
-  float s0 = 0.f, s1 = 0.f;
-  int p = 0;
-  for (; p + 1 < P; p += 2) {
-    s0 += ws[(size_t)p * kkc + i];
-    s1 += ws[(size_t)(p + 1) * kkc + i];
-  }
-  if (p < P) s0 += ws[(size_t)p * kkc + i];
-  dw[i] += s0 + s1;
 }
 
 // ------------------------------------------------------------------------------ data gradient
@@ -363,7 +378,7 @@ __global__ void k_wgrad_reduce(const float* __restrict__ ws, int P, int64_t kkc,
 // dy rows: row oy feeds ty = oy*S + ky, so K (+S-1) input rows are in flight; after dy row oy the rows
 // ty = oy*S .. oy*S + S-1 are complete and go through the epilogue (act', accumulate, BN backward sums).
 template <int K, int S, int CPT, bool GBN>
-__global__ __launch_bounds__(THREADS) void k_dgrad(const Args a) {
+__global__ __launch_bounds__(THREADS, 3) void k_dgrad(const Args a) {
   constexpr int D = (K + S - 1) / S;          // dy columns / rows a thread needs per step
   constexpr int RS = S * D;                   // ring of in-flight ty rows (>= K), divisible by S
   extern __shared__ float red[];
@@ -417,26 +432,52 @@ __global__ __launch_bounds__(THREADS) void k_dgrad(const Args a) {
     const size_t gimg = (size_t)n * a.oh * a.ow;
     // dy rows needed for ty rows [qy0*S, qy1*S): oy from qy0 - (D-1) to qy1 - 1; start aligned to D steps
     const int o_begin = ((qy0 - (D - 1)) >= 0 ? (qy0 - (D - 1)) / D : -((D - 1 - (qy0 - (D - 1))) / D)) * D;
+    Raw<CPT> cz[D], cy[GBN ? D : 1], nz[D], ny[GBN ? D : 1];
+    auto load_dyrow = [&](int oy, Raw<CPT> (&z)[D], Raw<CPT> (&y)[GBN ? D : 1]) {
+      if (oy < qy1 && oy >= 0 && oy < a.oh) {             // uniform
+        const size_t rowoff = (gimg + (size_t)oy * a.ow) * a.gy.ld + l.c;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          z[d] = raw_zero<CPT>();
+          if (GBN) y[d] = raw_zero<CPT>();
+          if ((dmask >> d) & 1u) {
+            const size_t off = rowoff + (size_t)(q - d) * a.gy.ld;
+            z[d] = raw_load<CPT>(DZ + off);
+            if (GBN) y[d] = raw_load<CPT>(YY + off);
+          }
+        }
+      }
+    };
+    load_dyrow(o_begin, cz, cy);
     for (int ob = o_begin; ob < qy1; ob += D) {
 #pragma unroll
       for (int oo = 0; oo < D; ++oo) {
         const int oy = ob + oo;
+        load_dyrow(oy + 1, nz, ny);                        // next dy row in flight during this step
+        // saved conv input of the S x S pixels this step completes (needed for act' / BN backward sums)
+        Raw<CPT> xr[S][S];
+#pragma unroll
+        for (int v = 0; v < S; ++v) {
+          const int iy = oy * S + v - a.pad_t;
+#pragma unroll
+          for (int u = 0; u < S; ++u) {
+            const int ix = q * S + u - a.pad_l;
+            xr[v][u] = raw_zero<CPT>();
+            if ((swish || want_stats) && oy >= qy0 && oy < qy1 && iy >= 0 && iy < H && qok && ix >= 0 && ix < W)
+              xr[v][u] = raw_load<CPT>(X + ((size_t)(n * H + iy) * W + ix) * a.in.ld + l.c);
+          }
+        }
         if (oy < qy1 && oy >= 0 && oy < a.oh) {            // uniform
-          const size_t rowoff = (gimg + (size_t)oy * a.ow) * a.gy.ld + l.c;
 #pragma unroll
           for (int d = 0; d < D; ++d) {
             float g[CPT];
+            raw_unpack<CPT>(cz[d], g);
+            if (GBN) {
+              float y[CPT];
+              raw_unpack<CPT>(cy[d], y);
+              const bool ok = (dmask >> d) & 1u;
 #pragma unroll
-            for (int e = 0; e < CPT; ++e) g[e] = 0.f;
-            if ((dmask >> d) & 1u) {
-              const size_t off = rowoff + (size_t)(q - d) * a.gy.ld;
-              raw_unpack<CPT>(raw_load<CPT>(DZ + off), g);
-              if (GBN) {
-                float y[CPT];
-                raw_unpack<CPT>(raw_load<CPT>(YY + off), y);
-#pragma unroll
-                for (int e = 0; e < CPT; ++e) g[e] = fmaf(ga[e], g[e], fmaf(gb[e], y[e], gc[e]));
-              }
+              for (int e = 0; e < CPT; ++e) g[e] = ok ? fmaf(ga[e], g[e], fmaf(gb[e], y[e], gc[e])) : 0.f;
             }
             // dy[oy][q-d] feeds tx = S*q + u with kx = u + S*d, and ty = oy*S + ky
 #pragma unroll
@@ -466,8 +507,8 @@ __global__ __launch_bounds__(THREADS) void k_dgrad(const Args a) {
                 const size_t off = ((size_t)(n * H + iy) * W + ix) * a.in.ld + l.c;
                 float g[CPT], x[CPT];
 #pragma unroll
-                for (int e = 0; e < CPT; ++e) { g[e] = acc[sl][u][e]; x[e] = 0.f; }
-                if (swish || want_stats) raw_unpack<CPT>(raw_load<CPT>(X + off), x);
+                for (int e = 0; e < CPT; ++e) g[e] = acc[sl][u][e];
+                raw_unpack<CPT>(xr[v][u], x);
                 if (swish) {
 #pragma unroll
                   for (int e = 0; e < CPT; ++e) g[e] *= swish_gradf_(fmaf(x[e], sc[e], sh[e]));
@@ -493,6 +534,11 @@ __global__ __launch_bounds__(THREADS) void k_dgrad(const Args a) {
           for (int u = 0; u < S; ++u)
 #pragma unroll
             for (int e = 0; e < CPT; ++e) acc[sl][u][e] = 0.f;
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          cz[d] = nz[d];
+          if (GBN) cy[d] = ny[d];
         }
       }
     }
@@ -547,7 +593,7 @@ int dwm_try_fwd(const edet_tview_t* in, const float* weight, int k, int s, void*
 #define DWM_FWD(K_, S_, CPT_)                                                             \
   do {                                                                                    \
     plan<CPT_>(a, in->c, in->n, a.ow, a.oh, EDET_MAX_PARTS);                              \
-    k_fwd<K_, S_, CPT_><<<dim3(a.P * a.ngroups), dim3(THREADS), 2 * a.nch * CPT_ * sizeof(float), st>>>(a); \
+    k_fwd<K_, S_, CPT_><<<dim3(a.P * a.ngroups), dim3(THREADS), (THREADS * CPT_ + a.nch * CPT_) * sizeof(float), st>>>(a); \
   } while (0)
   if (k == 3 && s == 1) DWM_FWD(3, 1, 4);
   else if (k == 3 && s == 2) DWM_FWD(3, 2, 4);
@@ -577,7 +623,7 @@ int dwm_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, 
 #define DWM_WG(K_, S_, CPT_)                                                              \
   do {                                                                                    \
     plan<CPT_>(a, in->c, in->n, a.ow, a.oh, max_p);                                       \
-    const size_t lds = (size_t)K_ * K_ * a.nch * CPT_ * sizeof(float);                    \
+    const size_t lds = (size_t)(THREADS * CPT_ + a.nch * CPT_) * sizeof(float);           \
     if (gbn) k_wgrad<K_, S_, CPT_, true><<<dim3(a.P * a.ngroups), dim3(THREADS), lds, st>>>(a);   \
     else k_wgrad<K_, S_, CPT_, false><<<dim3(a.P * a.ngroups), dim3(THREADS), lds, st>>>(a);      \
   } while (0)
@@ -588,8 +634,7 @@ int dwm_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, 
   else return 0;
 #undef DWM_WG
   EDET_LAUNCH_CHECK("edet_dw_bwd_weight(march)");
-  k_wgrad_reduce<<<dim3((unsigned)((kkc + 255) / 256)), dim3(256), 0, st>>>(a.ws, a.P, kkc, dweight);
-  EDET_LAUNCH_CHECK("edet_dw_bwd_weight(reduce)");
+  if (edet_reduce_partials(a.ws, a.P, kkc, dweight, st) != 0) return -2;
   return 1;
 }
 
@@ -607,7 +652,7 @@ int dwm_try_dgrad(const edet_gview_t* dy, const float* weight, int k, int s, con
 #define DWM_DG(K_, S_, CPT_)                                                              \
   do {                                                                                    \
     plan<CPT_>(a, in->c, in->n, QW, QH, EDET_MAX_PARTS);                                  \
-    const size_t lds = (size_t)2 * a.nch * CPT_ * sizeof(float);                          \
+    const size_t lds = (size_t)(THREADS * CPT_ + a.nch * CPT_) * sizeof(float);           \
     if (gbn) k_dgrad<K_, S_, CPT_, true><<<dim3(a.P * a.ngroups), dim3(THREADS), lds, st>>>(a);   \
     else k_dgrad<K_, S_, CPT_, false><<<dim3(a.P * a.ngroups), dim3(THREADS), lds, st>>>(a);      \
   } while (0)

@@ -48,13 +48,15 @@ inline ColMap make_colmap(int channels) {
   return m;
 }
 
-// LDS row stride (bytes) of a bf16 tile whose rows are read as MFMA fragments (lane = row, 16 B per lane).
+// LDS row stride (bytes) of a bf16 tile whose rows are read as MFMA fragments (lane = row, 16 B per lane):
+// a multiple of 16 B with an ODD number of 16-B slots, so that the 16 rows one ds_read_b128 lane group
+// touches fall on 16 different slots of the 64-bank row (a dense 128-B stride is 8-way conflicted:
+// SQ_LDS_BANK_CONFLICT was 2x the useful LDS cycles of the 64-channel BiFPN / head layers).
 // `need_zero_tail` reserves 16 zero bytes after the row for the k-step that overhangs K (K % 16 == 8).
-// Rows are kept dense (no bank padding): the fragment reads are a small part of the per-tile work and the
-// LDS bytes saved buy an extra resident workgroup per CU.
 inline int frag_stride(int cols, bool need_zero_tail) {
   int b = (cols * 2 + 15) / 16 * 16;
   if (need_zero_tail) b += 16;
+  if ((b / 16) % 2 == 0) b += 16;
   return b;
 }
 // stride of the C tile (written 8 B per lane by rows, read 16 B per lane): one 16-B slot of padding
@@ -828,21 +830,6 @@ __global__ __launch_bounds__(THREADS, 2) void k_pw_wgrad(const WgArgs a) {
     }
 }
 
-__global__ void k_wgrad_reduce(const float* __restrict__ ws, int S, int64_t kn, float* __restrict__ dw) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= kn) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int s = 0;
-  for (; s + 3 < S; s += 4) {
-    s0 += ws[(size_t)s * kn + i];
-    s1 += ws[(size_t)(s + 1) * kn + i];
-    s2 += ws[(size_t)(s + 2) * kn + i];
-    s3 += ws[(size_t)(s + 3) * kn + i];
-  }
-  for (; s < S; ++s) s0 += ws[(size_t)s * kn + i];
-  dw[i] += (s0 + s1) + (s2 + s3);
-}
-
 template <typename KernelT>
 inline bool allow_big_lds(KernelT kern, size_t lds) {
   if (lds <= 64 * 1024) return true;
@@ -994,7 +981,6 @@ int pws_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight
   else { if (gbn) PWS_WG(false, true); else PWS_WG(false, false); }
 #undef PWS_WG
   EDET_LAUNCH_CHECK("edet_pw_bwd_weight(stream)");
-  k_wgrad_reduce<<<dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, st>>>(a.ws, a.S, kn, dweight);
-  EDET_LAUNCH_CHECK("edet_pw_bwd_weight(reduce)");
+  if (edet_reduce_partials(a.ws, a.S, kn, dweight, st) != 0) return -2;
   return 1;
 }
