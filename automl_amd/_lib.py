@@ -13,6 +13,7 @@ EDET_F32, EDET_BF16 = 0, 1
 ACT_NONE, ACT_SWISH = 0, 1
 RS_IDENTITY, RS_UP2, RS_POOL = 0, 1, 2
 MAX_PARTS = 1024
+OPT_SPLIT = 16   # EDET_OPT_SPLIT: partial squared norms per tensor segment
 
 c_void_p, c_int, c_float, c_double, c_int64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
                                                ctypes.c_double, ctypes.c_int64)
@@ -69,9 +70,9 @@ SIGNATURES = {
     'edet_fuse_fwd': [PT, PT, PT, PI, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                       c_void_p],
     'edet_fuse_bwd_pre': [PT, PT, PT, PI, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
-                          c_void_p, c_void_p, c_int, c_void_p],
-    'edet_fuse_bwd_input': [PT, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
-                            c_int, c_void_p],
+                          c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    'edet_fuse_bwd_input': [PT, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                            c_int, c_int, c_void_p],
     'edet_fuse_weights_bwd': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p],
     'edet_focal_loss': [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float,

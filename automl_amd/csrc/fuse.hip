@@ -32,9 +32,9 @@ __device__ __forceinline__ void affine8(const edet_tview_t& v, const ViewCoef& k
 }
 
 // value of resampled input i at output pixel (n, oy, ox), channels c0..c0+7
-template <typename T>
+template <typename T, bool ARGMAX>
 __device__ __forceinline__ void sample_input(const FuseArgs& a, int i, const ViewCoef& k, int n, int oy,
-                                             int ox, int c0, float x[8]) {
+                                             int ox, int c0, float x[8], uint32_t (&am)[2]) {
   const edet_tview_t& v = a.in[i];
   const T* base = reinterpret_cast<const T*>(v.data);
   if (a.mode[i] == EDET_RS_IDENTITY) {
@@ -49,6 +49,9 @@ __device__ __forceinline__ void sample_input(const FuseArgs& a, int i, const Vie
   } else {  // max-pool 3x3 stride 2, padding excluded
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = -INFINITY;
+    int idx[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) idx[e] = 0;
     for (int ky = 0; ky < 3; ++ky) {
       const int sy = oy * 2 - a.pad_t[i] + ky;
       if (sy < 0 || sy >= v.h) continue;
@@ -58,9 +61,23 @@ __device__ __forceinline__ void sample_input(const FuseArgs& a, int i, const Vie
         float t[8];
         load8<T>(base + ((size_t)(n * v.h + sy) * v.w + sx) * v.ld + c0, t);
         affine8(v, k, t);
+        if (ARGMAX) {
+          // first maximum of the row-major scan wins ties (the oracle's argmax convention)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], t[e]);
+          for (int e = 0; e < 8; ++e) {
+            const bool gt = t[e] > x[e];
+            idx[e] = gt ? ky * 3 + kx : idx[e];
+            x[e] = gt ? t[e] : x[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], t[e]);
+        }
       }
+    }
+    if (ARGMAX) {
+      am[0] = (uint32_t)idx[0] | ((uint32_t)idx[1] << 8) | ((uint32_t)idx[2] << 16) | ((uint32_t)idx[3] << 24);
+      am[1] = (uint32_t)idx[4] | ((uint32_t)idx[5] << 8) | ((uint32_t)idx[6] << 16) | ((uint32_t)idx[7] << 24);
     }
   }
 }
@@ -68,7 +85,7 @@ __device__ __forceinline__ void sample_input(const FuseArgs& a, int i, const Vie
 template <typename T, bool BWD>
 __global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restrict__ out,
                                                  const T* __restrict__ dout, T* __restrict__ ds,
-                                                 float* dwn) {
+                                                 float* dwn, unsigned char* __restrict__ pool_argmax) {
   const int nvec = a.c / 8;
   const int64_t total = (int64_t)a.n * a.oh * a.ow * nvec;
   float wn[3] = {0.f, 0.f, 0.f};
@@ -85,14 +102,25 @@ __global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restric
     float s[8], xi[3][8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    const size_t opix = (size_t)(n * a.oh + oy) * a.ow + ox;
+    int plane = 0;
     for (int i = 0; i < a.nin; ++i) {
       ViewCoef k;
       view_load_coef(a.in[i], c0, k);
-      sample_input<T>(a, i, k, n, oy, ox, c0, xi[i]);
+      uint32_t am[2];
+      if (BWD && pool_argmax && a.mode[i] == EDET_RS_POOL) {
+        sample_input<T, true>(a, i, k, n, oy, ox, c0, xi[i], am);
+        // plane p = [n][oh][ow][c] bytes: winning tap (ky*3+kx) of every pooled element
+        *reinterpret_cast<uint2*>(pool_argmax + ((size_t)plane * a.n * a.oh * a.ow + opix) * a.c + c0) =
+            make_uint2(am[0], am[1]);
+        ++plane;
+      } else {
+        sample_input<T, false>(a, i, k, n, oy, ox, c0, xi[i], am);
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) s[e] = fmaf(wn[i], xi[i][e], s[e]);
     }
-    const size_t off = ((size_t)(n * a.oh + oy) * a.ow + ox) * a.ldo + c0;
+    const size_t off = opix * a.ldo + c0;
     if (!BWD) {
       if (a.act == EDET_ACT_SWISH) {
 #pragma unroll
@@ -141,7 +169,8 @@ struct FuseInArgs {
 
 template <typename T>
 __global__ __launch_bounds__(THREADS) void k_fuse_bwd_input(const FuseInArgs a, const T* __restrict__ ds,
-                                                           T* __restrict__ gout) {
+                                                           T* __restrict__ gout,
+                                                           const unsigned char* __restrict__ argmax) {
   const edet_tview_t& v = a.in;
   const int nvec = v.c / 8;
   const int64_t total = (int64_t)v.n * v.h * v.w * nvec;
@@ -175,9 +204,28 @@ __global__ __launch_bounds__(THREADS) void k_fuse_bwd_input(const FuseInArgs a, 
 #pragma unroll
           for (int e = 0; e < 8; ++e) g[e] += t[e];
         }
+    } else if (argmax) {
+      // max-pool with the winners recorded by edet_fuse_bwd_pre: this pixel takes ds of every window
+      // (at most 4) whose argmax tap is this pixel
+      for (int oy = (sy + a.pad_t - 2 + 1) / 2; oy <= (sy + a.pad_t) / 2; ++oy) {
+        if (oy < 0 || oy >= a.oh) continue;
+        for (int ox = (sx + a.pad_l - 2 + 1) / 2; ox <= (sx + a.pad_l) / 2; ++ox) {
+          if (ox < 0 || ox >= a.ow) continue;
+          const uint32_t tap = (uint32_t)((sy - (oy * 2 - a.pad_t)) * 3 + (sx - (ox * 2 - a.pad_l)));
+          const size_t opix = (size_t)(n * a.oh + oy) * a.ow + ox;
+          const uint2 am = *reinterpret_cast<const uint2*>(argmax + opix * v.c + c0);
+          float t[8];
+          load8<T>(ds + opix * a.ldds + c0, t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const uint32_t w = e < 4 ? am.x : am.y;
+            if (((w >> (8 * (e & 3))) & 0xffu) == tap) g[e] += t[e];
+          }
+        }
+      }
     } else {
-      // max-pool: this pixel receives ds of every window in which it is the FIRST maximum
-      // (row-major scan), matching the argmax convention of the oracle.
+      // max-pool, winners recomputed: this pixel receives ds of every window in which it is the FIRST
+      // maximum (row-major scan), matching the argmax convention of the oracle.
       ViewCoef k;
       view_load_coef(v, c0, k);
       float mine[8];
@@ -321,8 +369,8 @@ extern "C" int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, c
   if (int rc = fill_args(a, in0, in1, in2, modes, nin, wn, act, oh, ow, ldo)) return rc;
   EDET_CHECK(out, "edet_fuse_fwd: null output");
   const int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8));
-  if (dtype == EDET_BF16) k_fuse<bf16_t, false><<<grid, THREADS, 0, to_stream(stream)>>>(a, (bf16_t*)out, nullptr, nullptr, nullptr);
-  else if (dtype == EDET_F32) k_fuse<float, false><<<grid, THREADS, 0, to_stream(stream)>>>(a, (float*)out, nullptr, nullptr, nullptr);
+  if (dtype == EDET_BF16) k_fuse<bf16_t, false><<<grid, THREADS, 0, to_stream(stream)>>>(a, (bf16_t*)out, nullptr, nullptr, nullptr, nullptr);
+  else if (dtype == EDET_F32) k_fuse<float, false><<<grid, THREADS, 0, to_stream(stream)>>>(a, (float*)out, nullptr, nullptr, nullptr, nullptr);
   else EDET_CHECK(false, "edet_fuse_fwd: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_fuse_fwd");
   return 0;
@@ -331,20 +379,20 @@ extern "C" int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, c
 extern "C" int edet_fuse_bwd_pre(const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
                                  const int* modes, int nin, const float* wn, int act,
                                  const void* dout, int oh, int ow, int ldo,
-                                 void* ds, float* dwn, int dtype, void* stream) {
+                                 void* ds, float* dwn, void* pool_argmax, int dtype, void* stream) {
   FuseArgs a;
   if (int rc = fill_args(a, in0, in1, in2, modes, nin, wn, act, oh, ow, ldo)) return rc;
   EDET_CHECK(dout && ds, "edet_fuse_bwd_pre: null pointer");
   const int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8));
-  if (dtype == EDET_BF16) k_fuse<bf16_t, true><<<grid, THREADS, 0, to_stream(stream)>>>(a, nullptr, (const bf16_t*)dout, (bf16_t*)ds, dwn);
-  else if (dtype == EDET_F32) k_fuse<float, true><<<grid, THREADS, 0, to_stream(stream)>>>(a, nullptr, (const float*)dout, (float*)ds, dwn);
+  if (dtype == EDET_BF16) k_fuse<bf16_t, true><<<grid, THREADS, 0, to_stream(stream)>>>(a, nullptr, (const bf16_t*)dout, (bf16_t*)ds, dwn, (unsigned char*)pool_argmax);
+  else if (dtype == EDET_F32) k_fuse<float, true><<<grid, THREADS, 0, to_stream(stream)>>>(a, nullptr, (const float*)dout, (float*)ds, dwn, (unsigned char*)pool_argmax);
   else EDET_CHECK(false, "edet_fuse_bwd_pre: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_fuse_bwd_pre");
   return 0;
 }
 
 extern "C" int edet_fuse_bwd_input(const edet_tview_t* in, int mode, const float* wn, int idx,
-                                   const void* ds, int oh, int ow, int lds_,
+                                   const void* ds, int oh, int ow, int lds_, const void* pool_argmax,
                                    void* gout, int beta, int dtype, void* stream) {
   EDET_CHECK(in && in->data && wn && ds && gout && idx >= 0 && idx < 3, "edet_fuse_bwd_input: bad arguments");
   EDET_CHECK(in->c % 8 == 0 && in->ld % 8 == 0 && lds_ % 8 == 0, "edet_fuse_bwd_input: c/ld % 8");
@@ -357,8 +405,9 @@ extern "C" int edet_fuse_bwd_input(const edet_tview_t* in, int mode, const float
     a.pad_l = same_pad_before(in->w, 3, 2);
   }
   const int grid = ew_grid((int64_t)in->n * in->h * in->w * (in->c / 8));
-  if (dtype == EDET_BF16) k_fuse_bwd_input<bf16_t><<<grid, THREADS, 0, to_stream(stream)>>>(a, (const bf16_t*)ds, (bf16_t*)gout);
-  else if (dtype == EDET_F32) k_fuse_bwd_input<float><<<grid, THREADS, 0, to_stream(stream)>>>(a, (const float*)ds, (float*)gout);
+  const unsigned char* am = mode == EDET_RS_POOL ? reinterpret_cast<const unsigned char*>(pool_argmax) : nullptr;
+  if (dtype == EDET_BF16) k_fuse_bwd_input<bf16_t><<<grid, THREADS, 0, to_stream(stream)>>>(a, (const bf16_t*)ds, (bf16_t*)gout, am);
+  else if (dtype == EDET_F32) k_fuse_bwd_input<float><<<grid, THREADS, 0, to_stream(stream)>>>(a, (const float*)ds, (float*)gout, am);
   else EDET_CHECK(false, "edet_fuse_bwd_input: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_fuse_bwd_input");
   return 0;

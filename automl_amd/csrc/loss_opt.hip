@@ -153,30 +153,62 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
   return t;
 }
 
-// one workgroup per tensor segment
+// Every tensor segment is cut into up to OPT_SPLIT slices of >= 1024 elements, one workgroup per
+// (segment, slice): the few large kernels (>100 k elements) no longer serialise on one workgroup, the
+// many small tensors still cost one workgroup each, and every reduction keeps a fixed order.
+constexpr int OPT_SPLIT = EDET_OPT_SPLIT;
+
+__device__ __forceinline__ bool slice_range(const int64_t* seg_off, int s, int j, int64_t& b, int64_t& e) {
+  const int64_t sb = seg_off[s], se = seg_off[s + 1];
+  int64_t chunk = ((se - sb + OPT_SPLIT - 1) / OPT_SPLIT + 3) / 4 * 4;
+  if (chunk < 1024) chunk = 1024;
+  b = sb + (int64_t)j * chunk;
+  e = b + chunk < se ? b + chunk : se;
+  return b < e;
+}
+
 __global__ __launch_bounds__(THREADS) void k_l2_norms(float* grads, const float* params,
                                                      const int64_t* seg_off, const int32_t* seg_flags,
                                                      float wd, float* seg_sqnorm, float* l2_sum) {
   __shared__ float sh[THREADS / 64];
-  const int s = blockIdx.x;
-  const int64_t b = seg_off[s], e = seg_off[s + 1];
+  const int s = blockIdx.x, j = blockIdx.y;
+  int64_t b, e;
+  const bool any = slice_range(seg_off, s, j, b, e);
   const bool reg = (seg_flags[s] & 1) != 0;
   float gsq = 0.f, wsq = 0.f;
-  for (int64_t i = b + threadIdx.x; i < e; i += THREADS) {
-    float g = grads[i];
-    if (reg) {
-      const float w = params[i];
-      g = fmaf(wd, w, g);
-      grads[i] = g;
-      wsq = fmaf(w, w, wsq);
+  if (any) {
+    if ((b & 3) == 0) {
+      const int64_t nv = (e - b) >> 2;
+      float4* g4 = reinterpret_cast<float4*>(grads + b);
+      const float4* w4 = reinterpret_cast<const float4*>(params + b);
+      for (int64_t i = threadIdx.x; i < nv; i += THREADS) {
+        float4 g = g4[i];
+        if (reg) {
+          const float4 w = w4[i];
+          g.x = fmaf(wd, w.x, g.x); g.y = fmaf(wd, w.y, g.y); g.z = fmaf(wd, w.z, g.z); g.w = fmaf(wd, w.w, g.w);
+          g4[i] = g;
+          wsq += w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
+        }
+        gsq += g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
+      }
+      b += nv << 2;
     }
-    gsq = fmaf(g, g, gsq);
+    for (int64_t i = b + threadIdx.x; i < e; i += THREADS) {
+      float g = grads[i];
+      if (reg) {
+        const float w = params[i];
+        g = fmaf(wd, w, g);
+        grads[i] = g;
+        wsq = fmaf(w, w, wsq);
+      }
+      gsq = fmaf(g, g, gsq);
+    }
   }
   const float tg = block_sum(gsq, sh);
   const float tw = block_sum(wsq, sh);
   if (threadIdx.x == 0) {
-    seg_sqnorm[s] = tg;
-    if (reg && l2_sum) atomicAdd(l2_sum, 0.5f * wd * tw);
+    seg_sqnorm[(size_t)s * OPT_SPLIT + j] = tg;
+    if (any && reg && l2_sum) atomicAdd(l2_sum, 0.5f * wd * tw);
   }
 }
 
@@ -186,7 +218,10 @@ __global__ __launch_bounds__(THREADS) void k_clip_factors(const float* seg_sqnor
   __shared__ float sh[THREADS / 64];
   float acc = 0.f;
   for (int s = threadIdx.x; s < nseg; s += THREADS) {
-    const float nrm = sqrtf(seg_sqnorm[s]);
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < OPT_SPLIT; ++j) sq += seg_sqnorm[(size_t)s * OPT_SPLIT + j];
+    const float nrm = sqrtf(sq);
     float f = 1.f;
     if (clip > 0.f) f = clip / fmaxf(nrm, clip);
     seg_factor[s] = f;
@@ -205,24 +240,64 @@ __global__ __launch_bounds__(THREADS) void k_clip_factors(const float* seg_sqnor
 __global__ __launch_bounds__(THREADS) void k_scale(float* grads, const int64_t* seg_off,
                                                   const float* seg_factor) {
   const int s = blockIdx.x;
+  int64_t b, e;
+  if (!slice_range(seg_off, s, blockIdx.y, b, e)) return;
   const float f = seg_factor[s];
-  for (int64_t i = seg_off[s] + threadIdx.x; i < seg_off[s + 1]; i += THREADS) grads[i] *= f;
+  if ((b & 3) == 0) {
+    const int64_t nv = (e - b) >> 2;
+    float4* g4 = reinterpret_cast<float4*>(grads + b);
+    for (int64_t i = threadIdx.x; i < nv; i += THREADS) {
+      float4 g = g4[i];
+      g.x *= f; g.y *= f; g.z *= f; g.w *= f;
+      g4[i] = g;
+    }
+    b += nv << 2;
+  }
+  for (int64_t i = b + threadIdx.x; i < e; i += THREADS) grads[i] *= f;
 }
 
 // Keras SGD: v = m*v - lr*g ; w += v.  TFA MovingAverage: ema -= (1-decay)*(ema - w)
+__device__ __forceinline__ void sgd1(float g, float& v, float& w, float& em, float lr, float momentum,
+                                     float decay, bool has_ema) {
+  v = momentum * v - lr * g;
+  w += v;
+  if (has_ema) em -= (1.f - decay) * (em - w);
+}
+
 __global__ __launch_bounds__(THREADS) void k_sgd_ema(float* params, float* grads, float* vel, float* ema,
                                                     const int64_t* seg_off, const float* seg_factor,
                                                     const float* hyper, float momentum) {
   const int s = blockIdx.x;
+  int64_t b, e;
+  if (!slice_range(seg_off, s, blockIdx.y, b, e)) return;
   const float f = seg_factor ? seg_factor[s] : 1.f;
   const float lr = hyper[0], decay = hyper[1];
-  for (int64_t i = seg_off[s] + threadIdx.x; i < seg_off[s + 1]; i += THREADS) {
-    const float g = grads[i] * f;
-    const float v = momentum * vel[i] - lr * g;
+  const bool has_ema = ema != nullptr;
+  if ((b & 3) == 0) {
+    const int64_t nv = (e - b) >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(grads + b);
+    float4* v4 = reinterpret_cast<float4*>(vel + b);
+    float4* w4 = reinterpret_cast<float4*>(params + b);
+    float4* e4 = has_ema ? reinterpret_cast<float4*>(ema + b) : nullptr;
+    for (int64_t i = threadIdx.x; i < nv; i += THREADS) {
+      const float4 g = g4[i];
+      float4 v = v4[i], w = w4[i], em = has_ema ? e4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      sgd1(g.x * f, v.x, w.x, em.x, lr, momentum, decay, has_ema);
+      sgd1(g.y * f, v.y, w.y, em.y, lr, momentum, decay, has_ema);
+      sgd1(g.z * f, v.z, w.z, em.z, lr, momentum, decay, has_ema);
+      sgd1(g.w * f, v.w, w.w, em.w, lr, momentum, decay, has_ema);
+      v4[i] = v;
+      w4[i] = w;
+      if (has_ema) e4[i] = em;
+    }
+    b += nv << 2;
+  }
+  for (int64_t i = b + threadIdx.x; i < e; i += THREADS) {
+    float v = vel[i], w = params[i], em = has_ema ? ema[i] : 0.f;
+    sgd1(grads[i] * f, v, w, em, lr, momentum, decay, has_ema);
     vel[i] = v;
-    const float w = params[i] + v;
     params[i] = w;
-    if (ema) ema[i] -= (1.f - decay) * (ema[i] - w);
+    if (has_ema) ema[i] = em;
   }
 }
 
@@ -278,7 +353,7 @@ extern "C" int edet_opt_l2_norms(float* grads, const float* params, const int64_
                                  const int32_t* seg_flags, int nseg, float weight_decay,
                                  float* seg_sqnorm, float* l2_sum, void* stream) {
   EDET_CHECK(grads && params && seg_offsets && seg_flags && seg_sqnorm && nseg > 0, "edet_opt_l2_norms: bad arguments");
-  k_l2_norms<<<nseg, THREADS, 0, to_stream(stream)>>>(grads, params, seg_offsets, seg_flags, weight_decay, seg_sqnorm, l2_sum);
+  k_l2_norms<<<dim3(nseg, OPT_SPLIT), THREADS, 0, to_stream(stream)>>>(grads, params, seg_offsets, seg_flags, weight_decay, seg_sqnorm, l2_sum);
   EDET_LAUNCH_CHECK("edet_opt_l2_norms");
   return 0;
 }
@@ -294,7 +369,7 @@ extern "C" int edet_opt_clip_factors(const float* seg_sqnorm, int nseg, float cl
 extern "C" int edet_opt_scale(float* grads, const int64_t* seg_offsets, const float* seg_factor,
                               int nseg, void* stream) {
   EDET_CHECK(grads && seg_offsets && seg_factor && nseg > 0, "edet_opt_scale: bad arguments");
-  k_scale<<<nseg, THREADS, 0, to_stream(stream)>>>(grads, seg_offsets, seg_factor);
+  k_scale<<<dim3(nseg, OPT_SPLIT), THREADS, 0, to_stream(stream)>>>(grads, seg_offsets, seg_factor);
   EDET_LAUNCH_CHECK("edet_opt_scale");
   return 0;
 }
@@ -303,7 +378,7 @@ extern "C" int edet_opt_sgd_ema(float* params, float* grads, float* velocity, fl
                                 const int64_t* seg_offsets, const float* seg_factor, int nseg,
                                 const float* hyper_dev, float momentum, void* stream) {
   EDET_CHECK(params && grads && velocity && seg_offsets && hyper_dev && nseg > 0, "edet_opt_sgd_ema: bad arguments");
-  k_sgd_ema<<<nseg, THREADS, 0, to_stream(stream)>>>(params, grads, velocity, ema, seg_offsets, seg_factor, hyper_dev, momentum);
+  k_sgd_ema<<<dim3(nseg, OPT_SPLIT), THREADS, 0, to_stream(stream)>>>(params, grads, velocity, ema, seg_offsets, seg_factor, hyper_dev, momentum);
   EDET_LAUNCH_CHECK("edet_opt_sgd_ema");
   return 0;
 }

@@ -15,6 +15,7 @@ efficientdet/backbone/efficientnet_model.py:360-416,710-779, efficientdet/tf2/tr
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -115,6 +116,7 @@ class Engine(object):
     self.loss_sums = self.zbuf('loss_sums', (4,))
     self.hyper = torch.zeros(2, dtype=torch.float32, device=self.device)
     self.gnorm = torch.zeros(1, dtype=torch.float32, device=self.device)
+    self.pool_argmax = os.environ.get('EDET_POOL_ARGMAX', '1') != '0'
 
   @property
   def esize(self):
@@ -178,7 +180,7 @@ class Engine(object):
     self.seg_offsets = torch.tensor(seg, dtype=torch.int64, device=dev)
     self.seg_flags = torch.tensor(flags, dtype=torch.int32, device=dev)
     self.nseg = len(flags)
-    self.seg_sqnorm = torch.zeros(self.nseg, dtype=torch.float32, device=dev)
+    self.seg_sqnorm = torch.zeros(self.nseg * _lib.OPT_SPLIT, dtype=torch.float32, device=dev)
     self.seg_factor = torch.ones(self.nseg, dtype=torch.float32, device=dev)
     self.set_params(values)
     self.ema.copy_(self.params_flat)
@@ -428,19 +430,28 @@ class Engine(object):
     if self.training:
       ds = self.buf(key + ':ds', (n, oh, ow, out.ld), self.tdtype)
       dwn = self.zbuf(key + ':dwn', (4,))
+      npool = sum(1 for m in modes if m == RS_POOL)
+      amax = self.buf(key + ':amax', (npool, n, oh, ow, c), torch.uint8) if npool and self.pool_argmax else None
 
       def bwd():
         assert out.grad_written, key
         tv2 = [v.tview() for v in inputs]
         tvp2 = [ctypes.byref(t) for t in tv2] + [None] * (3 - nin)
         call('edet_fuse_bwd_pre', tvp2[0], tvp2[1], tvp2[2], marr, nin, ptr(wn), act, ptr(out.grad), oh, ow,
-             out.ld, ptr(ds), ptr(dwn), self.dtype, self.stream)
+             out.ld, ptr(ds), ptr(dwn), ptr(amax), self.dtype, self.stream, nbytes=fbytes + out.rows * c * self.esize)
+        plane = 0
         for i, v in enumerate(inputs):
+          am = None
+          if modes[i] == RS_POOL and amax is not None:
+            am = amax[plane].data_ptr()
+            plane += 1
           if not v.raw.needs_grad:
             continue
           g = v.raw.ensure_grad()
-          call('edet_fuse_bwd_input', ctypes.byref(tv2[i]), modes[i], ptr(wn), i, ptr(ds), oh, ow, out.ld,
-               ptr(g), 1 if v.raw.grad_written else 0, self.dtype, self.stream)
+          call('edet_fuse_bwd_input', ctypes.byref(tv2[i]), modes[i], ptr(wn), i, ptr(ds), oh, ow, out.ld, am,
+               ptr(g), 1 if v.raw.grad_written else 0, self.dtype, self.stream,
+               nbytes=(out.rows + v.raw.rows) * c * self.esize,
+               tag='%dx%dx%d %s' % (v.raw.h, v.raw.w, c, ('id', 'up2', 'pool')[modes[i]]))
           v.raw.grad_written = True
         if wnames:
           gp = [ptr(self.grad(w)) for w in wnames] + [None] * (3 - len(wnames))

@@ -210,14 +210,18 @@ int edet_fuse_weights(const float* w0, const float* w1, const float* w2, int nin
 int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
                   const int* modes, int nin, const float* wn, int act,
                   void* out, int oh, int ow, int ldo, int dtype, void* stream);
-/* ds = dout * act'(s) (s recomputed) written to `ds`; dwn[i] += sum ds * x_i */
+/* ds = dout * act'(s) (s recomputed) written to `ds`; dwn[i] += sum ds * x_i.
+ * pool_argmax (may be NULL): caller-owned bytes [npool][n][oh][ow][c], one plane per EDET_RS_POOL
+ * input in input order; receives the winning tap (ky*3+kx, first maximum of the row-major scan) of
+ * every pooled element so that edet_fuse_bwd_input does not have to recompute the 3x3 windows.  */
 int edet_fuse_bwd_pre(const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
                       const int* modes, int nin, const float* wn, int act,
                       const void* dout, int oh, int ow, int ldo,
-                      void* ds, float* dwn, int dtype, void* stream);
-/* gradient of one fusion input: gout (+)= wn[i] * resample_i^T(ds) */
+                      void* ds, float* dwn, void* pool_argmax, int dtype, void* stream);
+/* gradient of one fusion input: gout (+)= wn[i] * resample_i^T(ds).  pool_argmax: this input's
+ * plane written by edet_fuse_bwd_pre (EDET_RS_POOL only; NULL -> the windows are recomputed).  */
 int edet_fuse_bwd_input(const edet_tview_t* in, int mode, const float* wn, int idx,
-                        const void* ds, int oh, int ow, int lds_,
+                        const void* ds, int oh, int ow, int lds_, const void* pool_argmax,
                         void* gout, int beta, int dtype, void* stream);
 /* raw weight gradients from dwn (fast-attention normalisation backward) */
 int edet_fuse_weights_bwd(const float* w0, const float* w1, const float* w2, int nin,
@@ -243,6 +247,10 @@ int edet_box_loss(const void* box_out, int ld, const float* box_targets,
  * clip_by_global_norm), Keras SGD momentum, TFA MovingAverage (:176-199).
  * All parameters live in one flat fp32 arena; seg_offsets[nseg+1] delimits the
  * tensors, seg_flags bit0 = L2-regularised (kernel/weight variables).  */
+/* seg_sqnorm holds EDET_OPT_SPLIT partial squared norms per tensor ([nseg][EDET_OPT_SPLIT], written by
+ * edet_opt_l2_norms in a fixed order, summed by edet_opt_clip_factors): large tensors are processed by
+ * up to EDET_OPT_SPLIT workgroups.  */
+#define EDET_OPT_SPLIT 16
 int edet_opt_l2_norms(float* grads, const float* params, const int64_t* seg_offsets,
                       const int32_t* seg_flags, int nseg, float weight_decay,
                       float* seg_sqnorm, float* l2_sum, void* stream);

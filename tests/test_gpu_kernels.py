@@ -539,15 +539,23 @@ def test_fuse(dt, case):
   dd = gu.to_dev(dout, tdt)
   ds = torch.empty_like(dd)
   dwn = torch.zeros(4, dtype=torch.float32, device=gu.DEV)
+  npool = sum(1 for m in ins if m[0] == _lib.RS_POOL)
+  amax = torch.full((max(npool, 1), n, oh, ow, c), 255, dtype=torch.uint8, device=gu.DEV)
   call('edet_fuse_bwd_pre', tvp[0], tvp[1], tvp[2], modes, nin, ptr(wn), act, ptr(dd), oh, ow, c, ptr(ds),
-       ptr(dwn), edt, gu.stream())
+       ptr(dwn), ptr(amax) if npool else None, edt, gu.stream())
+  plane = 0
   for i in range(nin):
-    g = torch.full_like(xd[i], float('nan'))
-    call('edet_fuse_bwd_input', ctypes.byref(tvs[i]), ins[i][0], ptr(wn), i, ptr(ds), oh, ow, c, ptr(g), 0, edt,
-         gu.stream())
-    torch.cuda.synchronize()
-    # engine convention: gradient w.r.t. the BN *output* (scale is applied by the BN-backward coefficients)
-    gu.check(g, xq[i].grad / scs[i], name, 'fuse_bwd_input %d %s' % (i, case,))
+    planes = [None]
+    if ins[i][0] == _lib.RS_POOL:      # both pool-backward paths: recorded winners and recomputed windows
+      planes = [amax[plane].data_ptr(), None]
+      plane += 1
+    for am in planes:
+      g = torch.full_like(xd[i], float('nan'))
+      call('edet_fuse_bwd_input', ctypes.byref(tvs[i]), ins[i][0], ptr(wn), i, ptr(ds), oh, ow, c, am, ptr(g), 0,
+           edt, gu.stream())
+      torch.cuda.synchronize()
+      # engine convention: gradient w.r.t. the BN *output* (scale is applied by the BN-backward coefficients)
+      gu.check(g, xq[i].grad / scs[i], name, 'fuse_bwd_input %d %s argmax=%s' % (i, case, am is not None))
   if method == 'fastattn':
     dws = [torch.zeros(1, dtype=torch.float32, device=gu.DEV) for _ in range(3)]
     call('edet_fuse_weights_bwd', ptr(wd[0]), ptr(wd[1]), ptr(wd[2]), nin, meth, ptr(dwn), ptr(dws[0]),
@@ -601,8 +609,8 @@ def test_detection_loss(dt):
 # ------------------------------------------------------------------------------------ optimizer
 def test_optimizer():
   rng = np.random.default_rng(11)
-  sizes = [7, 64, 1, 1000, 33, 4096]
-  flags = [1, 0, 0, 1, 1, 0]
+  sizes = [7, 64, 1, 1000, 33, 4096, 40003, 3, 65536]   # unaligned, multi-slice and vectorised segments
+  flags = [1, 0, 0, 1, 1, 0, 1, 1, 1]
   offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
   tot = int(offs[-1])
   p = torch.from_numpy(rng.standard_normal(tot).astype(np.float32))
@@ -629,7 +637,7 @@ def test_optimizer():
   pd, gd, vd, ed = (t.to(gu.DEV) for t in (p, g, v, ema))
   od = torch.from_numpy(offs).to(gu.DEV)
   fd = torch.tensor(flags, dtype=torch.int32, device=gu.DEV)
-  sq = torch.zeros(len(sizes), dtype=torch.float32, device=gu.DEV)
+  sq = torch.zeros(len(sizes) * _lib.OPT_SPLIT, dtype=torch.float32, device=gu.DEV)
   fac = torch.zeros(len(sizes), dtype=torch.float32, device=gu.DEV)
   l2d = torch.zeros(1, dtype=torch.float32, device=gu.DEV)
   gnd = torch.zeros(1, dtype=torch.float32, device=gu.DEV)
