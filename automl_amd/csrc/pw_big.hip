@@ -1,0 +1,666 @@
+// Tiled MFMA kernels for the wide pointwise (1x1) convolutions of the bf16 path on gfx950.
+//
+// The 1x1 convolutions of the late EfficientNet stages (40x40 and 20x20 feature maps, 80..1152 channels
+// on one side and 480..1152 on the other; D7x: up to 3840) have 100-600 FLOP per byte of the streamed
+// operand: they are the only layers of this network where the matrix cores, not the HBM stream, set the
+// pace, and the wave-private streaming kernels of pw_stream.hip (one MFMA tile per wave, weights resident
+// in LDS) do not fit them.  These kernels are classic workgroup-tiled GEMMs, with the producer's BatchNorm /
+// swish / SE gate (forward) or the BatchNorm backward (gradients) applied between the global load and the
+// LDS store of the streamed operand:
+//
+//   k_big_gemm<BWD=false>  out[m][j]  = sum_k view(in)[m][k] * Wt[j][k] + bias[j]      (+ BN stat partials)
+//   k_big_gemm<BWD=true>   d in[m][k] = sum_n dy[m][n] * W[k][n], chained through act'(z), the optional
+//                          accumulate, the BN-backward sums and the SE dgate sums in the epilogue
+//   k_big_wgrad            dW[k][n]   = sum_m view(in)[m][k] * dy[m][n]  (split over m, partials -> workspace)
+//
+// Tile 128 x 128 per 256-thread workgroup (2 x 2 waves, 64 x 64 per wave = 2 x 2 v_mfma_f32_32x32x16_bf16),
+// reduction step 64, two LDS stages of 2 x 18 KB (rows padded to 144 B: 9 sixteen-byte slots, so the 16
+// rows a ds_read_b128 lane group touches fall on 16 different slots), one register set of raw loads in
+// flight across the MFMA phase (issue t+2 / write t+1 / compute t), one barrier per step, two workgroups
+// per CU.  Blocks are ordered so that the column tiles of one row tile run back to back on ONE XCD
+// (block b runs on XCD b % 8): the streamed operand is read from HBM once and re-read from that XCD's L2.
+//
+// Reference call sites replaced: tf.keras.layers.Conv2D 1x1 in efficientdet/backbone/efficientnet_model.py
+// :304-312 (expand), :345-353 (project), efficientdet/tf2/efficientdet_keras.py:286-290 (resample) and their
+// gradients (TF Conv2DBackpropInput / Conv2DBackpropFilter under tf.GradientTape, train_lib.py:623-669).
+#include "common.h"
+
+namespace pwb {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int THREADS = 256;
+constexpr int BM = 128, BJ = 128, BK = 64;
+constexpr int LDT = BK * 2 + 16;             // staged tile row stride in bytes (144)
+constexpr int TILE_BYTES = BM * LDT;         // one operand tile (18432)
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // A + B
+constexpr int SMEM_BYTES = 2 * STAGE_BYTES;  // two stages (73728)
+constexpr int LDC_BF = BJ * 2 + 16;          // bf16 C tile row stride (272)
+constexpr int LDC_F32 = BJ * 4 + 16;         // fp32 C tile row stride (528)
+static_assert(BM * LDC_F32 <= SMEM_BYTES, "fp32 C tile must fit in the staging buffers");
+
+__device__ __forceinline__ void unpack8(const uint4 raw, float x[8]) {
+  x[0] = __uint_as_float(raw.x << 16); x[1] = __uint_as_float(raw.x & 0xffff0000u);
+  x[2] = __uint_as_float(raw.y << 16); x[3] = __uint_as_float(raw.y & 0xffff0000u);
+  x[4] = __uint_as_float(raw.z << 16); x[5] = __uint_as_float(raw.z & 0xffff0000u);
+  x[6] = __uint_as_float(raw.w << 16); x[7] = __uint_as_float(raw.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float x[8]) {
+  uint4 o;
+  o.x = pack2bf(x[0], x[1]); o.y = pack2bf(x[2], x[3]);
+  o.z = pack2bf(x[4], x[5]); o.w = pack2bf(x[6], x[7]);
+  return o;
+}
+
+struct GemmArgs {
+  edet_tview_t tv;    // fwd: streamed operand.  bwd: the conv's input view (epilogue chain target)
+  edet_gview_t gv;    // bwd: streamed operand (dy)
+  const bf16_t* Bm;   // [J][ldb], reduction index contiguous
+  int ldb;
+  int M, R, J;        // rows, reduction length, output columns
+  int hw;             // pixels per image
+  int ntm, ntj;       // row tiles, column tiles
+  int tpw;            // consecutive row tiles per workgroup
+  int ngrp;           // row-tile groups = stat partial rows
+  const float* bias;  // fwd
+  bf16_t* out;        // fwd
+  int ldo;
+  edet_bwd_epi_t epi; // bwd
+  float* stat_partials;
+};
+
+// 64 x 64 per wave: acc[nj][mi] = D[i = output column within the 32-tile][j = row within the 32-tile]
+__device__ __forceinline__ void mma_stage(const unsigned char* As, const unsigned char* Bs, int wm, int wj, int lane,
+                                          int ksub, f32x16 (&acc)[2][2]) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int kk = 0; kk < BK / 16; ++kk) {
+    if (kk < ksub) {
+      const int koff = (kk * 16 + h * 8) * 2;
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bs + (wj * 64 + r) * LDT + koff);
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bs + (wj * 64 + 32 + r) * LDT + koff);
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(As + (wm * 64 + r) * LDT + koff);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(As + (wm * 64 + 32 + r) * LDT + koff);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[1][1], 0, 0, 0);
+    }
+  }
+}
+
+template <bool BWD, bool GBN>
+__global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave & 1, wj = wave >> 1;
+  // block -> (row-tile group, column tile): all column tiles of a group back to back on one XCD
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int jt = q % a.ntj;
+  const int grp = (q / a.ntj) * 8 + xcd;
+  if (grp >= a.ngrp) return;
+  const int j0 = jt * BJ;
+  const bool want_stats = a.stat_partials != nullptr;
+  const bool want_gate = BWD && a.epi.dgate != nullptr;
+  const bool swish = a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr;
+  const bool gated = !BWD && a.tv.gate != nullptr;
+
+  // staging geometry: thread -> chunk column lc (8 reduction elements), rows lr + 32*i
+  const int lc = tid & 7, lr = tid >> 3;
+  // epilogue geometry: thread -> 8 output columns ec*8.., rows er + 16*i
+  const int ec = tid & 15, er = tid >> 4;
+  const int ej = j0 + ec * 8;
+  const bool ecol_ok = ej < a.J;
+
+  const bf16_t* SRC = reinterpret_cast<const bf16_t*>(BWD ? a.gv.dz : a.tv.data);
+  const bf16_t* SRCY = reinterpret_cast<const bf16_t*>(a.gv.y);
+  const int lds_src = BWD ? a.gv.ld : a.tv.ld;
+  const int nk = (a.R + BK - 1) / BK;
+
+  float tot1 = 0.f, tot2 = 0.f;     // thread j < BJ: running column sums of this workgroup (stat partials)
+
+  for (int mt = grp * a.tpw; mt < min(a.ntm, (grp + 1) * a.tpw); ++mt) {
+    const int m0 = mt * BM;
+    int64_t arow[4];
+    int aimg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = min(m0 + lr + 32 * i, a.M - 1);     // rows past M re-read row M-1 (never stored)
+      arow[i] = (int64_t)m * lds_src;
+      aimg[i] = gated ? m / a.hw : 0;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[x][y][e] = 0.f;
+
+    uint4 ra[4], ry[GBN ? 4 : 1], rb[4];
+    auto issue = [&](int kt) {
+      const int k = kt * BK + lc * 8;
+      const bool kok = k < a.R;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = make_uint4(0, 0, 0, 0);
+        if (GBN) ry[i] = make_uint4(0, 0, 0, 0);
+        rb[i] = make_uint4(0, 0, 0, 0);
+        if (kok) {
+          ra[i] = *reinterpret_cast<const uint4*>(SRC + arow[i] + k);
+          if (GBN) ry[i] = *reinterpret_cast<const uint4*>(SRCY + arow[i] + k);
+          const int j = j0 + lr + 32 * i;
+          if (j < a.J) rb[i] = *reinterpret_cast<const uint4*>(a.Bm + (size_t)j * a.ldb + k);
+        }
+      }
+    };
+    auto commit = [&](int kt, unsigned char* stage) {
+      const int k = kt * BK + lc * 8;
+      const bool kok = k < a.R;
+      unsigned char* As = stage;
+      unsigned char* Bs = stage + TILE_BYTES;
+      float c0[8], c1[8], c2[8];
+      if (kok) {
+        if (!BWD) {
+          if (affine) { loadf8(a.tv.scale + k, c0); loadf8(a.tv.shift + k, c1); }
+        } else if (GBN) {
+          loadf8(a.gv.a + k, c0); loadf8(a.gv.b + k, c1); loadf8(a.gv.cc + k, c2);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint4 v = ra[i];
+        if (kok) {
+          if (!BWD) {
+            if (affine || swish || gated) {
+              float x[8];
+              unpack8(ra[i], x);
+              if (affine) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], c0[e], c1[e]);
+              }
+              if (swish) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = swishf_(x[e]);
+              }
+              if (gated) {
+                float gt[8];
+                loadf8(a.tv.gate + (size_t)aimg[i] * a.R + k, gt);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] *= gt[e];
+              }
+              v = pack8(x);
+            }
+          } else if (GBN) {
+            float x[8], y[8];
+            unpack8(ra[i], x);
+            unpack8(ry[i], y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = fmaf(c0[e], x[e], fmaf(c1[e], y[e], c2[e]));
+            v = pack8(x);
+          }
+        }
+        *reinterpret_cast<uint4*>(As + (lr + 32 * i) * LDT + lc * 16) = v;
+        *reinterpret_cast<uint4*>(Bs + (lr + 32 * i) * LDT + lc * 16) = rb[i];
+      }
+    };
+
+    __syncthreads();                     // the previous row tile's epilogue is done with the LDS
+    issue(0);
+    commit(0, smem);
+    if (nk > 1) issue(1);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      unsigned char* cur = smem + (kt & 1) * STAGE_BYTES;
+      unsigned char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+      if (kt + 1 < nk) commit(kt + 1, nxt);
+      if (kt + 2 < nk) issue(kt + 2);
+      const int krem = a.R - kt * BK;
+      mma_stage(cur, cur + TILE_BYTES, wm, wj, lane, krem >= BK ? BK / 16 : (krem + 15) / 16, acc);
+      __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- epilogue through LDS
+    const int r = lane & 31, h = lane >> 5;
+    if (!BWD) {
+      // C tile as bf16 [BM][LDC_BF]: bias added, rounded once
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ch = wj * 64 + nj * 32 + 8 * g + 4 * h;
+          float b4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (a.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (j0 + ch + e < a.J) b4[e] = a.bias[j0 + ch + e];
+          }
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            uint2 pk;
+            pk.x = pack2bf(acc[nj][mi][4 * g + 0] + b4[0], acc[nj][mi][4 * g + 1] + b4[1]);
+            pk.y = pack2bf(acc[nj][mi][4 * g + 2] + b4[2], acc[nj][mi][4 * g + 3] + b4[3]);
+            *reinterpret_cast<uint2*>(smem + (wm * 64 + mi * 32 + r) * LDC_BF + ch * 2) = pk;
+          }
+        }
+      }
+      __syncthreads();
+      float s1[8], s2[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+#pragma unroll
+      for (int i = 0; i < BM / 16; ++i) {
+        const int row = er + 16 * i;
+        const int m = m0 + row;
+        if (ecol_ok && m < a.M) {
+          const uint4 v = *reinterpret_cast<const uint4*>(smem + row * LDC_BF + ec * 16);
+          *reinterpret_cast<uint4*>(a.out + (size_t)m * a.ldo + ej) = v;
+          if (want_stats) {
+            float x[8];
+            unpack8(v, x);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s1[e] += x[e]; s2[e] = fmaf(x[e], x[e], s2[e]); }
+          }
+        }
+      }
+      if (want_stats) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);            // [2][16][BJ]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          red[er * BJ + ec * 8 + e] = s1[e];
+          red[(16 + er) * BJ + ec * 8 + e] = s2[e];
+        }
+        __syncthreads();
+        if (tid < BJ) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { tot1 += red[i * BJ + tid]; tot2 += red[(16 + i) * BJ + tid]; }
+        }
+      }
+    } else {
+      // C tile as fp32 [BM][LDC_F32]
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int ch = wj * 64 + nj * 32 + 8 * g + 4 * h;
+            *reinterpret_cast<float4*>(smem + (wm * 64 + mi * 32 + r) * LDC_F32 + ch * 4) =
+                make_float4(acc[nj][mi][4 * g + 0], acc[nj][mi][4 * g + 1], acc[nj][mi][4 * g + 2],
+                            acc[nj][mi][4 * g + 3]);
+          }
+      __syncthreads();
+      const bf16_t* X = reinterpret_cast<const bf16_t*>(a.tv.data);
+      bf16_t* GO = reinterpret_cast<bf16_t*>(a.epi.gout);
+      const bool need_x = swish || want_gate || want_stats;
+      float sc[8], sh[8], s1[8], s2[8], gp[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; s1[e] = s2[e] = gp[e] = 0.f; }
+      if (ecol_ok && affine) { loadf8(a.tv.scale + ej, sc); loadf8(a.tv.shift + ej, sh); }
+      // dgate sums: a tile inside one image (the common case) is reduced through LDS to one atomic per
+      // channel; a tile that straddles images flushes per thread whenever the image changes
+      const int timg0 = m0 / a.hw, timg1 = (min(m0 + BM, a.M) - 1) / a.hw;
+      const bool single_img = timg0 == timg1;
+      int gp_img = -1;
+      auto flush_gate = [&]() {
+        if (gp_img >= 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) atomicAdd(&a.epi.dgate[(size_t)gp_img * a.J + ej + e], gp[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gp[e] = 0.f;
+      };
+      // the 16 threads of one row group walk the rows er, er+16, ...: the saved input of the next row is
+      // requested before the current one is finished
+      uint4 xr[BM / 16];
+#pragma unroll
+      for (int i = 0; i < BM / 16; ++i) {
+        const int m = m0 + er + 16 * i;
+        xr[i] = make_uint4(0, 0, 0, 0);
+        if (need_x && ecol_ok && m < a.M) xr[i] = *reinterpret_cast<const uint4*>(X + (size_t)m * a.tv.ld + ej);
+      }
+#pragma unroll
+      for (int i = 0; i < BM / 16; ++i) {
+        const int row = er + 16 * i;
+        const int m = m0 + row;
+        if (ecol_ok && m < a.M) {
+          const float4 d0 = *reinterpret_cast<const float4*>(smem + row * LDC_F32 + ec * 32);
+          const float4 d1 = *reinterpret_cast<const float4*>(smem + row * LDC_F32 + ec * 32 + 16);
+          const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+          float x[8], g[8];
+          unpack8(xr[i], x);
+          const size_t off = (size_t)m * a.tv.ld + ej;
+          if (want_gate) {
+            if (!single_img) {
+              const int img = m / a.hw;
+              if (img != gp_img) { flush_gate(); gp_img = img; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float z = fmaf(x[e], sc[e], sh[e]);
+              gp[e] = fmaf(d[e], swish ? swishf_(z) : z, gp[e]);
+              g[e] = d[e];
+            }
+          } else if (swish) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = d[e] * swish_gradf_(fmaf(x[e], sc[e], sh[e]));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = d[e];
+          }
+          if (a.epi.beta) {
+            float old[8];
+            unpack8(*reinterpret_cast<const uint4*>(GO + off), old);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] += old[e];
+          }
+          *reinterpret_cast<uint4*>(GO + off) = pack8(g);
+          if (want_stats) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s1[e] += g[e]; s2[e] = fmaf(g[e], x[e], s2[e]); }
+          }
+        }
+      }
+      if (want_gate) {
+        if (single_img) {
+          __syncthreads();
+          float* red = reinterpret_cast<float*>(smem);          // [16][BJ]
+#pragma unroll
+          for (int e = 0; e < 8; ++e) red[er * BJ + ec * 8 + e] = gp[e];
+          __syncthreads();
+          if (tid < BJ && j0 + tid < a.J) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t += red[i * BJ + tid];
+            atomicAdd(&a.epi.dgate[(size_t)timg0 * a.J + j0 + tid], t);
+          }
+        } else if (ecol_ok) {
+          flush_gate();
+        }
+      }
+      if (want_stats) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);            // [2][16][BJ]
+        float mu[8], rs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mu[e] = 0.f; rs[e] = 0.f; }
+        if (ecol_ok) { loadf8(a.epi.mean + ej, mu); loadf8(a.epi.rstd + ej, rs); }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          red[er * BJ + ec * 8 + e] = s1[e];
+          red[(16 + er) * BJ + ec * 8 + e] = rs[e] * (s2[e] - mu[e] * s1[e]);    // sum g * (x - mean) * rstd
+        }
+        __syncthreads();
+        if (tid < BJ) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { tot1 += red[i * BJ + tid]; tot2 += red[(16 + i) * BJ + tid]; }
+        }
+      }
+    }
+  }
+  if (want_stats && tid < BJ && j0 + tid < a.J) {
+    float* dst = a.stat_partials + (size_t)grp * 2 * a.J;
+    dst[j0 + tid] = tot1;
+    dst[a.J + j0 + tid] = tot2;
+  }
+}
+
+// ---------------------------------------------------------------------------- weight gradient
+// dW[k][n] = sum_m X[m][k] * dY[m][n].  The contraction runs over the rows, so both operands are staged
+// TRANSPOSED ([channel][64 rows], row index contiguous): a staging task is an 8-row x 8-channel block that
+// a thread loads as 8 x 16 B (one per row), transforms, transposes on 16-bit units with v_perm_b32 and
+// writes as 8 x 16 B (one per channel).  Waves 0-1 stage X (activated view), waves 2-3 stage dY (BatchNorm
+// backward on load); lane -> (row group l % 8, channel chunk l / 8) so that the 8 lanes of a ds_write_b128
+// group fill one contiguous 128-byte LDS row.
+struct WgArgs {
+  edet_tview_t tv;    // conv input view, K = tv.c
+  edet_gview_t gv;    // dy, N = gv.c
+  float* ws;          // [S][K][N] fp32 partial sums (or dW itself when S == 1 and accumulate)
+  int M, K, N, hw;
+  int ntk, ntn;       // 128-wide tiles over K and N
+  int S;              // row splits
+  int rows_per_split; // multiple of 64
+};
+
+__device__ __forceinline__ uint32_t perm_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+__device__ __forceinline__ uint32_t perm_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+// p[r] = 8 bf16 channels of row r  ->  LDS rows (cb + e), 8 consecutive row indices starting at rb
+__device__ __forceinline__ void store_transposed(unsigned char* tile, int cb, int rb, const uint4 (&p)[8]) {
+  const uint32_t w[8][4] = {{p[0].x, p[0].y, p[0].z, p[0].w}, {p[1].x, p[1].y, p[1].z, p[1].w},
+                            {p[2].x, p[2].y, p[2].z, p[2].w}, {p[3].x, p[3].y, p[3].z, p[3].w},
+                            {p[4].x, p[4].y, p[4].z, p[4].w}, {p[5].x, p[5].y, p[5].z, p[5].w},
+                            {p[6].x, p[6].y, p[6].z, p[6].w}, {p[7].x, p[7].y, p[7].z, p[7].w}};
+#pragma unroll
+  for (int c2 = 0; c2 < 4; ++c2) {       // channel pair (2*c2, 2*c2+1) lives in word c2 of every row
+    uint4 lo, hi;
+    lo.x = perm_lo(w[0][c2], w[1][c2]); lo.y = perm_lo(w[2][c2], w[3][c2]);
+    lo.z = perm_lo(w[4][c2], w[5][c2]); lo.w = perm_lo(w[6][c2], w[7][c2]);
+    hi.x = perm_hi(w[0][c2], w[1][c2]); hi.y = perm_hi(w[2][c2], w[3][c2]);
+    hi.z = perm_hi(w[4][c2], w[5][c2]); hi.w = perm_hi(w[6][c2], w[7][c2]);
+    *reinterpret_cast<uint4*>(tile + (cb + 2 * c2) * LDT + rb * 2) = lo;
+    *reinterpret_cast<uint4*>(tile + (cb + 2 * c2 + 1) * LDT + rb * 2) = hi;
+  }
+}
+
+template <bool GBN>
+__global__ __launch_bounds__(THREADS, 2) void k_big_wgrad(const WgArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave & 1, wj = wave >> 1;    // MFMA: wm -> K half (first operand), wj -> N half
+  const int ntile = a.ntk * a.ntn;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int tile = q % ntile;
+  const int split = (q / ntile) * 8 + xcd;
+  if (split >= a.S) return;
+  const int kt0 = (tile / a.ntn) * 128, nt0 = (tile % a.ntn) * 128;
+  const int m_begin = split * a.rows_per_split;
+  const int m_end = min(a.M, m_begin + a.rows_per_split);
+
+  // staging task of this thread
+  const bool is_x = wave < 2;
+  const int rg = lane & 7;                          // row group: rows rg*8 .. rg*8+7 of the 64-row step
+  const int cchunk = (lane >> 3) + 8 * (wave & 1);  // channel chunk 0..15 of the 128-wide tile
+  const int cb = cchunk * 8;
+  const int cglob = (is_x ? kt0 : nt0) + cb;
+  const bool c_ok = cglob < (is_x ? a.K : a.N);
+  const bf16_t* SRC = reinterpret_cast<const bf16_t*>(is_x ? a.tv.data : a.gv.dz);
+  const bf16_t* SRCY = reinterpret_cast<const bf16_t*>(a.gv.y);
+  const int ld = is_x ? a.tv.ld : a.gv.ld;
+  const bool swish = a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr, gated = a.tv.gate != nullptr;
+  float c0[8], c1[8], c2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { c0[e] = 1.f; c1[e] = 0.f; c2[e] = 0.f; }
+  if (c_ok) {
+    if (is_x) {
+      if (affine) { loadf8(a.tv.scale + cglob, c0); loadf8(a.tv.shift + cglob, c1); }
+    } else if (GBN) {
+      loadf8(a.gv.a + cglob, c0); loadf8(a.gv.b + cglob, c1); loadf8(a.gv.cc + cglob, c2);
+    }
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[x][y][e] = 0.f;
+
+  uint4 ra[8], ry[GBN ? 8 : 1];
+  auto issue = [&](int mb) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int m = mb + rg * 8 + r;
+      ra[r] = make_uint4(0, 0, 0, 0);
+      if (GBN) ry[r] = make_uint4(0, 0, 0, 0);
+      if (c_ok && m < m_end) {
+        ra[r] = *reinterpret_cast<const uint4*>(SRC + (size_t)m * ld + cglob);
+        if (GBN && !is_x) ry[r] = *reinterpret_cast<const uint4*>(SRCY + (size_t)m * ld + cglob);
+      }
+    }
+  };
+  auto commit = [&](int mb, unsigned char* stage) {
+    unsigned char* tile_lds = stage + (is_x ? 0 : TILE_BYTES);
+    uint4 p[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int m = mb + rg * 8 + r;
+      p[r] = ra[r];
+      if (c_ok && m < m_end) {
+        if (is_x) {
+          if (affine || swish || gated) {
+            float x[8];
+            unpack8(ra[r], x);
+            if (affine) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], c0[e], c1[e]);
+            }
+            if (swish) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[e] = swishf_(x[e]);
+            }
+            if (gated) {
+              float gt[8];
+              loadf8(a.tv.gate + (size_t)(m / a.hw) * a.K + cglob, gt);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[e] *= gt[e];
+            }
+            p[r] = pack8(x);
+          }
+        } else if (GBN) {
+          float x[8], y[8];
+          unpack8(ra[r], x);
+          unpack8(ry[r], y);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = fmaf(c0[e], x[e], fmaf(c1[e], y[e], c2[e]));
+          p[r] = pack8(x);
+        }
+      } else {
+        p[r] = make_uint4(0, 0, 0, 0);      // rows past the split / channels past K, N contribute zero
+      }
+    }
+    store_transposed(tile_lds, cb, rg * 8, p);
+  };
+
+  const int nst = (m_end - m_begin + BK - 1) / BK;
+  if (nst > 0) {
+    issue(m_begin);
+    commit(m_begin, smem);
+    if (nst > 1) issue(m_begin + BK);
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+      unsigned char* cur = smem + (st & 1) * STAGE_BYTES;
+      unsigned char* nxt = smem + ((st + 1) & 1) * STAGE_BYTES;
+      if (st + 1 < nst) commit(m_begin + (st + 1) * BK, nxt);
+      if (st + 2 < nst) issue(m_begin + (st + 2) * BK);
+      mma_stage(cur + TILE_BYTES, cur, wj, wm, lane, BK / 16, acc);
+      __syncthreads();
+    }
+  }
+  // mma_stage(As := dY^T tile, Bs := X^T tile, wm := wj, wj := wm): its first MFMA operand comes from "Bs"
+  // rows (wj_arg*64 + ...) = X^T rows = k, its second from "As" rows (wm_arg*64 + ...) = dY^T rows = n, so
+  // acc[kk][nn] = D[i = k within the 32-tile][j = n within the 32-tile]: lane holds n = lane & 31 and
+  // k = (e & 3) + 8*(e >> 2) + 4*(lane >> 5).
+  float* dst = a.ws + (size_t)split * a.K * a.N;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) {
+      const int n = nt0 + wj * 64 + nn * 32 + r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int k = kt0 + wm * 64 + kk * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (k < a.K && n < a.N) dst[(size_t)k * a.N + n] = acc[kk][nn][e];
+      }
+    }
+}
+
+inline bool big_lds_ok(const void* kern) {
+  return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES) == hipSuccess;
+}
+
+}  // namespace pwb
+
+// return 1 = handled, 0 = shape outside the envelope (caller falls back), < 0 = error
+int pwb_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bias, void* out, int cout,
+                int ldo, float* stat_partials, int* nparts_out, hipStream_t st) {
+  using namespace pwb;
+  const int K = in->c, N = cout;
+  if (K % 8 != 0 || in->ld % 8 != 0 || ldw % 8 != 0 || ldo % 8 != 0 || ldo < (N + 7) / 8 * 8) return 0;
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tv = *in;
+  a.Bm = reinterpret_cast<const bf16_t*>(wt); a.ldb = ldw;
+  a.M = in->n * in->h * in->w; a.R = K; a.J = N; a.hw = in->h * in->w;
+  a.bias = bias; a.out = reinterpret_cast<bf16_t*>(out); a.ldo = ldo; a.stat_partials = stat_partials;
+  a.ntm = (a.M + BM - 1) / BM; a.ntj = (N + BJ - 1) / BJ;
+  a.tpw = (a.ntm + EDET_MAX_PARTS - 1) / EDET_MAX_PARTS;
+  a.ngrp = (a.ntm + a.tpw - 1) / a.tpw;
+  if (nparts_out) *nparts_out = a.ngrp;
+  static const bool ok = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<false, false>));
+  if (!ok) return 0;
+  const int grid = (a.ngrp + 7) / 8 * 8 * a.ntj;
+  k_big_gemm<false, false><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+  EDET_LAUNCH_CHECK("edet_pw_fwd(big)");
+  return 1;
+}
+
+int pwb_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tview_t* in,
+                  const edet_bwd_epi_t* epi, int* nparts_out, hipStream_t st) {
+  using namespace pwb;
+  const int R = dy->c, KO = in->c;
+  if (KO % 8 != 0 || in->ld % 8 != 0 || dy->ld % 8 != 0 || ldw % 8 != 0 || R % 8 != 0) return 0;
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tv = *in; a.gv = *dy;
+  a.Bm = reinterpret_cast<const bf16_t*>(w); a.ldb = ldw;
+  a.M = in->n * in->h * in->w; a.R = R; a.J = KO; a.hw = in->h * in->w;
+  a.epi = *epi; a.stat_partials = epi->stat_partials;
+  a.ntm = (a.M + BM - 1) / BM; a.ntj = (KO + BJ - 1) / BJ;
+  a.tpw = (a.ntm + EDET_MAX_PARTS - 1) / EDET_MAX_PARTS;
+  a.ngrp = (a.ntm + a.tpw - 1) / a.tpw;
+  if (nparts_out) *nparts_out = a.ngrp;
+  static const bool ok1 = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<true, false>));
+  static const bool ok2 = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<true, true>));
+  if (!ok1 || !ok2) return 0;
+  const int grid = (a.ngrp + 7) / 8 * 8 * a.ntj;
+  if (dy->a) k_big_gemm<true, true><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+  else k_big_gemm<true, false><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+  EDET_LAUNCH_CHECK("edet_pw_bwd_data(big)");
+  return 1;
+}
+
+int pwb_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight, void* workspace,
+                  size_t workspace_bytes, hipStream_t st) {
+  using namespace pwb;
+  const int K = in->c, N = dy->c;
+  if (!workspace || K % 8 != 0 || N % 8 != 0 || dy->ld % 8 != 0 || in->ld % 8 != 0) return 0;
+  WgArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tv = *in; a.gv = *dy; a.ws = reinterpret_cast<float*>(workspace);
+  a.M = in->n * in->h * in->w; a.K = K; a.N = N; a.hw = in->h * in->w;
+  a.ntk = (K + 127) / 128; a.ntn = (N + 127) / 128;
+  const int ntile = a.ntk * a.ntn;
+  const int64_t kn = (int64_t)K * N;
+  // ~2048 workgroups, at least 4 steps of 64 rows each, bounded by the workspace
+  int S = (2048 + ntile - 1) / ntile;
+  const int max_by_rows = (a.M + 4 * BK - 1) / (4 * BK);
+  if (S > max_by_rows) S = max_by_rows;
+  const int64_t max_by_ws = (int64_t)(workspace_bytes / sizeof(float)) / kn;
+  if (S > max_by_ws) S = (int)max_by_ws;
+  if (S < 1) return 0;
+  a.rows_per_split = ((a.M + S - 1) / S + BK - 1) / BK * BK;
+  a.S = (a.M + a.rows_per_split - 1) / a.rows_per_split;
+  static const bool ok1 = big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad<false>));
+  static const bool ok2 = big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad<true>));
+  if (!ok1 || !ok2) return 0;
+  const int grid = (a.S + 7) / 8 * 8 * ntile;
+  if (dy->a) k_big_wgrad<true><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+  else k_big_wgrad<false><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+  EDET_LAUNCH_CHECK("edet_pw_bwd_weight(big)");
+  if (edet_reduce_partials(a.ws, a.S, kn, dweight, st) != 0) return -2;
+  return 1;
+}

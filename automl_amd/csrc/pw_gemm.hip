@@ -14,6 +14,8 @@
 //
 // Reference call sites: efficientdet/backbone/efficientnet_model.py:304-312,345-353;
 // efficientdet/tf2/efficientdet_keras.py:195-207,286-290,459-464,546-556.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -636,6 +638,34 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// workgroup-tiled bf16 kernels for the wide layers (pw_big.hip); same return convention
+int pwb_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bias, void* out, int cout,
+                int ldo, float* stat_partials, int* nparts_out, hipStream_t st);
+int pwb_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tview_t* in,
+                  const edet_bwd_epi_t* epi, int* nparts_out, hipStream_t st);
+int pwb_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight, void* workspace,
+                  size_t workspace_bytes, hipStream_t st);
+
+// Which bf16 implementation serves a (rows, cin, cout) pointwise layer.  The streaming kernels own the
+// HBM-bound layers (few channels, many rows); the tiled kernels own the layers whose weight matrix is large
+// (cin*cout >= EDET_PW_BIG_MINKN, default 24576: from 80x480 / 112x672 upwards).  EDET_PW_IMPL = stream | big |
+// tiled forces one implementation where its envelope allows (parity tests, A/B timing); both variables are
+// read per call.
+enum { PW_AUTO = 0, PW_STREAM = 1, PW_BIG = 2, PW_TILED = 3 };
+static int pw_impl_env() {
+  const char* e = getenv("EDET_PW_IMPL");
+  if (!e || !*e) return PW_AUTO;
+  if (!strcmp(e, "stream")) return PW_STREAM;
+  if (!strcmp(e, "big")) return PW_BIG;
+  if (!strcmp(e, "tiled")) return PW_TILED;
+  return PW_AUTO;
+}
+static bool pw_prefers_big(int64_t rows, int cin, int cout) {
+  const char* e = getenv("EDET_PW_BIG_MINKN");
+  const int64_t minkn = e && *e ? atoll(e) : 24576;
+  return (int64_t)cin * cout >= minkn && rows >= 1024;
+}
+
 // streaming bf16 kernels (pw_stream.hip); return 1 = handled, 0 = shape outside their envelope
 int pws_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bias, void* out, int cout,
                 int ldo, float* stat_partials, int* nparts_out, hipStream_t st);
@@ -658,7 +688,14 @@ extern "C" int edet_pw_fwd(const edet_tview_t* in, const void* wt, int ldw, cons
   a.M = in->n * in->h * in->w; a.R = in->c; a.J = cout; a.hw = in->h * in->w;
   a.bias = bias; a.out = out; a.ldo = ldo; a.stat_partials = stat_partials;
   if (dtype == EDET_BF16) {
-    const int rc = pws_try_fwd(in, wt, ldw, bias, out, cout, ldo, stat_partials, nparts_out, to_stream(stream));
+    const int impl = pw_impl_env();
+    const bool big_first = impl == PW_BIG || (impl == PW_AUTO && pw_prefers_big(a.M, in->c, cout));
+    int rc = 0;
+    if (big_first) rc = pwb_try_fwd(in, wt, ldw, bias, out, cout, ldo, stat_partials, nparts_out, to_stream(stream));
+    if (rc == 0 && impl != PW_TILED && impl != PW_BIG)
+      rc = pws_try_fwd(in, wt, ldw, bias, out, cout, ldo, stat_partials, nparts_out, to_stream(stream));
+    if (rc == 0 && !big_first && impl == PW_AUTO && (int64_t)in->c * cout >= 4096)
+      rc = pwb_try_fwd(in, wt, ldw, bias, out, cout, ldo, stat_partials, nparts_out, to_stream(stream));
     if (rc != 0) return rc < 0 ? rc : 0;
     return launch_gemm<bf16_t, false>(a, nparts_out, to_stream(stream));
   }
@@ -681,7 +718,14 @@ extern "C" int edet_pw_bwd_data(const edet_gview_t* dy, const void* w, int ldw,
   a.M = in->n * in->h * in->w; a.R = dy->c; a.J = in->c; a.hw = in->h * in->w;
   a.epi = *epi; a.stat_partials = epi->stat_partials;
   if (dtype == EDET_BF16) {
-    const int rc = pws_try_dgrad(dy, w, ldw, in, epi, nparts_out, to_stream(stream));
+    const int impl = pw_impl_env();
+    const bool big_first = impl == PW_BIG || (impl == PW_AUTO && pw_prefers_big(a.M, in->c, dy->c));
+    int rc = 0;
+    if (big_first) rc = pwb_try_dgrad(dy, w, ldw, in, epi, nparts_out, to_stream(stream));
+    if (rc == 0 && impl != PW_TILED && impl != PW_BIG)
+      rc = pws_try_dgrad(dy, w, ldw, in, epi, nparts_out, to_stream(stream));
+    if (rc == 0 && !big_first && impl == PW_AUTO && (int64_t)in->c * dy->c >= 4096)
+      rc = pwb_try_dgrad(dy, w, ldw, in, epi, nparts_out, to_stream(stream));
     if (rc != 0) return rc < 0 ? rc : 0;
     return launch_gemm<bf16_t, true>(a, nparts_out, to_stream(stream));
   }
@@ -702,7 +746,14 @@ extern "C" int edet_pw_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy
   a.M = in->n * in->h * in->w; a.hw = in->h * in->w;
   a.dw = dweight;
   if (dtype == EDET_BF16) {
-    const int rc = pws_try_wgrad(in, dy, dweight, workspace, workspace_bytes, to_stream(stream));
+    const int impl = pw_impl_env();
+    const bool big_first = impl == PW_BIG || (impl == PW_AUTO && pw_prefers_big(a.M, in->c, dy->c));
+    int rc = 0;
+    if (big_first) rc = pwb_try_wgrad(in, dy, dweight, workspace, workspace_bytes, to_stream(stream));
+    if (rc == 0 && impl != PW_TILED && impl != PW_BIG)
+      rc = pws_try_wgrad(in, dy, dweight, workspace, workspace_bytes, to_stream(stream));
+    if (rc == 0 && !big_first && impl == PW_AUTO && (int64_t)in->c * dy->c >= 4096)
+      rc = pwb_try_wgrad(in, dy, dweight, workspace, workspace_bytes, to_stream(stream));
     if (rc != 0) return rc < 0 ? rc : 0;
     return launch_wgrad<bf16_t>(a, to_stream(stream));
   }

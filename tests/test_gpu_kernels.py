@@ -35,6 +35,19 @@ def apply_view(x, scale, shift, act, gate):
   return z
 
 
+@pytest.fixture(params=['auto', 'big'])
+def pw_impl(request, monkeypatch):
+  """EDET_PW_IMPL (read per call by the library): 'big' forces the workgroup-tiled kernels of pw_big.hip."""
+  if request.param != 'auto':
+    monkeypatch.setenv('EDET_PW_IMPL', request.param)
+  return request.param
+
+
+def skip_f32_big(name, impl):
+  if name == 'f32' and impl != 'auto':
+    pytest.skip('the fp32 validation mode has a single implementation')
+
+
 def partial_buf(c):
   return torch.zeros(_lib.MAX_PARTS * 2 * c, dtype=torch.float32, device=gu.DEV)
 
@@ -42,10 +55,13 @@ def partial_buf(c):
 # ------------------------------------------------------------------------------------ pointwise fwd
 @pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
 @pytest.mark.parametrize('shape', [(2, 9, 7, 24, 40), (1, 16, 16, 16, 96), (2, 5, 5, 64, 810),
-                                   (3, 13, 11, 144, 24), (1, 20, 20, 1152, 192), (2, 8, 8, 64, 36)])
+                                   (3, 13, 11, 144, 24), (1, 20, 20, 1152, 192), (2, 8, 8, 64, 36),
+                                   (2, 23, 17, 112, 672), (3, 7, 9, 192, 1152), (2, 12, 12, 480, 80),
+                                   (5, 5, 5, 320, 64)])
 @pytest.mark.parametrize('mode', ['plain', 'bn_swish', 'bn_swish_gate'])
-def test_pw_fwd(dt, shape, mode):
+def test_pw_fwd(dt, shape, mode, pw_impl):
   name, edt, tdt = dt
+  skip_f32_big(name, pw_impl)
   n, h, w, cin, cout = shape
   rng = np.random.default_rng(gu.seed_of((shape, mode)))
   x = gu.rnd(rng, (n, h, w, cin), tdt)
@@ -99,11 +115,13 @@ def make_grad_view(rng, n, h, w, c, tdt, with_bn):
 
 @pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
 @pytest.mark.parametrize('shape', [(2, 9, 7, 24, 40), (2, 5, 5, 64, 810), (3, 13, 11, 144, 24),
-                                   (2, 12, 12, 96, 16), (1, 20, 20, 1152, 192)])
+                                   (2, 12, 12, 96, 16), (1, 20, 20, 1152, 192), (2, 23, 17, 112, 672),
+                                   (3, 7, 9, 672, 112), (5, 5, 5, 192, 1152)])
 @pytest.mark.parametrize('mode', ['plain', 'plain_beta', 'bn', 'bn_swish_stats', 'gate'])
 @pytest.mark.parametrize('gbn', [False, True])
-def test_pw_bwd_data(dt, shape, mode, gbn):
+def test_pw_bwd_data(dt, shape, mode, gbn, pw_impl):
   name, edt, tdt = dt
+  skip_f32_big(name, pw_impl)
   n, h, w, cin, cout = shape
   rng = np.random.default_rng(gu.seed_of((shape, mode, gbn)))
   dz, y, ga, gb, gcc, dy = make_grad_view(rng, n, h, w, cout, tdt, gbn)
@@ -171,11 +189,13 @@ def test_pw_bwd_data(dt, shape, mode, gbn):
 @pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
 @pytest.mark.parametrize('shape', [(2, 9, 7, 24, 40), (2, 5, 5, 64, 810), (3, 13, 11, 144, 24),
                                    (2, 12, 12, 96, 16), (1, 20, 20, 1152, 192), (2, 8, 8, 64, 36),
-                                   (4, 33, 31, 16, 96), (1, 10, 10, 320, 64)])
+                                   (4, 33, 31, 16, 96), (1, 10, 10, 320, 64), (2, 23, 17, 112, 672),
+                                   (3, 7, 9, 1152, 192), (5, 5, 5, 480, 80)])
 @pytest.mark.parametrize('mode', ['plain', 'bn_swish_gate'])
 @pytest.mark.parametrize('use_ws', [True, False], ids=['workspace', 'atomics'])
-def test_pw_bwd_weight(dt, shape, mode, use_ws):
+def test_pw_bwd_weight(dt, shape, mode, use_ws, pw_impl):
   name, edt, tdt = dt
+  skip_f32_big(name, pw_impl)
   n, h, w, cin, cout = shape
   rng = np.random.default_rng(gu.seed_of((shape, mode, 3)))
   dz, y, ga, gb, gcc, dy = make_grad_view(rng, n, h, w, cout, tdt, mode != 'plain')
