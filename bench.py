@@ -30,6 +30,33 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
 ALG_GFLOP_PER_IMG = 23.36
 ALG_MB_PER_IMG = 925.0
 
+# C-ABI entry point -> substrings of the kernel names it launches (for the PMC traffic lookup)
+ENTRY_KERNELS = {
+    'edet_dw_bwd_data': ['dwm::k_dgrad', 'k_dw_bwd_data'],
+    'edet_dw_bwd_weight': ['dwm::k_wgrad', 'k_dw_bwd_weight'],
+    'edet_dw_fwd': ['dwm::k_fwd', 'k_dw_fwd'],
+    'edet_dw_bwd': ['dwf::k_bwd'],
+    'edet_pw_bwd_weight': ['pws::k_pw_wgrad', 'pwb::k_big_wgrad', 'k_wgrad<unsigned short'],
+    'edet_pw_bwd_data': ['pws::k_pw_dgrad', 'pwb::k_big_gemm<true', 'k_gemm<unsigned short, 8, true', 'k_gemm<unsigned short, 4, true', 'k_gemm<unsigned short, 2, true'],
+    'edet_pw_fwd': ['pws::k_pw_fwd', 'pwb::k_big_gemm<false', 'k_gemm<unsigned short, 8, false', 'k_gemm<unsigned short, 4, false'],
+}
+
+
+def pmc_traffic(entry, launches_per_step):
+  """HBM bytes per launch of `entry` from the newest committed PMC passes (profiles/*_traffic.json, made by
+  scripts/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE rocprofv3 runs of this same workload).
+  Returns (bytes_per_launch, source) or (None, None): PMC counters cannot be read from inside this process."""
+  import glob
+  files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_traffic.json')))
+  pats = ENTRY_KERNELS.get(entry)
+  if not files or not pats or not launches_per_step:
+    return None, None
+  d = json.load(open(files[-1]))
+  total = sum(v['fetch_bytes'] + v['write_bytes'] for k, v in d['kernels'].items() if any(p in k for p in pats))
+  if total <= 0:
+    return None, None
+  return total / (d['steps_in_run'] * launches_per_step), os.path.basename(files[-1])
+
 
 def synth_batch(config, batch, size, seed, device, tdtype):
   """Images N(0,1); ~100 positive anchors / image, ~50 ignored."""
@@ -152,6 +179,7 @@ def main():
   t0 = time.perf_counter()
   for _ in range(args.steps):
     step()
+  host_enqueue = time.perf_counter() - t0      # host time to enqueue K steps (launches are asynchronous)
   torch.cuda.synchronize()
   if dist is not None:
     dist.barrier()
@@ -169,6 +197,9 @@ def main():
     value = args.batch * world * args.steps / elapsed
     n_l, ms_l, bytes_l = prof[dominant]
     achieved = bytes_l / (ms_l * 1e-3) / 1e9
+    is_headline = args.model == 'efficientdet-d0' and args.image_size == 640 and args.batch == 128 and \
+        args.dtype == 'bf16'
+    traffic, traffic_src = pmc_traffic(dominant, n_l / args.steps) if is_headline else (None, None)
     out = {
         'metric': 'images/sec EfficientDet-D0 640x640 fwd+bwd (whole job; per-GPU = value / n_gpus)',
         'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -178,10 +209,12 @@ def main():
                                'DP replicas of it for n_gpus>1)' % (args.model, args.image_size,
                                                                    args.image_size, args.batch),
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
-                   'loss': losses.get('loss')},
+                   'loss': losses.get('loss'),
+                   'host_enqueue_ms_per_step': host_enqueue / args.steps * 1e3},
         'roofline': {
             'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+            'traffic_source': traffic_src,
             'launches_per_step': n_l / args.steps, 'avg_launch_ms': ms_l / n_l,
             'algorithmic_bytes_per_launch': bytes_l / n_l,
             'kernel_time_share': full[dominant][1] / kernel_ms_total,
