@@ -67,6 +67,9 @@ struct GemmArgs {
   int ldo;
   edet_bwd_epi_t epi; // bwd
   float* stat_partials;
+  // CONV (implicit GEMM of a dense ck x ck convolution, stride cs, TF 'SAME'): rows = output pixels,
+  // reduction index = (ky*ck + kx)*cin + c; tv is the conv INPUT view [n][ih][iw][cin]
+  int ck, cs, cin, ih, iw, cow, cohw, pad_t, pad_l;
 };
 
 // 64 x 64 per wave: acc[nj][mi] = D[i = output column within the 32-tile][j = row within the 32-tile]
@@ -89,8 +92,9 @@ __device__ __forceinline__ void mma_stage(const unsigned char* As, const unsigne
   }
 }
 
-template <bool BWD, bool GBN>
+template <bool BWD, bool GBN, bool CONV = false>
 __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
+  static_assert(!(CONV && BWD), "the implicit-GEMM gather is a forward-only variant");
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave & 1, wj = wave >> 1;
@@ -123,11 +127,22 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
     const int m0 = mt * BM;
     int64_t arow[4];
     int aimg[4];
+    int ciy[CONV ? 4 : 1], cix[CONV ? 4 : 1];          // CONV: top-left input pixel of the row's window
+    unsigned cvalid = 0;                               // CONV: taps of the chunk in flight that hit the image
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = min(m0 + lr + 32 * i, a.M - 1);     // rows past M re-read row M-1 (never stored)
-      arow[i] = (int64_t)m * lds_src;
-      aimg[i] = gated ? m / a.hw : 0;
+      if (CONV) {
+        const int img = m / a.cohw, rem = m - img * a.cohw;
+        const int oy = rem / a.cow, ox = rem - oy * a.cow;
+        ciy[i] = oy * a.cs - a.pad_t;
+        cix[i] = ox * a.cs - a.pad_l;
+        arow[i] = (int64_t)img * a.ih * a.iw;           // pixel index of the image's first pixel
+        aimg[i] = img;
+      } else {
+        arow[i] = (int64_t)m * lds_src;
+        aimg[i] = gated ? m / a.hw : 0;
+      }
     }
     f32x16 acc[2][2];
 #pragma unroll
@@ -141,13 +156,29 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
     auto issue = [&](int kt) {
       const int k = kt * BK + lc * 8;
       const bool kok = k < a.R;
+      int cky = 0, ckx = 0, cc = 0;
+      if (CONV) {
+        const int tap = k / a.cin;
+        cc = k - tap * a.cin;
+        cky = tap / a.ck;
+        ckx = tap - cky * a.ck;
+        cvalid = 0;
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         ra[i] = make_uint4(0, 0, 0, 0);
         if (GBN) ry[i] = make_uint4(0, 0, 0, 0);
         rb[i] = make_uint4(0, 0, 0, 0);
         if (kok) {
-          ra[i] = *reinterpret_cast<const uint4*>(SRC + arow[i] + k);
+          if (CONV) {
+            const int iy = ciy[i] + cky, ix = cix[i] + ckx;
+            if (iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw) {
+              cvalid |= 1u << i;
+              ra[i] = *reinterpret_cast<const uint4*>(SRC + (arow[i] + (int64_t)iy * a.iw + ix) * lds_src + cc);
+            }
+          } else {
+            ra[i] = *reinterpret_cast<const uint4*>(SRC + arow[i] + k);
+          }
           if (GBN) ry[i] = *reinterpret_cast<const uint4*>(SRCY + arow[i] + k);
           const int j = j0 + lr + 32 * i;
           if (j < a.J) rb[i] = *reinterpret_cast<const uint4*>(a.Bm + (size_t)j * a.ldb + k);
@@ -160,9 +191,10 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
       unsigned char* As = stage;
       unsigned char* Bs = stage + TILE_BYTES;
       float c0[8], c1[8], c2[8];
+      const int kc = CONV ? k % a.cin : k;     // channel of the streamed operand this chunk starts at
       if (kok) {
         if (!BWD) {
-          if (affine) { loadf8(a.tv.scale + k, c0); loadf8(a.tv.shift + k, c1); }
+          if (affine) { loadf8(a.tv.scale + kc, c0); loadf8(a.tv.shift + kc, c1); }
         } else if (GBN) {
           loadf8(a.gv.a + k, c0); loadf8(a.gv.b + k, c1); loadf8(a.gv.cc + k, c2);
         }
@@ -185,11 +217,13 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
               }
               if (gated) {
                 float gt[8];
-                loadf8(a.tv.gate + (size_t)aimg[i] * a.R + k, gt);
+                loadf8(a.tv.gate + (size_t)aimg[i] * (CONV ? a.cin : a.R) + kc, gt);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] *= gt[e];
               }
               v = pack8(x);
+              // 'SAME' padding is zero in the activated domain
+              if (CONV && !((cvalid >> i) & 1u)) v = make_uint4(0, 0, 0, 0);
             }
           } else if (GBN) {
             float x[8], y[8];
@@ -605,6 +639,34 @@ int pwb_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
   const int grid = (a.ngrp + 7) / 8 * 8 * a.ntj;
   k_big_gemm<false, false><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
   EDET_LAUNCH_CHECK("edet_pw_fwd(big)");
+  return 1;
+}
+
+// dense k x k convolution (stride s, TF 'SAME') as an implicit GEMM: wt [cout][k*k*cin], reduction index
+// (ky*k + kx)*cin + c contiguous.  return 1 = handled, 0 = shape outside the envelope, < 0 = error
+int pwb_try_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, int k, int s, const float* bias, void* out,
+                     int cout, int ldo, float* stat_partials, int* nparts_out, hipStream_t st) {
+  using namespace pwb;
+  const int cin = in->c, N = cout;
+  if (cin % 8 != 0 || in->ld % 8 != 0 || ldw % 8 != 0 || ldo % 8 != 0 || ldo < (N + 7) / 8 * 8) return 0;
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tv = *in;
+  a.Bm = reinterpret_cast<const bf16_t*>(wt); a.ldb = ldw;
+  const int oh = same_out(in->h, s), ow = same_out(in->w, s);
+  a.M = in->n * oh * ow; a.R = k * k * cin; a.J = N; a.hw = oh * ow;
+  a.ck = k; a.cs = s; a.cin = cin; a.ih = in->h; a.iw = in->w; a.cow = ow; a.cohw = oh * ow;
+  a.pad_t = same_pad_before(in->h, k, s); a.pad_l = same_pad_before(in->w, k, s);
+  a.bias = bias; a.out = reinterpret_cast<bf16_t*>(out); a.ldo = ldo; a.stat_partials = stat_partials;
+  a.ntm = (a.M + BM - 1) / BM; a.ntj = (N + BJ - 1) / BJ;
+  a.tpw = (a.ntm + EDET_MAX_PARTS - 1) / EDET_MAX_PARTS;
+  a.ngrp = (a.ntm + a.tpw - 1) / a.tpw;
+  if (nparts_out) *nparts_out = a.ngrp;
+  static const bool ok = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<false, false, true>));
+  if (!ok) return 0;
+  const int grid = (a.ngrp + 7) / 8 * 8 * a.ntj;
+  k_big_gemm<false, false, true><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+  EDET_LAUNCH_CHECK("edet_conv_fwd(big)");
   return 1;
 }
 

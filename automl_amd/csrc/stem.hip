@@ -365,9 +365,9 @@ int stem_launch(bool fwd, StemArgs& a, hipStream_t st) {
     }                                                                   \
     break;
   switch (a.cout / 8) {
-    STEM_CASE(4) STEM_CASE(5) STEM_CASE(6) STEM_CASE(7) STEM_CASE(8)
+    STEM_CASE(3) STEM_CASE(4) STEM_CASE(5) STEM_CASE(6) STEM_CASE(7) STEM_CASE(8)
     default:
-      EDET_CHECK(false, "stem: cout %d unsupported (need 32,40,48,56,64)", a.cout);
+      EDET_CHECK(false, "stem: cout %d unsupported (need 24,32,40,48,56,64)", a.cout);
   }
 #undef STEM_CASE
   EDET_LAUNCH_CHECK("edet_stem");

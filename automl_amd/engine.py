@@ -89,12 +89,14 @@ class Engine(object):
   """Builds buffers for (config, batch, image size, dtype) and runs forward / backward / update."""
 
   def __init__(self, config, batch_size, image_size=None, dtype='bf16', device='cuda:0', seed=0,
-               params=None):
+               params=None, spec=None):
     if not torch.cuda.is_available():
       raise _lib.EdetError('no HIP device visible: the EfficientDet engine has no CPU path')
     _lib.load()
     self.config = config
-    self.spec = netspec_lib.NetSpec(config)
+    self.spec = spec if spec is not None else netspec_lib.NetSpec(config)
+    self.bn_momentum = getattr(self.spec, 'bn_momentum', netspec_lib.BN_MOMENTUM)
+    self.bn_epsilon = getattr(self.spec, 'bn_epsilon', netspec_lib.BN_EPSILON)
     self.device = torch.device(device)
     torch.cuda.set_device(self.device)
     self.dtype = EDET_BF16 if dtype in ('bf16', EDET_BF16) else EDET_F32
@@ -243,11 +245,11 @@ class Engine(object):
     if self.training:
       bn.count = count
       call('edet_bn_finalize', ptr(self.partials), nparts, bn.c, float(count), ptr(bn.gamma), ptr(bn.beta),
-           netspec_lib.BN_EPSILON, netspec_lib.BN_MOMENTUM if self.update_moving else -1.0,
+           self.bn_epsilon, self.bn_momentum if self.update_moving else -1.0,
            ptr(bn.mm), ptr(bn.mv), ptr(bn.scale), ptr(bn.shift), ptr(bn.mean), ptr(bn.rstd), self.stream)
       bn.bwd_ready = False
     else:
-      call('edet_bn_eval', bn.c, ptr(bn.gamma), ptr(bn.beta), netspec_lib.BN_EPSILON, ptr(bn.mm), ptr(bn.mv),
+      call('edet_bn_eval', bn.c, ptr(bn.gamma), ptr(bn.beta), self.bn_epsilon, ptr(bn.mm), ptr(bn.mv),
            ptr(bn.scale), ptr(bn.shift), self.stream)
 
   def _bn_bwd_finalize(self, bn, nparts):
@@ -319,6 +321,38 @@ class Engine(object):
       if fused:
         self._bn_bwd_finalize(vin.bn, self._nparts.value)
 
+  def conv(self, key, vin, wname, k, stride, cout, bn=None, act=ACT_NONE):
+    """Dense k x k convolution, TF 'SAME', no bias [-> BN -> act as a view] (Fused-MBConv,
+    efficientnetv2/effnetv2_model.py:338-346,362-371).  Forward only: the V2 classifier's training
+    is outside the hot path, so the tape entry refuses to run."""
+    r = vin.raw
+    cin = r.c
+    if cin % 8 != 0 or r.ld != cin:
+      raise ValueError('dense convolution needs an input channel count divisible by 8, got %d' % cin)
+    kk = k * k * cin
+    wt = self.buf('wtc:' + wname, (cout, kk), self.tdtype)
+    if wname not in self._cast_done:
+      call('edet_cast_matrix', ptr(self.param(wname)), ptr(wt), kk, cout, kk, 1, self.dtype, self.stream)
+      self._cast_done.add(wname)
+    oh, _, _ = utils.same_padding(r.h, k, stride)
+    ow, _, _ = utils.same_padding(r.w, k, stride)
+    out = Raw(self, key, r.n, oh, ow, cout)
+    bnl = self.get_bn(bn, cout) if bn else None
+    stats = ptr(self.partials) if (bnl and self.training) else None
+    call('edet_conv_fwd', ctypes.byref(vin.tview()), ptr(wt), kk, k, stride, ptr(out.data), cout, out.ld,
+         stats, ctypes.byref(self._nparts), self.dtype, self.stream,
+         nbytes=(r.rows * cin + out.rows * cout) * self.esize,
+         tag='%dx%dx%d->%d k%ds%d' % (r.h, r.w, cin, cout, k, stride))
+    if bnl:
+      self._bn_forward(bnl, out.rows, self._nparts.value)
+    vout = View(out, bnl, act)
+    vin.consumers += 1
+    if self.training:
+      def bwd():
+        raise _lib.EdetError('the dense-convolution backward (EfficientNetV2 classifier training) is not built')
+      self.tape.append(bwd)
+    return vout
+
   def dw(self, key, vin, wname, k, stride, bn=None, act=ACT_NONE):
     r = vin.raw
     oh, _, _ = utils.same_padding(r.h, k, stride)
@@ -388,6 +422,8 @@ class Engine(object):
   def bn_res(self, key, vy, residual):
     """Materialise a block output: bn(y) (+ residual)."""
     r = vy.raw
+    if residual is not None and (residual.bn is not None or residual.act != ACT_NONE or residual.gate is not None):
+      raise ValueError('bn_res: the residual operand must be a stored (plain) tensor')
     out = Raw(self, key, r.n, r.h, r.w, r.c)
     call('edet_bn_res', ctypes.byref(vy.tview()), ptr(residual.raw.data) if residual else None, ptr(out.data),
          out.ld, self.dtype, self.stream, nbytes=(3 if residual else 2) * r.rows * r.c * self.esize)
@@ -469,9 +505,9 @@ class Engine(object):
     self._cast_done = set()
     for bn in self.bns.values():
       bn.bwd_ready = False
+    for t in self._zero_list:      # atomic accumulation targets (SE pooled sums, ...) start every pass at zero
+      t.zero_()
     if training:
-      for t in self._zero_list:
-        t.zero_()
       self.grads_flat.zero_()
 
   def forward(self, images, training=False, update_moving=True):

@@ -136,6 +136,16 @@ int edet_pw_bwd_data(const edet_gview_t* dy, const void* w, int ldw,
 int edet_pw_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy, float* dweight,
                        void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
+/* ---- dense k x k convolution, k in {1,3,5}, stride in {1,2}, TF 'SAME', no bias ----
+ * Fused-MBConv call sites: efficientnetv2/effnetv2_model.py:338-346 (k x k expand conv) and
+ * :362-371 (the single k x k conv of an expand_ratio == 1 block).  wt is the compute copy
+ * [cout][ldw] with the reduction index (ky*k + kx)*cin + c contiguous (edet_cast_matrix of the
+ * HWIO kernel viewed as [k*k*cin][cout], transposed; ldw >= k*k*cin).  Writes the raw conv output
+ * and BatchNorm statistic partials like edet_pw_fwd.  */
+int edet_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, int k, int stride,
+                  void* out, int cout, int ldo, float* stat_partials, int* nparts_out,
+                  int dtype, void* stream);
+
 /* ---- depthwise convolution k in {3,5}, stride in {1,2}, TF 'SAME' ----------
  * DepthwiseConv2D call sites: efficientnet_model.py:320-327 and the depthwise
  * half of SeparableConv2D.  weight fp32 [k,k,c] (HWIO with multiplier 1).  */

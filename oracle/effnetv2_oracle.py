@@ -1,0 +1,128 @@
+"""CPU oracle of the EfficientNetV2 forward path -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Only tests/ and bench.py's cpu_baseline leg may import this module.  Plain fp32 PyTorch-CPU restatement
+of ``efficientnetv2/effnetv2_model.py`` (paths relative to the reference root): Stem :409-432,
+MBConvBlock.call :279-310, FusedMBConvBlock.call :373-406, SE.call :135-147, Head.call :472-497,
+EffNetV2Model.call :595-658; activation ``silu`` = x*sigmoid(x) (efficientnetv2/utils.py:27-31);
+BatchNorm momentum 0.9, epsilon 1e-3 (efficientnetv2/hparams.py:228-229).
+
+PARITY STATUS: as for oracle/efficientdet_oracle.py -- the arithmetic lives in TensorFlow, which cannot
+be installed here; this restatement is pinned by the reference's RNG-free known answers for the path
+(the 15 parameter counts of effnetv2_model_test.py:24-52, checked in tests/test_effnetv2.py), by the
+direct-loop twin for the dense convolution (oracle/direct_loops.py) and by the TF 'SAME' padding rule
+shared with the EfficientDet oracle.  Conv-output parity versus the TensorFlow binary is UNPINNED.
+"""
+import torch
+
+from automl_amd import effnetv2_configs
+from oracle import efficientdet_oracle as det
+
+conv2d_same, depthwise_same, swish = det.conv2d_same, det.depthwise_same, det.swish
+
+
+class V2Oracle(object):
+  """forward(images NHWC fp32, training) -> dict of endpoints (NHWC) incl. 'head' (logits or pooled)."""
+
+  def __init__(self, model_name='efficientnetv2-s', model_config=None, include_top=True, params=None, seed=0):
+    self.mconfig = effnetv2_configs.model_config(model_name, model_config)
+    self.include_top = include_top
+    self.store = det.ParamStore(params, seed)
+    self.new_moving = {}
+
+  def bn(self, x, name, training):
+    c = x.shape[1]
+    g = self.store.get(name + '/gamma', (c,), det.ones)
+    b = self.store.get(name + '/beta', (c,), det.zeros)
+    mm = self.store.get(name + '/moving_mean', (c,), det.zeros, trainable=False)
+    mv = self.store.get(name + '/moving_variance', (c,), det.ones, trainable=False)
+    eps, mom = self.mconfig.bn_epsilon, self.mconfig.bn_momentum
+    if training:
+      mean = x.mean(dim=(0, 2, 3))
+      var = x.var(dim=(0, 2, 3), unbiased=False)
+      n = x.numel() // c
+      with torch.no_grad():
+        unbiased = var * (n / (n - 1.0)) if n > 1 else var
+        self.new_moving[name + '/moving_mean'] = mm * mom + mean * (1 - mom)
+        self.new_moving[name + '/moving_variance'] = mv * mom + unbiased * (1 - mom)
+    else:
+      mean, var = mm, mv
+    inv = torch.rsqrt(var + eps) * g
+    return x * inv.view(1, -1, 1, 1) + (b - mean * inv).view(1, -1, 1, 1)
+
+  def se(self, x, scope, c, se_filters):
+    P = self.store
+    w1 = P.get(scope + '/se/conv2d/kernel', (1, 1, c, se_filters), det.conv_kernel_init)
+    b1 = P.get(scope + '/se/conv2d/bias', (se_filters,), det.zeros)
+    w2 = P.get(scope + '/se/conv2d_1/kernel', (1, 1, se_filters, c), det.conv_kernel_init)
+    b2 = P.get(scope + '/se/conv2d_1/bias', (c,), det.zeros)
+    s = x.mean(dim=(2, 3), keepdim=True)
+    s = conv2d_same(swish(conv2d_same(s, w1, 1, b1)), w2, 1, b2)
+    return torch.sigmoid(s) * x
+
+  def mbconv(self, inputs, b, scope, training):
+    P = self.store
+    x = inputs
+    cexp = b.input_filters * b.expand_ratio
+    bn = ['tpu_batch_normalization', 'tpu_batch_normalization_1', 'tpu_batch_normalization_2']
+    bi = ci = 0
+    if b.expand_ratio != 1:
+      w = P.get(scope + '/conv2d/kernel', (1, 1, b.input_filters, cexp), det.conv_kernel_init)
+      x = swish(self.bn(conv2d_same(x, w), '%s/%s' % (scope, bn[bi]), training))
+      ci, bi = 1, 1
+    wd = P.get(scope + '/depthwise_conv2d/depthwise_kernel', (b.kernel_size, b.kernel_size, cexp, 1),
+               det.conv_kernel_init)
+    x = swish(self.bn(depthwise_same(x, wd, b.stride), '%s/%s' % (scope, bn[bi]), training))
+    bi += 1
+    if b.se_filters:
+      x = self.se(x, scope, cexp, b.se_filters)
+    wp = P.get('%s/%s/kernel' % (scope, 'conv2d_1' if ci else 'conv2d'), (1, 1, cexp, b.output_filters),
+               det.conv_kernel_init)
+    x = self.bn(conv2d_same(x, wp), '%s/%s' % (scope, bn[bi]), training)
+    return x + inputs if b.has_residual else x
+
+  def fused_mbconv(self, inputs, b, scope, training):
+    P = self.store
+    x = inputs
+    cexp = b.input_filters * b.expand_ratio
+    k = b.kernel_size
+    if b.expand_ratio != 1:
+      w = P.get(scope + '/conv2d/kernel', (k, k, b.input_filters, cexp), det.conv_kernel_init)
+      x = swish(self.bn(conv2d_same(x, w, b.stride), scope + '/tpu_batch_normalization', training))
+      if b.se_filters:
+        x = self.se(x, scope, cexp, b.se_filters)
+      wp = P.get(scope + '/conv2d_1/kernel', (1, 1, cexp, b.output_filters), det.conv_kernel_init)
+      x = self.bn(conv2d_same(x, wp), scope + '/tpu_batch_normalization_1', training)
+    else:
+      w = P.get(scope + '/conv2d/kernel', (k, k, cexp, b.output_filters), det.conv_kernel_init)
+      x = swish(self.bn(conv2d_same(x, w, b.stride), scope + '/tpu_batch_normalization', training))
+    return x + inputs if b.has_residual else x
+
+  def forward(self, images_nhwc, training=False):
+    m = self.mconfig
+    name = m.model_name
+    P = self.store
+    stem, blocks = effnetv2_configs.expand_blocks(m)
+    x = images_nhwc.permute(0, 3, 1, 2)
+    w = P.get(name + '/stem/conv2d/kernel', (3, 3, 3, stem), det.conv_kernel_init)
+    x = swish(self.bn(conv2d_same(x, w, 2), name + '/stem/tpu_batch_normalization', training))
+    ends = {}
+    ridx = 0
+    for i, b in enumerate(blocks):
+      scope = '%s/blocks_%d' % (name, b.index)
+      x = (self.mbconv if b.conv_type == 0 else self.fused_mbconv)(x, b, scope, training)
+      if i == len(blocks) - 1 or blocks[i + 1].stride > 1:
+        ridx += 1
+        ends['reduction_%d' % ridx] = x.permute(0, 2, 3, 1)
+    ends['features'] = x.permute(0, 2, 3, 1)
+    hf = effnetv2_configs.round_filters(m.feature_size or 1280, m)
+    wh = P.get(name + '/head/conv2d/kernel', (1, 1, blocks[-1].output_filters, hf), det.conv_kernel_init)
+    x = swish(self.bn(conv2d_same(x, wh), name + '/head/tpu_batch_normalization', training))
+    pooled = x.mean(dim=(2, 3))
+    ends['pooled_features'] = pooled
+    out = pooled
+    if self.include_top and m.num_classes:
+      wf = P.get(name + '/head/dense/kernel', (hf, m.num_classes), det.zeros)
+      bf = P.get(name + '/head/dense/bias', (m.num_classes,), det.zeros)
+      out = pooled @ wf + bf
+    ends['head'] = out
+    return ends

@@ -1,0 +1,213 @@
+"""EfficientNetV2 path: host tables against the reference's
+known answers (CPU), the dense-convolution kernel and the whole forward model against the oracle (-m gpu).
+
+Known answers: the 15 parameter counts of efficientnetv2/effnetv2_model_test.py:24-52 (Keras
+count_params(): all weights including BatchNorm moving statistics) and the model-name checks of
+efficientnetv2/effnetv2_configs_test.py:22-28.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from automl_amd import effnetv2_configs, effnetv2_model
+from automl_amd._lib import ACT_NONE, ACT_SWISH, call, ptr
+from oracle import effnetv2_oracle as v2orc
+from oracle import efficientdet_oracle as orc
+from tests import gpu_util as gu
+
+PARAM_KATS = [('efficientnet-b0', 5330564), ('efficientnet-b1', 7856232), ('efficientnet-b2', 9177562),
+              ('efficientnet-b3', 12314268), ('efficientnet-b4', 19466816), ('efficientnet-b5', 30562520),
+              ('efficientnet-b6', 43265136), ('efficientnetv2-b0', 7200312), ('efficientnetv2-b1', 8212124),
+              ('efficientnetv2-b2', 10178374), ('efficientnetv2-b3', 14467622), ('efficientnetv2-s', 21612360),
+              ('efficientnetv2-m', 54431388), ('efficientnetv2-l', 119027848), ('efficientnetv2-xl', 208896832)]
+
+
+@pytest.mark.parametrize('model_name,expected', PARAM_KATS)
+def test_param_counts_match_reference(model_name, expected):
+  spec = effnetv2_model.V2Spec(effnetv2_configs.model_config(model_name))
+  assert spec.count_params() == expected
+
+
+def test_model_config_names():
+  assert effnetv2_configs.get_model_config('efficientnet-b0').model.model_name == 'efficientnet-b0'
+  assert effnetv2_configs.get_model_config('efficientnetv2-s').model.model_name == 'efficientnetv2-s'
+  with pytest.raises(ValueError):
+    effnetv2_configs.get_model_config('resnet50')
+
+
+def test_v2s_stage_table():
+  """40 blocks, stem 24, fused stages r2/r4/r4, MBConv+SE r6/r9/r15."""
+  m = effnetv2_configs.model_config('efficientnetv2-s')
+  assert (m.bn_momentum, m.bn_epsilon, m.act_fn, m.survival_prob, m.feature_size) == (0.9, 1e-3, 'silu', 0.8, 1280)
+  stem, blocks = effnetv2_configs.expand_blocks(m)
+  assert stem == 24 and len(blocks) == 40
+  assert [b.conv_type for b in blocks] == [1] * 10 + [0] * 30
+  assert [(b.input_filters, b.output_filters, b.stride, b.expand_ratio) for b in blocks[:3]] == \
+      [(24, 24, 1, 1), (24, 24, 1, 1), (24, 48, 2, 4)]
+  assert blocks[10].se_filters == 16 and blocks[16].se_filters == 32 and blocks[25].se_filters == 40
+  assert all(b.se_filters is None for b in blocks[:10])
+  assert [b.has_residual for b in blocks[:4]] == [True, True, False, True]
+  spec = effnetv2_model.V2Spec(m)
+  assert spec.reduction_indices() == [1, 5, 9, 24, 39]
+
+
+def test_block_decoder_roundtrip():
+  dec = effnetv2_configs.BlockDecoder()
+  blocks = dec.decode(effnetv2_configs.v2_s_block)
+  assert blocks[0].conv_type == 1 and blocks[0].se_ratio is None and blocks[3].se_ratio == 0.25
+  again = dec.decode(dec.encode(blocks))
+  assert [b.as_dict() for b in again] == [b.as_dict() for b in blocks]
+
+
+def test_round_filters_v2_has_no_ten_percent_floor():
+  m = effnetv2_configs.model_config('efficientnetv2-b2')    # width 1.1
+  assert effnetv2_configs.round_filters(32, m) == 32        # 35.2 -> 32 (V1 code base would bump to 40)
+  assert effnetv2_configs.round_filters(16, m) == 16
+  assert effnetv2_configs.round_repeats(3, 1.2) == 4
+
+
+def test_oracle_shapes_cpu():
+  o = v2orc.V2Oracle('efficientnetv2-b0', model_config='num_classes=10')
+  with torch.no_grad():
+    ends = o.forward(torch.zeros(1, 64, 64, 3), training=False)
+  assert tuple(ends['head'].shape) == (1, 10)
+  assert [tuple(ends['reduction_%d' % i].shape[1:3]) for i in range(1, 6)] == [(32, 32), (16, 16), (8, 8), (4, 4), (2, 2)]
+  assert sum(int(np.prod(v.shape)) for v in o.store.values.values()) == \
+      effnetv2_model.V2Spec(effnetv2_configs.model_config('efficientnetv2-b0', 'num_classes=10')).count_params()
+
+
+# ------------------------------------------------------------------------------------------- GPU
+def _apply_view(x, scale, shift, act):
+  z = x if scale is None else x * scale + shift
+  return orc.swish(z) if act == ACT_SWISH else z
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
+@pytest.mark.parametrize('shape', [(2, 9, 7, 24, 24), (1, 16, 16, 24, 96), (2, 14, 14, 48, 192), (3, 7, 9, 64, 256),
+                                   (1, 5, 5, 8, 8), (2, 12, 13, 32, 136), (1, 1, 1, 16, 24)])
+@pytest.mark.parametrize('ks', [(3, 1), (3, 2), (5, 1), (1, 1)])
+@pytest.mark.parametrize('mode', ['plain', 'bn_swish'])
+def test_conv_fwd(dt, shape, ks, mode):
+  name, edt, tdt = dt
+  n, h, w, cin, cout = shape
+  k, s = ks
+  rng = np.random.default_rng(gu.seed_of((shape, ks, mode)))
+  x = gu.rnd(rng, (n, h, w, cin), tdt)
+  wk = gu.rnd(rng, (k, k, cin, cout), tdt, 1.0 / np.sqrt(k * k * cin))
+  scale = shift = None
+  act = ACT_NONE
+  if mode != 'plain':
+    scale = torch.from_numpy((1 + 0.3 * rng.standard_normal(cin)).astype(np.float32))
+    shift = torch.from_numpy((0.3 * rng.standard_normal(cin)).astype(np.float32))
+    act = ACT_SWISH
+  a = _apply_view(x, scale, shift, act)
+  if name == 'bf16':
+    a = a.to(torch.bfloat16).float()
+  want = orc.conv2d_same(a.permute(0, 3, 1, 2), wk, s).permute(0, 2, 3, 1).contiguous()
+  oh, ow = want.shape[1], want.shape[2]
+
+  xd = gu.to_dev(x, tdt)
+  kk = k * k * cin
+  wt = torch.zeros(cout, kk, dtype=tdt, device=gu.DEV)
+  call('edet_cast_matrix', ptr(gu.fdev(wk.reshape(kk, cout))), ptr(wt), kk, cout, kk, 1, edt, gu.stream())
+  ldo = gu.pad8(cout)
+  out = torch.full((n, oh, ow, ldo), float('nan'), dtype=tdt, device=gu.DEV)
+  parts = torch.zeros(1024 * 2 * cout, dtype=torch.float32, device=gu.DEV)
+  npart = ctypes.c_int(0)
+  tv = gu.tview(xd, cin, scale, shift, None, act)
+  call('edet_conv_fwd', ctypes.byref(tv), ptr(wt), kk, k, s, ptr(out), cout, ldo, ptr(parts),
+       ctypes.byref(npart), edt, gu.stream())
+  torch.cuda.synchronize()
+  gu.check(out[..., :cout], want, name, 'conv_fwd out %s %s %s' % (shape, ks, mode))
+  s1, s2 = gu.sum_partials(parts, npart.value, cout)
+  rows = n * oh * ow
+  gu.check(s1, want.sum((0, 1, 2)), name, 'conv_fwd sum', rtol=3e-2 if name == 'bf16' else 1e-3,
+           atol=1e-2 * rows if name == 'bf16' else 1e-4 * rows, scale_by_max=False)
+  gu.check(s2, (want * want).sum((0, 1, 2)), name, 'conv_fwd sumsq', rtol=3e-2 if name == 'bf16' else 1e-3)
+
+
+def _perturbed(spec, seed):
+  vals = effnetv2_model.init_params(spec, seed)
+  rng = np.random.default_rng(seed + 1)
+  for p in spec.params:
+    v = vals[p.name]
+    if p.name.endswith('/gamma'):
+      v += 0.2 * rng.standard_normal(v.shape).astype(np.float32)
+    elif p.name.endswith('/beta') or p.name.endswith('/moving_mean'):
+      v += 0.2 * rng.standard_normal(v.shape).astype(np.float32)
+    elif p.name.endswith('/moving_variance'):
+      v *= rng.uniform(0.5, 1.5, v.shape).astype(np.float32)
+    elif p.name.endswith('/bias'):
+      v += 0.1 * rng.standard_normal(v.shape).astype(np.float32)
+    vals[p.name] = v
+  return vals
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('model_name,size', [('efficientnetv2-s', 128), ('efficientnetv2-b0', 128),
+                                             ('efficientnet-b0', 96)])
+@pytest.mark.parametrize('dtype,tol', [('f32', 1e-3), ('bf16', 2e-1)])
+@pytest.mark.parametrize('training', [False, True])
+def test_model_forward_matches_oracle(model_name, size, dtype, tol, training):
+  """Logits, pooled features and every reduction endpoint vs the oracle; fp32 storage within 1e-3 of the
+  tensor's max (north_star tolerance).  bf16 storage: relative L2 error within 2e-1 (measured 0.10-0.15
+  at reduction_5, <= 0.1 for the logits) -- every stored tensor is
+  rounded to 2^-8, and on random (untrained) weights the SE-gated residual stages amplify a perturbation by
+  ~1.2x per block (measured: 0.7 % after stage 1, 1.5 % after stage 3, 6 % after stage 4), so a max-norm
+  bound over 40-57 blocks would only measure the conditioning of the random network."""
+  over = 'num_classes=40,survival_prob=0,dropout_rate=0'
+  batch = 4
+  spec = effnetv2_model.V2Spec(effnetv2_configs.model_config(model_name, over))
+  vals = _perturbed(spec, 5)
+  rng = np.random.default_rng(11)
+  images = rng.standard_normal((batch, size, size, 3)).astype(np.float32)
+  if dtype == 'bf16':
+    images = torch.from_numpy(images).to(torch.bfloat16).float().numpy()
+  if not training:
+    # inference statistics that match the data (as after training): with arbitrary moving statistics a
+    # 40-block network is not normalised, activations grow by orders of magnitude and the comparison
+    # becomes ill-conditioned.  bn_momentum=0 makes the oracle's updated moving statistics the batch ones.
+    warm = v2orc.V2Oracle(model_name, over + ',bn_momentum=0.0',
+                          params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
+    with torch.no_grad():
+      warm.forward(torch.from_numpy(images), True)
+    for k, v in warm.new_moving.items():
+      vals[k] = v.numpy().copy()
+  else:
+    pass
+  oracle = v2orc.V2Oracle(model_name, over, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
+  with torch.no_grad():
+    want = oracle.forward(torch.from_numpy(images), training)
+  net = effnetv2_model.EffNetV2Model(model_name, over, dtype=dtype, params=vals)
+  outs = net(torch.from_numpy(images), training=training, with_endpoints=True)
+  torch.cuda.synchronize()
+  outs = [o.float().cpu() for o in outs]
+  assert len(outs) == 6
+  names = ['head'] + ['reduction_%d' % i for i in range(1, 6)]
+  errs = {}
+  for nm, got in list(zip(names, outs)) + [('pooled_features', net.endpoints['pooled_features'])]:
+    ref = want[nm]
+    d = got.float().cpu() - ref
+    if dtype == 'f32':
+      errs[nm] = float(d.abs().max()) / max(float(ref.abs().max()), 1e-20)       # max-norm, north_star 1e-3
+    else:
+      errs[nm] = float(d.norm()) / max(float(ref.norm()), 1e-20)                 # relative L2 (see docstring)
+  assert all(e <= tol for e in errs.values()), '%s %s: relative errors vs the oracle %s (tol %.1e)' % (
+      model_name, dtype, {k: '%.2e' % v for k, v in errs.items()}, tol)
+  # a second call must give the same answer (accumulation buffers are re-zeroed)
+  again = net(torch.from_numpy(images), training=training)
+  torch.cuda.synchronize()
+  # (atomic fp32 pooling sums may round differently from run to run; in bf16 storage a flipped rounding
+  # propagates, so the bound is the storage tolerance, not bit equality)
+  first = outs[0].float().cpu()
+  assert float((again.float().cpu() - first).abs().max()) <= tol * float(first.abs().max()) + 1e-6
+
+
+@pytest.mark.gpu
+def test_training_with_stochastic_depth_is_refused():
+  net = effnetv2_model.EffNetV2Model('efficientnetv2-b0')
+  with pytest.raises(ValueError):
+    net(torch.zeros(1, 32, 32, 3), training=True)
