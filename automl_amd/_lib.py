@@ -77,9 +77,9 @@ SIGNATURES = {
     'edet_fuse_weights_bwd': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p],
     'edet_focal_loss': [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float,
-                        c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+                        c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     'edet_box_loss': [c_void_p, c_int, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_void_p,
-                      c_void_p, c_void_p, c_int, c_void_p],
+                      c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     'edet_opt_l2_norms': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
                           c_void_p],
     'edet_opt_clip_factors': [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p],

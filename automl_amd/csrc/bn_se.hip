@@ -243,9 +243,26 @@ __global__ __launch_bounds__(THREADS) void k_se_fc(const float* __restrict__ poo
   const int n = blockIdx.x, tid = threadIdx.x;
   for (int i = tid; i < c; i += THREADS) p[i] = pooled[(size_t)n * c + i] * inv_hw;
   __syncthreads();
+  for (int j = tid; j < se; j += THREADS) h[j] = 0.f;
+  __syncthreads();
+  // thread (j, part): hidden unit j over the channels i = part, part + nparts, ... (w1 loads coalesced along j)
+  if (se <= THREADS) {
+    const int nparts = THREADS / se, j = tid % se, part = tid / se;
+    if (part < nparts) {
+      float acc = 0.f;
+      for (int i = part; i < c; i += nparts) acc = fmaf(p[i], w1[(size_t)i * se + j], acc);
+      atomicAdd(&h[j], acc);
+    }
+  } else {
+    for (int j = tid; j < se; j += THREADS) {
+      float acc = 0.f;
+      for (int i = 0; i < c; ++i) acc = fmaf(p[i], w1[(size_t)i * se + j], acc);
+      h[j] = acc;
+    }
+  }
+  __syncthreads();
   for (int j = tid; j < se; j += THREADS) {
-    float acc = b1[j];
-    for (int i = 0; i < c; ++i) acc = fmaf(p[i], w1[(size_t)i * se + j], acc);
+    const float acc = h[j] + b1[j];
     hidden_pre[(size_t)n * se + j] = acc;
     h[j] = swishf_(acc);
   }
@@ -301,33 +318,40 @@ __global__ __launch_bounds__(THREADS) void k_se_fc_bwd_img(const float* __restri
   }
 }
 
-// parameter gradients.  Workgroup = 64 channels i x 4 hidden-unit groups; thread (i, jg) owns the
-// (i, j) pairs with j % 4 == jg and sums over the images (loads coalesced along i).
+// parameter gradients.  Workgroup = 64 channels i x 4 hidden-unit groups, for one slice of the images
+// (blockIdx.y) and one block of SE_JB hidden units (blockIdx.z); thread (i, jg) owns the (i, j) pairs with
+// j % 4 == jg and sums over its images (loads coalesced along i); the image slices are combined with fp32
+// atomics (<= SE_SPLIT per address).
 //   dw1[i][j] += sum_n pooled[n][i]*inv_hw * dpre1[n][j];  dw2[j][i] += sum_n hact[n][j] * dpre2[n][i]
-constexpr int SE_MAX_JPT = 12;  // hidden units per thread: se <= 48
-constexpr int SE_NB = 64;       // images per LDS chunk
+constexpr int SE_MAX_JPT = 12;           // hidden units per thread
+constexpr int SE_JB = 4 * SE_MAX_JPT;    // hidden units per workgroup (48)
+constexpr int SE_NB = 64;                // images per LDS chunk
+constexpr int SE_SPLIT = 8;              // image slices
 __global__ __launch_bounds__(THREADS) void k_se_fc_bwd_par(const float* __restrict__ pooled,
                                                           const float* __restrict__ scratch, int nimg, int c,
                                                           int se, float inv_hw, float* dw1, float* db1,
-                                                          float* dw2, float* db2) {
-  extern __shared__ float sm[];  // dpre1 [NB][se], hact [NB][se] for the current chunk of images
+                                                          float* dw2, float* db2, int per_split) {
+  extern __shared__ float sm[];  // dpre1 [NB][jb], hact [NB][jb] for the current chunk of images
   const float* dpre2 = scratch;
   const float* dpre1_g = scratch + (size_t)nimg * c;
   const float* hact_g = scratch + (size_t)nimg * (c + se);
+  const int j0 = blockIdx.z * SE_JB, jb = min(SE_JB, se - j0);
   float* d1 = sm;
-  float* ha = sm + (size_t)SE_NB * se;
+  float* ha = sm + (size_t)SE_NB * SE_JB;
   const int tid = threadIdx.x;
   const int i = blockIdx.x * 64 + (tid & 63), jg = tid >> 6;
+  const int nbeg = blockIdx.y * per_split, nend = min(nimg, nbeg + per_split);
   float a1[SE_MAX_JPT], a2[SE_MAX_JPT];
 #pragma unroll
   for (int t = 0; t < SE_MAX_JPT; ++t) a1[t] = a2[t] = 0.f;
   float sb2 = 0.f, sb1 = 0.f;
-  for (int n0 = 0; n0 < nimg; n0 += SE_NB) {
-    const int nb = min(SE_NB, nimg - n0);
+  for (int n0 = nbeg; n0 < nend; n0 += SE_NB) {
+    const int nb = min(SE_NB, nend - n0);
     __syncthreads();
-    for (int q = tid; q < nb * se; q += THREADS) {
-      d1[q] = dpre1_g[(size_t)n0 * se + q];
-      ha[q] = hact_g[(size_t)n0 * se + q];
+    for (int q = tid; q < nb * jb; q += THREADS) {
+      const int n = q / jb, j = q - n * jb;
+      d1[q] = dpre1_g[(size_t)(n0 + n) * se + j0 + j];
+      ha[q] = hact_g[(size_t)(n0 + n) * se + j0 + j];
     }
     __syncthreads();
     if (i < c) {
@@ -338,25 +362,25 @@ __global__ __launch_bounds__(THREADS) void k_se_fc_bwd_par(const float* __restri
 #pragma unroll
         for (int t = 0; t < SE_MAX_JPT; ++t) {
           const int j = jg + 4 * t;
-          if (j < se) {
-            a1[t] = fmaf(pl, d1[n * se + j], a1[t]);
-            a2[t] = fmaf(ha[n * se + j], d2, a2[t]);
+          if (j < jb) {
+            a1[t] = fmaf(pl, d1[n * jb + j], a1[t]);
+            a2[t] = fmaf(ha[n * jb + j], d2, a2[t]);
           }
         }
       }
     }
-    if (blockIdx.x == 0 && tid < se)
-      for (int n = 0; n < nb; ++n) sb1 += d1[n * se + tid];
+    if (blockIdx.x == 0 && tid < jb)
+      for (int n = 0; n < nb; ++n) sb1 += d1[n * jb + tid];
   }
-  if (blockIdx.x == 0 && tid < se) db1[tid] += sb1;
+  if (blockIdx.x == 0 && tid < jb) atomicAdd(&db1[j0 + tid], sb1);
   if (i < c) {
-    if (jg == 0) db2[i] += sb2;
+    if (jg == 0 && blockIdx.z == 0) atomicAdd(&db2[i], sb2);
 #pragma unroll
     for (int t = 0; t < SE_MAX_JPT; ++t) {
       const int j = jg + 4 * t;
-      if (j < se) {
-        dw1[(size_t)i * se + j] += a1[t];
-        dw2[(size_t)j * c + i] += a2[t];
+      if (j < jb) {
+        atomicAdd(&dw1[(size_t)i * se + j0 + j], a1[t]);
+        atomicAdd(&dw2[(size_t)(j0 + j) * c + i], a2[t]);
       }
     }
   }
@@ -567,9 +591,12 @@ extern "C" int edet_se_fc_bwd(const float* pooled_sum, const float* hidden_pre, 
                               float* dpool, float* scratch, void* stream) {
   EDET_CHECK(pooled_sum && hidden_pre && gate && dgate && w1 && w2 && dw1 && db1 && dw2 && db2 && dpool && scratch,
              "edet_se_fc_bwd: null pointer");
-  EDET_CHECK(se <= 4 * SE_MAX_JPT, "edet_se_fc_bwd: se %d > %d unsupported", se, 4 * SE_MAX_JPT);
   k_se_fc_bwd_img<<<n, THREADS, (size_t)(c + se) * sizeof(float), to_stream(stream)>>>(hidden_pre, gate, dgate, n, c, se, inv_hw, w1, w2, dpool, scratch);
-  k_se_fc_bwd_par<<<cdiv(c, 64), THREADS, (size_t)2 * SE_NB * se * sizeof(float), to_stream(stream)>>>(pooled_sum, scratch, n, c, se, inv_hw, dw1, db1, dw2, db2);
+  const int nsplit = n >= 2 * SE_SPLIT ? SE_SPLIT : 1;
+  const int per_split = cdiv(n, nsplit);
+  k_se_fc_bwd_par<<<dim3(cdiv(c, 64), cdiv(n, per_split), cdiv(se, SE_JB)), THREADS,
+                    (size_t)2 * SE_NB * SE_JB * sizeof(float), to_stream(stream)>>>(
+      pooled_sum, scratch, n, c, se, inv_hw, dw1, db1, dw2, db2, per_split);
   EDET_LAUNCH_CHECK("edet_se_fc_bwd");
   return 0;
 }

@@ -26,8 +26,10 @@ inline RowMap row_map_ld(int ld) {
 template <typename T, bool G15>
 __global__ __launch_bounds__(THREADS) void k_focal(const T* __restrict__ logits, int ld,
                                                   const int32_t* __restrict__ tgt, int64_t positions,
-                                                  int na, int nc, float alpha, float gamma, float inv_norm,
+                                                  int na, int nc, float alpha, float gamma, float inv_norm_h,
+                                                  const float* __restrict__ norm_scale,
                                                   T* __restrict__ dlogits, float* dbias, float* sums, RowMap m) {
+  const float inv_norm = norm_scale ? inv_norm_h * norm_scale[0] : inv_norm_h;
   const int tid = threadIdx.x;
   const int cv = tid % m.tpr, rr = tid / m.tpr;
   const int j0 = cv * 8;
@@ -91,8 +93,10 @@ __global__ __launch_bounds__(THREADS) void k_focal(const T* __restrict__ logits,
 template <typename T>
 __global__ __launch_bounds__(THREADS) void k_box(const T* __restrict__ out, int ld,
                                                 const float* __restrict__ tgt, int64_t positions, int nch,
-                                                float delta, float inv_norm, float grad_scale,
+                                                float delta, float inv_norm_h, float grad_scale,
+                                                const float* __restrict__ norm_scale,
                                                 T* __restrict__ dbox, float* dbias, float* sums, RowMap m) {
+  const float inv_norm = norm_scale ? inv_norm_h * norm_scale[0] : inv_norm_h;
   const int tid = threadIdx.x;
   const int cv = tid % m.tpr, rr = tid / m.tpr;
   const int j0 = cv * 8;
@@ -306,6 +310,7 @@ __global__ __launch_bounds__(THREADS) void k_sgd_ema(float* params, float* grads
 extern "C" int edet_focal_loss(const void* logits, int ld, const int32_t* cls_targets,
                                int64_t positions, int num_anchors, int num_classes,
                                float alpha, float gamma, float inv_normalizer,
+                               const float* norm_scale_dev,
                                void* dlogits, float* dbias, float* sums, int dtype, void* stream) {
   EDET_CHECK(logits && cls_targets && dlogits && sums, "edet_focal_loss: null pointer");
   EDET_CHECK(ld % 8 == 0 && ld >= num_anchors * num_classes && ld <= 2048, "edet_focal_loss: bad ld %d", ld);
@@ -319,7 +324,7 @@ extern "C" int edet_focal_loss(const void* logits, int ld, const int32_t* cls_ta
   const bool g15 = gamma == 1.5f;
 #define FOCAL_LAUNCH(T, G)                                                                            \
   k_focal<T, G><<<(int)g, THREADS, lds, to_stream(stream)>>>((const T*)logits, ld, cls_targets, positions, \
-      num_anchors, num_classes, alpha, gamma, inv_normalizer, (T*)dlogits, dbias, sums, m)
+      num_anchors, num_classes, alpha, gamma, inv_normalizer, norm_scale_dev, (T*)dlogits, dbias, sums, m)
   if (dtype == EDET_BF16) { if (g15) FOCAL_LAUNCH(bf16_t, true); else FOCAL_LAUNCH(bf16_t, false); }
   else if (dtype == EDET_F32) { if (g15) FOCAL_LAUNCH(float, true); else FOCAL_LAUNCH(float, false); }
 #undef FOCAL_LAUNCH
@@ -330,8 +335,8 @@ extern "C" int edet_focal_loss(const void* logits, int ld, const int32_t* cls_ta
 
 extern "C" int edet_box_loss(const void* box_out, int ld, const float* box_targets,
                              int64_t positions, int nch, float delta, float inv_normalizer,
-                             float grad_scale, void* dbox, float* dbias, float* sums,
-                             int dtype, void* stream) {
+                             float grad_scale, const float* norm_scale_dev, void* dbox, float* dbias,
+                             float* sums, int dtype, void* stream) {
   EDET_CHECK(box_out && box_targets && dbox && sums, "edet_box_loss: null pointer");
   EDET_CHECK(ld % 8 == 0 && ld >= nch && ld <= 2048, "edet_box_loss: bad ld %d", ld);
   const RowMap m = row_map_ld(ld);
@@ -341,9 +346,9 @@ extern "C" int edet_box_loss(const void* box_out, int ld, const float* box_targe
   if (g < 1) g = 1;
   const size_t lds = (size_t)ld * sizeof(float);
   if (dtype == EDET_BF16)
-    k_box<bf16_t><<<(int)g, THREADS, lds, to_stream(stream)>>>((const bf16_t*)box_out, ld, box_targets, positions, nch, delta, inv_normalizer, grad_scale, (bf16_t*)dbox, dbias, sums, m);
+    k_box<bf16_t><<<(int)g, THREADS, lds, to_stream(stream)>>>((const bf16_t*)box_out, ld, box_targets, positions, nch, delta, inv_normalizer, grad_scale, norm_scale_dev, (bf16_t*)dbox, dbias, sums, m);
   else if (dtype == EDET_F32)
-    k_box<float><<<(int)g, THREADS, lds, to_stream(stream)>>>((const float*)box_out, ld, box_targets, positions, nch, delta, inv_normalizer, grad_scale, (float*)dbox, dbias, sums, m);
+    k_box<float><<<(int)g, THREADS, lds, to_stream(stream)>>>((const float*)box_out, ld, box_targets, positions, nch, delta, inv_normalizer, grad_scale, norm_scale_dev, (float*)dbox, dbias, sums, m);
   else EDET_CHECK(false, "edet_box_loss: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_box_loss");
   return 0;

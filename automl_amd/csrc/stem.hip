@@ -249,20 +249,29 @@ __global__ __launch_bounds__(THREADS) void k_stem_fwd(const StemArgs a) {
   }
 }
 
-// dW[tap][co] = sum_pixels x[pixel, tap] * dy[pixel, co]; tap = (ky*3+kx)*3+ci
+// dW[tap][co] = sum_pixels x[pixel, tap] * dy[pixel, co]; tap = (ky*3+kx)*3+ci.
+// Thread = (pixel slice s, window position ky*3+kx, channel quad q): per pixel it reads the 3 input channels
+// of its window position (LDS broadcast across the quads) and one float4 of dy, and does 12 FMAs into
+// register accumulators -- 1/3 LDS instruction per FMA (the tap-major version needed 5/4).  The slices are
+// combined through LDS, so a workgroup issues one atomic per weight.
 template <typename T, int CV>
 __global__ __launch_bounds__(THREADS) void k_stem_bwd_weight(const StemArgs a) {
   constexpr int CO = CV * 8;
-  constexpr int TG = THREADS / CO;            // tap groups
-  constexpr int TPT = (27 + TG - 1) / TG;     // taps per thread
+  constexpr int NQ = CO / 4;                  // channel quads
+  constexpr int S = THREADS / (9 * NQ);       // pixel slices
+  static_assert(S >= 1, "cout too large for one workgroup");
+  constexpr int HP = TH * TW / 2;             // pixels per half tile
   __shared__ __align__(16) float tile[IH * IW * 3];
-  __shared__ __align__(16) float dyt[TH * TW / 2 * CO];
+  __shared__ __align__(16) float dyt[HP * CO];
   const int tid = threadIdx.x;
-  const int co = tid % CO, tg = tid / CO;
-  float acc[TPT];
+  const int q = tid % NQ, kk = (tid / NQ) % 9, sl = tid / (9 * NQ);
+  const int ky = kk / 3, kx = kk - ky * 3;
+  const bool active = sl < S;
+  float acc[3][4];
 #pragma unroll
-  for (int t = 0; t < TPT; ++t) acc[t] = 0.f;
-  const bool active = tg < TG;
+  for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[ci][e] = 0.f;
 
   for (int sp = blockIdx.x; sp < a.nsp; sp += a.P) {
     const int per_img = a.tiles_y * a.tiles_x;
@@ -271,10 +280,9 @@ __global__ __launch_bounds__(THREADS) void k_stem_bwd_weight(const StemArgs a) {
     __syncthreads();
     stage_image_tile<T>(a, n, oy0 * 2 - a.pad_t, ox0 * 2 - a.pad_l, tile);
     for (int half = 0; half < 2; ++half) {
-      constexpr int HP = TH * TW / 2;  // pixels per half tile
       if (half) __syncthreads();
-      for (int q = tid; q < HP * CV; q += THREADS) {
-        const int v = q % CV, lp = q / CV, pix = half * HP + lp;
+      for (int i = tid; i < HP * CV; i += THREADS) {
+        const int v = i % CV, lp = i / CV, pix = half * HP + lp;
         const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
         float g[8];
         if (oy < a.oh && ox < a.ow) {
@@ -289,29 +297,37 @@ __global__ __launch_bounds__(THREADS) void k_stem_bwd_weight(const StemArgs a) {
       }
       __syncthreads();
       if (active) {
-        for (int lp = 0; lp < HP; ++lp) {
-          const float g = dyt[lp * CO + co];
+#pragma unroll 4
+        for (int lp = sl; lp < HP; lp += S) {
+          const float4 g = *reinterpret_cast<const float4*>(&dyt[lp * CO + q * 4]);
           const int pix = half * HP + lp;
           const int ty = pix / TW, tx = pix % TW;
+          const float* xp = &tile[(ty * 2 + ky) * (IW * 3) + (tx * 2 + kx) * 3];
 #pragma unroll
-          for (int t = 0; t < TPT; ++t) {
-            const int tap = tg * TPT + t;
-            if (tap < 27) {
-              const int ky = tap / 9, kx = (tap / 3) % 3, ci = tap % 3;
-              acc[t] = fmaf(tile[(ty * 2 + ky) * (IW * 3) + (tx * 2 + kx) * 3 + ci], g, acc[t]);
-            }
+          for (int ci = 0; ci < 3; ++ci) {
+            const float x = xp[ci];
+            acc[ci][0] = fmaf(x, g.x, acc[ci][0]);
+            acc[ci][1] = fmaf(x, g.y, acc[ci][1]);
+            acc[ci][2] = fmaf(x, g.z, acc[ci][2]);
+            acc[ci][3] = fmaf(x, g.w, acc[ci][3]);
           }
         }
       }
     }
   }
+  // combine the pixel slices: dyt is free after the last barrier-separated use
+  __syncthreads();
+  float* red = dyt;                           // [27][CO]
+  for (int i = tid; i < 27 * CO; i += THREADS) red[i] = 0.f;
+  __syncthreads();
   if (active) {
 #pragma unroll
-    for (int t = 0; t < TPT; ++t) {
-      const int tap = tg * TPT + t;
-      if (tap < 27) atomicAdd(&a.dweight[tap * CO + co], acc[t]);
-    }
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(&red[(kk * 3 + ci) * CO + q * 4 + e], acc[ci][e]);
   }
+  __syncthreads();
+  for (int i = tid; i < 27 * CO; i += THREADS) atomicAdd(&a.dweight[i], red[i]);
 }
 
 template <typename T>

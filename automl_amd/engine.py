@@ -116,7 +116,7 @@ class Engine(object):
     self.bns = {}
     self._cast_plan = None
     self.loss_sums = self.zbuf('loss_sums', (4,))
-    self.hyper = torch.zeros(2, dtype=torch.float32, device=self.device)
+    self.hyper = torch.zeros(4, dtype=torch.float32, device=self.device)   # lr, ema decay, 1/normalizer, -
     self.gnorm = torch.zeros(1, dtype=torch.float32, device=self.device)
     self.pool_argmax = os.environ.get('EDET_POOL_ARGMAX', '1') != '0'
 
@@ -666,7 +666,12 @@ class Engine(object):
     """
     c = self.config
     assert self.training
-    if 'normalizer' in labels:   # host float supplied by the caller: no device sync
+    norm_dev = None
+    if labels.get('normalizer') == 'device':
+      # 1/normalizer lives in self.hyper[2] (set_normalizer): nothing of the step depends on a host value,
+      # so the launches below can be captured once and replayed for every batch
+      normalizer, norm_dev = 1.0, ptr(self.hyper[2:])
+    elif 'normalizer' in labels:   # host float supplied by the caller: no device sync
       normalizer = float(labels['normalizer'])
     else:
       normalizer = float(labels['mean_num_positives'].sum().item()) + 1.0
@@ -678,12 +683,12 @@ class Engine(object):
       assert ct.dtype == torch.int32 and ct.is_contiguous() and bt.dtype == torch.float32 and bt.is_contiguous()
       r = cv.raw
       call('edet_focal_loss', ptr(r.data), r.ld, ptr(ct), r.rows, na, c.num_classes, c.alpha, c.gamma,
-           1.0 / normalizer, ptr(r.ensure_grad()), ptr(self.grad('class_net/class-predict/bias')),
+           1.0 / normalizer, norm_dev, ptr(r.ensure_grad()), ptr(self.grad('class_net/class-predict/bias')),
            ptr(self.loss_sums), self.dtype, self.stream, nbytes=2 * r.rows * r.c * self.esize)
       r.grad_written = True
       rb = bv.raw
       call('edet_box_loss', ptr(rb.data), rb.ld, ptr(bt), rb.rows, 4 * na, c.delta, 1.0 / (normalizer * 4.0),
-           float(c.box_loss_weight), ptr(rb.ensure_grad()), ptr(self.grad('box_net/box-predict/bias')),
+           float(c.box_loss_weight), norm_dev, ptr(rb.ensure_grad()), ptr(self.grad('box_net/box-predict/bias')),
            ptr(self.loss_sums), self.dtype, self.stream)
       rb.grad_written = True
     self.backward()
@@ -693,8 +698,19 @@ class Engine(object):
       fn()
     self.tape = []
 
-  def optimizer_step(self, lr, ema_decay=None, all_reduce=None):
-    """L2 + clip (local, before the reduce) + [all-reduce SUM] + SGD momentum + EMA."""
+  def set_hyper(self, lr, ema_decay=None):
+    """Per-step scalars -> device (hyper[0] = learning rate, hyper[1] = EMA decay).  Stream-ordered H2D
+    copy from pageable memory (staged synchronously by the runtime, so the host values may change at once);
+    kept OUTSIDE the captured step."""
+    self.hyper[:2].copy_(torch.tensor([lr, ema_decay or 0.0], dtype=torch.float32), non_blocking=True)
+
+  def set_normalizer(self, mean_num_positives):
+    """hyper[2] = 1 / (sum(mean_num_positives) + 1) computed on the device (train_lib.py:517), no host sync."""
+    torch.reciprocal(mean_num_positives.reshape(-1).float().sum() + 1.0, out=self.hyper[2])
+
+  def optimizer_local(self, scale_for_reduce):
+    """L2 (train_lib.py:486-491) + per-tensor and global-norm clip factors of the LOCAL gradient (:675-682);
+    scale_for_reduce applies the factors in place (the data-parallel path all-reduces the clipped gradient)."""
     c = self.config
     st = self.stream
     call('edet_opt_l2_norms', ptr(self.grads_flat), ptr(self.params_flat), ptr(self.seg_offsets),
@@ -703,20 +719,24 @@ class Engine(object):
     clip = abs(c.clip_gradients_norm) if c.clip_gradients_norm else 0.0
     call('edet_opt_clip_factors', ptr(self.seg_sqnorm), self.nseg, float(clip), ptr(self.seg_factor),
          ptr(self.gnorm), st)
-    if ema_decay is None:
-      ema_decay = 0.0
-      ema_ptr = None
-    else:
-      ema_ptr = ptr(self.ema)
-    self.hyper.copy_(torch.tensor([lr, ema_decay], dtype=torch.float32), non_blocking=True)
-    factor = ptr(self.seg_factor)
-    if all_reduce is not None:
+    if scale_for_reduce:
       call('edet_opt_scale', ptr(self.grads_flat), ptr(self.seg_offsets), ptr(self.seg_factor), self.nseg, st)
-      all_reduce(self.grads_flat)
-      factor = None
-    call('edet_opt_sgd_ema', ptr(self.params_flat), ptr(self.grads_flat), ptr(self.velocity), ema_ptr,
-         ptr(self.seg_offsets), factor, self.nseg, ptr(self.hyper), float(c.momentum), st)
+
+  def optimizer_apply(self, use_ema, already_scaled):
+    """SGD momentum + EMA (train_lib.py:176-199) with lr / decay from self.hyper (set_hyper)."""
+    call('edet_opt_sgd_ema', ptr(self.params_flat), ptr(self.grads_flat), ptr(self.velocity),
+         ptr(self.ema) if use_ema else None, ptr(self.seg_offsets),
+         None if already_scaled else ptr(self.seg_factor), self.nseg, ptr(self.hyper),
+         float(self.config.momentum), self.stream)
     self.step_count += 1
+
+  def optimizer_step(self, lr, ema_decay=None, all_reduce=None):
+    """L2 + clip (local, before the reduce) + [all-reduce SUM] + SGD momentum + EMA."""
+    self.set_hyper(lr, ema_decay)
+    self.optimizer_local(all_reduce is not None)
+    if all_reduce is not None:
+      all_reduce(self.grads_flat)
+    self.optimizer_apply(ema_decay is not None, all_reduce is not None)
 
   def loss_values(self):
     s = self.loss_sums.detach().cpu().numpy()

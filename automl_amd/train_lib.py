@@ -119,8 +119,15 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
   """
 
   def __init__(self, *args, steps_per_epoch=1000, global_batch_size=None, process_group=None,
-               use_dist=False, **kwargs):
+               use_dist=False, use_graph=False, **kwargs):
+    """use_graph: capture the whole step (forward, loss, backward, L2/clip, update: ~1600 kernel launches)
+    into a hipGraph at the second call for a given batch shape and replay it afterwards; inputs are
+    copied into static device buffers (input_buffers() exposes them for in-place filling), learning
+    rate / EMA decay / loss normalizer travel through a small device vector.  With data parallelism the
+    gradient all-reduce stays an eager RCCL call between two captured halves."""
     super().__init__(*args, **kwargs)
+    self.use_graph = use_graph
+    self._graph = None
     self.steps_per_epoch = steps_per_epoch
     self.global_batch_size = global_batch_size
     self.process_group = process_group
@@ -150,11 +157,81 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
       out[k] = t.contiguous()
     return out
 
+  # ---- hipGraph replay of the step ---------------------------------------------------------------
+  def input_buffers(self):
+    """(images, labels) static device buffers of the captured step (None before the first graph step):
+    fill them in place and pass them to train_step to skip the staging copy."""
+    g = self._graph
+    return (g['images'], g['labels']) if g else None
+
+  def _graph_step(self, eng, images, labels, lr, decay):
+    g = self._graph
+    if g is None or g['engine'] is not eng:
+      g = self._graph = {'engine': eng, 'steps': 0, 'graphs': None,
+                         'images': torch.empty_like(images),
+                         'labels': {k: torch.empty_like(v) for k, v in labels.items() if torch.is_tensor(v)}}
+    if images.data_ptr() != g['images'].data_ptr():
+      g['images'].copy_(images, non_blocking=True)
+    for k, buf in g['labels'].items():
+      if labels[k].data_ptr() != buf.data_ptr():
+        buf.copy_(labels[k], non_blocking=True)
+    eng.set_hyper(lr, decay)
+    eng.set_normalizer(g['labels']['mean_num_positives'])
+    glabels = dict(g['labels'])
+    glabels['normalizer'] = 'device'
+    reduce_fn = make_grad_all_reduce(self.process_group) if self.use_dist else None
+
+    def body_a():
+      eng.forward(g['images'], training=True)
+      eng.loss_backward(glabels)
+      eng.optimizer_local(reduce_fn is not None)
+      if reduce_fn is None:
+        eng.optimizer_apply(decay is not None, False)
+
+    def body_b():
+      eng.optimizer_apply(decay is not None, True)
+
+    if g['steps'] == 0:
+      # first step eager: allocates every buffer and runs the one-time kernel attribute setup
+      body_a()
+      if reduce_fn is not None:
+        reduce_fn(eng.grads_flat)
+        body_b()
+    else:
+      if g['graphs'] is None:
+        torch.cuda.synchronize()
+        ga = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+          body_a()
+        gb = None
+        if reduce_fn is not None:
+          gb = torch.cuda.CUDAGraph()
+          with torch.cuda.graph(gb, pool=ga.pool()):
+            body_b()
+        g['graphs'] = (ga, gb)
+      ga, gb = g['graphs']
+      ga.replay()
+      if gb is not None:
+        reduce_fn(eng.grads_flat)
+        gb.replay()
+    g['steps'] += 1
+
   def train_step(self, data, sync_loss=True):
     images, labels = data
     b, h, w = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
     eng = self._ensure_engine(b, h, w)
     lr = self._lr(b)
+    if self.use_graph:
+      decay = None
+      if self.config.moving_average_decay:
+        decay = ema_decay_dynamic(self.config.moving_average_decay, self.iterations)
+      self._graph_step(eng, self._to_device_images(images, eng), self._labels_to_device(labels, eng), lr, decay)
+      self.iterations += 1
+      if not sync_loss:
+        return {'learning_rate': lr}
+      vals = eng.loss_values()
+      vals['learning_rate'] = lr
+      return vals
     eng.forward(self._to_device_images(images, eng), training=True)
     eng.loss_backward(self._labels_to_device(labels, eng))
     decay = None

@@ -125,6 +125,8 @@ def main():
   ap.add_argument('--dtype', default='bf16')
   ap.add_argument('--no_cpu_baseline', action='store_true')
   ap.add_argument('--dump_launches', default='', help='write the per-(kernel, shape) launch table of one step here')
+  ap.add_argument('--graph', type=int, default=int(os.environ.get('EDET_GRAPH', '1')),
+                  help='1: the timed steps replay the step captured as a hipGraph; 0: eager launches')
   args = ap.parse_args()
 
   rank = int(os.environ.get('RANK', '0'))
@@ -144,20 +146,27 @@ def main():
   config.override('image_size=%d' % args.image_size)
   net = train_lib.EfficientDetNetTrain(config=config, dtype=args.dtype, device=device, seed=0,
                                        global_batch_size=args.batch * world, use_dist=world > 1,
-                                       steps_per_epoch=1000)
+                                       steps_per_epoch=1000, use_graph=bool(args.graph))
   eng = net._ensure_engine(args.batch, args.image_size, args.image_size)
   images, labels = synth_batch(config, args.batch, args.image_size, 3 + rank, device, eng.tdtype)
+  norm_host = labels.pop('normalizer')     # graph mode computes the normalizer on the device instead
 
   def step():
-    net.train_step((images, labels), sync_loss=False)
+    lb = labels if net.use_graph else dict(labels, normalizer=norm_host)
+    net.train_step((images, lb), sync_loss=False)
 
-  # ---- warm-up; the last warm-up step is fully profiled to find the dominant kernel family
-  for i in range(args.warmup):
+  # ---- warm-up (graph mode: step 1 eager, step 2 captures, then replays; at least 3 so that the timed
+  # region only replays), then one eager, fully profiled step to find the dominant kernel family
+  for i in range(max(args.warmup, 3) if args.graph else args.warmup):
     step()
+  if args.graph:      # from here on the synthetic batch lives in the captured step's own input buffers
+    images, labels = net.input_buffers()
   torch.cuda.synchronize()
+  net.use_graph = False
   _lib.profiler = _lib.Profiler(None)
   step()
   torch.cuda.synchronize()
+  net.use_graph = bool(args.graph)
   full = _lib.profiler.summary()
   if args.dump_launches and rank == 0:
     rows = sorted(_lib.profiler.by_shape().items(), key=lambda kv: -kv[1][1])
@@ -171,8 +180,10 @@ def main():
   dominant = max(full.items(), key=lambda kv: kv[1][1])[0]
   kernel_ms_total = sum(v[1] for v in full.values())
 
-  # ---- timed region: exactly K steps between barrier + synchronize
-  _lib.profiler = _lib.Profiler({dominant})
+  # ---- timed region: exactly K steps between barrier + synchronize.  Eager mode: the dominant kernel is
+  # HIP-event timed inside this region.  Graph mode: a replayed graph has no per-launch host call to bracket,
+  # so the same K steps are repeated eagerly right after the timed region for the roofline leg.
+  _lib.profiler = None if args.graph else _lib.Profiler({dominant})
   if dist is not None:
     dist.barrier()
   torch.cuda.synchronize()
@@ -184,6 +195,16 @@ def main():
   if dist is not None:
     dist.barrier()
   elapsed = time.perf_counter() - t0
+  eager_ms_per_step = None
+  if args.graph:
+    net.use_graph = False
+    _lib.profiler = _lib.Profiler({dominant})
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+      step()
+    torch.cuda.synchronize()
+    eager_ms_per_step = (time.perf_counter() - t1) / args.steps * 1e3
   prof = _lib.profiler.summary()
   _lib.profiler = None
   if dist is not None:
@@ -210,12 +231,16 @@ def main():
                                                                    args.image_size, args.batch),
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                    'loss': losses.get('loss'),
-                   'host_enqueue_ms_per_step': host_enqueue / args.steps * 1e3},
+                   'launch': 'hipGraph replay of the captured step' if args.graph else 'eager',
+                   'host_enqueue_ms_per_step': host_enqueue / args.steps * 1e3,
+                   'eager_ms_per_step': eager_ms_per_step},
         'roofline': {
             'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
             'traffic_source': traffic_src,
             'launches_per_step': n_l / args.steps, 'avg_launch_ms': ms_l / n_l,
+            'timed_over': ('%d eager steps run right after the timed (graph replay) region' % args.steps)
+            if args.graph else 'the timed region',
             'algorithmic_bytes_per_launch': bytes_l / n_l,
             'kernel_time_share': full[dominant][1] / kernel_ms_total,
             'whole_step_hbm_frac': (ALG_MB_PER_IMG * 1e6 * args.batch / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS

@@ -199,7 +199,7 @@ int edet_se_fc(const float* pooled_sum, int n, int c, int se, float inv_hw,
                const float* w1, const float* b1, const float* w2, const float* b2,
                float* hidden_pre, float* gate, void* stream);
 /* dgate [n,c] -> dpool [n,c] (already divided by H*W), parameter gradients.
- * scratch: caller-owned fp32 workspace of n*(c + 2*se) elements; se <= 48.  */
+ * scratch: caller-owned fp32 workspace of n*(c + 2*se) elements.  */
 int edet_se_fc_bwd(const float* pooled_sum, const float* hidden_pre, const float* gate,
                    const float* dgate, int n, int c, int se, float inv_hw,
                    const float* w1, const float* w2,
@@ -242,14 +242,17 @@ int edet_fuse_weights_bwd(const float* w0, const float* w1, const float* w2, int
  * train_lib.py:357-437,493-604: focal loss (alpha, gamma) on class logits,
  * Huber(delta) on box codes; writes d(loss)/d(logits) and accumulates
  * sums[0] += cls_loss, sums[1] += box_loss (already normalised).
- * cls_targets int32 [n,h,w,a] (-1 background, -2 ignore).  */
+ * cls_targets int32 [n,h,w,a] (-1 background, -2 ignore).
+ * norm_scale_dev (may be NULL): device scalar multiplied into inv_normalizer at run time, so that a
+ * captured hipGraph of the step can be replayed with the next batch's normalizer
+ * (sum(mean_num_positives) + 1, train_lib.py:517).  */
 int edet_focal_loss(const void* logits, int ld, const int32_t* cls_targets,
                     int64_t positions, int num_anchors, int num_classes,
-                    float alpha, float gamma, float inv_normalizer,
+                    float alpha, float gamma, float inv_normalizer, const float* norm_scale_dev,
                     void* dlogits, float* dbias, float* sums, int dtype, void* stream);
 int edet_box_loss(const void* box_out, int ld, const float* box_targets,
                   int64_t positions, int nch, float delta, float inv_normalizer,
-                  float grad_scale, void* dbox, float* dbias, float* sums,
+                  float grad_scale, const float* norm_scale_dev, void* dbox, float* dbias, float* sums,
                   int dtype, void* stream);
 
 /* ---- optimizer -----------------------------------------------------------------

@@ -611,9 +611,11 @@ def test_detection_loss(dt):
   sums = torch.zeros(4, dtype=torch.float32, device=gu.DEV)
   dbias_c = torch.zeros(na * nc, dtype=torch.float32, device=gu.DEV)
   dbias_b = torch.zeros(4 * na, dtype=torch.float32, device=gu.DEV)
-  call('edet_focal_loss', ptr(ld), ld.shape[-1], ptr(ctd), n * h * w, na, nc, 0.25, 1.5, 1.0 / norm, ptr(dl),
+  # the normalizer reaches the kernels either as a host float or as a device scalar (graph replay): both ways
+  inv_dev = torch.tensor([1.0 / norm], dtype=torch.float32, device=gu.DEV)
+  call('edet_focal_loss', ptr(ld), ld.shape[-1], ptr(ctd), n * h * w, na, nc, 0.25, 1.5, 1.0 / norm, None, ptr(dl),
        ptr(dbias_c), ptr(sums), edt, gu.stream())
-  call('edet_box_loss', ptr(bd), bd.shape[-1], ptr(btd), n * h * w, 4 * na, 0.1, 1.0 / (norm * 4), 50.0, ptr(db),
+  call('edet_box_loss', ptr(bd), bd.shape[-1], ptr(btd), n * h * w, 4 * na, 0.1, 0.25, 50.0, ptr(inv_dev), ptr(db),
        ptr(dbias_b), ptr(sums), edt, gu.stream())
   torch.cuda.synchronize()
   s = sums.cpu()

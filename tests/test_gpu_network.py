@@ -213,3 +213,49 @@ def test_two_steps_decrease_loss_and_are_deterministic_in_shape():
     for k in ('loss', 'det_loss', 'cls_loss', 'box_loss', 'reg_l2_loss', 'learning_rate', 'gradient_norm'):
       assert k in v and np.isfinite(v[k]), (k, v)
   assert v2['learning_rate'] > v1['learning_rate']      # linear warm-up
+
+
+@pytest.mark.parametrize('use_dist', [False, True])
+def test_graph_replay_matches_eager_steps(use_dist):
+  """The captured-and-replayed step (hipGraph) equals the eager step: 4 steps on 4 different batches (so the
+  static input buffers, the device-side normalizer and the per-step learning rate / EMA decay are all
+  exercised), fp32 storage, same start.  use_dist runs the two-graph variant around an eager all-reduce
+  (world size 1: RCCL with a single rank is an identity, the launch structure is the multi-GPU one)."""
+  import os
+  import torch.distributed as dist
+  config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  size, batch = 128, 2
+  vals = perturbed_params(config, 3)
+  rng = np.random.default_rng(53)
+  batches = []
+  for i in range(4):
+    images = rng.standard_normal((batch, size, size, 3)).astype(np.float32)
+    labels = make_labels(config, batch, size, 59 + i)
+    labels['mean_num_positives'] = np.full((batch,), 3.0 + i, np.float32)
+    batches.append((images, labels))
+  created = False
+  if use_dist and not dist.is_initialized():
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+    created = True
+  try:
+    results = []
+    for use_graph in (False, True):
+      net = train_lib.EfficientDetNetTrain(config=config, dtype='f32', params=vals, steps_per_epoch=10,
+                                           global_batch_size=64, use_graph=use_graph, use_dist=use_dist)
+      losses = [net.train_step(b) for b in batches]
+      torch.cuda.synchronize()
+      results.append((losses, net.get_weights(), net.engine.ema.cpu().numpy().copy()))
+    (l0, w0, e0), (l1, w1, e1) = results
+    for a, b in zip(l0, l1):
+      for k in ('loss', 'cls_loss', 'box_loss', 'reg_l2_loss', 'gradient_norm', 'learning_rate'):
+        assert abs(a[k] - b[k]) <= 1e-4 * abs(a[k]) + 1e-6, (k, a[k], b[k])
+    assert l0[0]['learning_rate'] < l0[3]['learning_rate']
+    for name in w0:
+      d = float(np.abs(w0[name] - w1[name]).max())
+      assert d <= 1e-4 * float(np.abs(w0[name]).max()) + 1e-6, (name, d)
+    assert float(np.abs(e0 - e1).max()) <= 1e-4 * float(np.abs(e0).max()) + 1e-6
+  finally:
+    if created:
+      dist.destroy_process_group()
