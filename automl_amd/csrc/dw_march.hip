@@ -17,6 +17,8 @@
 //
 // Reference call sites: efficientdet/backbone/efficientnet_model.py:320-327 (MBConv DepthwiseConv2D),
 // efficientdet/tf2/efficientdet_keras.py:195-207,459-464,546-556 (depthwise half of SeparableConv2D).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dwm {
@@ -546,6 +548,593 @@ __global__ __launch_bounds__(THREADS, 3) void k_dgrad(const Args a) {
   if (want_stats) block_channel_sums<CPT, 2>(a, l, C, st, a.epi.stat_partials, red);
 }
 
+// =====================================================================================================
+// LDS row-exchange variants (the default).  PMC counters of the kernels above showed them 50-76 % VALU-bound,
+// not HBM-bound: every thread re-applied the producer's BatchNorm + swish (or the BatchNorm backward) to
+// each of the K horizontally adjacent pixels it loaded, i.e. K times per element.  Here a thread loads and
+// transforms only ITS OWN pixel of a row (plus one halo pixel for the first K - S threads), parks the
+// fp32 result in a two-row LDS ring, and after one workgroup barrier per row reads the K neighbours back
+// from LDS (conflict-free: consecutive lanes = consecutive channels).  Global loads stay two rows ahead of
+// the barrier, so the HBM latency is still covered by the march; VALU work per element drops from
+// K*(act) + K*K to act + K*K and the L1 traffic from K to 1 load per element.
+template <int CPT> __device__ __forceinline__ void lds_put(float* p, const float x[CPT]);
+template <> __device__ __forceinline__ void lds_put<4>(float* p, const float x[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]);
+}
+template <> __device__ __forceinline__ void lds_put<2>(float* p, const float x[2]) {
+  *reinterpret_cast<float2*>(p) = make_float2(x[0], x[1]);
+}
+template <> __device__ __forceinline__ void lds_put<8>(float* p, const float x[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(x[4], x[5], x[6], x[7]);
+}
+template <int CPT> __device__ __forceinline__ void lds_get(const float* p, float x[CPT]);
+template <> __device__ __forceinline__ void lds_get<8>(const float* p, float x[8]) {
+  const float4 u = *reinterpret_cast<const float4*>(p);
+  const float4 v = *reinterpret_cast<const float4*>(p + 4);
+  x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
+}
+template <> __device__ __forceinline__ void lds_get<4>(const float* p, float x[4]) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+}
+template <> __device__ __forceinline__ void lds_get<2>(const float* p, float x[2]) {
+  const float2 v = *reinterpret_cast<const float2*>(p);
+  x[0] = v.x; x[1] = v.y;
+}
+
+// floats of LDS in front of the row ring (block_channel_sums scratch)
+__host__ __device__ inline int red_floats(int nch, int cpt) { return THREADS * cpt + nch * cpt; }
+
+// PF = rows of global loads in flight per thread ahead of the row being consumed (register FIFO).  With two
+// rows the march was latency-bound: a row step (~0.3 us of work) had to wait for a load issued only two
+// steps earlier (HBM latency under load ~2 us).
+template <int S, int CPT> struct PfDepth {
+  static constexpr int fwd = CPT == 8 ? 3 : (S == 1 ? 6 : 4);
+  static constexpr int bwd = CPT == 4 ? (S == 1 ? 4 : 2) : (S == 1 ? 6 : 3);   // register budget of the 3-wave kernels
+  static constexpr int dgrad = CPT == 4 ? (S == 1 ? 3 : 1) : (S == 1 ? 6 : 3);
+};
+
+template <int K, int S, int CPT>
+__global__ __launch_bounds__(THREADS) void k_fwd_lx(const Args a) {
+  constexpr int PF = PfDepth<S, CPT>::fwd;
+  constexpr int NSL = (K + S - 1) / S;   // output rows in flight
+  constexpr int U = S * NSL;             // static unroll of the row loop
+  constexpr int HALO = K - S;            // window columns beyond TX * S
+  extern __shared__ float red[];
+  const int C = a.in.c, H = a.in.h, W = a.in.w;
+  const Lane l = lane_setup<CPT>(a, C);
+  const int width = a.nch * CPT;
+  const int WIN = a.TX * S + HALO;
+  float* ring = red + red_floats(a.nch, CPT);          // [2][WIN][width]
+  const bool in_tile = l.px < a.TX;                    // thread owns window columns
+  const bf16_t* IN = reinterpret_cast<const bf16_t*>(a.in.data);
+  float w[K * K][CPT], sc[CPT], sh[CPT];
+  float st[2][CPT];
+#pragma unroll
+  for (int e = 0; e < CPT; ++e) { sc[e] = 1.f; sh[e] = 0.f; st[0][e] = st[1][e] = 0.f; }
+#pragma unroll
+  for (int t = 0; t < K * K; ++t)
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) w[t][e] = l.active ? a.w[(size_t)t * C + l.c + e] : 0.f;
+  if (l.active && a.in.scale) { loadf<CPT>(a.in.scale + l.c, sc); loadf<CPT>(a.in.shift + l.c, sh); }
+  const bool want_stats = a.stat_partials != nullptr;
+
+  for (int tile = l.p; tile < a.ntiles; tile += a.P) {
+    const int per_img = a.tiles_y * a.tiles_x;
+    const int n = tile / per_img, rr = tile - n * per_img;
+    const int ty = rr / a.tiles_x, tx = rr - ty * a.tiles_x;
+    const int oy0 = ty * a.TY, oy1 = min(a.oh, oy0 + a.TY);
+    const int ox = tx * a.TX + l.px;
+    const bool xok = l.active && ox < a.ow;
+    const int wc0 = tx * a.TX * S - a.pad_l;           // input column of window column 0
+    bool mok[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      const int ix = wc0 + l.px * S + j;
+      mok[j] = l.active && ix >= 0 && ix < W;
+    }
+    const int ixh = wc0 + a.TX * S + l.px;
+    const bool hown = HALO > 0 && l.px < HALO && in_tile;
+    const bool hok = hown && l.c < C && ixh >= 0 && ixh < W;
+    const bf16_t* ibase = IN + ((int64_t)n * H * W * a.in.ld + l.c);
+    bf16_t* obase = a.out + ((size_t)n * a.oh * a.ow + ox) * a.ldo + l.c;
+    float acc[NSL][CPT];
+#pragma unroll
+    for (int s = 0; s < NSL; ++s)
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) acc[s][e] = 0.f;
+
+    const int t0 = (oy0 * S / U) * U, t_last = (oy1 - 1) * S + K - 1;   // t = input row + pad_t
+    Raw<CPT> fm[PF + 1][S], fh[PF + 1];                     // fm[0] = row being consumed, fm[PF] = newest
+#pragma unroll
+    for (int i = 0; i <= PF; ++i) {
+      fh[i] = raw_zero<CPT>();
+#pragma unroll
+      for (int j = 0; j < S; ++j) fm[i][j] = raw_zero<CPT>();
+    }
+    auto load_row = [&](int t, Raw<CPT> (&dst)[S], Raw<CPT>& hdst) {
+      const int r = t - a.pad_t;
+      if (t <= t_last && r >= 0 && r < H) {
+        const bf16_t* rp = ibase + (int64_t)r * W * a.in.ld;
+#pragma unroll
+        for (int j = 0; j < S; ++j)
+          dst[j] = mok[j] ? raw_load<CPT>(rp + (int64_t)(wc0 + l.px * S + j) * a.in.ld) : raw_zero<CPT>();
+        if (HALO > 0) hdst = hok ? raw_load<CPT>(rp + (int64_t)ixh * a.in.ld) : raw_zero<CPT>();
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) load_row(t0 + i, fm[i], fh[i]);
+    for (int tb = t0; tb <= t_last; tb += U) {
+#pragma unroll
+      for (int tt = 0; tt < U; ++tt) {
+        const int t = tb + tt;
+        load_row(t + PF, fm[PF], fh[PF]);                  // PF input rows in flight per thread
+        const int r = t - a.pad_t;
+        const bool row_ok = t <= t_last && r >= 0 && r < H;   // uniform over the workgroup
+        float* buf = ring + (t & 1) * WIN * width;
+        if (row_ok && in_tile) {
+#pragma unroll
+          for (int j = 0; j < S; ++j) {
+            float x[CPT];
+            raw_unpack<CPT>(fm[0][j], x);
+            view_act<CPT>(a.in, sc, sh, x);
+            if (!mok[j]) {
+#pragma unroll
+              for (int e = 0; e < CPT; ++e) x[e] = 0.f;   // 'SAME' padding is zero in the activated domain
+            }
+            lds_put<CPT>(buf + (l.px * S + j) * width + l.chunk * CPT, x);
+          }
+          if (hown) {
+            float x[CPT];
+            raw_unpack<CPT>(fh[0], x);
+            view_act<CPT>(a.in, sc, sh, x);
+            if (!hok) {
+#pragma unroll
+              for (int e = 0; e < CPT; ++e) x[e] = 0.f;
+            }
+            lds_put<CPT>(buf + (a.TX * S + l.px) * width + l.chunk * CPT, x);
+          }
+        }
+        __syncthreads();
+        if (row_ok && in_tile) {
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) {
+            float x[CPT];
+            lds_get<CPT>(buf + (l.px * S + kx) * width + l.chunk * CPT, x);
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+              if ((tt - ky) % S == 0) {                    // static: this input row feeds output (t - ky) / S
+                const int sl = slot_of((tt - ky) / S, NSL);
+#pragma unroll
+                for (int e = 0; e < CPT; ++e) acc[sl][e] = fmaf(w[ky * K + kx][e], x[e], acc[sl][e]);
+              }
+            }
+          }
+        }
+        if ((tt - (K - 1)) % S == 0) {                     // static: output row (t - K + 1) / S is complete
+          const int sl = slot_of((tt - (K - 1)) / S, NSL);
+          const int oy = (t - (K - 1)) / S;
+          if (t <= t_last && t >= K - 1 && oy >= oy0 && oy < oy1 && xok) {
+            store_bf<CPT>(obase + (size_t)oy * a.ow * a.ldo, acc[sl]);
+            if (want_stats) {
+#pragma unroll
+              for (int e = 0; e < CPT; ++e) {
+                const float v = bf2f(f2bf(acc[sl][e]));
+                st[0][e] += v;
+                st[1][e] = fmaf(v, v, st[1][e]);
+              }
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < CPT; ++e) acc[sl][e] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+          fh[i] = fh[i + 1];
+#pragma unroll
+          for (int j = 0; j < S; ++j) fm[i][j] = fm[i + 1][j];
+        }
+      }
+    }
+    __syncthreads();      // the next tile's first row reuses the ring slot of this tile's last rows
+  }
+  if (want_stats) block_channel_sums<CPT, 2>(a, l, C, st, a.stat_partials, red);
+}
+
+// weight gradient with the activated input row exchanged through LDS (see k_fwd_lx); dy is the thread's own
+// column, so its BatchNorm backward was already applied once per element.
+template <int K, int S, int CPT, bool GBN>
+__global__ __launch_bounds__(THREADS) void k_wgrad_lx(const Args a) {
+  constexpr int PF = PfDepth<S, CPT>::bwd;          // input rows in flight
+  constexpr int PG = (PF + S - 1) / S + 1;     // dy rows in flight
+  constexpr int NSL = (K + S - 1) / S;
+  constexpr int U = S * NSL;
+  constexpr int HALO = K - S;
+  extern __shared__ float red[];
+  const int C = a.in.c, H = a.in.h, W = a.in.w;
+  const Lane l = lane_setup<CPT>(a, C);
+  const int width = a.nch * CPT;
+  const int WIN = a.TX * S + HALO;
+  float* ring = red + red_floats(a.nch, CPT);
+  const bool in_tile = l.px < a.TX;
+  const bf16_t* IN = reinterpret_cast<const bf16_t*>(a.in.data);
+  const bf16_t* DZ = reinterpret_cast<const bf16_t*>(a.gy.dz);
+  const bf16_t* YY = reinterpret_cast<const bf16_t*>(a.gy.y);
+  float wacc[K * K][CPT], sc[CPT], sh[CPT], ga[CPT], gb[CPT], gc[CPT];
+#pragma unroll
+  for (int e = 0; e < CPT; ++e) { sc[e] = 1.f; sh[e] = 0.f; ga[e] = 1.f; gb[e] = 0.f; gc[e] = 0.f; }
+#pragma unroll
+  for (int t = 0; t < K * K; ++t)
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) wacc[t][e] = 0.f;
+  if (l.active) {
+    if (a.in.scale) { loadf<CPT>(a.in.scale + l.c, sc); loadf<CPT>(a.in.shift + l.c, sh); }
+    if (GBN) { loadf<CPT>(a.gy.a + l.c, ga); loadf<CPT>(a.gy.b + l.c, gb); loadf<CPT>(a.gy.cc + l.c, gc); }
+  }
+
+  for (int tile = l.p; tile < a.ntiles; tile += a.P) {
+    const int per_img = a.tiles_y * a.tiles_x;
+    const int n = tile / per_img, rr = tile - n * per_img;
+    const int ty = rr / a.tiles_x, tx = rr - ty * a.tiles_x;
+    const int oy0 = ty * a.TY, oy1 = min(a.oh, oy0 + a.TY);
+    const int ox = tx * a.TX + l.px;
+    const bool xok = l.active && ox < a.ow;
+    const int wc0 = tx * a.TX * S - a.pad_l;
+    bool mok[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      const int ix = wc0 + l.px * S + j;
+      mok[j] = l.active && ix >= 0 && ix < W;
+    }
+    const int ixh = wc0 + a.TX * S + l.px;
+    const bool hown = HALO > 0 && l.px < HALO && in_tile;
+    const bool hok = hown && l.c < C && ixh >= 0 && ixh < W;
+    const bf16_t* ibase = IN + ((int64_t)n * H * W * a.in.ld + l.c);
+    const size_t gbase = ((size_t)n * a.oh * a.ow + ox) * a.gy.ld + l.c;
+    float dyw[NSL][CPT];                       // dy rows in flight, slot = oy mod NSL
+#pragma unroll
+    for (int s = 0; s < NSL; ++s)
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) dyw[s][e] = 0.f;
+
+    const int t0 = (oy0 * S / U) * U, t_last = (oy1 - 1) * S + K - 1;
+    Raw<CPT> fm[PF + 1][S], fh[PF + 1], fz[PG + 1], fy[GBN ? PG + 1 : 1];
+#pragma unroll
+    for (int i = 0; i <= PF; ++i) {
+      fh[i] = raw_zero<CPT>();
+#pragma unroll
+      for (int j = 0; j < S; ++j) fm[i][j] = raw_zero<CPT>();
+    }
+#pragma unroll
+    for (int i = 0; i <= PG; ++i) {
+      fz[i] = raw_zero<CPT>();
+      if (GBN) fy[i] = raw_zero<CPT>();
+    }
+    auto load_row = [&](int t, Raw<CPT> (&dst)[S], Raw<CPT>& hdst) {
+      const int r = t - a.pad_t;
+      if (t <= t_last && r >= 0 && r < H) {
+        const bf16_t* rp = ibase + (int64_t)r * W * a.in.ld;
+#pragma unroll
+        for (int j = 0; j < S; ++j)
+          dst[j] = mok[j] ? raw_load<CPT>(rp + (int64_t)(wc0 + l.px * S + j) * a.in.ld) : raw_zero<CPT>();
+        if (HALO > 0) hdst = hok ? raw_load<CPT>(rp + (int64_t)ixh * a.in.ld) : raw_zero<CPT>();
+      }
+    };
+    auto load_dy = [&](int oy, Raw<CPT>& gz, Raw<CPT>& gyr) {   // raw dy row oy (zero outside the tile / image)
+      gz = raw_zero<CPT>();
+      if (GBN) gyr = raw_zero<CPT>();
+      if (oy >= oy0 && oy < oy1 && xok) {
+        const size_t off = gbase + (size_t)oy * a.ow * a.gy.ld;
+        gz = raw_load<CPT>(DZ + off);
+        if (GBN) gyr = raw_load<CPT>(YY + off);
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) load_row(t0 + i, fm[i], fh[i]);
+#pragma unroll
+    for (int i = 0; i < PG; ++i) load_dy(t0 / S + i, fz[i], fy[GBN ? i : 0]);
+    for (int tb = t0; tb <= t_last; tb += U) {
+#pragma unroll
+      for (int tt = 0; tt < U; ++tt) {
+        const int t = tb + tt;
+        load_row(t + PF, fm[PF], fh[PF]);
+        if (tt % S == 0) {                     // static: dy row oy = t / S enters the window at ky = 0
+          const int sl = slot_of(tt / S, NSL);
+          const int oy = t / S;
+          load_dy(oy + PG, fz[PG], fy[GBN ? PG : 0]);
+          float g[CPT];
+          raw_unpack<CPT>(fz[0], g);
+          if (GBN) {
+            float y[CPT];
+            raw_unpack<CPT>(fy[0], y);
+            const bool in_t = oy >= oy0 && oy < oy1 && xok;
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) g[e] = in_t ? fmaf(ga[e], g[e], fmaf(gb[e], y[e], gc[e])) : 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < CPT; ++e) dyw[sl][e] = g[e];
+#pragma unroll
+          for (int i = 0; i < PG; ++i) {
+            fz[i] = fz[i + 1];
+            if (GBN) fy[i] = fy[i + 1];
+          }
+        }
+        const int r = t - a.pad_t;
+        const bool row_ok = t <= t_last && r >= 0 && r < H;
+        float* buf = ring + (t & 1) * WIN * width;
+        if (row_ok && in_tile) {
+#pragma unroll
+          for (int j = 0; j < S; ++j) {
+            float x[CPT];
+            raw_unpack<CPT>(fm[0][j], x);
+            view_act<CPT>(a.in, sc, sh, x);
+            if (!mok[j]) {
+#pragma unroll
+              for (int e = 0; e < CPT; ++e) x[e] = 0.f;
+            }
+            lds_put<CPT>(buf + (l.px * S + j) * width + l.chunk * CPT, x);
+          }
+          if (hown) {
+            float x[CPT];
+            raw_unpack<CPT>(fh[0], x);
+            view_act<CPT>(a.in, sc, sh, x);
+            if (!hok) {
+#pragma unroll
+              for (int e = 0; e < CPT; ++e) x[e] = 0.f;
+            }
+            lds_put<CPT>(buf + (a.TX * S + l.px) * width + l.chunk * CPT, x);
+          }
+        }
+        __syncthreads();
+        if (row_ok && in_tile) {
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) {
+            float x[CPT];
+            lds_get<CPT>(buf + (l.px * S + kx) * width + l.chunk * CPT, x);
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+              if ((tt - ky) % S == 0) {
+                const int sl = slot_of((tt - ky) / S, NSL);
+#pragma unroll
+                for (int e = 0; e < CPT; ++e) wacc[ky * K + kx][e] = fmaf(x[e], dyw[sl][e], wacc[ky * K + kx][e]);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+          fh[i] = fh[i + 1];
+#pragma unroll
+          for (int j = 0; j < S; ++j) fm[i][j] = fm[i + 1][j];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  block_channel_sums<CPT, K * K>(a, l, C, wacc, a.ws, red);
+}
+
+// data gradient with the BatchNorm-backward-transformed dy row exchanged through LDS: thread q loads and
+// transforms dy[oy][q] (plus the halo columns q0 - (D-1) .. q0 - 1 by the first D - 1 threads) and reads
+// dy[oy][q - d] (d < D) back after the barrier.  Window column wc <-> dy column q0 - (D-1) + wc.
+template <int K, int S, int CPT, bool GBN>
+__global__ __launch_bounds__(THREADS, 3) void k_dgrad_lx(const Args a) {
+  constexpr int PF = PfDepth<S, CPT>::dgrad;       // dy rows (and the saved-input rows they complete) in flight
+  constexpr int D = (K + S - 1) / S;
+  constexpr int RS = S * D;
+  extern __shared__ float red[];
+  const int C = a.in.c, H = a.in.h, W = a.in.w;
+  const Lane l = lane_setup<CPT>(a, C);
+  const int width = a.nch * CPT;
+  const int WIN = a.TX + D - 1;
+  float* ring = red + red_floats(a.nch, CPT);
+  const bool in_tile = l.px < a.TX;
+  const bf16_t* X = reinterpret_cast<const bf16_t*>(a.in.data);
+  const bf16_t* DZ = reinterpret_cast<const bf16_t*>(a.gy.dz);
+  const bf16_t* YY = reinterpret_cast<const bf16_t*>(a.gy.y);
+  bf16_t* GO = reinterpret_cast<bf16_t*>(a.epi.gout);
+  float w[K * K][CPT], sc[CPT], sh[CPT], ga[CPT], gb[CPT], gc[CPT], mu[CPT], rs[CPT];
+  float st[2][CPT];
+#pragma unroll
+  for (int e = 0; e < CPT; ++e) {
+    sc[e] = 1.f; sh[e] = 0.f; ga[e] = 1.f; gb[e] = 0.f; gc[e] = 0.f; mu[e] = 0.f; rs[e] = 1.f;
+    st[0][e] = st[1][e] = 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < K * K; ++t)
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) w[t][e] = l.active ? a.w[(size_t)t * C + l.c + e] : 0.f;
+  const bool want_stats = a.epi.stat_partials != nullptr;
+  const bool swish = a.in.act == EDET_ACT_SWISH;
+  if (l.active) {
+    if (a.in.scale) { loadf<CPT>(a.in.scale + l.c, sc); loadf<CPT>(a.in.shift + l.c, sh); }
+    if (GBN) { loadf<CPT>(a.gy.a + l.c, ga); loadf<CPT>(a.gy.b + l.c, gb); loadf<CPT>(a.gy.cc + l.c, gc); }
+    if (want_stats) { loadf<CPT>(a.epi.mean + l.c, mu); loadf<CPT>(a.epi.rstd + l.c, rs); }
+  }
+
+  const int QW = (W + a.pad_l + S - 1) / S, QH = (H + a.pad_t + S - 1) / S;
+  for (int tile = l.p; tile < a.ntiles; tile += a.P) {
+    const int per_img = a.tiles_y * a.tiles_x;
+    const int n = tile / per_img, rr = tile - n * per_img;
+    const int ty_ = rr / a.tiles_x, tx_ = rr - ty_ * a.tiles_x;
+    const int q0 = tx_ * a.TX;
+    const int q = q0 + l.px;
+    const bool qok = l.active && q < QW;
+    const int qy0 = ty_ * a.TY, qy1 = min(QH, qy0 + a.TY);
+    const bool mok = l.active && in_tile && q < a.ow;               // own dy column q (>= 0 always)
+    const int qh = q0 - (D - 1) + l.px;                            // halo dy column
+    const bool hown = D > 1 && l.px < D - 1 && in_tile;
+    const bool hok = hown && l.c < C && qh >= 0 && qh < a.ow;
+    float acc[RS][S][CPT];
+#pragma unroll
+    for (int s = 0; s < RS; ++s)
+#pragma unroll
+      for (int u = 0; u < S; ++u)
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) acc[s][u][e] = 0.f;
+    const size_t gimg = (size_t)n * a.oh * a.ow;
+    const int o_begin = ((qy0 - (D - 1)) >= 0 ? (qy0 - (D - 1)) / D : -((D - 1 - (qy0 - (D - 1))) / D)) * D;
+    Raw<CPT> fz[PF + 1], fy[GBN ? PF + 1 : 1], fhz[PF + 1], fhy[GBN ? PF + 1 : 1], fx[PF + 1][S][S];
+#pragma unroll
+    for (int i = 0; i <= PF; ++i) {
+      fz[i] = fhz[i] = raw_zero<CPT>();
+      if (GBN) fy[i] = fhy[i] = raw_zero<CPT>();
+#pragma unroll
+      for (int v = 0; v < S; ++v)
+#pragma unroll
+        for (int u = 0; u < S; ++u) fx[i][v][u] = raw_zero<CPT>();
+    }
+    if (!GBN) fy[0] = fhy[0] = raw_zero<CPT>();
+    const bool need_x = swish || want_stats;
+    // saved conv input of the S x S pixels that dy step oy completes (needed for act' / BN backward sums)
+    auto load_x = [&](int oy, Raw<CPT> (&xr)[S][S]) {
+#pragma unroll
+      for (int v = 0; v < S; ++v) {
+        const int iy = oy * S + v - a.pad_t;
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+          const int ix = q * S + u - a.pad_l;
+          xr[v][u] = raw_zero<CPT>();
+          if (need_x && oy >= qy0 && oy < qy1 && iy >= 0 && iy < H && qok && ix >= 0 && ix < W)
+            xr[v][u] = raw_load<CPT>(X + ((size_t)(n * H + iy) * W + ix) * a.in.ld + l.c);
+        }
+      }
+    };
+    auto load_dyrow = [&](int oy, Raw<CPT>& z, Raw<CPT>& y, Raw<CPT>& hz, Raw<CPT>& hy) {
+      if (oy < qy1 && oy >= 0 && oy < a.oh) {             // uniform
+        const size_t rowoff = (gimg + (size_t)oy * a.ow) * a.gy.ld + l.c;
+        z = raw_zero<CPT>();
+        if (GBN) y = raw_zero<CPT>();
+        if (mok) {
+          z = raw_load<CPT>(DZ + rowoff + (size_t)q * a.gy.ld);
+          if (GBN) y = raw_load<CPT>(YY + rowoff + (size_t)q * a.gy.ld);
+        }
+        if (D > 1) {
+          hz = raw_zero<CPT>();
+          if (GBN) hy = raw_zero<CPT>();
+          if (hok) {
+            hz = raw_load<CPT>(DZ + rowoff + (size_t)qh * a.gy.ld);
+            if (GBN) hy = raw_load<CPT>(YY + rowoff + (size_t)qh * a.gy.ld);
+          }
+        }
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      load_dyrow(o_begin + i, fz[i], fy[GBN ? i : 0], fhz[i], fhy[GBN ? i : 0]);
+      load_x(o_begin + i, fx[i]);
+    }
+    for (int ob = o_begin; ob < qy1; ob += D) {
+#pragma unroll
+      for (int oo = 0; oo < D; ++oo) {
+        const int oy = ob + oo;
+        load_dyrow(oy + PF, fz[PF], fy[GBN ? PF : 0], fhz[PF], fhy[GBN ? PF : 0]);   // PF rows in flight
+        load_x(oy + PF, fx[PF]);
+        Raw<CPT> (&xr)[S][S] = fx[0];
+        const Raw<CPT> cz = fz[0], cy = fy[0], hcz = fhz[0], hcy = fhy[0];
+        const bool row_ok = oy < qy1 && oy >= 0 && oy < a.oh;   // uniform
+        float* buf = ring + (oy & 1) * WIN * width;
+        if (row_ok && in_tile) {
+          float g[CPT];
+          raw_unpack<CPT>(cz, g);
+          if (GBN) {
+            float y[CPT];
+            raw_unpack<CPT>(cy, y);
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) g[e] = mok ? fmaf(ga[e], g[e], fmaf(gb[e], y[e], gc[e])) : 0.f;
+          }
+          lds_put<CPT>(buf + (l.px + D - 1) * width + l.chunk * CPT, g);
+          if (hown) {
+            raw_unpack<CPT>(hcz, g);
+            if (GBN) {
+              float y[CPT];
+              raw_unpack<CPT>(hcy, y);
+#pragma unroll
+              for (int e = 0; e < CPT; ++e) g[e] = hok ? fmaf(ga[e], g[e], fmaf(gb[e], y[e], gc[e])) : 0.f;
+            }
+            lds_put<CPT>(buf + l.px * width + l.chunk * CPT, g);
+          }
+        }
+        __syncthreads();
+        if (row_ok && in_tile) {
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            float g[CPT];
+            lds_get<CPT>(buf + (l.px + D - 1 - d) * width + l.chunk * CPT, g);
+            // dy[oy][q-d] feeds tx = S*q + u with kx = u + S*d, and ty = oy*S + ky
+#pragma unroll
+            for (int u = 0; u < S; ++u) {
+              if (u + S * d < K) {
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky) {
+                  const int sl = slot_of(oo * S + ky, RS);     // (oy*S + ky) mod RS, ob*S = 0 mod RS
+#pragma unroll
+                  for (int e = 0; e < CPT; ++e)
+                    acc[sl][u][e] = fmaf(w[ky * K + u + S * d][e], g[e], acc[sl][u][e]);
+                }
+              }
+            }
+          }
+        }
+        // rows ty = oy*S + v (v < S) are complete
+#pragma unroll
+        for (int v = 0; v < S; ++v) {
+          const int sl = slot_of(oo * S + v, RS);
+          const int iy = oy * S + v - a.pad_t;
+          if (oy >= qy0 && oy < qy1 && iy >= 0 && iy < H) {   // uniform
+#pragma unroll
+            for (int u = 0; u < S; ++u) {
+              const int ix = q * S + u - a.pad_l;
+              if (qok && ix >= 0 && ix < W) {
+                const size_t off = ((size_t)(n * H + iy) * W + ix) * a.in.ld + l.c;
+                float g[CPT], x[CPT];
+#pragma unroll
+                for (int e = 0; e < CPT; ++e) g[e] = acc[sl][u][e];
+                raw_unpack<CPT>(xr[v][u], x);
+                if (swish) {
+#pragma unroll
+                  for (int e = 0; e < CPT; ++e) g[e] *= swish_gradf_(fmaf(x[e], sc[e], sh[e]));
+                }
+                if (a.epi.beta) {
+                  float old[CPT];
+                  raw_unpack<CPT>(raw_load<CPT>(GO + off), old);
+#pragma unroll
+                  for (int e = 0; e < CPT; ++e) g[e] += old[e];
+                }
+                store_bf<CPT>(GO + off, g);
+                if (want_stats) {
+#pragma unroll
+                  for (int e = 0; e < CPT; ++e) {
+                    st[0][e] += g[e];
+                    st[1][e] = fmaf(g[e], (x[e] - mu[e]) * rs[e], st[1][e]);
+                  }
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < S; ++u)
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) acc[sl][u][e] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+          fz[i] = fz[i + 1];
+          fhz[i] = fhz[i + 1];
+          if (GBN) { fy[i] = fy[i + 1]; fhy[i] = fhy[i + 1]; }
+#pragma unroll
+          for (int v = 0; v < S; ++v)
+#pragma unroll
+            for (int u = 0; u < S; ++u) fx[i][v][u] = fx[i + 1][v][u];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (want_stats) block_channel_sums<CPT, 2>(a, l, C, st, a.epi.stat_partials, red);
+}
+
 // ------------------------------------------------------------------------------------- host
 inline int pick_nch(int nvec, int maxch) {
   if (nvec <= maxch) return nvec;
@@ -578,6 +1167,12 @@ inline void plan(Args& a, int C, int n, int space_w, int space_h, int max_p) {
   a.P = P;
 }
 
+// EDET_DW_LX=0 selects the register-only variants (A/B measurements)
+inline bool dw_lx_enabled() {
+  const char* e = getenv("EDET_DW_LX");
+  return !(e && e[0] == '0');
+}
+
 }  // namespace dwm
 
 // return 1 = handled, 0 = not applicable (caller falls back), < 0 = error
@@ -590,12 +1185,22 @@ int dwm_try_fwd(const edet_tview_t* in, const float* weight, int k, int s, void*
   a.in = *in; a.w = weight; a.out = reinterpret_cast<bf16_t*>(out); a.ldo = ldo; a.stat_partials = stat_partials;
   a.oh = same_out(in->h, s); a.ow = same_out(in->w, s);
   a.pad_t = same_pad_before(in->h, k, s); a.pad_l = same_pad_before(in->w, k, s);
+  static const bool lx = dw_lx_enabled();
 #define DWM_FWD(K_, S_, CPT_)                                                             \
   do {                                                                                    \
     plan<CPT_>(a, in->c, in->n, a.ow, a.oh, EDET_MAX_PARTS);                              \
-    k_fwd<K_, S_, CPT_><<<dim3(a.P * a.ngroups), dim3(THREADS), (THREADS * CPT_ + a.nch * CPT_) * sizeof(float), st>>>(a); \
+    const size_t lds0 = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                  \
+    if (lx) {                                                                             \
+      const size_t ring = (size_t)2 * (a.TX * S_ + K_ - S_) * a.nch * CPT_ * sizeof(float); \
+      k_fwd_lx<K_, S_, CPT_><<<dim3(a.P * a.ngroups), dim3(THREADS), lds0 + ring, st>>>(a); \
+    } else {                                                                              \
+      k_fwd<K_, S_, CPT_><<<dim3(a.P * a.ngroups), dim3(THREADS), lds0, st>>>(a);         \
+    }                                                                                     \
   } while (0)
-  if (k == 3 && s == 1) DWM_FWD(3, 1, 4);
+  static const bool cpt8 = getenv("EDET_DW_CPT8") && getenv("EDET_DW_CPT8")[0] == '1';
+  if (k == 3 && s == 1 && cpt8 && lx) DWM_FWD(3, 1, 8);
+  else if (k == 3 && s == 2 && cpt8 && lx) DWM_FWD(3, 2, 8);
+  else if (k == 3 && s == 1) DWM_FWD(3, 1, 4);
   else if (k == 3 && s == 2) DWM_FWD(3, 2, 4);
   else if (k == 5 && s == 1) DWM_FWD(5, 1, 2);
   else if (k == 5 && s == 2) DWM_FWD(5, 2, 2);
@@ -620,12 +1225,20 @@ int dwm_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, 
   if (max_p < 1) return 0;
   if (max_p > 1024) max_p = 1024;
   const bool gbn = dy->a != nullptr;
+  static const bool lx = dw_lx_enabled();
 #define DWM_WG(K_, S_, CPT_)                                                              \
   do {                                                                                    \
     plan<CPT_>(a, in->c, in->n, a.ow, a.oh, max_p);                                       \
-    const size_t lds = (size_t)(THREADS * CPT_ + a.nch * CPT_) * sizeof(float);           \
-    if (gbn) k_wgrad<K_, S_, CPT_, true><<<dim3(a.P * a.ngroups), dim3(THREADS), lds, st>>>(a);   \
-    else k_wgrad<K_, S_, CPT_, false><<<dim3(a.P * a.ngroups), dim3(THREADS), lds, st>>>(a);      \
+    const size_t lds = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                   \
+    const size_t ring = (size_t)2 * (a.TX * S_ + K_ - S_) * a.nch * CPT_ * sizeof(float); \
+    const dim3 grid(a.P * a.ngroups), block(THREADS);                                     \
+    if (lx) {                                                                             \
+      if (gbn) k_wgrad_lx<K_, S_, CPT_, true><<<grid, block, lds + ring, st>>>(a);        \
+      else k_wgrad_lx<K_, S_, CPT_, false><<<grid, block, lds + ring, st>>>(a);           \
+    } else {                                                                              \
+      if (gbn) k_wgrad<K_, S_, CPT_, true><<<grid, block, lds, st>>>(a);                  \
+      else k_wgrad<K_, S_, CPT_, false><<<grid, block, lds, st>>>(a);                     \
+    }                                                                                     \
   } while (0)
   if (k == 3 && s == 1) DWM_WG(3, 1, 4);
   else if (k == 3 && s == 2) DWM_WG(3, 2, 4);
@@ -649,12 +1262,20 @@ int dwm_try_dgrad(const edet_gview_t* dy, const float* weight, int k, int s, con
   a.pad_t = same_pad_before(in->h, k, s); a.pad_l = same_pad_before(in->w, k, s);
   const int QW = (in->w + a.pad_l + s - 1) / s, QH = (in->h + a.pad_t + s - 1) / s;
   const bool gbn = dy->a != nullptr;
+  static const bool lx = dw_lx_enabled();
 #define DWM_DG(K_, S_, CPT_)                                                              \
   do {                                                                                    \
     plan<CPT_>(a, in->c, in->n, QW, QH, EDET_MAX_PARTS);                                  \
-    const size_t lds = (size_t)(THREADS * CPT_ + a.nch * CPT_) * sizeof(float);           \
-    if (gbn) k_dgrad<K_, S_, CPT_, true><<<dim3(a.P * a.ngroups), dim3(THREADS), lds, st>>>(a);   \
-    else k_dgrad<K_, S_, CPT_, false><<<dim3(a.P * a.ngroups), dim3(THREADS), lds, st>>>(a);      \
+    const size_t lds = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                   \
+    const size_t ring = (size_t)2 * (a.TX + (K_ + S_ - 1) / S_ - 1) * a.nch * CPT_ * sizeof(float); \
+    const dim3 grid(a.P * a.ngroups), block(THREADS);                                     \
+    if (lx) {                                                                             \
+      if (gbn) k_dgrad_lx<K_, S_, CPT_, true><<<grid, block, lds + ring, st>>>(a);        \
+      else k_dgrad_lx<K_, S_, CPT_, false><<<grid, block, lds + ring, st>>>(a);           \
+    } else {                                                                              \
+      if (gbn) k_dgrad<K_, S_, CPT_, true><<<grid, block, lds, st>>>(a);                  \
+      else k_dgrad<K_, S_, CPT_, false><<<grid, block, lds, st>>>(a);                     \
+    }                                                                                     \
   } while (0)
   if (k == 3 && s == 1) DWM_DG(3, 1, 4);
   else if (k == 3 && s == 2) DWM_DG(3, 2, 4);
