@@ -155,6 +155,7 @@ __global__ void k_bn_res(const edet_tview_t y, const T* __restrict__ res, T* __r
                          int64_t rows) {
   const int nvec = y.c / 8;
   const int64_t total = rows * nvec;
+  const int hw = y.h * y.w;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
        q += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = q / nvec;
@@ -163,7 +164,7 @@ __global__ void k_bn_res(const edet_tview_t y, const T* __restrict__ res, T* __r
     load8<T>(reinterpret_cast<const T*>(y.data) + r * y.ld + c0, x);
     ViewCoef vc;
     view_load_coef(y, c0, vc);
-    view_apply(y, vc, c0, 0, x);
+    view_apply(y, vc, c0, y.gate ? (int)(r / hw) : 0, x);   // gate [n][c]: stochastic-depth scale per image
     if (res) {
       float rr[8];
       load8<T>(res + r * ldo + c0, rr);

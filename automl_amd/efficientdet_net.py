@@ -19,7 +19,7 @@ class EfficientDetNet(object):
   """EfficientDet network without pre/post-processing."""
 
   def __init__(self, model_name=None, config=None, name='', feature_only=False, dtype='bf16',
-               device='cuda:0', seed=0, params=None):
+               device='cuda:0', seed=0, params=None, stochastic_depth=True):
     if feature_only:
       raise ValueError('feature_only=True is out of scope')
     config = config or hparams_config.get_efficientdet_config(model_name)
@@ -29,6 +29,7 @@ class EfficientDetNet(object):
     self.name = name
     self._dtype, self._device, self._seed = dtype, device, seed
     self._init_params = params
+    self._stochastic_depth = stochastic_depth   # False: survival_prob off for every backbone (deterministic)
     self.engine = None
 
   def _ensure_engine(self, batch, height, width):
@@ -38,7 +39,8 @@ class EfficientDetNet(object):
       if e is not None:
         params = e.get_params()      # keep the current weights when shapes change
       self.engine = engine_lib.Engine(self.config, batch, (height, width), dtype=self._dtype,
-                                      device=self._device, seed=self._seed, params=params)
+                                      device=self._device, seed=self._seed, params=params,
+                                      stochastic_depth=self._stochastic_depth)
     return self.engine
 
   def _to_device_images(self, images, eng):

@@ -89,7 +89,7 @@ class Engine(object):
   """Builds buffers for (config, batch, image size, dtype) and runs forward / backward / update."""
 
   def __init__(self, config, batch_size, image_size=None, dtype='bf16', device='cuda:0', seed=0,
-               params=None, spec=None):
+               params=None, spec=None, stochastic_depth=True):
     if not torch.cuda.is_available():
       raise _lib.EdetError('no HIP device visible: the EfficientDet engine has no CPU path')
     _lib.load()
@@ -119,6 +119,10 @@ class Engine(object):
     self.hyper = torch.zeros(4, dtype=torch.float32, device=self.device)   # lr, ema decay, 1/normalizer, -
     self.gnorm = torch.zeros(1, dtype=torch.float32, device=self.device)
     self.pool_argmax = os.environ.get('EDET_POOL_ARGMAX', '1') != '0'
+    self.stochastic_depth = stochastic_depth
+    self.drop_masks = {}      # block scope -> (mask [n,c] fp32 = floor(p + u_n) / p, survival probability p)
+    self._rng = torch.Generator(device=self.device)
+    self._rng.manual_seed(1000003 * seed + 17)
 
   @property
   def esize(self):
@@ -419,12 +423,31 @@ class Engine(object):
       self.tape.append(bwd)
     return vg
 
-  def bn_res(self, key, vy, residual):
-    """Materialise a block output: bn(y) (+ residual)."""
+  def refresh_drop_masks(self):
+    """New stochastic-depth draws: mask[n, :] = floor(p + u_n) / p, u_n ~ U[0,1) per image
+    (utils.drop_connect, utils.py:329-344).  Device-side torch ops, outside any captured graph."""
+    for mask, p in self.drop_masks.values():
+      u = torch.rand(mask.shape[0], 1, device=self.device, generator=self._rng)
+      mask.copy_(((u + p).floor() / p).expand_as(mask))
+
+  def bn_res(self, key, vy, residual, survival_prob=None):
+    """Materialise a block output: bn(y) [* stochastic-depth scale] (+ residual)."""
     r = vy.raw
     if residual is not None and (residual.bn is not None or residual.act != ACT_NONE or residual.gate is not None):
       raise ValueError('bn_res: the residual operand must be a stored (plain) tensor')
     out = Raw(self, key, r.n, r.h, r.w, r.c)
+    mask = None
+    if self.training and self.stochastic_depth and survival_prob and residual is not None:
+      if key not in self.drop_masks:
+        self.drop_masks[key] = (self.buf(key + ':dc', (r.n, r.c), torch.float32), float(survival_prob))
+        if not torch.cuda.is_current_stream_capturing():
+          saved = self.drop_masks
+          self.drop_masks = {key: saved[key]}
+          self.refresh_drop_masks()
+          self.drop_masks = saved
+      mask = self.drop_masks[key][0]
+      vy.consumers += 1
+      vy = View(r, vy.bn, vy.act, mask)
     call('edet_bn_res', ctypes.byref(vy.tview()), ptr(residual.raw.data) if residual else None, ptr(out.data),
          out.ld, self.dtype, self.stream, nbytes=(3 if residual else 2) * r.rows * r.c * self.esize)
     vout = View(out)
@@ -434,7 +457,15 @@ class Engine(object):
     if self.training:
       def bwd():
         assert out.grad_written, key
-        r.grad = out.grad           # d(bn output) aliases d(block output)
+        if mask is not None:
+          # d(bn output) = d(block output) * mask[n]: the same kernel, applied to the gradient
+          gbuf = self.buf(key + ':dcg', (r.n, r.h, r.w, r.ld), self.tdtype)
+          gv = TView(ptr(out.grad), None, None, ptr(mask), ACT_NONE, r.n, r.h, r.w, r.c, out.ld)
+          call('edet_bn_res', ctypes.byref(gv), None, ptr(gbuf), r.ld, self.dtype, self.stream,
+               nbytes=2 * r.rows * r.c * self.esize)
+          r.grad = gbuf
+        else:
+          r.grad = out.grad         # d(bn output) aliases d(block output)
         r.grad_written = True
         if residual is not None and residual.raw.needs_grad:
           rr = residual.raw
@@ -517,6 +548,8 @@ class Engine(object):
     assert tuple(images.shape) == (self.batch, self.image_size[0], self.image_size[1], 3), images.shape
     assert images.dtype == self.tdtype and images.is_contiguous()
     self._begin(training, update_moving)
+    if training and self.drop_masks and not torch.cuda.is_current_stream_capturing():
+      self.refresh_drop_masks()
     self.images = images
     n, h, w = self.batch, self.image_size[0], self.image_size[1]
     bb = c.backbone_name
@@ -585,7 +618,9 @@ class Engine(object):
       x = self.se(scope + ':se', x, scope, b.se_filters)
     y = self.pw(scope + ':proj', x, '%s/%s/kernel' % (scope, conv_names[ci]), b.output_filters,
                 bn='%s/%s' % (scope, bn_names[bi]), act=ACT_NONE)
-    return self.bn_res(scope + ':out', y, xin if b.has_residual else None)
+    sps = getattr(self.spec, 'survival_probs', None)
+    return self.bn_res(scope + ':out', y, xin if b.has_residual else None,
+                       survival_prob=sps[b.index] if sps else None)
 
   def _fpn_cell(self, feats, cell_scope):
     c = self.config

@@ -41,6 +41,11 @@ class NetSpec(object):
     self.stem_filters, self.blocks = eb.backbone_blocks(
         c.backbone_name, c.backbone_config.blocks if c.backbone_config is not None else None)
     self.reductions = eb.reduction_indices(self.blocks)
+    # stochastic depth (efficientdet_keras.py:811-812; efficientnet_builder.py:174; efficientnet_model.py:751-756):
+    # the builder's survival_prob 0.8, forced to 0 (= off) for the b0 backbone, per block 1 - 0.2 * idx / n.
+    sp = 0.0 if 'b0' in c.backbone_name else 0.8
+    self.survival_probs = [(1.0 - (1.0 - sp) * float(b.index) / len(self.blocks)) if sp else None
+                           for b in self.blocks]
     self.fpn = c.fpn_config or fpn_configs.get_fpn_config(c.fpn_name, c.min_level, c.max_level,
                                                          c.fpn_weight_method)
     if self.fpn.weight_method not in ('fastattn', 'sum'):

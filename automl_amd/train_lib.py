@@ -210,6 +210,7 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
             body_b()
         g['graphs'] = (ga, gb)
       ga, gb = g['graphs']
+      eng.refresh_drop_masks()      # stochastic-depth draws live in static buffers the graph reads
       ga.replay()
       if gb is not None:
         reduce_fn(eng.grads_flat)

@@ -183,8 +183,9 @@ int edet_bn_bwd_finalize(const float* partials, int nparts, int c, double count,
                          float* dgamma, float* dbeta, float* dbias,
                          float* a, float* b, float* cc, void* stream);
 
-/* ---- block output: out = y*scale+shift (+ residual) ------------------------
- * efficientnet_model.py:393-410 (project BN, identity skip).  */
+/* ---- block output: out = view(y) (+ residual) ---------------------------------
+ * efficientnet_model.py:393-410 (project BN, identity skip).  y->gate [n][c], when set, is the
+ * stochastic-depth scale floor(p + u_n) / p of utils.drop_connect (utils.py:329-344), constant along c.  */
 int edet_bn_res(const edet_tview_t* y, const void* residual, void* out, int ldo,
                 int dtype, void* stream);
 /* dst = (beta ? dst : 0) + src, elementwise on [rows][c] with ld */

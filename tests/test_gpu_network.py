@@ -64,6 +64,11 @@ def rel_err(got, want):
   return float((got - want).abs().max()) / max(float(want.abs().max()), 1e-20)
 
 
+def drop_scales(eng):
+  """The stochastic-depth draws of the device path, as the oracle's input (block scope -> [B] scale)."""
+  return {k[:-len(':out')]: m[:, 0].detach().cpu().clone() for k, (m, p) in eng.drop_masks.items()}
+
+
 CASES = [
     ('efficientdet-d0', '', 128, 2),
     ('efficientdet-d0', 'max_level=8,fpn_weight_method=sum', 128, 1),   # d7x-style pyramid and fusion
@@ -88,12 +93,14 @@ def test_forward_matches_oracle(case, training, dtype, tol):
   images = rng.standard_normal((batch, size, size, 3)).astype(np.float32)
   if dtype == 'bf16':
     images = torch.from_numpy(images).to(torch.bfloat16).float().numpy()
-  oracle = orc.Oracle(config=config, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
-  with torch.no_grad():
-    cls_ref, box_ref = oracle.forward(torch.from_numpy(images), training)
   net = efficientdet_net.EfficientDetNet(config=config, dtype=dtype, params=vals)
   cls, box = net(torch.from_numpy(images), training=training)
   torch.cuda.synchronize()
+  oracle = orc.Oracle(config=config, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
+  oracle.drop_scale = drop_scales(net.engine)     # d1: 16 residual blocks with survival_prob < 1
+  assert bool(oracle.drop_scale) == (training and 'd1' in model)
+  with torch.no_grad():
+    cls_ref, box_ref = oracle.forward(torch.from_numpy(images), training)
   errs = []
   for lvl, (c, cr, b, br) in enumerate(zip(cls, cls_ref, box, box_ref)):
     assert tuple(c.shape) == tuple(cr.shape) and tuple(b.shape) == tuple(br.shape)
@@ -110,7 +117,8 @@ def test_forward_matches_oracle(case, training, dtype, tol):
     assert worst <= (1e-3 if dtype == 'f32' else 0.2), 'moving statistics differ: %g' % worst
 
 
-@pytest.mark.parametrize('case', CASES[:2], ids=lambda c: '%s[%s]@%d' % (c[0], c[1], c[2]))
+@pytest.mark.parametrize('case', CASES[:2] + [('efficientdet-d1', '', 96, 3)],
+                         ids=lambda c: '%s[%s]@%d' % (c[0], c[1], c[2]))
 def test_train_step_matches_oracle_fp32(case):
   """loss values, clipped gradients of every variable, and the updated variables after one step."""
   model, override, size, batch = case
@@ -120,16 +128,22 @@ def test_train_step_matches_oracle_fp32(case):
   rng = np.random.default_rng(23)
   images = rng.standard_normal((batch, size, size, 3)).astype(np.float32)
   labels = make_labels(config, batch, size, 29)
+  net = train_lib.EfficientDetNetTrain(config=config, dtype='f32', params=vals)
+  eng = net._ensure_engine(batch, size, size)
+  eng.forward(net._to_device_images(torch.from_numpy(images), eng), training=True)
+  torch.cuda.synchronize()
+
   oracle = orc.Oracle(config=config, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
   with torch.no_grad():
     oracle.forward(torch.from_numpy(images), False)   # registers the trainable list
+  oracle.drop_scale = drop_scales(eng)                # stochastic depth (d1): same draws on both sides
+  if 'd1' in model:
+    scales = torch.stack(list(oracle.drop_scale.values()))
+    assert scales.shape[0] == 16 and float(scales.max()) > 1.0, scales     # 1/p for the surviving images
   tl = {k: torch.from_numpy(v) for k, v in labels.items()}
   lr, decay = 0.02, 0.9
   ref_vals, ref_grads = orc.train_step(oracle, torch.from_numpy(images), tl, {}, lr, decay)
 
-  net = train_lib.EfficientDetNetTrain(config=config, dtype='f32', params=vals)
-  eng = net._ensure_engine(batch, size, size)
-  eng.forward(net._to_device_images(torch.from_numpy(images), eng), training=True)
   eng.loss_backward(net._labels_to_device(labels, eng))
   torch.cuda.synchronize()
   raw = eng.get_grads()          # before L2 / clipping
