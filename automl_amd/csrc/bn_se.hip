@@ -234,44 +234,57 @@ __global__ __launch_bounds__(THREADS) void k_se_pool(const edet_tview_t in, floa
   for (int i = tid; i < in.c; i += THREADS) atomicAdd(&pooled[(size_t)n * in.c + i], red[i]);
 }
 
-// one workgroup per image
-__global__ __launch_bounds__(THREADS) void k_se_fc(const float* __restrict__ pooled, int c, int se, float inv_hw,
-                                                  const float* w1, const float* b1, const float* w2,
-                                                  const float* b2, float* hidden_pre, float* gate) {
+// one workgroup (SE_FC_THREADS lanes) per image
+constexpr int SE_FC_THREADS = 1024;
+__global__ __launch_bounds__(SE_FC_THREADS) void k_se_fc(const float* __restrict__ pooled, int c, int se, float inv_hw,
+                                                        const float* w1, const float* b1, const float* w2,
+                                                        const float* b2, float* hidden_pre, float* gate) {
   extern __shared__ float sm[];  // p[c], h[se]
   float* p = sm;
   float* h = sm + c;
-  const int n = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < c; i += THREADS) p[i] = pooled[(size_t)n * c + i] * inv_hw;
+  const int n = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  for (int i = tid; i < c; i += nthr) p[i] = pooled[(size_t)n * c + i] * inv_hw;
+  for (int j = tid; j < se; j += nthr) h[j] = 0.f;
   __syncthreads();
-  for (int j = tid; j < se; j += THREADS) h[j] = 0.f;
-  __syncthreads();
-  // thread (j, part): hidden unit j over the channels i = part, part + nparts, ... (w1 loads coalesced along j)
-  if (se <= THREADS) {
-    const int nparts = THREADS / se, j = tid % se, part = tid / se;
+  // thread (j, part): hidden unit j over the channels i = part, part + nparts, ... (w1 loads coalesced along
+  // j; four independent partial sums keep four loads in flight)
+  if (se <= nthr) {
+    const int nparts = nthr / se, j = tid % se, part = tid / se;
     if (part < nparts) {
-      float acc = 0.f;
-      for (int i = part; i < c; i += nparts) acc = fmaf(p[i], w1[(size_t)i * se + j], acc);
-      atomicAdd(&h[j], acc);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int i = part;
+      for (; i + 3 * nparts < c; i += 4 * nparts) {
+        a0 = fmaf(p[i], w1[(size_t)i * se + j], a0);
+        a1 = fmaf(p[i + nparts], w1[(size_t)(i + nparts) * se + j], a1);
+        a2 = fmaf(p[i + 2 * nparts], w1[(size_t)(i + 2 * nparts) * se + j], a2);
+        a3 = fmaf(p[i + 3 * nparts], w1[(size_t)(i + 3 * nparts) * se + j], a3);
+      }
+      for (; i < c; i += nparts) a0 = fmaf(p[i], w1[(size_t)i * se + j], a0);
+      atomicAdd(&h[j], (a0 + a1) + (a2 + a3));
     }
   } else {
-    for (int j = tid; j < se; j += THREADS) {
+    for (int j = tid; j < se; j += nthr) {
       float acc = 0.f;
       for (int i = 0; i < c; ++i) acc = fmaf(p[i], w1[(size_t)i * se + j], acc);
       h[j] = acc;
     }
   }
   __syncthreads();
-  for (int j = tid; j < se; j += THREADS) {
+  for (int j = tid; j < se; j += nthr) {
     const float acc = h[j] + b1[j];
     hidden_pre[(size_t)n * se + j] = acc;
     h[j] = swishf_(acc);
   }
   __syncthreads();
-  for (int i = tid; i < c; i += THREADS) {
-    float acc = b2[i];
-    for (int j = 0; j < se; ++j) acc = fmaf(h[j], w2[(size_t)j * c + i], acc);
-    gate[(size_t)n * c + i] = sigmoidf_(acc);
+  for (int i = tid; i < c; i += nthr) {
+    float a0 = b2[i], a1 = 0.f;
+    int j = 0;
+    for (; j + 1 < se; j += 2) {
+      a0 = fmaf(h[j], w2[(size_t)j * c + i], a0);
+      a1 = fmaf(h[j + 1], w2[(size_t)(j + 1) * c + i], a1);
+    }
+    if (j < se) a0 = fmaf(h[j], w2[(size_t)j * c + i], a0);
+    gate[(size_t)n * c + i] = sigmoidf_(a0 + a1);
   }
 }
 
@@ -580,7 +593,8 @@ extern "C" int edet_se_fc(const float* pooled_sum, int n, int c, int se, float i
                           const float* w1, const float* b1, const float* w2, const float* b2,
                           float* hidden_pre, float* gate, void* stream) {
   EDET_CHECK(pooled_sum && w1 && b1 && w2 && b2 && hidden_pre && gate, "edet_se_fc: null pointer");
-  k_se_fc<<<n, THREADS, (size_t)(c + se) * sizeof(float), to_stream(stream)>>>(pooled_sum, c, se, inv_hw, w1, b1, w2, b2, hidden_pre, gate);
+  const int fc_threads = c >= 512 ? SE_FC_THREADS : THREADS;
+  k_se_fc<<<n, fc_threads, (size_t)(c + se) * sizeof(float), to_stream(stream)>>>(pooled_sum, c, se, inv_hw, w1, b1, w2, b2, hidden_pre, gate);
   EDET_LAUNCH_CHECK("edet_se_fc");
   return 0;
 }

@@ -252,9 +252,12 @@ class Engine(object):
            self.bn_epsilon, self.bn_momentum if self.update_moving else -1.0,
            ptr(bn.mm), ptr(bn.mv), ptr(bn.scale), ptr(bn.shift), ptr(bn.mean), ptr(bn.rstd), self.stream)
       bn.bwd_ready = False
-    else:
+      bn.eval_done = False
+      self._cast_dirty = True          # moving statistics (and soon the weights) change
+    elif not bn.eval_done:
       call('edet_bn_eval', bn.c, ptr(bn.gamma), ptr(bn.beta), self.bn_epsilon, ptr(bn.mm), ptr(bn.mv),
            ptr(bn.scale), ptr(bn.shift), self.stream)
+      bn.eval_done = True
 
   def _bn_bwd_finalize(self, bn, nparts):
     call('edet_bn_bwd_finalize', ptr(self.partials), nparts, bn.c, float(bn.count), ptr(bn.gamma),
@@ -533,7 +536,13 @@ class Engine(object):
     self.training = training
     self.update_moving = update_moving
     self.tape = []
-    self._cast_done = set()
+    # compute copies of the kernels and the inference BatchNorm vectors are rebuilt only when a variable
+    # changed since they were made (every training step; in inference only after set_params)
+    if self._cast_dirty or not hasattr(self, '_cast_done'):
+      self._cast_done = set()
+      for bn in self.bns.values():
+        bn.eval_done = False
+      self._cast_dirty = False
     for bn in self.bns.values():
       bn.bwd_ready = False
     for t in self._zero_list:      # atomic accumulation targets (SE pooled sums, ...) start every pass at zero
@@ -763,6 +772,7 @@ class Engine(object):
          ptr(self.ema) if use_ema else None, ptr(self.seg_offsets),
          None if already_scaled else ptr(self.seg_factor), self.nseg, ptr(self.hyper),
          float(self.config.momentum), self.stream)
+    self._cast_dirty = True
     self.step_count += 1
 
   def optimizer_step(self, lr, ema_decay=None, all_reduce=None):
