@@ -120,6 +120,9 @@ class Engine(object):
     self.gnorm = torch.zeros(1, dtype=torch.float32, device=self.device)
     self.pool_argmax = os.environ.get('EDET_POOL_ARGMAX', '1') != '0'
     self.stochastic_depth = stochastic_depth
+    # cross-replica BatchNorm (utils.SyncBatchNormalization / TpuBatchNormalization, utils.py:166-241):
+    # (all_reduce_fn, world_size) or None.  Set by train_lib when sync_bn=True.
+    self.sync_bn = None
     self.drop_masks = {}      # block scope -> (mask [n,c] fp32 = floor(p + u_n) / p, survival probability p)
     self._rng = torch.Generator(device=self.device)
     self._rng.manual_seed(1000003 * seed + 17)
@@ -245,8 +248,22 @@ class Engine(object):
       self.bns[name] = bn
     return bn
 
+  def _sync_partials(self, nparts, c):
+    """Cross-replica sum of the [nparts][2][c] partial rows -> one row at partials[0:2c] (every replica
+    normalises with the statistics of the GLOBAL batch: mean of the shard means / mean squares over equal
+    shards, utils.py:176-195,215-241).  Returns the local sums."""
+    reduce_fn, _ = self.sync_bn
+    local = self.partials[:nparts * 2 * c].view(nparts, 2 * c).sum(0)
+    total = local.clone()
+    reduce_fn(total)
+    self.partials[:2 * c].copy_(total)
+    return local
+
   def _bn_forward(self, bn, count, nparts):
     if self.training:
+      if self.sync_bn is not None:
+        self._sync_partials(nparts, bn.c)
+        nparts, count = 1, count * self.sync_bn[1]
       bn.count = count
       call('edet_bn_finalize', ptr(self.partials), nparts, bn.c, float(count), ptr(bn.gamma), ptr(bn.beta),
            self.bn_epsilon, self.bn_momentum if self.update_moving else -1.0,
@@ -260,8 +277,16 @@ class Engine(object):
       bn.eval_done = True
 
   def _bn_bwd_finalize(self, bn, nparts):
+    dgamma, dbeta = ptr(bn.dgamma), ptr(bn.dbeta)
+    if self.sync_bn is not None:
+      # gamma / beta gradients from the LOCAL sums (the gradient all-reduce adds the replicas up), the
+      # on-load coefficients (a, b, cc) from the GLOBAL sums over the global count
+      call('edet_bn_bwd_finalize', ptr(self.partials), nparts, bn.c, float(bn.count), ptr(bn.gamma),
+           ptr(bn.mean), ptr(bn.rstd), dgamma, dbeta, None, ptr(bn.a), ptr(bn.b), ptr(bn.cc), self.stream)
+      self._sync_partials(nparts, bn.c)
+      nparts, dgamma, dbeta = 1, None, None
     call('edet_bn_bwd_finalize', ptr(self.partials), nparts, bn.c, float(bn.count), ptr(bn.gamma),
-         ptr(bn.mean), ptr(bn.rstd), ptr(bn.dgamma), ptr(bn.dbeta), None, ptr(bn.a), ptr(bn.b), ptr(bn.cc),
+         ptr(bn.mean), ptr(bn.rstd), dgamma, dbeta, None, ptr(bn.a), ptr(bn.b), ptr(bn.cc),
          self.stream)
     bn.bwd_ready = True
 

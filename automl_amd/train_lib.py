@@ -119,14 +119,17 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
   """
 
   def __init__(self, *args, steps_per_epoch=1000, global_batch_size=None, process_group=None,
-               use_dist=False, use_graph=False, **kwargs):
+               use_dist=False, use_graph=False, sync_bn=False, **kwargs):
     """use_graph: capture the whole step (forward, loss, backward, L2/clip, update: ~1600 kernel launches)
     into a hipGraph at the second call for a given batch shape and replay it afterwards; inputs are
     copied into static device buffers (input_buffers() exposes them for in-place filling), learning
     rate / EMA decay / loss normalizer travel through a small device vector.  With data parallelism the
     gradient all-reduce stays an eager RCCL call between two captured halves."""
     super().__init__(*args, **kwargs)
-    self.use_graph = use_graph
+    # sync_bn: cross-replica BatchNorm statistics (the reference's --strategy=gpus / tpu BatchNorm classes,
+    # utils.py:166-266): two small all-reduces per BatchNorm layer and step, eager launches only.
+    self.sync_bn = sync_bn
+    self.use_graph = use_graph and not sync_bn
     self._graph = None
     self.steps_per_epoch = steps_per_epoch
     self.global_batch_size = global_batch_size
@@ -201,12 +204,13 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
       if g['graphs'] is None:
         torch.cuda.synchronize()
         ga = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
+        # thread_local: other threads of the process (the RCCL watchdog) may touch the HIP runtime meanwhile
+        with torch.cuda.graph(ga, capture_error_mode='thread_local'):
           body_a()
         gb = None
         if reduce_fn is not None:
           gb = torch.cuda.CUDAGraph()
-          with torch.cuda.graph(gb, pool=ga.pool()):
+          with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode='thread_local'):
             body_b()
         g['graphs'] = (ga, gb)
       ga, gb = g['graphs']
@@ -221,6 +225,9 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
     images, labels = data
     b, h, w = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
     eng = self._ensure_engine(b, h, w)
+    if self.sync_bn and self.use_dist and eng.sync_bn is None:
+      import torch.distributed as dist
+      eng.sync_bn = (make_grad_all_reduce(self.process_group), dist.get_world_size(self.process_group))
     lr = self._lr(b)
     if self.use_graph:
       decay = None

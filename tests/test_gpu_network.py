@@ -264,12 +264,63 @@ def test_graph_replay_matches_eager_steps(use_dist):
     (l0, w0, e0), (l1, w1, e1) = results
     for a, b in zip(l0, l1):
       for k in ('loss', 'cls_loss', 'box_loss', 'reg_l2_loss', 'gradient_norm', 'learning_rate'):
-        assert abs(a[k] - b[k]) <= 1e-4 * abs(a[k]) + 1e-6, (k, a[k], b[k])
+        # not bit-equal: fp32 atomics (SE pooling / FC, stem wgrad) round differently from run to run and
+        # the 2-sample BatchNorm statistics of the top pyramid levels amplify that over the 4 steps; a stale
+        # learning rate, normalizer or input buffer would show up at the 1e-1 level
+        assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-6, (k, a[k], b[k])
     assert l0[0]['learning_rate'] < l0[3]['learning_rate']
     for name in w0:
       d = float(np.abs(w0[name] - w1[name]).max())
-      assert d <= 1e-4 * float(np.abs(w0[name]).max()) + 1e-6, (name, d)
-    assert float(np.abs(e0 - e1).max()) <= 1e-4 * float(np.abs(e0).max()) + 1e-6
+      assert d <= 2e-3 * float(np.abs(w0[name]).max()) + 1e-6, (name, d)
+    assert float(np.abs(e0 - e1).max()) <= 2e-3 * float(np.abs(e0).max()) + 1e-6
   finally:
     if created:
       dist.destroy_process_group()
+
+
+def test_two_replicas_equal_one_big_batch(tmp_path):
+  """Data-parallel semantics on the real kernels: 2 replicas x 2 images with cross-replica BatchNorm and the
+  SUM all-reduce of the gradients give the same updated variables as ONE process on the 4 images (no
+  clipping, shared loss normalizer, weight decay counted once per replica as in the reference).  The two
+  replicas share this box's single GPU and talk over gloo; without sync-BN the replicas must still agree
+  with EACH OTHER bit for bit in structure (same all-reduced gradient) but differ from the big batch."""
+  import os
+  import subprocess
+  import sys
+  from tests import dp_worker
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  outs = {}
+  for sync_bn in (True, False):
+    base = str(tmp_path / ('dp%d' % sync_bn))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29541 + int(sync_bn)), WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, 'tests', 'dp_worker.py'), base, '%d' % sync_bn],
+                              env=dict(env, RANK=str(r)), cwd=root) for r in range(2)]
+    for p in procs:
+      assert p.wait(timeout=600) == 0
+    outs[sync_bn] = [dict(np.load(base + '.rank%d.npz' % r)) for r in range(2)]
+  # single process, the whole batch, weight decay doubled (each replica adds its own L2 gradient)
+  config, vals, images, labels = dp_worker.problem(4, 128)
+  config.override('weight_decay=%g' % (2 * config.weight_decay))
+  net = train_lib.EfficientDetNetTrain(config=config, dtype='f32', params=vals, steps_per_epoch=10,
+                                       global_batch_size=64)
+  one = net.train_step((images, labels))
+  torch.cuda.synchronize()
+  want = net.get_weights()
+  for sync_bn in (True, False):
+    r0, r1 = outs[sync_bn]
+    worst_pair = worst_big = 0.0
+    for name, w in want.items():
+      if name.endswith('moving_mean') or name.endswith('moving_variance'):
+        if not sync_bn:
+          continue
+      k = name.replace('/', '|')
+      scale = max(float(np.abs(w).max()), 1e-6)
+      worst_pair = max(worst_pair, float(np.abs(r0[k] - r1[k]).max()) / scale)
+      worst_big = max(worst_big, float(np.abs(r0[k] - w).max()) / scale)
+    print('sync_bn=%s: replicas differ by %.2e, replica vs one big batch %.2e' % (sync_bn, worst_pair, worst_big))
+    assert worst_pair <= 1e-6, worst_pair
+    if sync_bn:
+      assert worst_big <= 2e-4, worst_big
+      assert abs(float(r0['loss']) + float(r1['loss']) - one['det_loss']) <= 1e-3 * abs(one['det_loss'])
+    else:
+      assert worst_big > 1e-4       # local BatchNorm statistics: a different (the reference's non-sync) model
