@@ -285,6 +285,13 @@ __global__ void k_fuse_weights(const float* w0, const float* w1, const float* w2
     for (int i = 0; i < nin; ++i) wn[i] = 1.f;
     return;
   }
+  if (method == 2) {      // 'attn': softmax over the inputs (efficientdet_keras.py:84-88)
+    float m = w[0][0], e[3], s = 0.f;
+    for (int i = 1; i < nin; ++i) m = fmaxf(m, w[i][0]);
+    for (int i = 0; i < nin; ++i) { e[i] = expf(w[i][0] - m); s += e[i]; }
+    for (int i = 0; i < nin; ++i) wn[i] = e[i] / s;
+    return;
+  }
   float r[3], s = 0.f;
   for (int i = 0; i < nin; ++i) { r[i] = fmaxf(w[i][0], 0.f); s += r[i]; }
   for (int i = 0; i < nin; ++i) wn[i] = r[i] / (s + 0.0001f);
@@ -295,6 +302,14 @@ __global__ void k_fuse_weights_bwd(const float* w0, const float* w1, const float
   if (threadIdx.x != 0 || blockIdx.x != 0 || method == 1) return;
   const float* w[3] = {w0, w1, w2};
   float* dw[3] = {dw0, dw1, dw2};
+  if (method == 2) {      // softmax backward: dw_i = p_i * (dwn_i - sum_j dwn_j p_j)
+    float m = w[0][0], p[3], s = 0.f, dot = 0.f;
+    for (int i = 1; i < nin; ++i) m = fmaxf(m, w[i][0]);
+    for (int i = 0; i < nin; ++i) { p[i] = expf(w[i][0] - m); s += p[i]; }
+    for (int i = 0; i < nin; ++i) { p[i] /= s; dot += dwn[i] * p[i]; }
+    for (int i = 0; i < nin; ++i) dw[i][0] += p[i] * (dwn[i] - dot);
+    return;
+  }
   float r[3], s = 0.0001f, dot = 0.f;
   for (int i = 0; i < nin; ++i) { r[i] = fmaxf(w[i][0], 0.f); s += r[i]; }
   for (int i = 0; i < nin; ++i) dot += dwn[i] * r[i];

@@ -510,7 +510,7 @@ class Engine(object):
     nin = len(inputs)
     out = Raw(self, key, n, oh, ow, c)
     wn = self.buf(key + ':wn', (4,), torch.float32)
-    method = 0 if wnames else 1
+    method = (2 if self.spec.fpn.weight_method == 'attn' else 0) if wnames else 1
     wp = [ptr(self.param(w)) for w in wnames] + [None] * (3 - len(wnames)) if wnames else [None] * 3
     call('edet_fuse_weights', wp[0], wp[1], wp[2], nin, method, ptr(wn), self.stream)
     tv = [v.tview() for v in inputs]
@@ -684,7 +684,7 @@ class Engine(object):
               fh, fw, th, tw))
         ins.append(f)
       wnames = []
-      if fpn.weight_method == 'fastattn':
+      if fpn.weight_method in ('fastattn', 'attn'):
         wnames = [scope + '/WSM' + ('' if i == 0 else '_%d' % i) for i in range(len(ins))]
       x = self.fuse(scope + ':fuse', ins, modes, wnames, th, tw, act=ACT_SWISH)
       oc = '%s/op_after_combine%d' % (scope, len(feats))

@@ -48,8 +48,9 @@ class NetSpec(object):
                            for b in self.blocks]
     self.fpn = c.fpn_config or fpn_configs.get_fpn_config(c.fpn_name, c.min_level, c.max_level,
                                                          c.fpn_weight_method)
-    if self.fpn.weight_method not in ('fastattn', 'sum'):
-      raise ValueError('fpn weight_method %r is out of scope' % self.fpn.weight_method)
+    if self.fpn.weight_method not in ('fastattn', 'sum', 'attn'):
+      raise ValueError('fpn weight_method %r is out of scope (per-channel channel_attn / channel_fastattn '
+                       'weights are not built)' % self.fpn.weight_method)
     self.num_anchors = len(c.aspect_ratios) * c.num_scales
     self._build()
 
@@ -115,7 +116,7 @@ class NetSpec(object):
             self._add(rs + '/conv2d/kernel', (1, 1, ch[off], wf), 'glorot')
             self._add(rs + '/conv2d/bias', (wf,), 'zeros')
             self._bn(rs + '/bn', wf)
-        if self.fpn.weight_method == 'fastattn':
+        if self.fpn.weight_method in ('fastattn', 'attn'):
           for i in range(len(node['inputs_offsets'])):
             self._add(s + '/WSM' + ('' if i == 0 else '_%d' % i), (), 'ones')
         oc = '%s/op_after_combine%d' % (s, len(ch))

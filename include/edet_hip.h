@@ -217,7 +217,7 @@ int edet_se_gate_bwd(const edet_tview_t* in, void* g, const float* dpool,
  * resample), :214-217 (swish before the separable conv).
  * out = act( sum_i wn_i * resample_i(view_i) ), wn = normalised weights (fp32[3]).  */
 int edet_fuse_weights(const float* w0, const float* w1, const float* w2, int nin,
-                      int method /*0 fastattn, 1 sum*/, float* wn, void* stream);
+                      int method /*0 fastattn, 1 sum, 2 attn (softmax)*/, float* wn, void* stream);
 int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
                   const int* modes, int nin, const float* wn, int act,
                   void* out, int oh, int ow, int ldo, int dtype, void* stream);
