@@ -1135,6 +1135,222 @@ __global__ __launch_bounds__(THREADS, 3) void k_dgrad_lx(const Args a) {
   if (want_stats) block_channel_sums<CPT, 2>(a, l, C, st, a.epi.stat_partials, red);
 }
 
+// =====================================================================================================
+// Fused backward for stride 1: data gradient AND weight gradient in one march (edet_dw_bwd).
+// Both need the same operands -- dy = BN-backward(dz, y) around a pixel and the saved input x of the pixel:
+//   d in[iy][ix]   = sum_{ky,kx} w[ky][kx] * dy[iy+p-ky][ix+p-kx]          (then * act'(z), + old, BN sums)
+//   dW[ky][kx]    += act(z)[iy][ix]        * dy[iy+p-ky][ix+p-kx]
+// so the separate kernels read (dz, y, x) twice and evaluate the BatchNorm backward and the sigmoid of z twice.
+// Here thread (column ix, CPT channels) marches over the dy rows oy: the transformed dy row goes through the
+// LDS ring (K column neighbours come back after the barrier), the thread's own column of x is kept as a
+// K-row register window of act(z) (for dW) and act'(z) (for the epilogue of the row that completes), and
+// every neighbour value g = dy[oy][ix+p-kx] feeds both accumulations:
+//   dacc[ky][.] += w[ky][kx] * g   (input row iy = oy - p + ky)      wacc[ky][kx] += act(z)[oy - p + ky] * g
+// One pass: reads dz, y, x once, writes d in once; one sigmoid and one BN-backward FMA pair per element.
+// A tile owns the input rows [r0, r1) x its columns: dy rows r0-p .. r1-1+p are marched (the 2p extra rows
+// are re-read by the neighbouring tile), x rows outside [r0, r1) enter the window as zeros so that every
+// (x pixel, dy pixel) pair is counted by exactly one tile.
+template <int K, int CPT, bool GBN>
+__global__ __launch_bounds__(THREADS, CPT * K >= 10 ? 2 : 3) void k_bwd_fused(const Args a) {
+  constexpr int PD = (K - 1) / 2;             // 'SAME' padding of an odd kernel at stride 1
+  constexpr int PF = 3;                       // rows of global loads in flight
+  extern __shared__ float red[];
+  const int C = a.in.c, H = a.in.h, W = a.in.w;
+  const Lane l = lane_setup<CPT>(a, C);
+  const int width = a.nch * CPT;
+  const int WIN = a.TX + K - 1;
+  float* ring = red + red_floats(a.nch, CPT);
+  const bool in_tile = l.px < a.TX;
+  const bf16_t* X = reinterpret_cast<const bf16_t*>(a.in.data);
+  const bf16_t* DZ = reinterpret_cast<const bf16_t*>(a.gy.dz);
+  const bf16_t* YY = reinterpret_cast<const bf16_t*>(a.gy.y);
+  bf16_t* GO = reinterpret_cast<bf16_t*>(a.epi.gout);
+  float w[K * K][CPT], wacc[K * K][CPT], sc[CPT], sh[CPT], ga[CPT], gb[CPT], gc[CPT], mu[CPT], rs[CPT];
+  float st[2][CPT];
+#pragma unroll
+  for (int e = 0; e < CPT; ++e) {
+    sc[e] = 1.f; sh[e] = 0.f; ga[e] = 1.f; gb[e] = 0.f; gc[e] = 0.f; mu[e] = 0.f; rs[e] = 1.f;
+    st[0][e] = st[1][e] = 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < K * K; ++t)
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) {
+      w[t][e] = l.active ? a.w[(size_t)t * C + l.c + e] : 0.f;
+      wacc[t][e] = 0.f;
+    }
+  const bool want_stats = a.epi.stat_partials != nullptr;
+  const bool swish = a.in.act == EDET_ACT_SWISH;
+  if (l.active) {
+    if (a.in.scale) { loadf<CPT>(a.in.scale + l.c, sc); loadf<CPT>(a.in.shift + l.c, sh); }
+    if (GBN) { loadf<CPT>(a.gy.a + l.c, ga); loadf<CPT>(a.gy.b + l.c, gb); loadf<CPT>(a.gy.cc + l.c, gc); }
+    if (want_stats) { loadf<CPT>(a.epi.mean + l.c, mu); loadf<CPT>(a.epi.rstd + l.c, rs); }
+  }
+
+  for (int tile = l.p; tile < a.ntiles; tile += a.P) {
+    const int per_img = a.tiles_y * a.tiles_x;
+    const int n = tile / per_img, rr = tile - n * per_img;
+    const int ty_ = rr / a.tiles_x, tx_ = rr - ty_ * a.tiles_x;
+    const int q0 = tx_ * a.TX;
+    const int q = q0 + l.px;                                   // own column (input == dy column at stride 1)
+    const bool qok = l.active && in_tile && q < W;
+    const int r0 = ty_ * a.TY, r1 = min(H, r0 + a.TY);
+    // halo columns of the dy window: px < PD -> left column q0 - PD + px (wc = px), PD <= px < 2 PD -> right
+    // column q0 + TX + (px - PD) (wc = TX + px)
+    const bool hown = l.px < K - 1 && in_tile;
+    const int qh = l.px < PD ? q0 - PD + l.px : q0 + a.TX + (l.px - PD);
+    const int wch = l.px < PD ? l.px : a.TX + l.px;
+    const bool hok = hown && l.c < C && qh >= 0 && qh < W;
+    const size_t img = (size_t)n * H * W;
+    float dacc[K][CPT], xt[K][CPT], dsw[K][CPT];
+    Raw<CPT> xw[K];                                            // raw x of the window rows (BN backward sums)
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      xw[s] = raw_zero<CPT>();
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) { dacc[s][e] = 0.f; xt[s][e] = 0.f; dsw[s][e] = 1.f; }
+    }
+    // step t: dy row oy = r0 - PD + t, newest x row iy = r0 + t, completed row iy = r0 - 2 PD + t
+    const int t_last = (r1 - r0) - 1 + 2 * PD;
+    Raw<CPT> fz[PF + 1], fy[GBN ? PF + 1 : 1], fhz[PF + 1], fhy[GBN ? PF + 1 : 1], fx[PF + 1];
+#pragma unroll
+    for (int i = 0; i <= PF; ++i) {
+      fz[i] = fhz[i] = fx[i] = raw_zero<CPT>();
+      if (GBN) fy[i] = fhy[i] = raw_zero<CPT>();
+    }
+    if (!GBN) fy[0] = fhy[0] = raw_zero<CPT>();
+    auto load_step = [&](int t, Raw<CPT>& z, Raw<CPT>& y, Raw<CPT>& hz, Raw<CPT>& hy, Raw<CPT>& x) {
+      const int oy = r0 - PD + t;
+      z = hz = raw_zero<CPT>();
+      if (GBN) y = hy = raw_zero<CPT>();
+      if (t <= t_last && oy >= 0 && oy < H) {                  // uniform
+        const size_t rowoff = (img + (size_t)oy * W) * a.gy.ld + l.c;
+        if (qok) {
+          z = raw_load<CPT>(DZ + rowoff + (size_t)q * a.gy.ld);
+          if (GBN) y = raw_load<CPT>(YY + rowoff + (size_t)q * a.gy.ld);
+        }
+        if (hok) {
+          hz = raw_load<CPT>(DZ + rowoff + (size_t)qh * a.gy.ld);
+          if (GBN) hy = raw_load<CPT>(YY + rowoff + (size_t)qh * a.gy.ld);
+        }
+      }
+      const int iy = r0 + t;
+      x = raw_zero<CPT>();
+      if (iy < r1 && qok) x = raw_load<CPT>(X + (img + (size_t)iy * W + q) * a.in.ld + l.c);
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) load_step(i, fz[i], fy[GBN ? i : 0], fhz[i], fhy[GBN ? i : 0], fx[i]);
+    for (int tb = 0; tb <= t_last; tb += K) {
+#pragma unroll
+      for (int tt = 0; tt < K; ++tt) {
+        const int t = tb + tt;
+        load_step(t + PF, fz[PF], fy[GBN ? PF : 0], fhz[PF], fhy[GBN ? PF : 0], fx[PF]);
+        const int oy = r0 - PD + t;
+        // ---- newest x row enters the window at slot (tt + K - 1) % K
+        {
+          constexpr int dummy = 0; (void)dummy;
+          const int sl = slot_of(tt + K - 1, K);
+          const int iy = r0 + t;
+          float x[CPT], z[CPT];
+          raw_unpack<CPT>(fx[0], x);
+          xw[sl] = fx[0];
+          const bool xin = iy < r1 && qok;
+#pragma unroll
+          for (int e = 0; e < CPT; ++e) z[e] = fmaf(x[e], sc[e], sh[e]);
+          if (swish) {
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) {
+              const float sg = sigmoidf_(z[e]);
+              xt[sl][e] = xin ? z[e] * sg : 0.f;
+              dsw[sl][e] = sg * (1.f + z[e] * (1.f - sg));
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) { xt[sl][e] = xin ? z[e] : 0.f; dsw[sl][e] = 1.f; }
+          }
+        }
+        // ---- dy row oy through the LDS ring
+        const bool row_ok = t <= t_last && oy >= 0 && oy < H;   // uniform
+        float* buf = ring + (t & 1) * WIN * width;
+        if (row_ok && in_tile) {
+          float g[CPT];
+          raw_unpack<CPT>(fz[0], g);
+          if (GBN) {
+            float y[CPT];
+            raw_unpack<CPT>(fy[0], y);
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) g[e] = qok ? fmaf(ga[e], g[e], fmaf(gb[e], y[e], gc[e])) : 0.f;
+          }
+          lds_put<CPT>(buf + (l.px + PD) * width + l.chunk * CPT, g);
+          if (hown) {
+            raw_unpack<CPT>(fhz[0], g);
+            if (GBN) {
+              float y[CPT];
+              raw_unpack<CPT>(fhy[0], y);
+#pragma unroll
+              for (int e = 0; e < CPT; ++e) g[e] = hok ? fmaf(ga[e], g[e], fmaf(gb[e], y[e], gc[e])) : 0.f;
+            }
+            lds_put<CPT>(buf + wch * width + l.chunk * CPT, g);
+          }
+        }
+        __syncthreads();
+        if (row_ok && in_tile) {
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) {
+            float g[CPT];
+            lds_get<CPT>(buf + (l.px + 2 * PD - kx) * width + l.chunk * CPT, g);   // dy[oy][q + PD - kx]
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+              const int sl = slot_of(tt + ky, K);                                 // input row oy - PD + ky
+#pragma unroll
+              for (int e = 0; e < CPT; ++e) {
+                dacc[sl][e] = fmaf(w[ky * K + kx][e], g[e], dacc[sl][e]);
+                wacc[ky * K + kx][e] = fmaf(xt[sl][e], g[e], wacc[ky * K + kx][e]);
+              }
+            }
+          }
+        }
+        // ---- input row iy = oy - PD is complete (slot tt % K)
+        {
+          const int sl = slot_of(tt, K);
+          const int iy = oy - PD;
+          if (t <= t_last && iy >= r0 && iy < r1 && qok) {
+            const size_t off = (img + (size_t)iy * W + q) * a.in.ld + l.c;
+            float g[CPT], x[CPT];
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) g[e] = dacc[sl][e] * dsw[sl][e];
+            if (a.epi.beta) {
+              float old[CPT];
+              raw_unpack<CPT>(raw_load<CPT>(GO + off), old);
+#pragma unroll
+              for (int e = 0; e < CPT; ++e) g[e] += old[e];
+            }
+            store_bf<CPT>(GO + off, g);
+            if (want_stats) {
+              raw_unpack<CPT>(xw[sl], x);
+#pragma unroll
+              for (int e = 0; e < CPT; ++e) {
+                st[0][e] += g[e];
+                st[1][e] = fmaf(g[e], (x[e] - mu[e]) * rs[e], st[1][e]);
+              }
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < CPT; ++e) dacc[sl][e] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+          fz[i] = fz[i + 1]; fhz[i] = fhz[i + 1]; fx[i] = fx[i + 1];
+          if (GBN) { fy[i] = fy[i + 1]; fhy[i] = fhy[i + 1]; }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (want_stats) block_channel_sums<CPT, 2>(a, l, C, st, a.epi.stat_partials, red);
+  block_channel_sums<CPT, K * K>(a, l, C, wacc, a.ws, red);
+}
+
 // ------------------------------------------------------------------------------------- host
 inline int pick_nch(int nvec, int maxch) {
   if (nvec <= maxch) return nvec;
@@ -1285,5 +1501,45 @@ int dwm_try_dgrad(const edet_gview_t* dy, const float* weight, int k, int s, con
 #undef DWM_DG
   if (nparts_out) *nparts_out = a.P;
   EDET_LAUNCH_CHECK("edet_dw_bwd_data(march)");
+  return 1;
+}
+
+// fused data + weight gradient (stride 1): 1 = handled, 0 = not applicable (the caller runs the two kernels)
+int dwm_try_bwd_fused(const edet_gview_t* dy, const float* weight, int k, int s, const edet_tview_t* in,
+                      const edet_bwd_epi_t* epi, int* nparts_out, float* dweight, void* workspace,
+                      size_t workspace_bytes, hipStream_t st) {
+  using namespace dwm;
+  static const bool enabled = !(getenv("EDET_DW_FUSED") && getenv("EDET_DW_FUSED")[0] == '0');
+  // k = 3: 4 channels per thread (8-byte loads, 2 waves/SIMD) wins on the large maps, 2 channels per thread
+  // (3-4 waves/SIMD) on the small ones (measured: 320x320x32 1.08 vs 1.55 ms, 40x40x64 1.25 vs 1.05 ms)
+  const char* c4env = getenv("EDET_DW_FUSED_C4");
+  const bool k3c4 = c4env ? c4env[0] == '1' : (int64_t)in->h * in->w >= 128 * 128;
+  if (!enabled || s != 1 || (k != 3 && k != 5) || in->gate || epi->dgate || in->c % 8 != 0 || !workspace) return 0;
+  Args a;
+  memset(&a, 0, sizeof(a));
+  a.in = *in; a.gy = *dy; a.w = weight; a.epi = *epi; a.ws = reinterpret_cast<float*>(workspace);
+  a.oh = in->h; a.ow = in->w;
+  a.pad_t = a.pad_l = (k - 1) / 2;
+  const int64_t kkc = (int64_t)k * k * in->c;
+  int max_p = (int)((int64_t)(workspace_bytes / sizeof(float)) / kkc);
+  if (max_p < 1) return 0;
+  if (max_p > EDET_MAX_PARTS) max_p = EDET_MAX_PARTS;
+  const bool gbn = dy->a != nullptr;
+#define DWM_FUSED(K_, CPT_)                                                               \
+  do {                                                                                    \
+    plan<CPT_>(a, in->c, in->n, in->w, in->h, max_p);                                     \
+    const size_t lds = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                   \
+    const size_t ring = (size_t)2 * (a.TX + K_ - 1) * a.nch * CPT_ * sizeof(float);       \
+    const dim3 grid(a.P * a.ngroups), block(THREADS);                                     \
+    if (gbn) k_bwd_fused<K_, CPT_, true><<<grid, block, lds + ring, st>>>(a);             \
+    else k_bwd_fused<K_, CPT_, false><<<grid, block, lds + ring, st>>>(a);                \
+  } while (0)
+  if (k == 3 && k3c4) DWM_FUSED(3, 4);
+  else if (k == 3) DWM_FUSED(3, 2);
+  else DWM_FUSED(5, 2);
+#undef DWM_FUSED
+  if (nparts_out) *nparts_out = a.P;
+  EDET_LAUNCH_CHECK("edet_dw_bwd(fused)");
+  if (edet_reduce_partials(a.ws, a.P, kkc, dweight, st) != 0) return -2;
   return 1;
 }

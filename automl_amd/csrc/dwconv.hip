@@ -471,6 +471,10 @@ int dwm_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, 
 int dwm_try_dgrad(const edet_gview_t* dy, const float* weight, int k, int s, const edet_tview_t* in,
                   const edet_bwd_epi_t* epi, int* nparts_out, hipStream_t st);
 
+int dwm_try_bwd_fused(const edet_gview_t* dy, const float* weight, int k, int s, const edet_tview_t* in,
+                      const edet_bwd_epi_t* epi, int* nparts_out, float* dweight, void* workspace,
+                      size_t workspace_bytes, hipStream_t st);
+
 extern "C" int edet_dw_fwd(const edet_tview_t* in, const float* weight, int k, int stride,
                            void* out, int ldo, float* stat_partials, int* nparts_out,
                            int dtype, void* stream) {
@@ -516,4 +520,21 @@ extern "C" int edet_dw_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy
     if (rc != 0) return rc < 0 ? rc : 0;
   }
   return run(DW_BWD_WEIGHT, k, stride, a, dtype, stream, nullptr);
+}
+
+// Data gradient and weight gradient of one depthwise layer.  Stride 1, bf16: one fused kernel (dw_march.hip,
+// k_bwd_fused) that reads (dz, y, x) once; everything else: the two separate entry points, in this order.
+extern "C" int edet_dw_bwd(const edet_gview_t* dy, const float* weight, int k, int stride,
+                           const edet_tview_t* in, const edet_bwd_epi_t* epi, int* nparts_out,
+                           float* dweight, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+  EDET_CHECK(dy && dy->dz && weight && in && in->data && epi && epi->gout && dweight, "edet_dw_bwd: null pointer");
+  EDET_CHECK(!(epi->stat_partials && epi->beta), "edet_dw_bwd: fused stats need beta == 0");
+  if (dtype == EDET_BF16 && dy->ld % 8 == 0) {
+    const int rc = dwm_try_bwd_fused(dy, weight, k, stride, in, epi, nparts_out, dweight, workspace,
+                                     workspace_bytes, to_stream(stream));
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
+  const int rc = edet_dw_bwd_weight(in, dy, k, stride, dweight, workspace, workspace_bytes, dtype, stream);
+  if (rc != 0) return rc;
+  return edet_dw_bwd_data(dy, weight, k, stride, in, epi, nparts_out, dtype, stream);
 }

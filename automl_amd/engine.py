@@ -120,6 +120,7 @@ class Engine(object):
     self.gnorm = torch.zeros(1, dtype=torch.float32, device=self.device)
     self.pool_argmax = os.environ.get('EDET_POOL_ARGMAX', '1') != '0'
     self.stochastic_depth = stochastic_depth
+    self.fused_dw_bwd = os.environ.get('EDET_DW_BWD_ENTRY', '1') != '0'   # one edet_dw_bwd call per stride-1 layer
     # cross-replica BatchNorm (utils.SyncBatchNormalization / TpuBatchNormalization, utils.py:166-241):
     # (all_reduce_fn, world_size) or None.  Set by train_lib when sync_bn=True.
     self.sync_bn = None
@@ -408,6 +409,15 @@ class Engine(object):
     g = self._gview(vout)
     nb = (vin.raw.rows + vout.raw.rows) * vin.raw.c * self.esize
     tag = '%dx%dx%d k%ds%d' % (vin.raw.h, vin.raw.w, vin.raw.c, k, stride)
+    if vin.raw.needs_grad and stride == 1 and self.fused_dw_bwd:
+      epi, fused = self._epi(vin)
+      call('edet_dw_bwd', ctypes.byref(g), ptr(self.param(wname)), k, stride, ctypes.byref(vin.tview()),
+           ctypes.byref(epi), ctypes.byref(self._nparts), ptr(self.grad(wname)), ptr(self.workspace),
+           self.workspace.numel() * 4, self.dtype, self.stream, nbytes=2 * nb, tag=tag)
+      vin.raw.grad_written = True
+      if fused:
+        self._bn_bwd_finalize(vin.bn, self._nparts.value)
+      return
     call('edet_dw_bwd_weight', ctypes.byref(vin.tview()), ctypes.byref(g), k, stride, ptr(self.grad(wname)),
          ptr(self.workspace), self.workspace.numel() * 4, self.dtype, self.stream, nbytes=nb, tag=tag)
     if vin.raw.needs_grad:

@@ -159,6 +159,13 @@ int edet_dw_bwd_data(const edet_gview_t* dy, const float* weight, int k, int str
 int edet_dw_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy, int k, int stride,
                        float* dweight, void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
+/* both gradients of one layer in one call: the same result as edet_dw_bwd_weight followed by
+ * edet_dw_bwd_data (same arguments); for stride 1 in bf16 a single fused kernel that reads dy, the
+ * saved conv output behind it and the saved input once.  */
+int edet_dw_bwd(const edet_gview_t* dy, const float* weight, int k, int stride,
+                const edet_tview_t* in, const edet_bwd_epi_t* epi, int* nparts_out,
+                float* dweight, void* workspace, size_t workspace_bytes, int dtype, void* stream);
+
 /* ---- BatchNorm statistics --------------------------------------------------
  * utils.py:244-266 / util_keras.py:29-66 (eps 1e-3, momentum 0.99).
  * finalize: partial sums -> batch mean / biased variance -> scale, shift, mean,

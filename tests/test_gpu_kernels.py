@@ -281,8 +281,10 @@ def test_dw_fwd(dt, shape, ks, mode):
 @pytest.mark.parametrize('shape', DW_SHAPES)
 @pytest.mark.parametrize('ks', [(3, 1), (3, 2), (5, 1), (5, 2)])
 @pytest.mark.parametrize('mode', ['plain_beta', 'bn_swish_stats'])
-def test_dw_bwd(dt, shape, ks, mode):
-  """data gradient (with epilogue chain) and weight gradient against autograd."""
+@pytest.mark.parametrize('entry', ['separate', 'one_call', 'one_call_plain_dy'])
+def test_dw_bwd(dt, shape, ks, mode, entry):
+  """data gradient (with epilogue chain) and weight gradient against autograd; through the two separate
+  entry points and through edet_dw_bwd (stride 1, bf16: the fused kernel), with and without BN-backward on dy."""
   name, edt, tdt = dt
   n, h, w, c = shape
   k, s = ks
@@ -291,7 +293,7 @@ def test_dw_bwd(dt, shape, ks, mode):
   wk = torch.from_numpy((rng.standard_normal((k, k, c)) / k).astype(np.float32))
   oh, _, _ = __import__('automl_amd.utils', fromlist=['x']).same_padding(h, k, s)
   ow, _, _ = __import__('automl_amd.utils', fromlist=['x']).same_padding(w, k, s)
-  dz, y, ga, gb, gcc, dy = make_grad_view(rng, n, oh, ow, c, tdt, True)
+  dz, y, ga, gb, gcc, dy = make_grad_view(rng, n, oh, ow, c, tdt, entry != 'one_call_plain_dy')
   scale = shift = mean = rstd = None
   act = ACT_NONE
   old = None
@@ -310,7 +312,7 @@ def test_dw_bwd(dt, shape, ks, mode):
   want_g = zz.grad + (old if old is not None else 0)
   want_dw = wq.grad
 
-  xd, dzd, yd = gu.to_dev(x, tdt), gu.to_dev(dz, tdt), gu.to_dev(y, tdt)
+  xd, dzd, yd = gu.to_dev(x, tdt), gu.to_dev(dz, tdt), (gu.to_dev(y, tdt) if y is not None else None)
   gv = gu.gview(dzd, c, yd, ga, gb, gcc)
   sc, sh, wd = gu.fdev(scale), gu.fdev(shift), gu.fdev(wk)
   tv = gu.tview(xd, c, sc, sh, None, act)
@@ -322,12 +324,16 @@ def test_dw_bwd(dt, shape, ks, mode):
   epi = BwdEpi(ptr(gout), 0 if stats else 1, ptr(md) if stats else None, ptr(rd) if stats else None,
                ptr(parts) if stats else None, None)
   npart = NP(0)
-  call('edet_dw_bwd_data', ctypes.byref(gv), ptr(wd), k, s, ctypes.byref(tv), ctypes.byref(epi),
-       ctypes.byref(npart), edt, gu.stream())
   dwd = torch.zeros(k, k, c, dtype=torch.float32, device=gu.DEV)
   wsp = torch.empty(4 * 1024 * 1024, dtype=torch.float32, device=gu.DEV)
-  call('edet_dw_bwd_weight', ctypes.byref(tv), ctypes.byref(gv), k, s, ptr(dwd), ptr(wsp), 16 * 1024 * 1024, edt,
-       gu.stream())
+  if entry == 'separate':
+    call('edet_dw_bwd_data', ctypes.byref(gv), ptr(wd), k, s, ctypes.byref(tv), ctypes.byref(epi),
+         ctypes.byref(npart), edt, gu.stream())
+    call('edet_dw_bwd_weight', ctypes.byref(tv), ctypes.byref(gv), k, s, ptr(dwd), ptr(wsp), 16 * 1024 * 1024, edt,
+         gu.stream())
+  else:
+    call('edet_dw_bwd', ctypes.byref(gv), ptr(wd), k, s, ctypes.byref(tv), ctypes.byref(epi), ctypes.byref(npart),
+         ptr(dwd), ptr(wsp), 16 * 1024 * 1024, edt, gu.stream())
   torch.cuda.synchronize()
   gu.check(gout, want_g, name, 'dw_bwd_data %s k%d s%d %s' % (shape, k, s, mode))
   gu.check(dwd, want_dw, name, 'dw_bwd_weight %s k%d s%d' % (shape, k, s), rtol=1e-3, atol=1e-3)
