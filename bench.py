@@ -134,13 +134,21 @@ def main():
   world = int(os.environ.get('WORLD_SIZE', '1'))
   if args.gpus > 1 and world != args.gpus:
     raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+  # EDET_BENCH_SAME_DEVICE=1 + EDET_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a 1-GPU box (all ranks
+  # on cuda:0, gloo between them); never set for a measurement
+  if os.environ.get('EDET_BENCH_SAME_DEVICE') == '1':
+    local_rank = 0
+  backend = os.environ.get('EDET_BENCH_BACKEND', 'nccl')
   device = 'cuda:%d' % local_rank
   torch.cuda.set_device(device)
   dist = None
   if world > 1:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device))
+    if backend == 'nccl':
+      dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device))
+    else:
+      dist.init_process_group(backend, rank=rank, world_size=world)
 
   config = hparams_config.get_efficientdet_config(args.model)
   config.override('image_size=%d' % args.image_size)
@@ -250,7 +258,7 @@ def main():
             'per_kernel_ms': {k: round(v[1], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1][1])[:12]},
         },
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
       out['cpu_baseline'] = cpu_baseline(config, args.image_size)
     print(json.dumps(out))
   if dist is not None:
