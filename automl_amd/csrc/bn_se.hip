@@ -106,26 +106,30 @@ __global__ __launch_bounds__(THREADS) void k_bn_bwd_reduce(const T* __restrict__
                                                           const float* rstd, float* partials, RowMap m) {
   const int tid = threadIdx.x;
   const int cv = tid % m.tpr, rr = tid / m.tpr;
-  const int c0 = cv * 8;
-  const bool ok = c0 < c;
-  float mu[8], rs[8], s1[8], s2[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { mu[e] = 0.f; rs[e] = 0.f; s1[e] = s2[e] = 0.f; }
-  if (ok) { loadf8(mean + c0, mu); loadf8(rstd + c0, rs); }
-  for (int64_t r = (int64_t)blockIdx.x * m.rpp + rr; r < rows; r += (int64_t)gridDim.x * m.rpp) {
-    if (!ok) continue;
-    float g[8], x[8];
-    load8<T>(dz + r * ld + c0, g);
-    load8<T>(y + r * ld + c0, x);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { s1[e] += g[e]; s2[e] += g[e] * (x[e] - mu[e]) * rs[e]; }
-  }
   extern __shared__ float red[];  // [2][c]
   for (int i = tid; i < 2 * c; i += THREADS) red[i] = 0.f;
   __syncthreads();
-  if (ok) {
+  // channel blocks of tpr*8 (<= 2048) channels: one iteration for every layer up to 2048 channels, two for the
+  // widest EfficientNet-B3..B7 stages
+  for (int cb = 0; cb < c; cb += m.tpr * 8) {
+    const int c0 = cb + cv * 8;
+    const bool ok = c0 < c;
+    float mu[8], rs[8], s1[8], s2[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { atomicAdd(&red[c0 + e], s1[e]); atomicAdd(&red[c + c0 + e], s2[e]); }
+    for (int e = 0; e < 8; ++e) { mu[e] = 0.f; rs[e] = 0.f; s1[e] = s2[e] = 0.f; }
+    if (ok) {
+      loadf8(mean + c0, mu);
+      loadf8(rstd + c0, rs);
+      for (int64_t r = (int64_t)blockIdx.x * m.rpp + rr; r < rows; r += (int64_t)gridDim.x * m.rpp) {
+        float g[8], x[8];
+        load8<T>(dz + r * ld + c0, g);
+        load8<T>(y + r * ld + c0, x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += g[e]; s2[e] += g[e] * (x[e] - mu[e]) * rs[e]; }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { atomicAdd(&red[c0 + e], s1[e]); atomicAdd(&red[c + c0 + e], s2[e]); }
+    }
   }
   __syncthreads();
   for (int i = tid; i < 2 * c; i += THREADS) partials[(size_t)blockIdx.x * 2 * c + i] = red[i];
@@ -203,32 +207,31 @@ __global__ __launch_bounds__(THREADS) void k_se_pool(const edet_tview_t in, floa
   const int tid = threadIdx.x;
   const int n = blockIdx.x / wg_per_img, part = blockIdx.x % wg_per_img;
   const int cv = tid % m.tpr, rr = tid / m.tpr;
-  const int c0 = cv * 8;
-  const bool ok = c0 < in.c;
   const int hw = in.h * in.w;
-  float s[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) s[e] = 0.f;
-  ViewCoef vc;
-  if (ok) view_load_coef(in, c0, vc);
-  edet_tview_t v = in;
-  v.gate = nullptr;
-  const T* base = reinterpret_cast<const T*>(in.data) + (size_t)n * hw * in.ld;
-  if (ok) {
-    for (int r = part * m.rpp + rr; r < hw; r += wg_per_img * m.rpp) {
-      float x[8];
-      load8<T>(base + (size_t)r * in.ld + c0, x);
-      view_apply(v, vc, c0, n, x);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s[e] += x[e];
-    }
-  }
   extern __shared__ float red[];  // [c]
   for (int i = tid; i < in.c; i += THREADS) red[i] = 0.f;
   __syncthreads();
-  if (ok) {
+  edet_tview_t v = in;
+  v.gate = nullptr;
+  const T* base = reinterpret_cast<const T*>(in.data) + (size_t)n * hw * in.ld;
+  for (int cb = 0; cb < in.c; cb += m.tpr * 8) {     // channel blocks of <= 2048 channels
+    const int c0 = cb + cv * 8;
+    if (c0 < in.c) {
+      float s[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(&red[c0 + e], s[e]);
+      for (int e = 0; e < 8; ++e) s[e] = 0.f;
+      ViewCoef vc;
+      view_load_coef(in, c0, vc);
+      for (int r = part * m.rpp + rr; r < hw; r += wg_per_img * m.rpp) {
+        float x[8];
+        load8<T>(base + (size_t)r * in.ld + c0, x);
+        view_apply(v, vc, c0, n, x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += x[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(&red[c0 + e], s[e]);
+    }
   }
   __syncthreads();
   for (int i = tid; i < in.c; i += THREADS) atomicAdd(&pooled[(size_t)n * in.c + i], red[i]);
@@ -408,9 +411,13 @@ __global__ __launch_bounds__(THREADS) void k_se_gate_bwd(const edet_tview_t in, 
   const int tid = threadIdx.x;
   const int n = blockIdx.x / wg_per_img, part = blockIdx.x % wg_per_img;
   const int cv = tid % m.tpr, rr = tid / m.tpr;
-  const int c0 = cv * 8;
-  const bool ok = c0 < in.c;
   const int hw = in.h * in.w;
+  extern __shared__ float red[];  // [2][c]
+  for (int i = tid; i < 2 * in.c; i += THREADS) red[i] = 0.f;
+  __syncthreads();
+  for (int cb = 0; cb < in.c; cb += m.tpr * 8) {     // channel blocks of <= 2048 channels
+  const int c0 = cb + cv * 8;
+  const bool ok = c0 < in.c;
   float s1[8], s2[8], sc[8], sh[8], mu[8], rs[8], gt[8], dp[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = s2[e] = 0.f; sc[e] = 1.f; sh[e] = 0.f; mu[e] = 0.f; rs[e] = 1.f; gt[e] = 1.f; dp[e] = 0.f; }
@@ -436,13 +443,9 @@ __global__ __launch_bounds__(THREADS) void k_se_gate_bwd(const edet_tview_t in, 
       }
       store8<T>(g + off, d);
     }
-  }
-  extern __shared__ float red[];  // [2][c]
-  for (int i = tid; i < 2 * in.c; i += THREADS) red[i] = 0.f;
-  __syncthreads();
-  if (ok) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { atomicAdd(&red[c0 + e], s1[e]); atomicAdd(&red[in.c + c0 + e], s2[e]); }
+  }
   }
   __syncthreads();
   for (int i = tid; i < 2 * in.c; i += THREADS) partials[(size_t)blockIdx.x * 2 * in.c + i] = red[i];
@@ -516,7 +519,7 @@ extern "C" int edet_bn_bwd_reduce(const void* dz, const void* y, int64_t rows, i
                                   const float* mean, const float* rstd, float* stat_partials,
                                   int* nparts_out, int dtype, void* stream) {
   EDET_CHECK(dz && y && mean && rstd && stat_partials, "edet_bn_bwd_reduce: null pointer");
-  EDET_CHECK(c % 8 == 0 && ld % 8 == 0 && c <= 2048, "edet_bn_bwd_reduce: c/ld must be multiples of 8, c <= 2048");
+  EDET_CHECK(c % 8 == 0 && ld % 8 == 0 && c <= 8192, "edet_bn_bwd_reduce: c/ld must be multiples of 8, c <= 8192");
   const RowMap m = row_map(c);
   const int grid = persistent_grid(rows, m.rpp, 512);
   if (nparts_out) *nparts_out = grid;
@@ -578,7 +581,7 @@ static int se_wg_per_img(int n, int hw, int rpp) {
 
 extern "C" int edet_se_pool(const edet_tview_t* in, float* pooled_sum, int dtype, void* stream) {
   EDET_CHECK(in && in->data && pooled_sum, "edet_se_pool: null pointer");
-  EDET_CHECK(in->c % 8 == 0 && in->ld % 8 == 0 && in->c <= 2048, "edet_se_pool: c/ld");
+  EDET_CHECK(in->c % 8 == 0 && in->ld % 8 == 0 && in->c <= 8192, "edet_se_pool: c/ld");
   const RowMap m = row_map(in->c);
   const int wpi = se_wg_per_img(in->n, in->h * in->w, m.rpp);
   const size_t lds = (size_t)in->c * sizeof(float);
@@ -620,7 +623,7 @@ extern "C" int edet_se_gate_bwd(const edet_tview_t* in, void* g, const float* dp
                                 const float* mean, const float* rstd,
                                 float* stat_partials, int* nparts_out, int dtype, void* stream) {
   EDET_CHECK(in && in->data && in->gate && g && dpool && mean && rstd && stat_partials, "edet_se_gate_bwd: null pointer");
-  EDET_CHECK(in->c % 8 == 0 && in->ld % 8 == 0 && in->c <= 2048, "edet_se_gate_bwd: c/ld");
+  EDET_CHECK(in->c % 8 == 0 && in->ld % 8 == 0 && in->c <= 8192, "edet_se_gate_bwd: c/ld");
   const RowMap m = row_map(in->c);
   int wpi = se_wg_per_img(in->n, in->h * in->w, m.rpp);
   while (in->n * wpi > EDET_MAX_PARTS && wpi > 1) --wpi;

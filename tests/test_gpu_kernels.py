@@ -57,7 +57,7 @@ def partial_buf(c):
 @pytest.mark.parametrize('shape', [(2, 9, 7, 24, 40), (1, 16, 16, 16, 96), (2, 5, 5, 64, 810),
                                    (3, 13, 11, 144, 24), (1, 20, 20, 1152, 192), (2, 8, 8, 64, 36),
                                    (2, 23, 17, 112, 672), (3, 7, 9, 192, 1152), (2, 12, 12, 480, 80),
-                                   (5, 5, 5, 320, 64)])
+                                   (5, 5, 5, 320, 64), (2, 6, 6, 3840, 640), (1, 7, 5, 640, 3840), (2, 9, 8, 384, 384)])
 @pytest.mark.parametrize('mode', ['plain', 'bn_swish', 'bn_swish_gate'])
 def test_pw_fwd(dt, shape, mode, pw_impl):
   name, edt, tdt = dt
@@ -116,7 +116,8 @@ def make_grad_view(rng, n, h, w, c, tdt, with_bn):
 @pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
 @pytest.mark.parametrize('shape', [(2, 9, 7, 24, 40), (2, 5, 5, 64, 810), (3, 13, 11, 144, 24),
                                    (2, 12, 12, 96, 16), (1, 20, 20, 1152, 192), (2, 23, 17, 112, 672),
-                                   (3, 7, 9, 672, 112), (5, 5, 5, 192, 1152)])
+                                   (3, 7, 9, 672, 112), (5, 5, 5, 192, 1152), (2, 6, 6, 3840, 640), (1, 7, 5, 640, 3840),
+                                   (2, 9, 8, 384, 384)])
 @pytest.mark.parametrize('mode', ['plain', 'plain_beta', 'bn', 'bn_swish_stats', 'gate'])
 @pytest.mark.parametrize('gbn', [False, True])
 def test_pw_bwd_data(dt, shape, mode, gbn, pw_impl):
@@ -190,7 +191,8 @@ def test_pw_bwd_data(dt, shape, mode, gbn, pw_impl):
 @pytest.mark.parametrize('shape', [(2, 9, 7, 24, 40), (2, 5, 5, 64, 810), (3, 13, 11, 144, 24),
                                    (2, 12, 12, 96, 16), (1, 20, 20, 1152, 192), (2, 8, 8, 64, 36),
                                    (4, 33, 31, 16, 96), (1, 10, 10, 320, 64), (2, 23, 17, 112, 672),
-                                   (3, 7, 9, 1152, 192), (5, 5, 5, 480, 80)])
+                                   (3, 7, 9, 1152, 192), (5, 5, 5, 480, 80), (2, 6, 6, 3840, 640), (1, 7, 5, 640, 3840),
+                                   (2, 9, 8, 384, 384)])
 @pytest.mark.parametrize('mode', ['plain', 'bn_swish_gate'])
 @pytest.mark.parametrize('use_ws', [True, False], ids=['workspace', 'atomics'])
 def test_pw_bwd_weight(dt, shape, mode, use_ws, pw_impl):
@@ -229,7 +231,8 @@ def test_pw_bwd_weight(dt, shape, mode, use_ws, pw_impl):
 
 
 # ------------------------------------------------------------------------------------ depthwise
-DW_SHAPES = [(2, 9, 11, 16), (1, 16, 16, 40), (2, 7, 5, 144), (1, 20, 20, 96), (2, 33, 17, 32)]
+DW_SHAPES = [(2, 9, 11, 16), (1, 16, 16, 40), (2, 7, 5, 144), (1, 20, 20, 96), (2, 33, 17, 32), (1, 9, 9, 2304),
+             (2, 6, 6, 3840)]
 
 
 def dw_oracle(x_nhwc, wk, k, s):
@@ -387,7 +390,7 @@ def test_stem(dt, shape):
 
 # ------------------------------------------------------------------------------------ BatchNorm
 @pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
-@pytest.mark.parametrize('shape', [(2, 9, 7, 24), (3, 5, 5, 144), (1, 16, 16, 1152)])
+@pytest.mark.parametrize('shape', [(2, 9, 7, 24), (3, 5, 5, 144), (1, 16, 16, 1152), (2, 6, 6, 2304), (1, 5, 7, 3840)])
 def test_batchnorm_train_fwd_bwd(dt, shape):
   """stats from a reduce over y -> finalize -> bn_res forward; backward reduce/finalize -> dy == autograd."""
   name, edt, tdt = dt
@@ -446,7 +449,8 @@ def test_batchnorm_train_fwd_bwd(dt, shape):
 
 # ------------------------------------------------------------------------------------ SE
 @pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
-@pytest.mark.parametrize('shape', [(2, 9, 7, 32, 8), (3, 20, 20, 144, 6), (2, 5, 5, 1152, 48)])
+@pytest.mark.parametrize('shape', [(2, 9, 7, 32, 8), (3, 20, 20, 144, 6), (2, 5, 5, 1152, 48), (3, 5, 5, 2304, 96),
+                                   (2, 6, 6, 3840, 160)])
 def test_squeeze_excite(dt, shape):
   name, edt, tdt = dt
   n, h, w, c, se = shape

