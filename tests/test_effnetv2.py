@@ -211,3 +211,20 @@ def test_training_with_stochastic_depth_is_refused():
   net = effnetv2_model.EffNetV2Model('efficientnetv2-b0')
   with pytest.raises(ValueError):
     net(torch.zeros(1, 32, 32, 3), training=True)
+
+
+def test_model_tables_equal_the_reference_modules():
+  """tests/golden/reference_v2_tables.json was produced by importing the reference's own
+  efficientnetv2/effnetv2_configs.py + hparams.py (tests/golden/make_golden_v2.py): every model name, the merged
+  model config and the decoded block list must be identical here."""
+  import json
+  import os
+  golden = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'reference_v2_tables.json')))
+  assert set(golden) == set(effnetv2_configs.efficientnetv1_params) | set(effnetv2_configs.efficientnetv2_params)
+  for name, ref in golden.items():
+    m = effnetv2_configs.model_config(name)
+    got = m.as_dict()
+    got['blocks_args'] = [b.as_dict() for b in m.blocks_args]
+    assert got == ref['model'], name
+    full = effnetv2_configs.get_model_config(name)
+    assert full.train.isize == ref['train_isize'] and full.eval.isize == ref['eval_isize'], name

@@ -164,3 +164,49 @@ def test_merge_level_outputs_order():
   assert c.shape == (2, 10, 9) and b.shape == (2, 10, 4)
   np.testing.assert_array_equal(c[0, 0], np.arange(9))
   np.testing.assert_array_equal(c[0, 1], np.arange(9, 18))   # second anchor of pixel (0,0)
+
+
+def test_anchor_boxes_equal_the_reference_code_bit_for_bit():
+  """tests/golden/reference_anchors.npz holds the float32 [N,4] boxes produced by EXECUTING the reference's
+  efficientdet/tf2/anchors.py (:117-165, numpy float64 grid -> float32) under a TensorFlow import stub
+  (tests/golden/make_golden_anchors.py): the level-major / y / x / (octave, aspect) ordering and every
+  coordinate must be identical here, including non-square and non-power-of-two image sizes."""
+  import os
+  import numpy as np
+  from automl_amd import anchors as anchors_lib
+  from tests.golden.make_golden_anchors import CONFIGS
+  gold = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'reference_anchors.npz'))
+  for key, (lo, hi, ns, ar, scale, size) in CONFIGS.items():
+    a = anchors_lib.Anchors(lo, hi, ns, ar, scale, size)
+    mine = np.asarray(a.boxes)
+    assert mine.dtype == np.float32 and mine.shape == gold[key].shape, (key, mine.shape, gold[key].shape)
+    assert np.array_equal(mine, gold[key]), (key, float(np.abs(mine - gold[key]).max()))
+
+
+def test_backbone_stage_tables_equal_the_reference_builder():
+  """tests/golden/reference_backbones.json: stem filters and per-stage rounded (input_filters, output_filters,
+  num_repeat), kernel, strides, expand / SE ratios of efficientnet-b0..b7, produced by executing the reference's
+  backbone/efficientnet_builder.py + efficientnet_model.round_filters / round_repeats under an import stub
+  (tests/golden/make_golden_backbone.py).  The expanded block list built here must realise exactly them."""
+  import json
+  import os
+  from automl_amd import efficientnet_builder as eb
+  gold = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'reference_backbones.json')))
+  assert sorted(gold) == ['efficientnet-b%d' % i for i in range(8)]
+  for name, ref in gold.items():
+    stem, blocks = eb.backbone_blocks(name)
+    assert stem == ref['stem_filters'], name
+    assert (eb.BN_MOMENTUM, eb.BN_EPSILON, eb.DEPTH_DIVISOR) == (ref['bn_momentum'], ref['bn_epsilon'], ref['depth_divisor'])
+    assert ref['survival_prob'] == 0.8
+    i = 0
+    for st in ref['stages']:
+      for r in range(st['num_repeat']):
+        b = blocks[i]
+        i += 1
+        assert b.kernel_size == st['kernel_size'] and b.expand_ratio == st['expand_ratio'], (name, i)
+        assert b.output_filters == st['output_filters'], (name, i)
+        assert b.input_filters == (st['input_filters'] if r == 0 else st['output_filters']), (name, i)
+        assert b.stride == (st['strides'][0] if r == 0 else 1), (name, i)
+        assert b.se_filters == max(1, int(b.input_filters * st['se_ratio'])), (name, i)
+        assert b.has_residual == (st['id_skip'] and b.stride == 1 and b.input_filters == b.output_filters)
+    assert i == len(blocks), (name, i, len(blocks))
