@@ -660,9 +660,15 @@ static int pw_impl_env() {
   if (!strcmp(e, "tiled")) return PW_TILED;
   return PW_AUTO;
 }
-static bool pw_prefers_big(int64_t rows, int cin, int cout) {
+// Which implementation goes first: the workgroup-tiled kernels (pw_big.hip) once cin*cout reaches a threshold,
+// else the wave-private streaming kernels.  Thresholds from A/B runs of the D0 640x640 step (r01g, per-op
+// totals in ms at threshold 2048 / 4096 / 8192 / 24576: forward 8.54 / 7.98 / 7.87 / 8.05, data gradient
+// 12.15 / 12.85 / 12.88 / 13.4, weight gradient 14.21 / 14.26 / 14.51 / 14.4); EDET_PW_BIG_MINKN overrides all.
+enum { PW_OP_FWD = 0, PW_OP_DGRAD = 1, PW_OP_WGRAD = 2 };
+static bool pw_prefers_big(int op, int64_t rows, int cin, int cout) {
+  static const int64_t defaults[3] = {8192, 2048, 4096};
   const char* e = getenv("EDET_PW_BIG_MINKN");
-  const int64_t minkn = e && *e ? atoll(e) : 24576;
+  const int64_t minkn = e && *e ? atoll(e) : defaults[op];
   return (int64_t)cin * cout >= minkn && rows >= 1024;
 }
 
@@ -689,7 +695,7 @@ extern "C" int edet_pw_fwd(const edet_tview_t* in, const void* wt, int ldw, cons
   a.bias = bias; a.out = out; a.ldo = ldo; a.stat_partials = stat_partials;
   if (dtype == EDET_BF16) {
     const int impl = pw_impl_env();
-    const bool big_first = impl == PW_BIG || (impl == PW_AUTO && pw_prefers_big(a.M, in->c, cout));
+    const bool big_first = impl == PW_BIG || (impl == PW_AUTO && pw_prefers_big(PW_OP_FWD, a.M, in->c, cout));
     int rc = 0;
     if (big_first) rc = pwb_try_fwd(in, wt, ldw, bias, out, cout, ldo, stat_partials, nparts_out, to_stream(stream));
     if (rc == 0 && impl != PW_TILED && impl != PW_BIG)
@@ -719,7 +725,7 @@ extern "C" int edet_pw_bwd_data(const edet_gview_t* dy, const void* w, int ldw,
   a.epi = *epi; a.stat_partials = epi->stat_partials;
   if (dtype == EDET_BF16) {
     const int impl = pw_impl_env();
-    const bool big_first = impl == PW_BIG || (impl == PW_AUTO && pw_prefers_big(a.M, in->c, dy->c));
+    const bool big_first = impl == PW_BIG || (impl == PW_AUTO && pw_prefers_big(PW_OP_DGRAD, a.M, in->c, dy->c));
     int rc = 0;
     if (big_first) rc = pwb_try_dgrad(dy, w, ldw, in, epi, nparts_out, to_stream(stream));
     if (rc == 0 && impl != PW_TILED && impl != PW_BIG)
@@ -747,7 +753,7 @@ extern "C" int edet_pw_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy
   a.dw = dweight;
   if (dtype == EDET_BF16) {
     const int impl = pw_impl_env();
-    const bool big_first = impl == PW_BIG || (impl == PW_AUTO && pw_prefers_big(a.M, in->c, dy->c));
+    const bool big_first = impl == PW_BIG || (impl == PW_AUTO && pw_prefers_big(PW_OP_WGRAD, a.M, in->c, dy->c));
     int rc = 0;
     if (big_first) rc = pwb_try_wgrad(in, dy, dweight, workspace, workspace_bytes, to_stream(stream));
     if (rc == 0 && impl != PW_TILED && impl != PW_BIG)
