@@ -230,13 +230,16 @@ def main():
         args.dtype == 'bf16'
     traffic, traffic_src = pmc_traffic(dominant, n_l / args.steps) if is_headline else (None, None)
     out = {
-        'metric': 'images/sec EfficientDet-D0 640x640 fwd+bwd (whole job; per-GPU = value / n_gpus)',
+        'metric': 'images/sec %s %dx%d fwd+bwd (whole job; per-GPU = value / n_gpus)' % (
+            args.model.replace('efficientdet-d', 'EfficientDet-D'), args.image_size, args.image_size),
         'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.dtype, 'data': 'synthetic',
-        'config': {'workload': '%s %dx%d batch %d/GPU forward+backward+SGD/EMA update (BASELINE configs[2]; '
-                               'DP replicas of it for n_gpus>1)' % (args.model, args.image_size,
-                                                                   args.image_size, args.batch),
+        'config': {'workload': '%s %dx%d batch %d/GPU forward+backward+SGD/EMA update (%s; '
+                               'DP replicas of it for n_gpus>1)' % (
+                                   args.model, args.image_size, args.image_size, args.batch,
+                                   'BASELINE configs[2]' if is_headline else
+                                   ('BASELINE configs[4] per-GPU leg' if 'd7x' in args.model else 'not a BASELINE config')),
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                    'loss': losses.get('loss'),
                    'launch': 'hipGraph replay of the captured step' if args.graph else 'eager',
