@@ -293,7 +293,7 @@ __global__ __launch_bounds__(SE_FC_THREADS) void k_se_fc(const float* __restrict
 
 // per image: dgate -> dpre2, dh, dpre1, dpool.
 // scratch: dpre2 [n][c], dpre1 [n][se], hact = swish(hidden_pre) [n][se]
-__global__ __launch_bounds__(THREADS) void k_se_fc_bwd_img(const float* __restrict__ hidden_pre,
+__global__ __launch_bounds__(SE_FC_THREADS) void k_se_fc_bwd_img(const float* __restrict__ hidden_pre,
                                                           const float* __restrict__ gate,
                                                           const float* __restrict__ dgate, int nimg, int c,
                                                           int se, float inv_hw, const float* w1,
@@ -301,11 +301,11 @@ __global__ __launch_bounds__(THREADS) void k_se_fc_bwd_img(const float* __restri
   extern __shared__ float sm[];  // dpre2[c], dpre1[se]
   float* d2 = sm;
   float* d1 = sm + c;
-  const int n = blockIdx.x, tid = threadIdx.x;
+  const int n = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   float* dpre2_g = scratch + (size_t)n * c;
   float* dpre1_g = scratch + (size_t)nimg * c + (size_t)n * se;
   float* hact_g = scratch + (size_t)nimg * (c + se) + (size_t)n * se;
-  for (int i = tid; i < c; i += THREADS) {
+  for (int i = tid; i < c; i += nthr) {
     const float g = gate[(size_t)n * c + i];
     const float v = dgate[(size_t)n * c + i] * g * (1.f - g);
     d2[i] = v;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(THREADS) void k_se_fc_bwd_img(const float* __restri
   __syncthreads();
   // dh[j] = sum_i dpre2[i] * w2[j][i]: one wave per j (coalesced along i), shuffle reduction
   const int wave = tid >> 6, lane = tid & 63;
-  for (int j = wave; j < se; j += THREADS / 64) {
+  for (int j = wave; j < se; j += nthr / 64) {
     float acc = 0.f;
     for (int i = lane; i < c; i += 64) acc = fmaf(d2[i], w2[(size_t)j * c + i], acc);
 #pragma unroll
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(THREADS) void k_se_fc_bwd_img(const float* __restri
     }
   }
   __syncthreads();
-  for (int i = tid; i < c; i += THREADS) {
+  for (int i = tid; i < c; i += nthr) {
     float acc = 0.f;
     for (int j = 0; j < se; ++j) acc = fmaf(d1[j], w1[(size_t)i * se + j], acc);
     dpool[(size_t)n * c + i] = acc * inv_hw;
@@ -609,7 +609,7 @@ extern "C" int edet_se_fc_bwd(const float* pooled_sum, const float* hidden_pre, 
                               float* dpool, float* scratch, void* stream) {
   EDET_CHECK(pooled_sum && hidden_pre && gate && dgate && w1 && w2 && dw1 && db1 && dw2 && db2 && dpool && scratch,
              "edet_se_fc_bwd: null pointer");
-  k_se_fc_bwd_img<<<n, THREADS, (size_t)(c + se) * sizeof(float), to_stream(stream)>>>(hidden_pre, gate, dgate, n, c, se, inv_hw, w1, w2, dpool, scratch);
+  k_se_fc_bwd_img<<<n, c >= 512 ? SE_FC_THREADS : THREADS, (size_t)(c + se) * sizeof(float), to_stream(stream)>>>(hidden_pre, gate, dgate, n, c, se, inv_hw, w1, w2, dpool, scratch);
   const int nsplit = n >= 2 * SE_SPLIT ? SE_SPLIT : 1;
   const int per_split = cdiv(n, nsplit);
   k_se_fc_bwd_par<<<dim3(cdiv(c, 64), cdiv(n, per_split), cdiv(se, SE_JB)), THREADS,
