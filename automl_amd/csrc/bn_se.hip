@@ -32,9 +32,9 @@ inline int persistent_grid(int64_t rows, int rpp, int max_wg) {
 }
 
 // ------------------------------------------------------------------ forward statistics finalize
-// Column sums of the [nparts][2][c] partial rows: one workgroup per 32 channels, 8 row slices per
+// Column sums of the [nparts][2][c] partial rows: one workgroup per 32 channels, 32 row slices per
 // channel (4 independent loads in flight per thread), fp64 accumulation, LDS tree at the end.
-constexpr int FIN_CH = 32, FIN_SL = 8;
+constexpr int FIN_CH = 32, FIN_SL = 32;   // 1024-lane workgroups: 32 rows of partials per step
 
 __device__ __forceinline__ void partial_colsum(const float* __restrict__ partials, int nparts, int c, int ch,
                                                int slice, double& s, double& s2) {
