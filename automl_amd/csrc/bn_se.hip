@@ -452,29 +452,28 @@ __global__ __launch_bounds__(THREADS) void k_se_gate_bwd(const edet_tview_t in, 
 }
 
 // dst[i] += sum over the P partial rows: thread (element e = tid & 15, slice sl = tid >> 4) sums rows
-// sl, sl+16, ... with four independent loads in flight, the 16 slices are combined through LDS.
-__global__ __launch_bounds__(THREADS) void k_reduce_partials(const float* __restrict__ ws, int P, int64_t n,
-                                                            float* __restrict__ dst) {
-  __shared__ float red[16][17];
+// sl, sl+64, ... with two independent loads in flight, the 64 slices are combined through LDS.
+constexpr int RED_SL = 64;      // row slices per element: 16 elements x 64 slices = 1024 lanes
+__global__ __launch_bounds__(16 * RED_SL) void k_reduce_partials(const float* __restrict__ ws, int P, int64_t n,
+                                                                float* __restrict__ dst) {
+  __shared__ float red[RED_SL][17];
   const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int64_t i = (int64_t)blockIdx.x * 16 + e;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float s0 = 0.f, s1 = 0.f;
   if (i < n) {
     int p = sl;
-    for (; p + 48 < P; p += 64) {
+    for (; p + RED_SL < P; p += 2 * RED_SL) {
       s0 += ws[(size_t)p * n + i];
-      s1 += ws[(size_t)(p + 16) * n + i];
-      s2 += ws[(size_t)(p + 32) * n + i];
-      s3 += ws[(size_t)(p + 48) * n + i];
+      s1 += ws[(size_t)(p + RED_SL) * n + i];
     }
-    for (; p < P; p += 16) s0 += ws[(size_t)p * n + i];
+    if (p < P) s0 += ws[(size_t)p * n + i];
   }
-  red[sl][e] = (s0 + s1) + (s2 + s3);
+  red[sl][e] = s0 + s1;
   __syncthreads();
   if (sl == 0 && i < n) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][e];
+    for (int k = 0; k < RED_SL; ++k) t += red[k][e];
     dst[i] += t;
   }
 }
@@ -489,7 +488,7 @@ inline int ew_grid(int64_t total) {
 }  // namespace
 
 int edet_reduce_partials(const float* ws, int P, int64_t n, float* dst, hipStream_t st) {
-  k_reduce_partials<<<dim3((unsigned)((n + 15) / 16)), dim3(THREADS), 0, st>>>(ws, P, n, dst);
+  k_reduce_partials<<<dim3((unsigned)((n + 15) / 16)), dim3(16 * RED_SL), 0, st>>>(ws, P, n, dst);
   EDET_LAUNCH_CHECK("edet_reduce_partials");
   return 0;
 }
