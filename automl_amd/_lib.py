@@ -42,6 +42,7 @@ PT, PG, PE, PI = (ctypes.POINTER(TView), ctypes.POINTER(GView), ctypes.POINTER(B
 SIGNATURES = {
     'edet_cast': [c_void_p, c_void_p, c_int64, c_int, c_void_p],
     'edet_cast_matrix': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'edet_cast_batch': [c_void_p, c_int, c_int, c_int, c_void_p],
     'edet_stem_fwd': [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, PI,
                       c_int, c_void_p],
     'edet_stem_bwd_weight': [c_void_p, c_int, c_int, c_int, PG, c_void_p, c_int, c_void_p],

@@ -354,6 +354,24 @@ __global__ void k_cast_matrix(const float* __restrict__ src, T* __restrict__ dst
   }
 }
 
+// every item of a cast plan in one launch: blockIdx.y = item, blockIdx.x strides over its elements
+template <typename T>
+__global__ void k_cast_batch(const edet_cast_item_t* __restrict__ items) {
+  const edet_cast_item_t it = items[blockIdx.y];
+  const float* src = it.src;
+  T* dst = reinterpret_cast<T*>(it.dst);
+  const int drows = it.transpose ? it.cols : it.rows;
+  const int dcols = it.transpose ? it.rows : it.cols;
+  const int64_t total = (int64_t)drows * it.ld_out;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / it.ld_out), c = (int)(i - (int64_t)r * it.ld_out);
+    float v = 0.f;
+    if (c < dcols) v = it.transpose ? src[(size_t)c * it.cols + r] : src[(size_t)r * it.cols + c];
+    dst[i] = from_f<T>(v);
+  }
+}
+
 template <typename T>
 int stem_launch(bool fwd, StemArgs& a, hipStream_t st) {
   if (fwd && sizeof(T) == 2) {
@@ -453,5 +471,16 @@ extern "C" int edet_cast_matrix(const float* src, void* dst, int rows, int cols,
     k_cast_matrix<float><<<grid, 256, 0, to_stream(stream)>>>(src, (float*)dst, rows, cols, ld_out, transpose);
   else EDET_CHECK(false, "edet_cast_matrix: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_cast_matrix");
+  return 0;
+}
+
+extern "C" int edet_cast_batch(const edet_cast_item_t* items_dev, int count, int max_blocks_per_item, int dtype,
+                               void* stream) {
+  EDET_CHECK(items_dev && count > 0 && max_blocks_per_item > 0, "edet_cast_batch: bad arguments");
+  const dim3 grid(max_blocks_per_item, count);
+  if (dtype == EDET_BF16) k_cast_batch<bf16_t><<<grid, 256, 0, to_stream(stream)>>>(items_dev);
+  else if (dtype == EDET_F32) k_cast_batch<float><<<grid, 256, 0, to_stream(stream)>>>(items_dev);
+  else EDET_CHECK(false, "edet_cast_batch: bad dtype %d", dtype);
+  EDET_LAUNCH_CHECK("edet_cast_batch");
   return 0;
 }

@@ -120,6 +120,9 @@ class Engine(object):
     self.gnorm = torch.zeros(1, dtype=torch.float32, device=self.device)
     self.pool_argmax = os.environ.get('EDET_POOL_ARGMAX', '1') != '0'
     self.stochastic_depth = stochastic_depth
+    self._cast_items = {}      # weight name -> descriptors of its compute copies (filled by the first pass)
+    self._cast_table = None
+    self.batched_casts = os.environ.get('EDET_BATCHED_CASTS', '1') != '0'
     self.fused_dw_bwd = os.environ.get('EDET_DW_BWD_ENTRY', '1') != '0'   # one edet_dw_bwd call per stride-1 layer
     # cross-replica BatchNorm (utils.SyncBatchNormalization / TpuBatchNormalization, utils.py:166-241):
     # (all_reduce_fn, world_size) or None.  Set by train_lib when sync_bn=True.
@@ -239,7 +242,24 @@ class Engine(object):
       call('edet_cast_matrix', src, ptr(wt), cin, cout, ldk, 1, self.dtype, self.stream)
       call('edet_cast_matrix', src, ptr(w), cin, cout, ldn, 0, self.dtype, self.stream)
       self._cast_done.add(name)
+      self._cast_items[name] = [(src, ptr(wt), cin, cout, ldk, 1), (src, ptr(w), cin, cout, ldn, 0)]
     return wt, ldk, w, ldn
+
+  def _cast_all(self):
+    """Every compute copy recorded by an earlier pass, re-made in one launch (edet_cast_batch)."""
+    names = list(self._cast_items)
+    if self._cast_table is None or self._cast_table[0] != names:
+      if torch.cuda.is_current_stream_capturing():
+        return                 # no host-to-device copy inside a capture: this pass casts layer by layer
+      import struct
+      flat = [it for n in names for it in self._cast_items[n]]
+      raw = b''.join(struct.pack('<QQiiii', s or 0, d, r, c, ld, t) for (s, d, r, c, ld, t) in flat)
+      dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+      biggest = max((t and c or r) * ld for (_, _, r, c, ld, t) in flat)
+      self._cast_table = (names, dev, len(flat), max(1, min(64, (biggest + 255) // 256)))
+    _, dev, count, blocks = self._cast_table
+    call('edet_cast_batch', ptr(dev), count, blocks, self.dtype, self.stream)
+    self._cast_done.update(names)
 
   # ------------------------------------------------------------------ BatchNorm plumbing
   def get_bn(self, name, c):
@@ -575,6 +595,8 @@ class Engine(object):
     # changed since they were made (every training step; in inference only after set_params)
     if self._cast_dirty or not hasattr(self, '_cast_done'):
       self._cast_done = set()
+      if self._cast_items and self.batched_casts:
+        self._cast_all()
       for bn in self.bns.values():
         bn.eval_done = False
       self._cast_dirty = False
@@ -642,6 +664,9 @@ class Engine(object):
     cls = self._head(feats, 'class_net', 'class', c.num_classes * na)
     box = self._head(feats, 'box_net', 'box', 4 * na)
     self.cls_views, self.box_views = cls, box
+    if self.batched_casts and self._cast_items and not torch.cuda.is_current_stream_capturing() and \
+        (self._cast_table is None or self._cast_table[0] != list(self._cast_items)):
+      self._cast_all()         # builds the descriptor table now (outside any capture); the casts it repeats are idempotent
     return cls, box
 
   def _mbconv(self, xin, b, scope):

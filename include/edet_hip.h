@@ -108,6 +108,16 @@ int edet_cast(const float* src, void* dst, int64_t count, int dtype, void* strea
 int edet_cast_matrix(const float* src, void* dst, int rows, int cols, int ld_out,
                      int transpose, int dtype, void* stream);
 
+/* all compute copies of a step in ONE launch: items_dev is a device array of `count` descriptors (the
+ * arguments of edet_cast_matrix), max_blocks_per_item bounds the 256-thread blocks that stride over one item.  */
+typedef struct edet_cast_item {
+  const float* src;
+  void* dst;
+  int rows, cols, ld_out, transpose;
+} edet_cast_item_t;
+int edet_cast_batch(const edet_cast_item_t* items_dev, int count, int max_blocks_per_item, int dtype,
+                    void* stream);
+
 /* ---- stem: Conv2D 3x3 stride 2 'SAME', Cin = 3, no bias --------------------
  * efficientnet_model.py:511-519.  images [n,h,w,3] (ld 3), weight fp32 HWIO
  * [3,3,3,cout].  Writes raw conv output and BN statistic partials.  */
