@@ -5,10 +5,13 @@
 
 One step = forward (training BatchNorm), focal+Huber loss, backward, L2, clip, [gradient all-reduce
 SUM over RCCL], SGD-momentum + EMA update on a synthetic COCO-shaped batch already resident in HBM
-(BASELINE.json configs[2]; weak scaling: 128 images per GPU).  Rank 0 prints ONE JSON line with
-`roofline` (dominant kernel family, HIP-event timed inside the timed region, algorithmic bytes per
-SURVEY.md section 8d) and `cpu_baseline` (the fp32 CPU oracle -- a port, not the reference's
-TensorFlow binary, which cannot be installed here -- on a bounded sample of the same workload).
+(BASELINE.json configs[2]; weak scaling: 128 images per GPU).  By default the timed steps REPLAY the step
+captured as a hipGraph (--graph 0 / EDET_GRAPH=0: eager launches).  Rank 0 prints ONE JSON line with
+`roofline` (dominant kernel family, algorithmic bytes per SURVEY.md section 8d, per-launch HIP events on the
+launch stream: inside the timed region in eager mode, over the same K steps repeated eagerly right after it in
+graph mode -- a replayed graph has no host-side launch to bracket; `traffic` from the committed PMC passes
+under profiles/) and, at N = 1, `cpu_baseline` (the fp32 CPU oracle -- a port, not the reference's TensorFlow
+binary, which cannot be installed here -- on a bounded sample of the same workload).
 """
 import argparse
 import json
