@@ -17,74 +17,67 @@ from automl_amd import hparams_config
 Config = hparams_config.Config
 
 
+_FIELDS = (('r', 'num_repeat', int), ('k', 'kernel_size', int), ('s', 'strides', int), ('e', 'expand_ratio', int),
+           ('i', 'input_filters', int), ('o', 'output_filters', int), ('c', 'conv_type', int))
+
+
 class BlockDecoder(object):
-  """'r2_k3_s1_e1_i24_o24_c1' <-> block Config (effnetv2_configs.py:22-89)."""
+  """Block string notation <-> block Config, e.g. 'r2_k3_s1_e1_i24_o24_c1' or 'r6_k3_s2_e4_i64_o128_se0.25'
+  (effnetv2_configs.py:22-89): r repeats, k kernel, s stride, e expand ratio, i/o filters, c conv type
+  (1 = fused), se squeeze-excite ratio."""
+
+  _TOKEN = re.compile(r'^([a-z]+)([0-9][0-9.]*)$')
 
   def _decode_block_string(self, block_string):
-    assert isinstance(block_string, str)
-    options = {}
-    for op in block_string.split('_'):
-      splits = re.split(r'(\d.*)', op)
-      if len(splits) >= 2:
-        key, value = splits[:2]
-        options[key] = value
-    return Config(dict(
-        kernel_size=int(options['k']),
-        num_repeat=int(options['r']),
-        input_filters=int(options['i']),
-        output_filters=int(options['o']),
-        expand_ratio=int(options['e']),
-        se_ratio=float(options['se']) if 'se' in options else None,
-        strides=int(options['s']),
-        conv_type=int(options['c']) if 'c' in options else 0,
-    ))
+    if not isinstance(block_string, str):
+      raise TypeError('block notation must be a string, got %r' % (block_string,))
+    opts = {}
+    for token in block_string.split('_'):
+      m = self._TOKEN.match(token)
+      if m:
+        opts[m.group(1)] = m.group(2)
+    block = {name: conv(opts[key]) for key, name, conv in _FIELDS if key in opts}
+    block.setdefault('conv_type', 0)
+    block['se_ratio'] = float(opts['se']) if 'se' in opts else None
+    return Config(block)
 
   def _encode_block_string(self, block):
-    args = [
-        'r%d' % block.num_repeat,
-        'k%d' % block.kernel_size,
-        's%d' % block.strides,
-        'e%s' % block.expand_ratio,
-        'i%d' % block.input_filters,
-        'o%d' % block.output_filters,
-        'c%d' % block.conv_type,
-    ]
+    parts = ['%s%s' % (key, block[name]) for key, name, _ in _FIELDS]
     if block.se_ratio is not None and 0 < block.se_ratio <= 1:
-      args.append('se%s' % block.se_ratio)
-    return '_'.join(args)
+      parts.append('se%s' % block.se_ratio)
+    return '_'.join(parts)
 
   def decode(self, string_list):
-    assert isinstance(string_list, list)
+    if not isinstance(string_list, list):
+      raise TypeError('expected a list of block strings')
     return [self._decode_block_string(s) for s in string_list]
 
   def encode(self, blocks_args):
     return [self._encode_block_string(b) for b in blocks_args]
 
 
-#################### EfficientNet V1 configs (as served by the V2 codebase) ####################
-v1_b0_block_str = [
-    'r1_k3_s1_e1_i32_o16_se0.25',
-    'r2_k3_s2_e6_i16_o24_se0.25',
-    'r2_k5_s2_e6_i24_o40_se0.25',
-    'r3_k3_s2_e6_i40_o80_se0.25',
-    'r3_k5_s1_e6_i80_o112_se0.25',
-    'r4_k5_s2_e6_i112_o192_se0.25',
-    'r1_k3_s1_e6_i192_o320_se0.25',
-]
+def _stages(rows):
+  """Stage rows (repeats, kernel, stride, expand, in, out, fused?, se) -> the reference's block strings."""
+  out = []
+  for r, k, st, e, i, o, fused, se in rows:
+    text = 'r%d_k%d_s%d_e%d_i%d_o%d' % (r, k, st, e, i, o)
+    out.append(text + ('_c1' if fused else '') + ('_se%s' % se if se else ''))
+  return out
 
-efficientnetv1_params = {
-    # (width_coefficient, depth_coefficient, resolution, dropout_rate)
-    'efficientnet-b0': (1.0, 1.0, 224, 0.2),
-    'efficientnet-b1': (1.0, 1.1, 240, 0.2),
-    'efficientnet-b2': (1.1, 1.2, 260, 0.3),
-    'efficientnet-b3': (1.2, 1.4, 300, 0.3),
-    'efficientnet-b4': (1.4, 1.8, 380, 0.4),
-    'efficientnet-b5': (1.6, 2.2, 456, 0.4),
-    'efficientnet-b6': (1.8, 2.6, 528, 0.5),
-    'efficientnet-b7': (2.0, 3.1, 600, 0.5),
-    'efficientnet-b8': (2.2, 3.6, 672, 0.5),
-    'efficientnet-l2': (4.3, 5.3, 800, 0.5),
-}
+
+#################### EfficientNet V1 (as served by the V2 code base) ####################
+# the seven MBConv stages of B0; wider / deeper variants scale them (effnetv2_configs.py:93-101)
+v1_b0_block_str = _stages([
+    (1, 3, 1, 1, 32, 16, 0, 0.25), (2, 3, 2, 6, 16, 24, 0, 0.25), (2, 5, 2, 6, 24, 40, 0, 0.25),
+    (3, 3, 2, 6, 40, 80, 0, 0.25), (3, 5, 1, 6, 80, 112, 0, 0.25), (4, 5, 2, 6, 112, 192, 0, 0.25),
+    (1, 3, 1, 6, 192, 320, 0, 0.25)])
+
+# name: (width_coefficient, depth_coefficient, resolution, dropout_rate)   (effnetv2_configs.py:104-116)
+efficientnetv1_params = dict(
+    [('efficientnet-b%d' % i, v) for i, v in enumerate([
+        (1.0, 1.0, 224, 0.2), (1.0, 1.1, 240, 0.2), (1.1, 1.2, 260, 0.3), (1.2, 1.4, 300, 0.3), (1.4, 1.8, 380, 0.4),
+        (1.6, 2.2, 456, 0.4), (1.8, 2.6, 528, 0.5), (2.0, 3.1, 600, 0.5), (2.2, 3.6, 672, 0.5)])] +
+    [('efficientnet-l2', (4.3, 5.3, 800, 0.5))])
 
 
 def efficientnetv1_config(model_name='efficientnet-b0'):
@@ -98,66 +91,38 @@ def efficientnetv1_config(model_name='efficientnet-b0'):
   ))
 
 
-#################### EfficientNet V2 configs ####################
-v2_base_block = [
-    'r1_k3_s1_e1_i32_o16_c1',
-    'r2_k3_s2_e4_i16_o32_c1',
-    'r2_k3_s2_e4_i32_o48_c1',
-    'r3_k3_s2_e4_i48_o96_se0.25',
-    'r5_k3_s1_e6_i96_o112_se0.25',
-    'r8_k3_s2_e6_i112_o192_se0.25',
-]
+#################### EfficientNet V2 (effnetv2_configs.py:139-179) ####################
+# fused stages first (conv type 1, no SE), then MBConv stages with SE 0.25
+v2_base_block = _stages([
+    (1, 3, 1, 1, 32, 16, 1, 0), (2, 3, 2, 4, 16, 32, 1, 0), (2, 3, 2, 4, 32, 48, 1, 0),
+    (3, 3, 2, 4, 48, 96, 0, 0.25), (5, 3, 1, 6, 96, 112, 0, 0.25), (8, 3, 2, 6, 112, 192, 0, 0.25)])
+v2_s_block = _stages([
+    (2, 3, 1, 1, 24, 24, 1, 0), (4, 3, 2, 4, 24, 48, 1, 0), (4, 3, 2, 4, 48, 64, 1, 0),
+    (6, 3, 2, 4, 64, 128, 0, 0.25), (9, 3, 1, 6, 128, 160, 0, 0.25), (15, 3, 2, 6, 160, 256, 0, 0.25)])
+v2_m_block = _stages([
+    (3, 3, 1, 1, 24, 24, 1, 0), (5, 3, 2, 4, 24, 48, 1, 0), (5, 3, 2, 4, 48, 80, 1, 0),
+    (7, 3, 2, 4, 80, 160, 0, 0.25), (14, 3, 1, 6, 160, 176, 0, 0.25), (18, 3, 2, 6, 176, 304, 0, 0.25),
+    (5, 3, 1, 6, 304, 512, 0, 0.25)])
+v2_l_block = _stages([
+    (4, 3, 1, 1, 32, 32, 1, 0), (7, 3, 2, 4, 32, 64, 1, 0), (7, 3, 2, 4, 64, 96, 1, 0),
+    (10, 3, 2, 4, 96, 192, 0, 0.25), (19, 3, 1, 6, 192, 224, 0, 0.25), (25, 3, 2, 6, 224, 384, 0, 0.25),
+    (7, 3, 1, 6, 384, 640, 0, 0.25)])
+v2_xl_block = _stages([
+    (4, 3, 1, 1, 32, 32, 1, 0), (8, 3, 2, 4, 32, 64, 1, 0), (8, 3, 2, 4, 64, 96, 1, 0),
+    (16, 3, 2, 4, 96, 192, 0, 0.25), (24, 3, 1, 6, 192, 256, 0, 0.25), (32, 3, 2, 6, 256, 512, 0, 0.25),
+    (8, 3, 1, 6, 512, 640, 0, 0.25)])
 
-v2_s_block = [
-    'r2_k3_s1_e1_i24_o24_c1',
-    'r4_k3_s2_e4_i24_o48_c1',
-    'r4_k3_s2_e4_i48_o64_c1',
-    'r6_k3_s2_e4_i64_o128_se0.25',
-    'r9_k3_s1_e6_i128_o160_se0.25',
-    'r15_k3_s2_e6_i160_o256_se0.25',
-]
-
-v2_m_block = [
-    'r3_k3_s1_e1_i24_o24_c1',
-    'r5_k3_s2_e4_i24_o48_c1',
-    'r5_k3_s2_e4_i48_o80_c1',
-    'r7_k3_s2_e4_i80_o160_se0.25',
-    'r14_k3_s1_e6_i160_o176_se0.25',
-    'r18_k3_s2_e6_i176_o304_se0.25',
-    'r5_k3_s1_e6_i304_o512_se0.25',
-]
-
-v2_l_block = [
-    'r4_k3_s1_e1_i32_o32_c1',
-    'r7_k3_s2_e4_i32_o64_c1',
-    'r7_k3_s2_e4_i64_o96_c1',
-    'r10_k3_s2_e4_i96_o192_se0.25',
-    'r19_k3_s1_e6_i192_o224_se0.25',
-    'r25_k3_s2_e6_i224_o384_se0.25',
-    'r7_k3_s1_e6_i384_o640_se0.25',
-]
-
-v2_xl_block = [
-    'r4_k3_s1_e1_i32_o32_c1',
-    'r8_k3_s2_e4_i32_o64_c1',
-    'r8_k3_s2_e4_i64_o96_c1',
-    'r16_k3_s2_e4_i96_o192_se0.25',
-    'r24_k3_s1_e6_i192_o256_se0.25',
-    'r32_k3_s2_e6_i256_o512_se0.25',
-    'r8_k3_s1_e6_i512_o640_se0.25',
-]
-
-efficientnetv2_params = {
-    # (block, width, depth, train_size, eval_size, dropout, randaug, mixup, aug)
-    'efficientnetv2-s': (v2_s_block, 1.0, 1.0, 300, 384, 0.2, 10, 0, 'randaug'),
-    'efficientnetv2-m': (v2_m_block, 1.0, 1.0, 384, 480, 0.3, 15, 0.2, 'randaug'),
-    'efficientnetv2-l': (v2_l_block, 1.0, 1.0, 384, 480, 0.4, 20, 0.5, 'randaug'),
-    'efficientnetv2-xl': (v2_xl_block, 1.0, 1.0, 384, 512, 0.4, 20, 0.5, 'randaug'),
-    'efficientnetv2-b0': (v2_base_block, 1.0, 1.0, 192, 224, 0.2, 0, 0, 'effnetv1_autoaug'),
-    'efficientnetv2-b1': (v2_base_block, 1.0, 1.1, 192, 240, 0.2, 0, 0, 'effnetv1_autoaug'),
-    'efficientnetv2-b2': (v2_base_block, 1.1, 1.2, 208, 260, 0.3, 0, 0, 'effnetv1_autoaug'),
-    'efficientnetv2-b3': (v2_base_block, 1.2, 1.4, 240, 300, 0.3, 0, 0, 'effnetv1_autoaug'),
-}
+# name: (block, width, depth, train_size, eval_size, dropout, randaug, mixup, aug)
+efficientnetv2_params = {}
+for _name, _row in (('s', (v2_s_block, 1.0, 1.0, 300, 384, 0.2, 10, 0, 'randaug')),
+                    ('m', (v2_m_block, 1.0, 1.0, 384, 480, 0.3, 15, 0.2, 'randaug')),
+                    ('l', (v2_l_block, 1.0, 1.0, 384, 480, 0.4, 20, 0.5, 'randaug')),
+                    ('xl', (v2_xl_block, 1.0, 1.0, 384, 512, 0.4, 20, 0.5, 'randaug')),
+                    ('b0', (v2_base_block, 1.0, 1.0, 192, 224, 0.2, 0, 0, 'effnetv1_autoaug')),
+                    ('b1', (v2_base_block, 1.0, 1.1, 192, 240, 0.2, 0, 0, 'effnetv1_autoaug')),
+                    ('b2', (v2_base_block, 1.1, 1.2, 208, 260, 0.3, 0, 0, 'effnetv1_autoaug')),
+                    ('b3', (v2_base_block, 1.2, 1.4, 240, 300, 0.3, 0, 0, 'effnetv1_autoaug'))):
+  efficientnetv2_params['efficientnetv2-' + _name] = _row
 
 
 def efficientnetv2_config(model_name='efficientnetv2-s'):

@@ -148,100 +148,44 @@ class Config(object):
     return d
 
 
+# defaults of the detection path (values of reference hparams_config.py:170-298, pinned by
+# tests/golden/reference_tables.json which is generated from the reference's own module), grouped by what
+# consumes them here; insertion order = the reference's attribute order, which as_dict()/yaml output follows
+_DEFAULT_GROUPS = (
+    ('identity', dict(name='efficientdet-d1', act_type='swish')),
+    # input pipeline: kept for interface completeness (the data pipeline is out of scope)
+    ('input', dict(image_size=640, target_size=None, input_rand_hflip=True, jitter_min=0.1, jitter_max=2.0,
+                   autoaugment_policy=None, grid_mask=False, sample_image=None, map_freq=5)),
+    ('dataset', dict(num_classes=90, seg_num_classes=3, heads=['object_detection'], skip_crowd_during_training=True,
+                     label_map=None, max_instances_per_image=100, regenerate_source_id=False)),
+    ('anchors', dict(min_level=3, max_level=7, num_scales=3, aspect_ratios=[1.0, 2.0, 0.5], anchor_scale=4.0)),
+    ('optimiser', dict(is_training_bn=True, momentum=0.9, optimizer='sgd', learning_rate=0.08, lr_warmup_init=0.008,
+                       lr_warmup_epoch=1.0, first_lr_drop_epoch=200.0, second_lr_drop_epoch=250.0,
+                       poly_lr_power=0.9, clip_gradients_norm=10.0, num_epochs=300, data_format='channels_last',
+                       mean_rgb=[0.485 * 255, 0.456 * 255, 0.406 * 255],
+                       stddev_rgb=[0.229 * 255, 0.224 * 255, 0.225 * 255], scale_range=False)),
+    ('losses', dict(label_smoothing=0.0, alpha=0.25, gamma=1.5, delta=0.1, box_loss_weight=50.0, iou_loss_type=None,
+                    iou_loss_weight=1.0, weight_decay=4e-5, strategy=None, mixed_precision=False, loss_scale=None)),
+    ('structure', dict(box_class_repeats=3, fpn_cell_repeats=3, fpn_num_filters=88, separable_conv=True,
+                       apply_bn_for_resampling=True, conv_after_downsample=False, conv_bn_act_pattern=False,
+                       drop_remainder=True,
+                       nms_configs=dict(method='gaussian', iou_thresh=None, score_thresh=0., sigma=None, pyfunc=False,
+                                        max_nms_inputs=0, max_output_size=100),
+                       tflite_max_detections=100, fpn_name=None, fpn_weight_method=None, fpn_config=None,
+                       survival_prob=None, img_summary_steps=None, lr_decay_method='cosine',
+                       moving_average_decay=0.9998, ckpt_var_scope=None, skip_mismatch=True,
+                       backbone_name='efficientnet-b1', backbone_config=None, var_freeze_expr=None,
+                       use_keras_model=True, dataset_type=None, positives_momentum=None, grad_checkpoint=False,
+                       verbose=1, save_freq='epoch')),
+)
+
+
 def default_detection_configs():
-  """Defaults of the detection path (reference hparams_config.py:170-298)."""
+  """A fresh Config holding the defaults of the detection path."""
   h = Config()
-  h.name = 'efficientdet-d1'
-  h.act_type = 'swish'
-  # input preprocessing (kept for interface completeness; data pipeline is out of scope)
-  h.image_size = 640
-  h.target_size = None
-  h.input_rand_hflip = True
-  h.jitter_min = 0.1
-  h.jitter_max = 2.0
-  h.autoaugment_policy = None
-  h.grid_mask = False
-  h.sample_image = None
-  h.map_freq = 5
-  # dataset
-  h.num_classes = 90
-  h.seg_num_classes = 3
-  h.heads = ['object_detection']
-  h.skip_crowd_during_training = True
-  h.label_map = None
-  h.max_instances_per_image = 100
-  h.regenerate_source_id = False
-  # architecture
-  h.min_level = 3
-  h.max_level = 7
-  h.num_scales = 3
-  h.aspect_ratios = [1.0, 2.0, 0.5]
-  h.anchor_scale = 4.0
-  h.is_training_bn = True
-  # optimisation
-  h.momentum = 0.9
-  h.optimizer = 'sgd'
-  h.learning_rate = 0.08
-  h.lr_warmup_init = 0.008
-  h.lr_warmup_epoch = 1.0
-  h.first_lr_drop_epoch = 200.0
-  h.second_lr_drop_epoch = 250.0
-  h.poly_lr_power = 0.9
-  h.clip_gradients_norm = 10.0
-  h.num_epochs = 300
-  h.data_format = 'channels_last'
-  h.mean_rgb = [0.485 * 255, 0.456 * 255, 0.406 * 255]
-  h.stddev_rgb = [0.229 * 255, 0.224 * 255, 0.225 * 255]
-  h.scale_range = False
-  # losses
-  h.label_smoothing = 0.0
-  h.alpha = 0.25
-  h.gamma = 1.5
-  h.delta = 0.1
-  h.box_loss_weight = 50.0
-  h.iou_loss_type = None
-  h.iou_loss_weight = 1.0
-  h.weight_decay = 4e-5
-  h.strategy = None
-  h.mixed_precision = False
-  h.loss_scale = None
-  # detection structure
-  h.box_class_repeats = 3
-  h.fpn_cell_repeats = 3
-  h.fpn_num_filters = 88
-  h.separable_conv = True
-  h.apply_bn_for_resampling = True
-  h.conv_after_downsample = False
-  h.conv_bn_act_pattern = False
-  h.drop_remainder = True
-  h.nms_configs = {
-      'method': 'gaussian',
-      'iou_thresh': None,
-      'score_thresh': 0.,
-      'sigma': None,
-      'pyfunc': False,
-      'max_nms_inputs': 0,
-      'max_output_size': 100,
-  }
-  h.tflite_max_detections = 100
-  h.fpn_name = None
-  h.fpn_weight_method = None
-  h.fpn_config = None
-  h.survival_prob = None
-  h.img_summary_steps = None
-  h.lr_decay_method = 'cosine'
-  h.moving_average_decay = 0.9998
-  h.ckpt_var_scope = None
-  h.skip_mismatch = True
-  h.backbone_name = 'efficientnet-b1'
-  h.backbone_config = None
-  h.var_freeze_expr = None
-  h.use_keras_model = True
-  h.dataset_type = None
-  h.positives_momentum = None
-  h.grad_checkpoint = False
-  h.verbose = 1
-  h.save_freq = 'epoch'
+  for _, group in _DEFAULT_GROUPS:
+    for key, value in group.items():
+      setattr(h, key, value)
   return h
 
 
