@@ -101,7 +101,147 @@ __global__ __launch_bounds__(DTHREADS) void k_conv_direct(const ConvArgs a) {
   }
 }
 
+// ---- backward, direct forms (fp32 validation mode / shapes outside the tiled kernels' envelope) ----------------
+struct ConvBwdArgs {
+  edet_tview_t in;      // conv input view (must be plain or affine/act handled by the caller: see entry point)
+  edet_gview_t gy;
+  const void* w;        // dgrad: [cin][ldw] compute copy, index (ky*k+kx)*cout + co
+  int ldw, k, s, oh, ow, pad_t, pad_l;
+  void* gout;
+  int beta;
+  float* dweight;       // wgrad: fp32 HWIO
+};
+
+template <typename T>
+__device__ __forceinline__ float conv_dy(const edet_gview_t& g, size_t off, int co) {
+  float v = to_f<T>(reinterpret_cast<const T*>(g.dz)[off]);
+  if (g.a) v = fmaf(g.a[co], v, fmaf(g.b[co], to_f<T>(reinterpret_cast<const T*>(g.y)[off]), g.cc[co]));
+  return v;
+}
+
+// thread = (input pixel, input channel): d in = sum over taps whose (iy + pad - ky) / s is an integer dy row
+template <typename T>
+__global__ __launch_bounds__(DTHREADS) void k_conv_dgrad_direct(const ConvBwdArgs a) {
+  const int cin = a.in.c, cout = a.gy.c;
+  const int64_t total = (int64_t)a.in.n * a.in.h * a.in.w * cin;
+  const T* W = reinterpret_cast<const T*>(a.w);
+  T* GO = reinterpret_cast<T*>(a.gout);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cin);
+    const int64_t pix = i / cin;
+    const int ix = (int)(pix % a.in.w), iy = (int)((pix / a.in.w) % a.in.h);
+    const int64_t img = pix / ((int64_t)a.in.w * a.in.h);
+    float acc = 0.f;
+    for (int ky = 0; ky < a.k; ++ky) {
+      const int ty = iy + a.pad_t - ky;
+      if (ty < 0 || ty % a.s != 0 || ty / a.s >= a.oh) continue;
+      for (int kx = 0; kx < a.k; ++kx) {
+        const int tx = ix + a.pad_l - kx;
+        if (tx < 0 || tx % a.s != 0 || tx / a.s >= a.ow) continue;
+        const size_t base = ((size_t)(img * a.oh + ty / a.s) * a.ow + tx / a.s) * a.gy.ld;
+        const T* wr = W + (size_t)c * a.ldw + (size_t)(ky * a.k + kx) * cout;
+        for (int co = 0; co < cout; ++co) acc = fmaf(conv_dy<T>(a.gy, base + co, co), to_f<T>(wr[co]), acc);
+      }
+    }
+    const size_t off = (size_t)pix * a.in.ld + c;
+    if (a.beta) acc += to_f<T>(GO[off]);
+    GO[off] = from_f<T>(acc);
+  }
+}
+
+// thread = one weight (tap, c, co): sums over all output pixels (slow, exact order-independent fp32 sum per thread)
+template <typename T>
+__global__ __launch_bounds__(DTHREADS) void k_conv_wgrad_direct(const ConvBwdArgs a) {
+  const int cin = a.in.c, cout = a.gy.c;
+  const int total = a.k * a.k * cin * cout;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int co = i % cout, c = (i / cout) % cin, tap = i / (cout * cin);
+  const int ky = tap / a.k, kx = tap - ky * a.k;
+  const T* X = reinterpret_cast<const T*>(a.in.data);
+  float acc = 0.f;
+  for (int img = 0; img < a.in.n; ++img)
+    for (int oy = 0; oy < a.oh; ++oy) {
+      const int iy = oy * a.s - a.pad_t + ky;
+      if (iy < 0 || iy >= a.in.h) continue;
+      for (int ox = 0; ox < a.ow; ++ox) {
+        const int ix = ox * a.s - a.pad_l + kx;
+        if (ix < 0 || ix >= a.in.w) continue;
+        float x = to_f<T>(X[((size_t)(img * a.in.h + iy) * a.in.w + ix) * a.in.ld + c]);
+        if (a.in.scale) x = fmaf(x, a.in.scale[c], a.in.shift[c]);
+        if (a.in.act == EDET_ACT_SWISH) x = swishf_(x);
+        if (a.in.gate) x *= a.in.gate[(size_t)img * cin + c];
+        acc = fmaf(x, conv_dy<T>(a.gy, ((size_t)(img * a.oh + oy) * a.ow + ox) * a.gy.ld + co, co), acc);
+      }
+    }
+  a.dweight[i] += acc;
+}
+
 }  // namespace
+
+int pwb_try_conv_dgrad(const edet_gview_t* dy, const void* w_t, int ldw, int k, int s, const edet_tview_t* in,
+                       const edet_bwd_epi_t* epi, int* nparts_out, hipStream_t st);
+int pwb_try_conv_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, float* dweight, void* workspace,
+                       size_t workspace_bytes, hipStream_t st);
+
+static int conv_bwd_common(ConvBwdArgs& a, const edet_tview_t* in, const edet_gview_t* dy, int k, int stride,
+                           const char* who) {
+  EDET_CHECK(k == 1 || k == 3 || k == 5, "%s: kernel size %d unsupported", who, k);
+  EDET_CHECK(stride == 1 || stride == 2, "%s: stride %d unsupported", who, stride);
+  memset(&a, 0, sizeof(a));
+  a.in = *in; a.gy = *dy; a.k = k; a.s = stride;
+  a.oh = same_out(in->h, stride); a.ow = same_out(in->w, stride);
+  a.pad_t = same_pad_before(in->h, k, stride); a.pad_l = same_pad_before(in->w, k, stride);
+  EDET_CHECK(a.oh == dy->h && a.ow == dy->w && dy->n == in->n, "%s: dy geometry does not match the input", who);
+  return 0;
+}
+
+extern "C" int edet_conv_bwd_data(const edet_gview_t* dy, const void* w_t, int ldw, int k, int stride,
+                                  const edet_tview_t* in, const edet_bwd_epi_t* epi, int* nparts_out,
+                                  int dtype, void* stream) {
+  EDET_CHECK(dy && dy->dz && w_t && in && in->data && epi && epi->gout, "edet_conv_bwd_data: null pointer");
+  EDET_CHECK(dtype == EDET_BF16 || dtype == EDET_F32, "edet_conv_bwd_data: bad dtype %d", dtype);
+  EDET_CHECK(ldw >= k * k * dy->c, "edet_conv_bwd_data: ldw too small");
+  EDET_CHECK(!epi->dgate && !in->gate, "edet_conv_bwd_data: gated inputs are not supported");
+  ConvBwdArgs a;
+  if (int rc = conv_bwd_common(a, in, dy, k, stride, "edet_conv_bwd_data")) return rc;
+  hipStream_t st = to_stream(stream);
+  if (dtype == EDET_BF16) {
+    const int rc = pwb_try_conv_dgrad(dy, w_t, ldw, k, stride, in, epi, nparts_out, st);
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
+  // direct form: plain inputs only (every dense convolution of EfficientNetV2 reads a stored block output)
+  EDET_CHECK(in->act == EDET_ACT_NONE && !in->scale && !epi->stat_partials,
+             "edet_conv_bwd_data: the direct kernel needs a plain input view (no BN / activation chain)");
+  a.w = w_t; a.ldw = ldw; a.gout = epi->gout; a.beta = epi->beta;
+  const int64_t total = (int64_t)in->n * in->h * in->w * in->c;
+  const int grid = (int)((total + DTHREADS - 1) / DTHREADS < 8192 ? (total + DTHREADS - 1) / DTHREADS : 8192);
+  if (dtype == EDET_BF16) k_conv_dgrad_direct<bf16_t><<<grid, DTHREADS, 0, st>>>(a);
+  else k_conv_dgrad_direct<float><<<grid, DTHREADS, 0, st>>>(a);
+  if (nparts_out) *nparts_out = 0;
+  EDET_LAUNCH_CHECK("edet_conv_bwd_data");
+  return 0;
+}
+
+extern "C" int edet_conv_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy, int k, int stride,
+                                    float* dweight, void* workspace, size_t workspace_bytes, int dtype,
+                                    void* stream) {
+  EDET_CHECK(in && in->data && dy && dy->dz && dweight, "edet_conv_bwd_weight: null pointer");
+  EDET_CHECK(dtype == EDET_BF16 || dtype == EDET_F32, "edet_conv_bwd_weight: bad dtype %d", dtype);
+  ConvBwdArgs a;
+  if (int rc = conv_bwd_common(a, in, dy, k, stride, "edet_conv_bwd_weight")) return rc;
+  hipStream_t st = to_stream(stream);
+  if (dtype == EDET_BF16) {
+    const int rc = pwb_try_conv_wgrad(in, dy, k, stride, dweight, workspace, workspace_bytes, st);
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
+  a.dweight = dweight;
+  const int total = k * k * in->c * dy->c;
+  if (dtype == EDET_BF16) k_conv_wgrad_direct<bf16_t><<<(total + DTHREADS - 1) / DTHREADS, DTHREADS, 0, st>>>(a);
+  else k_conv_wgrad_direct<float><<<(total + DTHREADS - 1) / DTHREADS, DTHREADS, 0, st>>>(a);
+  EDET_LAUNCH_CHECK("edet_conv_bwd_weight");
+  return 0;
+}
 
 extern "C" int edet_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, int k, int stride,
                              void* out, int cout, int ldo, float* stat_partials, int* nparts_out,

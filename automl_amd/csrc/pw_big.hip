@@ -94,7 +94,8 @@ __device__ __forceinline__ void mma_stage(const unsigned char* As, const unsigne
 
 template <bool BWD, bool GBN, bool CONV = false>
 __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
-  static_assert(!(CONV && BWD), "the implicit-GEMM gather is a forward-only variant");
+  // CONV && BWD: data gradient of the dense convolution -- rows = INPUT pixels, the streamed operand dy is
+  // gathered at (iy + pad - ky) / s when that is an integer inside the dy image, reduction index (ky*k+kx)*cout+co
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave & 1, wj = wave >> 1;
@@ -135,9 +136,9 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
       if (CONV) {
         const int img = m / a.cohw, rem = m - img * a.cohw;
         const int oy = rem / a.cow, ox = rem - oy * a.cow;
-        ciy[i] = oy * a.cs - a.pad_t;
-        cix[i] = ox * a.cs - a.pad_l;
-        arow[i] = (int64_t)img * a.ih * a.iw;           // pixel index of the image's first pixel
+        ciy[i] = BWD ? oy + a.pad_t : oy * a.cs - a.pad_t;     // BWD: (row, col) + pad, the tap is subtracted
+        cix[i] = BWD ? ox + a.pad_l : ox * a.cs - a.pad_l;
+        arow[i] = (int64_t)img * a.ih * a.iw;           // pixel index of the gathered image's first pixel
         aimg[i] = img;
       } else {
         arow[i] = (int64_t)m * lds_src;
@@ -171,15 +172,26 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
         rb[i] = make_uint4(0, 0, 0, 0);
         if (kok) {
           if (CONV) {
-            const int iy = ciy[i] + cky, ix = cix[i] + ckx;
-            if (iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw) {
+            int iy, ix;
+            bool hit;
+            if (BWD) {
+              const int ty = ciy[i] - cky, tx = cix[i] - ckx;
+              iy = ty / a.cs; ix = tx / a.cs;
+              hit = ty >= 0 && tx >= 0 && iy * a.cs == ty && ix * a.cs == tx && iy < a.ih && ix < a.iw;
+            } else {
+              iy = ciy[i] + cky; ix = cix[i] + ckx;
+              hit = iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw;
+            }
+            if (hit) {
               cvalid |= 1u << i;
-              ra[i] = *reinterpret_cast<const uint4*>(SRC + (arow[i] + (int64_t)iy * a.iw + ix) * lds_src + cc);
+              const int64_t off = (arow[i] + (int64_t)iy * a.iw + ix) * lds_src + cc;
+              ra[i] = *reinterpret_cast<const uint4*>(SRC + off);
+              if (GBN) ry[i] = *reinterpret_cast<const uint4*>(SRCY + off);
             }
           } else {
             ra[i] = *reinterpret_cast<const uint4*>(SRC + arow[i] + k);
+            if (GBN) ry[i] = *reinterpret_cast<const uint4*>(SRCY + arow[i] + k);
           }
-          if (GBN) ry[i] = *reinterpret_cast<const uint4*>(SRCY + arow[i] + k);
           const int j = j0 + lr + 32 * i;
           if (j < a.J) rb[i] = *reinterpret_cast<const uint4*>(a.Bm + (size_t)j * a.ldb + k);
         }
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
         if (!BWD) {
           if (affine) { loadf8(a.tv.scale + kc, c0); loadf8(a.tv.shift + kc, c1); }
         } else if (GBN) {
-          loadf8(a.gv.a + k, c0); loadf8(a.gv.b + k, c1); loadf8(a.gv.cc + k, c2);
+          loadf8(a.gv.a + kc, c0); loadf8(a.gv.b + kc, c1); loadf8(a.gv.cc + kc, c2);
         }
       }
 #pragma unroll
@@ -232,6 +244,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = fmaf(c0[e], x[e], fmaf(c1[e], y[e], c2[e]));
             v = pack8(x);
+            if (CONV && !((cvalid >> i) & 1u)) v = make_uint4(0, 0, 0, 0);   // taps outside dy contribute nothing
           }
         }
         *reinterpret_cast<uint4*>(As + (lr + 32 * i) * LDT + lc * 16) = v;
@@ -455,6 +468,9 @@ struct WgArgs {
   int ntk, ntn;       // 128-wide tiles over K and N
   int S;              // row splits
   int rows_per_split; // multiple of 64
+  // CONV (weight gradient of a dense ck x ck convolution): rows = OUTPUT pixels (dy rows); "channel" kk of the x
+  // operand = (tap, c): the activated input pixel shifted by the tap (zero outside the image); K = ck*ck*cin
+  int ck, cs, cin, ih, iw, cow, cohw, pad_t, pad_l;
 };
 
 __device__ __forceinline__ uint32_t perm_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
@@ -478,7 +494,7 @@ __device__ __forceinline__ void store_transposed(unsigned char* tile, int cb, in
   }
 }
 
-template <bool GBN>
+template <bool GBN, bool CONV = false>
 __global__ __launch_bounds__(THREADS, 2) void k_big_wgrad(const WgArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -499,6 +515,11 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_wgrad(const WgArgs a) {
   const int cb = cchunk * 8;
   const int cglob = (is_x ? kt0 : nt0) + cb;
   const bool c_ok = cglob < (is_x ? a.K : a.N);
+  // CONV: tap and input channel of this thread's x chunk (cin % 8 == 0: a chunk never straddles taps)
+  const int ctap = (CONV && is_x) ? cglob / a.cin : 0;
+  const int cch = (CONV && is_x) ? cglob - ctap * a.cin : cglob;
+  const int cky = CONV ? ctap / a.ck : 0, ckx = CONV ? ctap - (ctap / a.ck) * a.ck : 0;
+  unsigned cvalid = 0;
   const bf16_t* SRC = reinterpret_cast<const bf16_t*>(is_x ? a.tv.data : a.gv.dz);
   const bf16_t* SRCY = reinterpret_cast<const bf16_t*>(a.gv.y);
   const int ld = is_x ? a.tv.ld : a.gv.ld;
@@ -508,7 +529,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_wgrad(const WgArgs a) {
   for (int e = 0; e < 8; ++e) { c0[e] = 1.f; c1[e] = 0.f; c2[e] = 0.f; }
   if (c_ok) {
     if (is_x) {
-      if (affine) { loadf8(a.tv.scale + cglob, c0); loadf8(a.tv.shift + cglob, c1); }
+      if (affine) { loadf8(a.tv.scale + cch, c0); loadf8(a.tv.shift + cch, c1); }
     } else if (GBN) {
       loadf8(a.gv.a + cglob, c0); loadf8(a.gv.b + cglob, c1); loadf8(a.gv.cc + cglob, c2);
     }
@@ -524,14 +545,37 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_wgrad(const WgArgs a) {
 
   uint4 ra[8], ry[GBN ? 8 : 1];
   auto issue = [&](int mb) {
+    int cimg = 0, coy = 0, cox = 0;            // CONV: output pixel of row mb + rg*8, advanced row by row
+    if (CONV) {
+      cvalid = 0;
+      const int m8 = mb + rg * 8;
+      cimg = m8 / a.cohw;
+      const int rem = m8 - cimg * a.cohw;
+      coy = rem / a.cow;
+      cox = rem - coy * a.cow;
+    }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int m = mb + rg * 8 + r;
       ra[r] = make_uint4(0, 0, 0, 0);
       if (GBN) ry[r] = make_uint4(0, 0, 0, 0);
+      if (CONV && r > 0) {
+        if (++cox == a.cow) {
+          cox = 0;
+          if (++coy * a.cow == a.cohw) { coy = 0; ++cimg; }
+        }
+      }
       if (c_ok && m < m_end) {
-        ra[r] = *reinterpret_cast<const uint4*>(SRC + (size_t)m * ld + cglob);
-        if (GBN && !is_x) ry[r] = *reinterpret_cast<const uint4*>(SRCY + (size_t)m * ld + cglob);
+        if (CONV && is_x) {
+          const int iy = coy * a.cs - a.pad_t + cky, ix = cox * a.cs - a.pad_l + ckx;
+          if (iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw) {
+            cvalid |= 1u << r;
+            ra[r] = *reinterpret_cast<const uint4*>(SRC + (((size_t)cimg * a.ih + iy) * a.iw + ix) * ld + cch);
+          }
+        } else {
+          ra[r] = *reinterpret_cast<const uint4*>(SRC + (size_t)m * ld + cglob);
+          if (GBN && !is_x) ry[r] = *reinterpret_cast<const uint4*>(SRCY + (size_t)m * ld + cglob);
+        }
       }
     }
   };
@@ -557,12 +601,13 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_wgrad(const WgArgs a) {
             }
             if (gated) {
               float gt[8];
-              loadf8(a.tv.gate + (size_t)(m / a.hw) * a.K + cglob, gt);
+              loadf8(a.tv.gate + (size_t)(m / (CONV ? a.cohw : a.hw)) * (CONV ? a.cin : a.K) + cch, gt);
 #pragma unroll
               for (int e = 0; e < 8; ++e) x[e] *= gt[e];
             }
             p[r] = pack8(x);
           }
+          if (CONV && !((cvalid >> r) & 1u)) p[r] = make_uint4(0, 0, 0, 0);   // 'SAME' padding: zero after act
         } else if (GBN) {
           float x[8], y[8];
           unpack8(ra[r], x);
@@ -723,6 +768,71 @@ int pwb_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight
   if (dy->a) k_big_wgrad<true><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
   else k_big_wgrad<false><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
   EDET_LAUNCH_CHECK("edet_pw_bwd_weight(big)");
+  if (edet_reduce_partials(a.ws, a.S, kn, dweight, st) != 0) return -2;
+  return 1;
+}
+
+// ---- dense k x k convolution backward as implicit GEMMs (conv.hip dispatches here for bf16) -------------------
+// data gradient: w_t [cin][ldw] with the reduction index (ky*k + kx)*cout + co contiguous; rows = input pixels
+int pwb_try_conv_dgrad(const edet_gview_t* dy, const void* w_t, int ldw, int k, int s, const edet_tview_t* in,
+                       const edet_bwd_epi_t* epi, int* nparts_out, hipStream_t st) {
+  using namespace pwb;
+  const int cout = dy->c, cin = in->c;
+  if (cout % 8 != 0 || cin % 8 != 0 || in->ld % 8 != 0 || dy->ld % 8 != 0 || ldw % 8 != 0) return 0;
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tv = *in; a.gv = *dy;
+  a.Bm = reinterpret_cast<const bf16_t*>(w_t); a.ldb = ldw;
+  a.M = in->n * in->h * in->w; a.R = k * k * cout; a.J = cin; a.hw = in->h * in->w;
+  a.ck = k; a.cs = s; a.cin = cout;                 // channels of the STREAMED operand (dy)
+  a.ih = dy->h; a.iw = dy->w;                       // gathered image = dy
+  a.cow = in->w; a.cohw = in->h * in->w;            // row space = input pixels
+  a.pad_t = same_pad_before(in->h, k, s); a.pad_l = same_pad_before(in->w, k, s);
+  a.epi = *epi; a.stat_partials = epi->stat_partials;
+  a.ntm = (a.M + BM - 1) / BM; a.ntj = (cin + BJ - 1) / BJ;
+  a.tpw = (a.ntm + EDET_MAX_PARTS - 1) / EDET_MAX_PARTS;
+  a.ngrp = (a.ntm + a.tpw - 1) / a.tpw;
+  if (nparts_out) *nparts_out = a.ngrp;
+  static const bool ok1 = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<true, false, true>));
+  static const bool ok2 = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<true, true, true>));
+  if (!ok1 || !ok2) return 0;
+  const int grid = (a.ngrp + 7) / 8 * 8 * a.ntj;
+  if (dy->a) k_big_gemm<true, true, true><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+  else k_big_gemm<true, false, true><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+  EDET_LAUNCH_CHECK("edet_conv_bwd_data(big)");
+  return 1;
+}
+
+// weight gradient: dweight fp32 HWIO [k][k][cin][cout] += gathered(in)^T dy
+int pwb_try_conv_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, float* dweight, void* workspace,
+                       size_t workspace_bytes, hipStream_t st) {
+  using namespace pwb;
+  const int cin = in->c, N = dy->c, K = k * k * cin;
+  if (!workspace || cin % 8 != 0 || N % 8 != 0 || dy->ld % 8 != 0 || in->ld % 8 != 0) return 0;
+  WgArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tv = *in; a.gv = *dy; a.ws = reinterpret_cast<float*>(workspace);
+  a.M = dy->n * dy->h * dy->w; a.K = K; a.N = N; a.hw = dy->h * dy->w;
+  a.ck = k; a.cs = s; a.cin = cin; a.ih = in->h; a.iw = in->w; a.cow = dy->w; a.cohw = dy->h * dy->w;
+  a.pad_t = same_pad_before(in->h, k, s); a.pad_l = same_pad_before(in->w, k, s);
+  a.ntk = (K + 127) / 128; a.ntn = (N + 127) / 128;
+  const int ntile = a.ntk * a.ntn;
+  const int64_t kn = (int64_t)K * N;
+  int S = (2048 + ntile - 1) / ntile;
+  const int max_by_rows = (a.M + 4 * BK - 1) / (4 * BK);
+  if (S > max_by_rows) S = max_by_rows;
+  const int64_t max_by_ws = (int64_t)(workspace_bytes / sizeof(float)) / kn;
+  if (S > max_by_ws) S = (int)max_by_ws;
+  if (S < 1) return 0;
+  a.rows_per_split = ((a.M + S - 1) / S + BK - 1) / BK * BK;
+  a.S = (a.M + a.rows_per_split - 1) / a.rows_per_split;
+  static const bool ok1 = big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad<false, true>));
+  static const bool ok2 = big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad<true, true>));
+  if (!ok1 || !ok2) return 0;
+  const int grid = (a.S + 7) / 8 * 8 * ntile;
+  if (dy->a) k_big_wgrad<true, true><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+  else k_big_wgrad<false, true><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+  EDET_LAUNCH_CHECK("edet_conv_bwd_weight(big)");
   if (edet_reduce_partials(a.ws, a.S, kn, dweight, st) != 0) return -2;
   return 1;
 }

@@ -6,10 +6,10 @@ MBConvBlock (:187-310), FusedMBConvBlock (:313-406), SE (:105-147) and Head (:43
 Variable names follow the Keras model (model name as prefix, ``blocks_%d``, per-block ``conv2d[_1]`` /
 ``tpu_batch_normalization[_1,_2]`` counters, ``se/conv2d[_1]``, ``head/...``).
 
-Scope: the forward pass in both BatchNorm modes; stochastic
-depth and dropout act only in training and the V2 classifier's training is outside the hot path, so
-``training=True`` computes batch statistics but refuses survival_prob / dropout (pass
-``model_config='survival_prob=0,dropout_rate=0'`` or leave training=False).
+Scope: the forward pass in both BatchNorm modes and the backward
+pass of the whole graph (``backward(d_outputs)``: Fused-MBConv dense convolutions, MBConv, SE, stochastic depth,
+head, dense layer).  The classifier's loss / optimizer / dropout are outside the detection hot path:
+``training=True`` refuses dropout (pass ``model_config='dropout_rate=0'``).
 """
 import collections
 import ctypes
@@ -43,6 +43,10 @@ class V2Spec(object):
     self.bn_epsilon = float(mconfig.bn_epsilon)
     self.name = mconfig.model_name
     self.stem_filters, self.blocks = effnetv2_configs.expand_blocks(mconfig)
+    # stochastic depth (effnetv2_model.py:624-629): survival_prob 0.8 -> per block 1 - 0.2 * idx / n
+    sp = mconfig.survival_prob
+    self.survival_probs = [(1.0 - (1.0 - sp) * float(b.index) / len(self.blocks)) if sp else None
+                           for b in self.blocks]
     self.head_filters = effnetv2_configs.round_filters(mconfig.feature_size or 1280, mconfig)
     self.num_classes = mconfig.num_classes if include_top else 0
     self.params = []
@@ -159,9 +163,16 @@ class V2Engine(engine_lib.Engine):
     self._bn_forward(bn0, y0.rows, self._nparts.value)
     x = engine_lib.View(y0, bn0, ACT_SWISH)
     if training:
-      self.tape.append(self._no_backward)
-    if spec.blocks[0].has_residual:
-      # the first block adds its input back: the stem output has to exist in activated form
+      v0, wstem = x, name + '/stem/conv2d/kernel'
+
+      def stem_bwd():
+        g = self._gview(v0)
+        call('edet_stem_bwd_weight', ptr(images), n, h, w, ctypes.byref(g), ptr(self.grad(wstem)), self.dtype,
+             self.stream, nbytes=(n * h * w * 3 + y0.rows * y0.c) * self.esize)
+      self.tape.append(stem_bwd)
+    if training or spec.blocks[0].has_residual or spec.blocks[0].conv_type == 1:
+      # the dense convolutions (and a first block that adds its input back) read a STORED tensor: the stem
+      # output is materialised in activated form (one extra pass over a stride-2, 24..32-channel map)
       x = self.bn_res('stem:out', x, None)
     reds = set(spec.reduction_indices())
     self.endpoints = {'stem': x}
@@ -184,6 +195,7 @@ class V2Engine(engine_lib.Engine):
     call('edet_se_pool', ctypes.byref(hv.tview()), ptr(pooled), self.dtype, self.stream,
          nbytes=r.rows * r.c * self.esize)
     self.pooled_sum, self.pooled_inv_hw = pooled, 1.0 / (r.h * r.w)
+    self.head_view = hv
     self.logits = None
     if spec.num_classes:
       pv = engine_lib.Raw(self, 'head:pooled', n, 1, 1, r.c, needs_grad=False)
@@ -199,10 +211,55 @@ class V2Engine(engine_lib.Engine):
       call('edet_pw_fwd', ctypes.byref(tv), ptr(wt), ldk, ptr(self.param(name + '/head/dense/bias')),
            ptr(out.data), spec.num_classes, out.ld, None, ctypes.byref(self._nparts), self.dtype, self.stream)
       self.logits = out
+      self._fc = (pv, tv, inv)
     return self.logits
 
-  def _no_backward(self):
-    raise _lib.EdetError('EffNetV2Model is a forward path: the V2 classifier backward is not built')
+  def backward(self, d_out):
+    """Gradients of every variable for a given gradient of the model output (after forward(training=True)):
+    d_out = d(logits) [B, num_classes] with include_top, else d(pooled features) [B, feature_size].  Fills
+    grads_flat (get_grads()).  The loss itself -- softmax cross-entropy with label smoothing in the reference's
+    classifier training, efficientnetv2/main.py -- stays with the caller: classifier training is outside the
+    detection hot path, the backward of the Fused-MBConv / MBConv / SE / head graph is what is built here."""
+    spec = self.spec
+    assert self.training, 'run forward(training=True) first'
+    name = spec.name
+    hv = self.head_view
+    r = hv.raw
+    n, c = r.n, r.c
+    d_out = torch.as_tensor(d_out).to(device=self.device, dtype=torch.float32).reshape(n, -1)
+    if spec.num_classes:
+      pv, tv, inv = self._fc
+      ncls = spec.num_classes
+      dl = engine_lib.Raw(self, 'head:dlogits', n, 1, 1, ncls, needs_grad=False)
+      dl.data.zero_()
+      dl.data.reshape(n, -1)[:, :ncls] = d_out.to(self.tdtype)
+      g = _lib.GView(ptr(dl.data), None, None, None, None, n, 1, 1, ncls, dl.ld)
+      wname = name + '/head/dense/kernel'
+      _, _, wcopy, ldn = self._pw_copies(wname, c, ncls)
+      call('edet_pw_bwd_weight', ctypes.byref(tv), ctypes.byref(g), ptr(self.grad(wname)), ptr(self.workspace),
+           self.workspace.numel() * 4, self.dtype, self.stream)
+      self.grad(name + '/head/dense/bias').add_(dl.data.reshape(n, -1)[:, :ncls].float().sum(0))
+      dpv = self.buf('head:dpooled', (n, 1, 1, pv.ld), self.tdtype)
+      epi = _lib.BwdEpi(ptr(dpv), 0, None, None, None, None)
+      plain = _lib.TView(ptr(pv.data), None, None, None, ACT_NONE, n, 1, 1, c, pv.ld)
+      call('edet_pw_bwd_data', ctypes.byref(g), ptr(wcopy), ldn, ctypes.byref(plain), ctypes.byref(epi),
+           ctypes.byref(self._nparts), self.dtype, self.stream)
+      d_mean = dpv.reshape(n, -1)[:, :c].float()          # d(mean-pooled features)
+    else:
+      d_mean = d_out
+    # global average pooling backward: every pixel receives d_mean / (H*W); through swish' and the head BatchNorm
+    dpool = self.buf('head:dpool', (n, c), torch.float32)
+    dpool.copy_(d_mean * self.pooled_inv_hw)
+    gbuf = r.ensure_grad()
+    gbuf.zero_()
+    ones = self.buf('ones:%d:%d' % (n, c), (n, c), torch.float32)
+    ones.fill_(1.0)
+    gv = _lib.TView(ptr(r.data), ptr(hv.bn.scale), ptr(hv.bn.shift), ptr(ones), hv.act, r.n, r.h, r.w, c, r.ld)
+    call('edet_se_gate_bwd', ctypes.byref(gv), ptr(gbuf), ptr(dpool), ptr(hv.bn.mean), ptr(hv.bn.rstd),
+         ptr(self.partials), ctypes.byref(self._nparts), self.dtype, self.stream)
+    self._bn_bwd_finalize(hv.bn, self._nparts.value)
+    r.grad_written = True
+    super().backward()
 
   def _fused_mbconv(self, xin, b, scope):
     """FusedMBConvBlock.call (effnetv2_model.py:373-406)."""
@@ -220,7 +277,8 @@ class V2Engine(engine_lib.Engine):
         raise ValueError('SE in an expand_ratio == 1 fused block gates the block input: out of scope')
       y = self.conv(scope + ':conv', x, scope + '/conv2d/kernel', b.kernel_size, b.stride, b.output_filters,
                     bn=scope + '/tpu_batch_normalization', act=ACT_SWISH)     # act because no expansion
-    return self.bn_res(scope + ':out', y, xin if b.has_residual else None)
+    return self.bn_res(scope + ':out', y, xin if b.has_residual else None,
+                       survival_prob=self.spec.survival_probs[b.index])
 
 
 class EffNetV2Model(object):
@@ -248,12 +306,17 @@ class EffNetV2Model(object):
                              seed=self._seed, params=params)
     return self.engine
 
+  def backward(self, d_outputs):
+    """Gradients of every variable w.r.t. a given d(outputs) of the last training=True call -> {name: array}."""
+    self.engine.backward(d_outputs)
+    return self.engine.get_grads()
+
   def __call__(self, inputs, training=False, with_endpoints=False):
     """-> logits [B,num_classes] (include_top) or pooled features [B,feature_size]; with_endpoints:
     [outputs, reduction_1..5] (effnetv2_model.py:595-658).  Tensors are device torch tensors."""
-    if training and (self._mconfig.survival_prob or self._mconfig.dropout_rate or self._mconfig.conv_dropout):
-      raise ValueError('training=True with survival_prob / dropout is outside the built forward path; '
-                       "override model_config='survival_prob=0,dropout_rate=0'")
+    if training and (self._mconfig.dropout_rate or self._mconfig.conv_dropout):
+      raise ValueError('training=True with dropout is outside the built path; '
+                       "override model_config='dropout_rate=0'")
     if isinstance(inputs, np.ndarray):
       inputs = torch.from_numpy(inputs)
     if inputs.dim() != 4 or inputs.shape[-1] != 3:

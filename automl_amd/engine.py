@@ -401,10 +401,26 @@ class Engine(object):
     vout = View(out, bnl, act)
     vin.consumers += 1
     if self.training:
-      def bwd():
-        raise _lib.EdetError('the dense-convolution backward (EfficientNetV2 classifier training) is not built')
-      self.tape.append(bwd)
+      self.tape.append(lambda: self._conv_bwd(vin, vout, wname, k, stride, cin, cout))
     return vout
+
+  def _conv_bwd(self, vin, vout, wname, k, stride, cin, cout):
+    """Both gradients of a dense convolution (edet_conv_bwd_weight / edet_conv_bwd_data)."""
+    g = self._gview(vout)
+    nb = (vin.raw.rows * cin + vout.raw.rows * cout) * self.esize
+    tag = '%dx%dx%d->%d k%ds%d' % (vin.raw.h, vin.raw.w, cin, cout, k, stride)
+    call('edet_conv_bwd_weight', ctypes.byref(vin.tview()), ctypes.byref(g), k, stride, ptr(self.grad(wname)),
+         ptr(self.workspace), self.workspace.numel() * 4, self.dtype, self.stream, nbytes=nb, tag=tag)
+    if vin.raw.needs_grad:
+      # compute copy for the data gradient: HWIO -> [cin][k][k][cout] (reduction index (tap, co) contiguous)
+      wperm = self.buf('wtd:' + wname, (cin, k * k * cout), self.tdtype)
+      wperm.copy_(self.param(wname).view(k, k, cin, cout).permute(2, 0, 1, 3).reshape(cin, k * k * cout))
+      epi, fused = self._epi(vin)
+      call('edet_conv_bwd_data', ctypes.byref(g), ptr(wperm), k * k * cout, k, stride, ctypes.byref(vin.tview()),
+           ctypes.byref(epi), ctypes.byref(self._nparts), self.dtype, self.stream, nbytes=nb, tag=tag)
+      vin.raw.grad_written = True
+      if fused:
+        self._bn_bwd_finalize(vin.bn, self._nparts.value)
 
   def dw(self, key, vin, wname, k, stride, bn=None, act=ACT_NONE):
     r = vin.raw
@@ -513,8 +529,31 @@ class Engine(object):
     if residual is not None:
       residual.consumers += 1
     if self.training:
+      act_view = vy.act != ACT_NONE
+
       def bwd():
         assert out.grad_written, key
+        if act_view:
+          # out = act(bn(y)) [* mask] (+ residual): the residual takes d(out) as it is, then d(out) becomes
+          # dz = d(out) * mask * act'(z) in place (edet_se_gate_bwd with gate = mask or ones, dpool = 0), which
+          # also yields the BatchNorm-backward sums of y's BatchNorm
+          if residual is not None and residual.raw.needs_grad:
+            rr = residual.raw
+            call('edet_add', ptr(rr.ensure_grad()), ptr(out.grad), rr.rows, rr.c, rr.ld,
+                 1 if rr.grad_written else 0, self.dtype, self.stream)
+            rr.grad_written = True
+          ones = mask if mask is not None else self.buf('ones:%d:%d' % (r.n, r.c), (r.n, r.c), torch.float32)
+          if mask is None:
+            ones.fill_(1.0)
+          zeros = self.zbuf('zeros:%d:%d' % (r.n, r.c), (r.n, r.c))
+          gv = TView(ptr(r.data), ptr(vy.bn.scale), ptr(vy.bn.shift), ptr(ones), vy.act, r.n, r.h, r.w, r.c, r.ld)
+          call('edet_se_gate_bwd', ctypes.byref(gv), ptr(out.grad), ptr(zeros), ptr(vy.bn.mean), ptr(vy.bn.rstd),
+               ptr(self.partials), ctypes.byref(self._nparts), self.dtype, self.stream,
+               nbytes=2 * r.rows * r.c * self.esize)
+          self._bn_bwd_finalize(vy.bn, self._nparts.value)
+          r.grad = out.grad
+          r.grad_written = True
+          return
         if mask is not None:
           # d(bn output) = d(block output) * mask[n]: the same kernel, applied to the gradient
           gbuf = self.buf(key + ':dcg', (r.n, r.h, r.w, r.ld), self.tdtype)

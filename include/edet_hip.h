@@ -156,6 +156,16 @@ int edet_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, int k, int st
                   void* out, int cout, int ldo, float* stat_partials, int* nparts_out,
                   int dtype, void* stream);
 
+/* gradients of the dense convolution (TF Conv2DBackpropInput / Conv2DBackpropFilter under the reference's
+ * GradientTape).  w_t: compute copy [cin][ldw] with the reduction index (ky*k + kx)*cout + co contiguous (the HWIO
+ * kernel permuted to [cin][k][k][cout]); epi as for edet_pw_bwd_data (no gate).  dweight: fp32 HWIO
+ * [k][k][cin][cout], accumulated into; workspace as for edet_pw_bwd_weight.  */
+int edet_conv_bwd_data(const edet_gview_t* dy, const void* w_t, int ldw, int k, int stride,
+                       const edet_tview_t* in, const edet_bwd_epi_t* epi, int* nparts_out,
+                       int dtype, void* stream);
+int edet_conv_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy, int k, int stride,
+                         float* dweight, void* workspace, size_t workspace_bytes, int dtype, void* stream);
+
 /* ---- depthwise convolution k in {3,5}, stride in {1,2}, TF 'SAME' ----------
  * DepthwiseConv2D call sites: efficientnet_model.py:320-327 and the depthwise
  * half of SeparableConv2D.  weight fp32 [k,k,c] (HWIO with multiplier 1).  */

@@ -28,6 +28,16 @@ class V2Oracle(object):
     self.include_top = include_top
     self.store = det.ParamStore(params, seed)
     self.new_moving = {}
+    # stochastic depth: block scope -> per-image scale floor(p + u) / p ([B] tensor), an INPUT of the oracle
+    # (TF's RNG stream cannot be reproduced; the tests pass the draws of the device path).  Empty = off.
+    self.drop_scale = {}
+
+  def _residual(self, x, inputs, b, scope, training):
+    if not b.has_residual:
+      return x
+    if training and scope in self.drop_scale:
+      x = x * self.drop_scale[scope].view(-1, 1, 1, 1)      # utils.drop_connect (efficientnetv2/utils.py:292-307)
+    return x + inputs
 
   def bn(self, x, name, training):
     c = x.shape[1]
@@ -78,7 +88,7 @@ class V2Oracle(object):
     wp = P.get('%s/%s/kernel' % (scope, 'conv2d_1' if ci else 'conv2d'), (1, 1, cexp, b.output_filters),
                det.conv_kernel_init)
     x = self.bn(conv2d_same(x, wp), '%s/%s' % (scope, bn[bi]), training)
-    return x + inputs if b.has_residual else x
+    return self._residual(x, inputs, b, scope, training)
 
   def fused_mbconv(self, inputs, b, scope, training):
     P = self.store
@@ -95,7 +105,7 @@ class V2Oracle(object):
     else:
       w = P.get(scope + '/conv2d/kernel', (k, k, cexp, b.output_filters), det.conv_kernel_init)
       x = swish(self.bn(conv2d_same(x, w, b.stride), scope + '/tpu_batch_normalization', training))
-    return x + inputs if b.has_residual else x
+    return self._residual(x, inputs, b, scope, training)
 
   def forward(self, images_nhwc, training=False):
     m = self.mconfig

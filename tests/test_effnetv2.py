@@ -228,3 +228,104 @@ def test_model_tables_equal_the_reference_modules():
     assert got == ref['model'], name
     full = effnetv2_configs.get_model_config(name)
     assert full.train.isize == ref['train_isize'] and full.eval.isize == ref['eval_isize'], name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
+@pytest.mark.parametrize('shape', [(2, 9, 7, 24, 24), (1, 16, 16, 24, 96), (2, 14, 14, 48, 192), (3, 7, 9, 64, 256),
+                                   (1, 5, 5, 8, 8), (2, 12, 13, 32, 136)])
+@pytest.mark.parametrize('ks', [(3, 1), (3, 2), (5, 2), (1, 1)])
+@pytest.mark.parametrize('mode', ['plain', 'bn_dy_beta'])
+def test_conv_bwd(dt, shape, ks, mode):
+  """Data and weight gradient of the dense convolution against autograd (plain input view, the EfficientNetV2
+  case): with / without the BatchNorm backward applied on load to dy, with / without accumulation into d in."""
+  from automl_amd._lib import BwdEpi
+  name, edt, tdt = dt
+  n, h, w, cin, cout = shape
+  k, s = ks
+  rng = np.random.default_rng(gu.seed_of((shape, ks, mode, 3)))
+  x = gu.rnd(rng, (n, h, w, cin), tdt)
+  wk = gu.rnd(rng, (k, k, cin, cout), tdt, 1.0 / np.sqrt(k * k * cin))
+  xq, wq = x.clone().requires_grad_(True), wk.clone().requires_grad_(True)
+  out = orc.conv2d_same(xq.permute(0, 3, 1, 2), wq, s).permute(0, 2, 3, 1)
+  oh, ow = out.shape[1], out.shape[2]
+  dz = gu.rnd(rng, (n, oh, ow, cout), tdt)
+  y = ga = gb = gcc = None
+  dy = dz
+  old = None
+  if mode == 'bn_dy_beta':
+    y = gu.rnd(rng, (n, oh, ow, cout), tdt)
+    ga = torch.from_numpy((1 + 0.2 * rng.standard_normal(cout)).astype(np.float32))
+    gb = torch.from_numpy((0.2 * rng.standard_normal(cout)).astype(np.float32))
+    gcc = torch.from_numpy((0.2 * rng.standard_normal(cout)).astype(np.float32))
+    dy = ga * dz + gb * y + gcc
+    old = gu.rnd(rng, (n, h, w, cin), tdt)
+  if name == 'bf16':
+    dy = dy.to(torch.bfloat16).float()       # the kernels feed bf16 operands to the MFMA
+  out.backward(dy)
+  want_dx = xq.grad + (old if old is not None else 0)
+  want_dw = wq.grad
+
+  xd, dzd = gu.to_dev(x, tdt), gu.to_dev(dz, tdt)
+  yd = gu.to_dev(y, tdt) if y is not None else None
+  gv = gu.gview(dzd, cout, yd, ga, gb, gcc)
+  tv = gu.tview(xd, cin)
+  kk = k * k * cout
+  wperm = wk.permute(2, 0, 1, 3).reshape(cin, kk).contiguous().to(device=gu.DEV, dtype=tdt)
+  gout = gu.to_dev(old, tdt) if old is not None else torch.full((n, h, w, gu.pad8(cin)), float('nan'), dtype=tdt,
+                                                                 device=gu.DEV)
+  epi = BwdEpi(ptr(gout), 1 if old is not None else 0, None, None, None, None)
+  npart = ctypes.c_int(0)
+  call('edet_conv_bwd_data', ctypes.byref(gv), ptr(wperm), kk, k, s, ctypes.byref(tv), ctypes.byref(epi),
+       ctypes.byref(npart), edt, gu.stream())
+  dwd = torch.zeros(k, k, cin, cout, dtype=torch.float32, device=gu.DEV)
+  wsp = torch.empty(4 * 1024 * 1024, dtype=torch.float32, device=gu.DEV)
+  call('edet_conv_bwd_weight', ctypes.byref(tv), ctypes.byref(gv), k, s, ptr(dwd), ptr(wsp), 16 * 1024 * 1024, edt,
+       gu.stream())
+  torch.cuda.synchronize()
+  gu.check(gout[..., :cin], want_dx, name, 'conv_bwd_data %s k%d s%d %s' % (shape, k, s, mode))
+  gu.check(dwd, want_dw, name, 'conv_bwd_weight %s k%d s%d' % (shape, k, s), rtol=2e-2 if name == 'bf16' else 1e-3,
+           atol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('model_name,size,over', [
+    ('efficientnetv2-b0', 64, 'num_classes=24,survival_prob=0,dropout_rate=0'),
+    ('efficientnetv2-s', 96, 'num_classes=24,dropout_rate=0'),                 # stochastic depth on
+])
+def test_model_backward_matches_oracle_fp32(model_name, size, over):
+  """EffNetV2Model.backward(d logits): every variable's gradient against autograd through the oracle (fp32
+  storage).  With stochastic depth the oracle gets the per-image draws of the device path."""
+  batch = 4
+  spec = effnetv2_model.V2Spec(effnetv2_configs.model_config(model_name, over))
+  vals = _perturbed(spec, 9)
+  rng = np.random.default_rng(13)
+  images = rng.standard_normal((batch, size, size, 3)).astype(np.float32)
+  dlog = rng.standard_normal((batch, 24)).astype(np.float32)
+  net = effnetv2_model.EffNetV2Model(model_name, over, dtype='f32', params=vals)
+  logits = net(torch.from_numpy(images), training=True)
+  torch.cuda.synchronize()
+  got = net.backward(torch.from_numpy(dlog))
+  torch.cuda.synchronize()
+
+  params = {k: torch.from_numpy(v.copy()).requires_grad_(not k.endswith(('moving_mean', 'moving_variance')))
+            for k, v in vals.items()}
+  oracle = v2orc.V2Oracle(model_name, over, params=params)
+  oracle.drop_scale = {k[:-len(':out')]: m[:, 0].detach().cpu().clone() for k, (m, p) in net.engine.drop_masks.items()}
+  assert bool(oracle.drop_scale) == ('survival_prob=0' not in over)
+  ends = oracle.forward(torch.from_numpy(images), True)
+  err = float((logits.float().cpu() - ends['head'].detach()).abs().max()) / float(ends['head'].abs().max())
+  assert err <= 1e-3, err
+  (ends['head'] * torch.from_numpy(dlog)).sum().backward()
+  gmax = max(float(p.grad.abs().max()) for p in params.values() if p.requires_grad and p.grad is not None)
+  bad = []
+  for name, p in params.items():
+    if not p.requires_grad:
+      continue
+    g = p.grad if p.grad is not None else torch.zeros_like(p)
+    mine = torch.from_numpy(np.asarray(got[name])).reshape(g.shape)
+    e = float((mine - g).abs().max()) / max(float(g.abs().max()), 1e-4 * gmax)
+    if not e <= 1e-2:
+      bad.append((name, e))
+  bad.sort(key=lambda t: -t[1])
+  assert not bad, 'gradient mismatch in %d/%d tensors, worst %s' % (len(bad), len(params), bad[:8])
