@@ -71,15 +71,15 @@ SIGNATURES = {
     'edet_se_fc_bwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     'edet_se_gate_bwd': [PT, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, PI, c_int, c_void_p],
-    'edet_fuse_weights': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
-    'edet_fuse_fwd': [PT, PT, PT, PI, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+    'edet_fuse_weights': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p],
+    'edet_fuse_fwd': [PT, PT, PT, PI, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
                       c_void_p],
-    'edet_fuse_bwd_pre': [PT, PT, PT, PI, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+    'edet_fuse_bwd_pre': [PT, PT, PT, PI, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
                           c_void_p, c_void_p, c_void_p, c_int, c_void_p],
-    'edet_fuse_bwd_input': [PT, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+    'edet_fuse_bwd_input': [PT, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                             c_int, c_int, c_void_p],
     'edet_fuse_weights_bwd': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                              c_void_p, c_void_p],
+                              c_void_p, c_int, c_void_p],
     'edet_focal_loss': [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float,
                         c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     'edet_box_loss': [c_void_p, c_int, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_void_p,

@@ -18,7 +18,8 @@ struct FuseArgs {
   int mode[3];
   int pad_t[3], pad_l[3];
   int nin;
-  const float* wn;  // [3] normalised weights (device)
+  const float* wn;  // [3][wc] normalised weights (device); wc = 1 (one weight per input) or c (per channel)
+  int wc;
   int act;
   int n, oh, ow, c, ldo;
 };
@@ -88,9 +89,16 @@ __global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restric
                                                  float* dwn, unsigned char* __restrict__ pool_argmax) {
   const int nvec = a.c / 8;
   const int64_t total = (int64_t)a.n * a.oh * a.ow * nvec;
+  const bool per_ch = a.wc > 1;                      // channel_attn / channel_fastattn: one weight per channel
+  extern __shared__ float redc[];                    // per_ch && BWD: [3][c] dwn sums of this workgroup
   float wn[3] = {0.f, 0.f, 0.f};
-  for (int i = 0; i < a.nin; ++i) wn[i] = a.wn[i];
+  if (!per_ch)
+    for (int i = 0; i < a.nin; ++i) wn[i] = a.wn[i];
   float dw_acc[3] = {0.f, 0.f, 0.f};
+  if (BWD && per_ch && dwn) {
+    for (int i = threadIdx.x; i < 3 * a.c; i += THREADS) redc[i] = 0.f;
+    __syncthreads();
+  }
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
        q += (int64_t)gridDim.x * blockDim.x) {
     const int c0 = (int)(q % nvec) * 8;
@@ -117,8 +125,15 @@ __global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restric
       } else {
         sample_input<T, false>(a, i, k, n, oy, ox, c0, xi[i], am);
       }
+      if (per_ch) {
+        float wv[8];
+        loadf8(a.wn + (size_t)i * a.wc + c0, wv);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s[e] = fmaf(wn[i], xi[i][e], s[e]);
+        for (int e = 0; e < 8; ++e) s[e] = fmaf(wv[e], xi[i][e], s[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = fmaf(wn[i], xi[i][e], s[e]);
+      }
     }
     const size_t off = opix * a.ldo + c0;
     if (!BWD) {
@@ -136,12 +151,22 @@ __global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restric
       }
       store8<T>(ds + off, d);
       for (int i = 0; i < a.nin; ++i) {
+        if (per_ch) {
+          if (dwn) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dw_acc[i] = fmaf(d[e], xi[i][e], dw_acc[i]);
+            for (int e = 0; e < 8; ++e) atomicAdd(&redc[i * a.c + c0 + e], d[e] * xi[i][e]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dw_acc[i] = fmaf(d[e], xi[i][e], dw_acc[i]);
+        }
       }
     }
   }
-  if (BWD && dwn) {
+  if (BWD && dwn && per_ch) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.nin * a.c; i += THREADS) atomicAdd(&dwn[i], redc[i]);   // dwn [3][wc], wc == c
+  } else if (BWD && dwn) {
     __shared__ float red[3];
     if (threadIdx.x < 3) red[threadIdx.x] = 0.f;
     __syncthreads();
@@ -162,6 +187,7 @@ struct FuseInArgs {
   edet_tview_t in;
   int mode, pad_t, pad_l;
   const float* wn;
+  int wc;
   int idx;
   int n, oh, ow, ldds;
   int beta;
@@ -174,7 +200,7 @@ __global__ __launch_bounds__(THREADS) void k_fuse_bwd_input(const FuseInArgs a, 
   const edet_tview_t& v = a.in;
   const int nvec = v.c / 8;
   const int64_t total = (int64_t)v.n * v.h * v.w * nvec;
-  const float wn = a.wn[a.idx];
+  const float wn = a.wc > 1 ? 0.f : a.wn[a.idx];
   const T* base = reinterpret_cast<const T*>(v.data);
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
        q += (int64_t)gridDim.x * blockDim.x) {
@@ -265,8 +291,15 @@ __global__ __launch_bounds__(THREADS) void k_fuse_bwd_input(const FuseInArgs a, 
       }
     }
     const size_t off = ((size_t)(n * v.h + sy) * v.w + sx) * v.ld + c0;
+    if (a.wc > 1) {
+      float wv[8];
+      loadf8(a.wn + (size_t)a.idx * a.wc + c0, wv);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) g[e] *= wn;
+      for (int e = 0; e < 8; ++e) g[e] *= wv[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] *= wn;
+    }
     if (a.beta) {
       float old[8];
       load8<T>(gout + off, old);
@@ -277,45 +310,49 @@ __global__ __launch_bounds__(THREADS) void k_fuse_bwd_input(const FuseInArgs a, 
   }
 }
 
+// thread = channel ch < wc (wc = 1: the scalar weights of fastattn / attn; wc = c: channel_fastattn / channel_attn,
+// efficientdet_keras.py:100-113): wn[i*wc + ch] from w_i[ch]
 __global__ void k_fuse_weights(const float* w0, const float* w1, const float* w2, int nin, int method,
-                               float* wn) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+                               float* wn, int wc) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= wc) return;
   const float* w[3] = {w0, w1, w2};
   if (method == 1) {
-    for (int i = 0; i < nin; ++i) wn[i] = 1.f;
+    for (int i = 0; i < nin; ++i) wn[i * wc + ch] = 1.f;
     return;
   }
   if (method == 2) {      // 'attn': softmax over the inputs (efficientdet_keras.py:84-88)
-    float m = w[0][0], e[3], s = 0.f;
-    for (int i = 1; i < nin; ++i) m = fmaxf(m, w[i][0]);
-    for (int i = 0; i < nin; ++i) { e[i] = expf(w[i][0] - m); s += e[i]; }
-    for (int i = 0; i < nin; ++i) wn[i] = e[i] / s;
+    float m = w[0][ch], e[3], s = 0.f;
+    for (int i = 1; i < nin; ++i) m = fmaxf(m, w[i][ch]);
+    for (int i = 0; i < nin; ++i) { e[i] = expf(w[i][ch] - m); s += e[i]; }
+    for (int i = 0; i < nin; ++i) wn[i * wc + ch] = e[i] / s;
     return;
   }
   float r[3], s = 0.f;
-  for (int i = 0; i < nin; ++i) { r[i] = fmaxf(w[i][0], 0.f); s += r[i]; }
-  for (int i = 0; i < nin; ++i) wn[i] = r[i] / (s + 0.0001f);
+  for (int i = 0; i < nin; ++i) { r[i] = fmaxf(w[i][ch], 0.f); s += r[i]; }
+  for (int i = 0; i < nin; ++i) wn[i * wc + ch] = r[i] / (s + 0.0001f);
 }
 
 __global__ void k_fuse_weights_bwd(const float* w0, const float* w1, const float* w2, int nin, int method,
-                                   const float* dwn, float* dw0, float* dw1, float* dw2) {
-  if (threadIdx.x != 0 || blockIdx.x != 0 || method == 1) return;
+                                   const float* dwn, float* dw0, float* dw1, float* dw2, int wc) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= wc || method == 1) return;
   const float* w[3] = {w0, w1, w2};
   float* dw[3] = {dw0, dw1, dw2};
   if (method == 2) {      // softmax backward: dw_i = p_i * (dwn_i - sum_j dwn_j p_j)
-    float m = w[0][0], p[3], s = 0.f, dot = 0.f;
-    for (int i = 1; i < nin; ++i) m = fmaxf(m, w[i][0]);
-    for (int i = 0; i < nin; ++i) { p[i] = expf(w[i][0] - m); s += p[i]; }
-    for (int i = 0; i < nin; ++i) { p[i] /= s; dot += dwn[i] * p[i]; }
-    for (int i = 0; i < nin; ++i) dw[i][0] += p[i] * (dwn[i] - dot);
+    float m = w[0][ch], p[3], s = 0.f, dot = 0.f;
+    for (int i = 1; i < nin; ++i) m = fmaxf(m, w[i][ch]);
+    for (int i = 0; i < nin; ++i) { p[i] = expf(w[i][ch] - m); s += p[i]; }
+    for (int i = 0; i < nin; ++i) { p[i] /= s; dot += dwn[i * wc + ch] * p[i]; }
+    for (int i = 0; i < nin; ++i) dw[i][ch] += p[i] * (dwn[i * wc + ch] - dot);
     return;
   }
   float r[3], s = 0.0001f, dot = 0.f;
-  for (int i = 0; i < nin; ++i) { r[i] = fmaxf(w[i][0], 0.f); s += r[i]; }
-  for (int i = 0; i < nin; ++i) dot += dwn[i] * r[i];
+  for (int i = 0; i < nin; ++i) { r[i] = fmaxf(w[i][ch], 0.f); s += r[i]; }
+  for (int i = 0; i < nin; ++i) dot += dwn[i * wc + ch] * r[i];
   for (int i = 0; i < nin; ++i) {
-    const float dr = dwn[i] / s - dot / (s * s);
-    if (w[i][0] > 0.f) dw[i][0] += dr;
+    const float dr = dwn[i * wc + ch] / s - dot / (s * s);
+    if (w[i][ch] > 0.f) dw[i][ch] += dr;
   }
 }
 
@@ -327,11 +364,12 @@ inline int ew_grid(int64_t total) {
 }
 
 int fill_args(FuseArgs& a, const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
-              const int* modes, int nin, const float* wn, int act, int oh, int ow, int ldo) {
+              const int* modes, int nin, const float* wn, int wc, int act, int oh, int ow, int ldo) {
   EDET_CHECK(nin >= 1 && nin <= 3 && in0 && modes && wn, "edet_fuse: bad arguments");
+  EDET_CHECK(wc == 1 || wc == in0->c, "edet_fuse: wc must be 1 or the channel count (got %d)", wc);
   const edet_tview_t* ins[3] = {in0, in1, in2};
   memset(&a, 0, sizeof(a));
-  a.nin = nin; a.wn = wn; a.act = act; a.oh = oh; a.ow = ow; a.ldo = ldo;
+  a.nin = nin; a.wn = wn; a.wc = wc; a.act = act; a.oh = oh; a.ow = ow; a.ldo = ldo;
   for (int i = 0; i < nin; ++i) {
     EDET_CHECK(ins[i] && ins[i]->data, "edet_fuse: null input %d", i);
     a.in[i] = *ins[i];
@@ -360,28 +398,28 @@ int fill_args(FuseArgs& a, const edet_tview_t* in0, const edet_tview_t* in1, con
 }  // namespace
 
 extern "C" int edet_fuse_weights(const float* w0, const float* w1, const float* w2, int nin,
-                                 int method, float* wn, void* stream) {
-  EDET_CHECK(wn && (method == 1 || w0), "edet_fuse_weights: null pointer");
-  k_fuse_weights<<<1, 64, 0, to_stream(stream)>>>(w0, w1, w2, nin, method, wn);
+                                 int method, float* wn, int wc, void* stream) {
+  EDET_CHECK(wn && (method == 1 || w0) && wc >= 1, "edet_fuse_weights: bad arguments");
+  k_fuse_weights<<<(wc + 63) / 64, 64, 0, to_stream(stream)>>>(w0, w1, w2, nin, method, wn, wc);
   EDET_LAUNCH_CHECK("edet_fuse_weights");
   return 0;
 }
 
 extern "C" int edet_fuse_weights_bwd(const float* w0, const float* w1, const float* w2, int nin,
                                      int method, const float* dwn, float* dw0, float* dw1, float* dw2,
-                                     void* stream) {
+                                     int wc, void* stream) {
   if (method == 1) return 0;
-  EDET_CHECK(w0 && dwn && dw0, "edet_fuse_weights_bwd: null pointer");
-  k_fuse_weights_bwd<<<1, 64, 0, to_stream(stream)>>>(w0, w1, w2, nin, method, dwn, dw0, dw1, dw2);
+  EDET_CHECK(w0 && dwn && dw0 && wc >= 1, "edet_fuse_weights_bwd: bad arguments");
+  k_fuse_weights_bwd<<<(wc + 63) / 64, 64, 0, to_stream(stream)>>>(w0, w1, w2, nin, method, dwn, dw0, dw1, dw2, wc);
   EDET_LAUNCH_CHECK("edet_fuse_weights_bwd");
   return 0;
 }
 
 extern "C" int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
-                             const int* modes, int nin, const float* wn, int act,
+                             const int* modes, int nin, const float* wn, int wc, int act,
                              void* out, int oh, int ow, int ldo, int dtype, void* stream) {
   FuseArgs a;
-  if (int rc = fill_args(a, in0, in1, in2, modes, nin, wn, act, oh, ow, ldo)) return rc;
+  if (int rc = fill_args(a, in0, in1, in2, modes, nin, wn, wc, act, oh, ow, ldo)) return rc;
   EDET_CHECK(out, "edet_fuse_fwd: null output");
   const int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8));
   if (dtype == EDET_BF16) k_fuse<bf16_t, false><<<grid, THREADS, 0, to_stream(stream)>>>(a, (bf16_t*)out, nullptr, nullptr, nullptr, nullptr);
@@ -392,28 +430,30 @@ extern "C" int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, c
 }
 
 extern "C" int edet_fuse_bwd_pre(const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
-                                 const int* modes, int nin, const float* wn, int act,
+                                 const int* modes, int nin, const float* wn, int wc, int act,
                                  const void* dout, int oh, int ow, int ldo,
                                  void* ds, float* dwn, void* pool_argmax, int dtype, void* stream) {
   FuseArgs a;
-  if (int rc = fill_args(a, in0, in1, in2, modes, nin, wn, act, oh, ow, ldo)) return rc;
+  if (int rc = fill_args(a, in0, in1, in2, modes, nin, wn, wc, act, oh, ow, ldo)) return rc;
   EDET_CHECK(dout && ds, "edet_fuse_bwd_pre: null pointer");
   const int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8));
-  if (dtype == EDET_BF16) k_fuse<bf16_t, true><<<grid, THREADS, 0, to_stream(stream)>>>(a, nullptr, (const bf16_t*)dout, (bf16_t*)ds, dwn, (unsigned char*)pool_argmax);
-  else if (dtype == EDET_F32) k_fuse<float, true><<<grid, THREADS, 0, to_stream(stream)>>>(a, nullptr, (const float*)dout, (float*)ds, dwn, (unsigned char*)pool_argmax);
+  const size_t lds = wc > 1 ? (size_t)3 * a.c * sizeof(float) : 0;
+  if (dtype == EDET_BF16) k_fuse<bf16_t, true><<<grid, THREADS, lds, to_stream(stream)>>>(a, nullptr, (const bf16_t*)dout, (bf16_t*)ds, dwn, (unsigned char*)pool_argmax);
+  else if (dtype == EDET_F32) k_fuse<float, true><<<grid, THREADS, lds, to_stream(stream)>>>(a, nullptr, (const float*)dout, (float*)ds, dwn, (unsigned char*)pool_argmax);
   else EDET_CHECK(false, "edet_fuse_bwd_pre: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_fuse_bwd_pre");
   return 0;
 }
 
-extern "C" int edet_fuse_bwd_input(const edet_tview_t* in, int mode, const float* wn, int idx,
+extern "C" int edet_fuse_bwd_input(const edet_tview_t* in, int mode, const float* wn, int wc, int idx,
                                    const void* ds, int oh, int ow, int lds_, const void* pool_argmax,
                                    void* gout, int beta, int dtype, void* stream) {
   EDET_CHECK(in && in->data && wn && ds && gout && idx >= 0 && idx < 3, "edet_fuse_bwd_input: bad arguments");
   EDET_CHECK(in->c % 8 == 0 && in->ld % 8 == 0 && lds_ % 8 == 0, "edet_fuse_bwd_input: c/ld % 8");
+  EDET_CHECK(wc == 1 || wc == in->c, "edet_fuse_bwd_input: wc must be 1 or the channel count (got %d)", wc);
   FuseInArgs a;
   memset(&a, 0, sizeof(a));
-  a.in = *in; a.mode = mode; a.wn = wn; a.idx = idx; a.n = in->n; a.oh = oh; a.ow = ow; a.ldds = lds_;
+  a.in = *in; a.mode = mode; a.wn = wn; a.wc = wc; a.idx = idx; a.n = in->n; a.oh = oh; a.ow = ow; a.ldds = lds_;
   a.beta = beta;
   if (mode == EDET_RS_POOL) {
     a.pad_t = same_pad_before(in->h, 3, 2);

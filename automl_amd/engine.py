@@ -578,22 +578,24 @@ class Engine(object):
     n = inputs[0].raw.n
     nin = len(inputs)
     out = Raw(self, key, n, oh, ow, c)
-    wn = self.buf(key + ':wn', (4,), torch.float32)
-    method = (2 if self.spec.fpn.weight_method == 'attn' else 0) if wnames else 1
+    wm = self.spec.fpn.weight_method
+    wc = c if (wnames and wm.startswith('channel_')) else 1       # per-channel weight vectors (WSM shape [c])
+    wn = self.buf(key + ':wn', (max(4, 3 * wc),), torch.float32)
+    method = (2 if wm in ('attn', 'channel_attn') else 0) if wnames else 1
     wp = [ptr(self.param(w)) for w in wnames] + [None] * (3 - len(wnames)) if wnames else [None] * 3
-    call('edet_fuse_weights', wp[0], wp[1], wp[2], nin, method, ptr(wn), self.stream)
+    call('edet_fuse_weights', wp[0], wp[1], wp[2], nin, method, ptr(wn), wc, self.stream)
     tv = [v.tview() for v in inputs]
     tvp = [ctypes.byref(t) for t in tv] + [None] * (3 - nin)
     marr = (ctypes.c_int * 3)(*(list(modes) + [0] * (3 - nin)))
     fbytes = (sum(v.raw.rows for v in inputs) + out.rows) * c * self.esize
-    call('edet_fuse_fwd', tvp[0], tvp[1], tvp[2], marr, nin, ptr(wn), act, ptr(out.data), oh, ow, out.ld,
+    call('edet_fuse_fwd', tvp[0], tvp[1], tvp[2], marr, nin, ptr(wn), wc, act, ptr(out.data), oh, ow, out.ld,
          self.dtype, self.stream, nbytes=fbytes)
     vout = View(out)
     for v in inputs:
       v.consumers += 1
     if self.training:
       ds = self.buf(key + ':ds', (n, oh, ow, out.ld), self.tdtype)
-      dwn = self.zbuf(key + ':dwn', (4,))
+      dwn = self.zbuf(key + ':dwn', (max(4, 3 * wc),))
       npool = sum(1 for m in modes if m == RS_POOL)
       amax = self.buf(key + ':amax', (npool, n, oh, ow, c), torch.uint8) if npool and self.pool_argmax else None
 
@@ -601,7 +603,7 @@ class Engine(object):
         assert out.grad_written, key
         tv2 = [v.tview() for v in inputs]
         tvp2 = [ctypes.byref(t) for t in tv2] + [None] * (3 - nin)
-        call('edet_fuse_bwd_pre', tvp2[0], tvp2[1], tvp2[2], marr, nin, ptr(wn), act, ptr(out.grad), oh, ow,
+        call('edet_fuse_bwd_pre', tvp2[0], tvp2[1], tvp2[2], marr, nin, ptr(wn), wc, act, ptr(out.grad), oh, ow,
              out.ld, ptr(ds), ptr(dwn), ptr(amax), self.dtype, self.stream, nbytes=fbytes + out.rows * c * self.esize)
         plane = 0
         for i, v in enumerate(inputs):
@@ -612,7 +614,7 @@ class Engine(object):
           if not v.raw.needs_grad:
             continue
           g = v.raw.ensure_grad()
-          call('edet_fuse_bwd_input', ctypes.byref(tv2[i]), modes[i], ptr(wn), i, ptr(ds), oh, ow, out.ld, am,
+          call('edet_fuse_bwd_input', ctypes.byref(tv2[i]), modes[i], ptr(wn), wc, i, ptr(ds), oh, ow, out.ld, am,
                ptr(g), 1 if v.raw.grad_written else 0, self.dtype, self.stream,
                nbytes=(out.rows + v.raw.rows) * c * self.esize,
                tag='%dx%dx%d %s' % (v.raw.h, v.raw.w, c, ('id', 'up2', 'pool')[modes[i]]))
@@ -620,7 +622,7 @@ class Engine(object):
         if wnames:
           gp = [ptr(self.grad(w)) for w in wnames] + [None] * (3 - len(wnames))
           call('edet_fuse_weights_bwd', wp[0], wp[1], wp[2], nin, method, ptr(dwn), gp[0], gp[1], gp[2],
-               self.stream)
+               wc, self.stream)
 
       self.tape.append(bwd)
     return vout
@@ -758,7 +760,7 @@ class Engine(object):
               fh, fw, th, tw))
         ins.append(f)
       wnames = []
-      if fpn.weight_method in ('fastattn', 'attn'):
+      if fpn.weight_method in ('fastattn', 'attn', 'channel_fastattn', 'channel_attn'):
         wnames = [scope + '/WSM' + ('' if i == 0 else '_%d' % i) for i in range(len(ins))]
       x = self.fuse(scope + ':fuse', ins, modes, wnames, th, tw, act=ACT_SWISH)
       oc = '%s/op_after_combine%d' % (scope, len(feats))

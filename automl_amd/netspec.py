@@ -48,9 +48,8 @@ class NetSpec(object):
                            for b in self.blocks]
     self.fpn = c.fpn_config or fpn_configs.get_fpn_config(c.fpn_name, c.min_level, c.max_level,
                                                          c.fpn_weight_method)
-    if self.fpn.weight_method not in ('fastattn', 'sum', 'attn'):
-      raise ValueError('fpn weight_method %r is out of scope (per-channel channel_attn / channel_fastattn '
-                       'weights are not built)' % self.fpn.weight_method)
+    if self.fpn.weight_method not in ('fastattn', 'sum', 'attn', 'channel_fastattn', 'channel_attn'):
+      raise ValueError('unknown weight_method %s' % self.fpn.weight_method)
     self.num_anchors = len(c.aspect_ratios) * c.num_scales
     self._build()
 
@@ -116,9 +115,12 @@ class NetSpec(object):
             self._add(rs + '/conv2d/kernel', (1, 1, ch[off], wf), 'glorot')
             self._add(rs + '/conv2d/bias', (wf,), 'zeros')
             self._bn(rs + '/bn', wf)
-        if self.fpn.weight_method in ('fastattn', 'attn'):
+        if self.fpn.weight_method != 'sum':
+          # one scalar per input, or one weight per channel for the channel_* methods
+          # (efficientdet_keras.py:123-127,142-151)
+          wshape = (wf,) if self.fpn.weight_method.startswith('channel_') else ()
           for i in range(len(node['inputs_offsets'])):
-            self._add(s + '/WSM' + ('' if i == 0 else '_%d' % i), (), 'ones')
+            self._add(s + '/WSM' + ('' if i == 0 else '_%d' % i), wshape, 'ones')
         oc = '%s/op_after_combine%d' % (s, len(ch))
         self._add(oc + '/conv/depthwise_kernel', (3, 3, wf, 1), 'glorot')
         self._add(oc + '/conv/pointwise_kernel', (1, 1, wf, wf), 'glorot')

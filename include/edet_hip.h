@@ -242,29 +242,31 @@ int edet_se_gate_bwd(const edet_tview_t* in, void* g, const float* dpool,
 /* ---- BiFPN weighted fusion ---------------------------------------------------
  * efficientdet_keras.py:75-121 (fuse_features), :254-281 (max-pool / nearest
  * resample), :214-217 (swish before the separable conv).
- * out = act( sum_i wn_i * resample_i(view_i) ), wn = normalised weights (fp32[3]).  */
+ * out = act( sum_i wn_i * resample_i(view_i) ), wn = normalised weights, fp32 [3][wc]: wc = 1 for one weight per
+ * input (fastattn / attn / sum), wc = c for the per-channel methods channel_fastattn / channel_attn
+ * (efficientdet_keras.py:100-113: the same two formulas applied per channel; WSM variables of shape [c]).  */
 int edet_fuse_weights(const float* w0, const float* w1, const float* w2, int nin,
-                      int method /*0 fastattn, 1 sum, 2 attn (softmax)*/, float* wn, void* stream);
+                      int method /*0 fastattn, 1 sum, 2 attn (softmax)*/, float* wn, int wc, void* stream);
 int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
-                  const int* modes, int nin, const float* wn, int act,
+                  const int* modes, int nin, const float* wn, int wc, int act,
                   void* out, int oh, int ow, int ldo, int dtype, void* stream);
 /* ds = dout * act'(s) (s recomputed) written to `ds`; dwn[i] += sum ds * x_i.
  * pool_argmax (may be NULL): caller-owned bytes [npool][n][oh][ow][c], one plane per EDET_RS_POOL
  * input in input order; receives the winning tap (ky*3+kx, first maximum of the row-major scan) of
  * every pooled element so that edet_fuse_bwd_input does not have to recompute the 3x3 windows.  */
 int edet_fuse_bwd_pre(const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
-                      const int* modes, int nin, const float* wn, int act,
+                      const int* modes, int nin, const float* wn, int wc, int act,
                       const void* dout, int oh, int ow, int ldo,
                       void* ds, float* dwn, void* pool_argmax, int dtype, void* stream);
 /* gradient of one fusion input: gout (+)= wn[i] * resample_i^T(ds).  pool_argmax: this input's
  * plane written by edet_fuse_bwd_pre (EDET_RS_POOL only; NULL -> the windows are recomputed).  */
-int edet_fuse_bwd_input(const edet_tview_t* in, int mode, const float* wn, int idx,
+int edet_fuse_bwd_input(const edet_tview_t* in, int mode, const float* wn, int wc, int idx,
                         const void* ds, int oh, int ow, int lds_, const void* pool_argmax,
                         void* gout, int beta, int dtype, void* stream);
 /* raw weight gradients from dwn (fast-attention normalisation backward) */
 int edet_fuse_weights_bwd(const float* w0, const float* w1, const float* w2, int nin,
                           int method, const float* dwn, float* dw0, float* dw1, float* dw2,
-                          void* stream);
+                          int wc, void* stream);
 
 /* ---- detection loss forward + backward --------------------------------------
  * train_lib.py:357-437,493-604: focal loss (alpha, gamma) on class logits,

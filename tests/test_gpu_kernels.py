@@ -525,29 +525,41 @@ def resample_oracle(x_nhwc, mode, oh, ow):
     ((1, 4, 3, 16), [(_lib.RS_IDENTITY, 4, 3), (_lib.RS_POOL, 7, 5)], 'sum'),
     ((2, 7, 9, 24), [(_lib.RS_UP2, 4, 5), (_lib.RS_IDENTITY, 7, 9), (_lib.RS_UP2, 4, 5)], 'fastattn'),
     ((2, 5, 5, 64), [(_lib.RS_POOL, 10, 10)], 'none'),
+    ((2, 10, 10, 64), [(_lib.RS_IDENTITY, 10, 10), (_lib.RS_UP2, 5, 5)], 'attn'),
+    ((2, 5, 5, 64), [(_lib.RS_IDENTITY, 5, 5), (_lib.RS_IDENTITY, 5, 5), (_lib.RS_POOL, 10, 10)], 'channel_fastattn'),
+    ((2, 7, 9, 24), [(_lib.RS_UP2, 4, 5), (_lib.RS_IDENTITY, 7, 9), (_lib.RS_UP2, 4, 5)], 'channel_attn'),
+    ((3, 6, 6, 88), [(_lib.RS_IDENTITY, 6, 6), (_lib.RS_POOL, 12, 12)], 'channel_fastattn'),
 ])
 def test_fuse(dt, case):
+  """All five fusion methods of FNode.fuse_features (efficientdet_keras.py:75-121): forward, input gradients
+  (both max-pool backward paths) and the gradients of the fusion weights (scalars, or [c] vectors for channel_*)."""
   name, edt, tdt = dt
   (n, oh, ow, c), ins, method = case
   rng = np.random.default_rng(gu.seed_of(str(case)))
   nin = len(ins)
+  per_channel = method.startswith('channel_')
+  base = method[len('channel_'):] if per_channel else method
+  wc = c if per_channel else 1
   xs, scs, shs = [], [], []
   for (mode, ih, iw) in ins:
     xs.append(gu.rnd(rng, (n, ih, iw, c), tdt))
     scs.append(torch.from_numpy((1 + 0.3 * rng.standard_normal(c)).astype(np.float32)))
     shs.append(torch.from_numpy((0.3 * rng.standard_normal(c)).astype(np.float32)))
-  ws = [torch.tensor(float(v)) for v in rng.uniform(0.3, 1.5, nin)]
-  if method == 'fastattn':
-    ws[-1] = torch.tensor(-0.3) if nin == 3 else ws[-1]   # exercise the relu
+  ws = [torch.from_numpy(rng.uniform(0.3, 1.5, wc).astype(np.float32)) for _ in range(nin)]
+  if base == 'fastattn' and nin == 3:
+    ws[-1] = ws[-1] - 1.0 if per_channel else torch.full((1,), -0.3)    # exercise the relu
   act = ACT_NONE if method == 'none' else ACT_SWISH
   dout = gu.rnd(rng, (n, oh, ow, c), tdt)
   xq = [x.clone().requires_grad_(True) for x in xs]
   wq = [w.clone().requires_grad_(True) for w in ws]
   vals = [resample_oracle(x * sc + sh, m[0], oh, ow) for x, sc, sh, m in zip(xq, scs, shs, ins)]
-  if method == 'fastattn':
+  if base == 'fastattn':
     r = [torch.relu(w) for w in wq]
     tot = sum(r) + 0.0001
     s = sum(v * ri / tot for v, ri in zip(vals, r))
+  elif base == 'attn':
+    nw = torch.softmax(torch.stack(wq), 0)
+    s = sum(v * nw[i] for i, v in enumerate(vals))
   else:
     s = sum(vals)
   out = orc.swish(s) if act == ACT_SWISH else s
@@ -558,20 +570,20 @@ def test_fuse(dt, case):
   tvs = [gu.tview(x, c, sc, sh) for x, sc, sh in zip(xd, scd, shd)]
   tvp = [ctypes.byref(t) for t in tvs] + [None] * (3 - nin)
   modes = (ctypes.c_int * 3)(*([m[0] for m in ins] + [0] * (3 - nin)))
-  wd = [gu.fdev(w.reshape(1)) for w in ws] + [None] * (3 - nin)
-  wn = torch.zeros(4, dtype=torch.float32, device=gu.DEV)
-  meth = 0 if method == 'fastattn' else 1
-  call('edet_fuse_weights', ptr(wd[0]), ptr(wd[1]), ptr(wd[2]), nin, meth, ptr(wn), gu.stream())
+  wd = [gu.fdev(w) for w in ws] + [None] * (3 - nin)
+  wn = torch.zeros(max(4, 3 * wc), dtype=torch.float32, device=gu.DEV)
+  meth = {'fastattn': 0, 'attn': 2}.get(base, 1)
+  call('edet_fuse_weights', ptr(wd[0]), ptr(wd[1]), ptr(wd[2]), nin, meth, ptr(wn), wc, gu.stream())
   od = torch.full((n, oh, ow, c), float('nan'), dtype=tdt, device=gu.DEV)
-  call('edet_fuse_fwd', tvp[0], tvp[1], tvp[2], modes, nin, ptr(wn), act, ptr(od), oh, ow, c, edt, gu.stream())
+  call('edet_fuse_fwd', tvp[0], tvp[1], tvp[2], modes, nin, ptr(wn), wc, act, ptr(od), oh, ow, c, edt, gu.stream())
   torch.cuda.synchronize()
   gu.check(od, out.detach(), name, 'fuse_fwd %s' % (case,))
   dd = gu.to_dev(dout, tdt)
   ds = torch.empty_like(dd)
-  dwn = torch.zeros(4, dtype=torch.float32, device=gu.DEV)
+  dwn = torch.zeros(max(4, 3 * wc), dtype=torch.float32, device=gu.DEV)
   npool = sum(1 for m in ins if m[0] == _lib.RS_POOL)
   amax = torch.full((max(npool, 1), n, oh, ow, c), 255, dtype=torch.uint8, device=gu.DEV)
-  call('edet_fuse_bwd_pre', tvp[0], tvp[1], tvp[2], modes, nin, ptr(wn), act, ptr(dd), oh, ow, c, ptr(ds),
+  call('edet_fuse_bwd_pre', tvp[0], tvp[1], tvp[2], modes, nin, ptr(wn), wc, act, ptr(dd), oh, ow, c, ptr(ds),
        ptr(dwn), ptr(amax) if npool else None, edt, gu.stream())
   plane = 0
   for i in range(nin):
@@ -581,18 +593,18 @@ def test_fuse(dt, case):
       plane += 1
     for am in planes:
       g = torch.full_like(xd[i], float('nan'))
-      call('edet_fuse_bwd_input', ctypes.byref(tvs[i]), ins[i][0], ptr(wn), i, ptr(ds), oh, ow, c, am, ptr(g), 0,
+      call('edet_fuse_bwd_input', ctypes.byref(tvs[i]), ins[i][0], ptr(wn), wc, i, ptr(ds), oh, ow, c, am, ptr(g), 0,
            edt, gu.stream())
       torch.cuda.synchronize()
       # engine convention: gradient w.r.t. the BN *output* (scale is applied by the BN-backward coefficients)
       gu.check(g, xq[i].grad / scs[i], name, 'fuse_bwd_input %d %s argmax=%s' % (i, case, am is not None))
-  if method == 'fastattn':
-    dws = [torch.zeros(1, dtype=torch.float32, device=gu.DEV) for _ in range(3)]
+  if base in ('fastattn', 'attn'):
+    dws = [torch.zeros(wc, dtype=torch.float32, device=gu.DEV) for _ in range(3)]
     call('edet_fuse_weights_bwd', ptr(wd[0]), ptr(wd[1]), ptr(wd[2]), nin, meth, ptr(dwn), ptr(dws[0]),
-         ptr(dws[1]), ptr(dws[2]), gu.stream())
+         ptr(dws[1]), ptr(dws[2]), wc, gu.stream())
     torch.cuda.synchronize()
     for i in range(nin):
-      gu.check(dws[i].reshape(()), wq[i].grad, 'f32', 'fuse dW%d' % i, rtol=2e-2 if name == 'bf16' else 2e-3,
+      gu.check(dws[i], wq[i].grad, 'f32', 'fuse dW%d' % i, rtol=2e-2 if name == 'bf16' else 2e-3,
                atol=2e-2 if name == 'bf16' else 1e-3, scale_by_max=False)
 
 

@@ -74,6 +74,7 @@ CASES = [
     ('efficientdet-d0', 'max_level=8,fpn_weight_method=sum', 128, 1),   # d7x-style pyramid and fusion
     ('efficientdet-d1', '', 96, 1),
     ('efficientdet-d0', 'fpn_weight_method=attn', 128, 2),                # softmax fusion weights
+    ('efficientdet-d0', 'fpn_weight_method=channel_fastattn', 128, 2),    # per-channel weight vectors
     ('efficientdet-d7x', '', 256, 1),     # BASELINE configs[4] at a small image: b7 backbone (55 blocks, SE up to
                                           # 160 units, 3840 channels), levels 3-8, 8 BiFPN cells of 384 filters, 'sum'
 ]
@@ -120,7 +121,7 @@ def test_forward_matches_oracle(case, training, dtype, tol):
     assert worst <= (1e-3 if dtype == 'f32' else 0.2), 'moving statistics differ: %g' % worst
 
 
-@pytest.mark.parametrize('case', CASES[:2] + [('efficientdet-d1', '', 96, 3), CASES[3], ('efficientdet-d7x', '', 384, 2)],
+@pytest.mark.parametrize('case', CASES[:2] + [('efficientdet-d1', '', 96, 3), CASES[3], ('efficientdet-d7x', '', 384, 2), CASES[4]],
                          ids=lambda c: '%s[%s]@%d' % (c[0], c[1], c[2]))
 def test_train_step_matches_oracle_fp32(case):
   """loss values, clipped gradients of every variable, and the updated variables after one step."""
