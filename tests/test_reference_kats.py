@@ -292,3 +292,75 @@ def test_box_decoding_and_drop_connect_equal_the_executed_reference_code():
   scale = np.floor(p + g['drop_u']) / p                     # what Engine.refresh_drop_masks draws per image
   np.testing.assert_allclose(g['drop_x'] * scale, g['drop_out'], rtol=1e-6, atol=1e-7)
   assert set(np.unique(scale)) <= {0.0, np.float32(1.25)}
+
+
+GRAPH_CASES = [   # (fixture, model, override) -- tests/golden/make_golden_graph.py CASES
+    ('reference_graph_d0.npz', 'efficientdet-d0', 'image_size=64'),
+    ('reference_graph_d1.npz', 'efficientdet-d1', 'image_size=64'),
+    ('reference_graph_d0_l8sum.npz', 'efficientdet-d0', 'image_size=128,max_level=8,fpn_weight_method=sum'),
+]
+
+
+def load_graph_case(fixture, model, override):
+  """-> (npz, config, {variable name: fp32 tensor}) of one executed-reference-graph fixture."""
+  from tests.golden.name_values import value_for
+  g = np.load(os.path.join(os.path.dirname(__file__), 'golden', fixture))
+  config = hparams_config.get_efficientdet_config(model)
+  config.override(override)
+  shapes = {str(n): tuple(int(d) for d in str(s).split(',') if d) for n, s in zip(g['var_names'], g['var_shapes'])}
+  params = {n: torch.from_numpy(value_for(n, shp)) for n, shp in shapes.items()}
+  return g, config, shapes, params
+
+
+def graph_drop_scales(g, spec, model):
+  """The recorded tf.random.uniform draws of the training pass (one row per utils.drop_connect call, i.e. per
+  residual block with a survival probability, in block order) as the oracle's block scope -> [B] scale input."""
+  backbone = spec.config.backbone_name
+  scopes = [('%s/blocks_%d' % (backbone, b.index), p) for b, p in zip(spec.blocks, spec.survival_probs)
+            if b.has_residual and p]
+  draws = g['drop_draws']
+  assert len(draws) == len(scopes)
+  return {s: torch.floor(torch.tensor(p, dtype=torch.float32) + torch.from_numpy(u)) / p
+          for (s, p), u in zip(scopes, draws)}
+
+
+@pytest.mark.parametrize('fixture,model,override', GRAPH_CASES)
+def test_variable_inventory_equals_the_executed_reference_graph(fixture, model, override):
+  """tests/golden/reference_graph_*.npz come from EXECUTING the reference's own tf2/efficientdet_keras.EfficientDetNet
+  (backbone/efficientnet_model.Model, ResampleFeatureMap, FNode, FPNCells, ClassNet, BoxNet -- unmodified) on a
+  torch-backed stand-in for tf.keras (tests/golden/mini_keras.py).  Every variable name and shape the reference graph
+  creates must equal this package's inventory, which is what makes checkpoints interchangeable."""
+  g, config, shapes, _ = load_graph_case(fixture, model, override)
+  spec = netspec.NetSpec(config)
+  mine = {p.name: tuple(p.shape) for p in spec.params}
+  assert sorted(mine) == sorted(shapes)
+  assert mine == shapes
+
+
+@pytest.mark.parametrize('fixture,model,override', GRAPH_CASES)
+def test_oracle_outputs_equal_the_executed_reference_graph(fixture, model, override):
+  """Same fixtures: class / box outputs of every level, inference and training BatchNorm, from the reference graph
+  code with name-derived weights.  This pins the oracle's WIRING (block order, BiFPN node inputs, resampling,
+  fusion, head sharing, BN placement) against the reference's own Python.  The layer arithmetic under it is the
+  stand-in's (torch conv with the oracle's TF 'SAME' padding rule), not the TensorFlow binary's.
+
+  Inference mode: 5e-6 of the level's range (fp32 summation order only).  Training mode: batch statistics over
+  the 1x1 .. 8x8-pixel levels of a 64-pixel input are 2 .. 128 samples per channel, where x_hat amplifies the same
+  rounding differences; measured 7e-5 (level 3) .. 3e-3 (level 7), bound 2e-2."""
+  g, config, shapes, params = load_graph_case(fixture, model, override)
+  spec = netspec.NetSpec(config)
+  images = torch.from_numpy(g['images'])
+  for training, tol in ((False, 5e-6), (True, 2e-2)):
+    oracle = orc.Oracle(config=config, params={k: v.clone() for k, v in params.items()})
+    if training:
+      oracle.drop_scale = graph_drop_scales(g, spec, model)
+      assert bool(oracle.drop_scale) == (model != 'efficientdet-d0')
+    with torch.no_grad():
+      cls, box = oracle.forward(images, training=training)
+    assert len(cls) == config.max_level - config.min_level + 1
+    for i, (c, b) in enumerate(zip(cls, box)):
+      for got, key in ((c, 'cls_%d_%d' % (training, i)), (b, 'box_%d_%d' % (training, i))):
+        want = g[key]
+        assert tuple(got.shape) == want.shape
+        err = np.abs(got.numpy() - want).max() / max(np.abs(want).max(), 1e-20)
+        assert err < tol, (key, err)
