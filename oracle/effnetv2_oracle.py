@@ -10,7 +10,9 @@ PARITY STATUS: as for oracle/efficientdet_oracle.py -- the arithmetic lives in T
 be installed here; this restatement is pinned by the reference's RNG-free known answers for the path
 (the 15 parameter counts of effnetv2_model_test.py:24-52, checked in tests/test_effnetv2.py), by the
 direct-loop twin for the dense convolution (oracle/direct_loops.py) and by the TF 'SAME' padding rule
-shared with the EfficientDet oracle.  Conv-output parity versus the TensorFlow binary is UNPINNED.
+shared with the EfficientDet oracle, and by the outputs + variable inventory of the reference's own EffNetV2Model
+code executed on a torch-backed tf.keras stand-in (tests/golden/make_golden_graph_v2.py; wiring, not layer
+arithmetic).  Conv-output parity versus the TensorFlow binary is UNPINNED.
 """
 import torch
 

@@ -194,6 +194,39 @@ class BatchNormalization(Layer):
     return x * inv + (self.beta - mean * inv)
 
 
+class Dense(Layer):
+  def __init__(self, units, use_bias=True, name=None, **kwargs):
+    super().__init__(name=name or 'dense')
+    self.units, self.use_bias = units, use_bias
+
+  def build(self, shape):
+    self.kernel = self.add_weight('kernel', (shape[-1], self.units))
+    self.bias = self.add_weight('bias', (self.units,)) if self.use_bias else None
+
+  def call(self, x):
+    y = x @ self.kernel
+    return y + self.bias if self.use_bias else y
+
+
+class GlobalAveragePooling2D(Layer):
+  def __init__(self, data_format='channels_last', name=None, **kwargs):
+    super().__init__(name=name or 'global_average_pooling2d')
+    assert data_format == 'channels_last'
+
+  def call(self, x):
+    return x.mean(dim=(1, 2))
+
+
+class Dropout(Layer):
+  def __init__(self, rate, name=None, **kwargs):
+    super().__init__(name=name or 'dropout')
+    self.rate = rate
+
+  def call(self, x, training=None):
+    assert not (training and self.rate), 'random dropout is not reproducible: generate with dropout_rate=0'
+    return x
+
+
 class MaxPooling2D(Layer):
   def __init__(self, pool_size, strides, padding='valid', data_format='channels_last', name=None, **kwargs):
     super().__init__(name=name or 'max_pooling2d')
@@ -249,13 +282,16 @@ def build_tf():
       self.name = name
 
     def __enter__(self):
+      SCOPE.append(self.name)       # TF2: variables created inside a name scope carry its prefix
       return self
 
     def __exit__(self, *a):
+      SCOPE.pop()
       return False
-  tf.name_scope = lambda name=None, *a, **k: _Scope(name)     # op scopes do not prefix variable names in TF2 Keras
+  tf.name_scope = lambda name=None, *a, **k: _Scope(name)
   nn = ns('nn')
   nn.swish = lambda x: x * torch.sigmoid(x)
+  nn.silu = nn.swish
   nn.relu = torch.relu
   nn.sigmoid = torch.sigmoid
   nn.softmax = lambda x, axis=-1: torch.softmax(x, dim=axis)
@@ -267,7 +303,8 @@ def build_tf():
   tf.image = ns('image', resize_nearest_neighbor=resize_nearest)
   tf.compat = types.SimpleNamespace(v1=tf, v2=tf)     # `import tensorflow.compat.v1 as tf` resolves to this module
   layers = ns('layers', Layer=Layer, Conv2D=Conv2D, DepthwiseConv2D=DepthwiseConv2D,
-              SeparableConv2D=SeparableConv2D, BatchNormalization=BatchNormalization, MaxPooling2D=MaxPooling2D)
+              SeparableConv2D=SeparableConv2D, BatchNormalization=BatchNormalization, MaxPooling2D=MaxPooling2D,
+              Dense=Dense, GlobalAveragePooling2D=GlobalAveragePooling2D, Dropout=Dropout)
   layers.experimental = ns('experimental', SyncBatchNormalization=BatchNormalization)
   keras = stub_module('tensorflow.keras')
   keras.layers = layers
@@ -280,7 +317,7 @@ def build_tf():
 def install(tf):
   names = ['tensorflow', 'tensorflow.compat', 'absl', 'absl.logging', 'absl.flags', 'tensorflow.python',
            'tensorflow.python.eager', 'tensorflow.python.tpu', 'tensorflow.python.eager.tape',
-           'tensorflow.python.tpu.tpu_function', 'tensorflow_addons', 'tensorflow.python.framework',
+           'tensorflow.python.tpu.tpu_function', 'tensorflow_addons', 'tensorflow_addons.layers', 'tensorflow.python.framework',
            'tensorflow.python.ops', 'neural_structured_learning', 'tensorflow_hub', 'coco_metric', 'inference', 'PIL',
            'PIL.Image', 'pycocotools', 'tensorflow_model_optimization', 'dataloader', 'tf2.postprocess', 'tf2.label_util',
            'nms_np', 'det_model_fn']

@@ -329,3 +329,80 @@ def test_model_backward_matches_oracle_fp32(model_name, size, over):
       bad.append((name, e))
   bad.sort(key=lambda t: -t[1])
   assert not bad, 'gradient mismatch in %d/%d tensors, worst %s' % (len(bad), len(params), bad[:8])
+
+
+V2_GRAPH_CASES = [   # fixtures of tests/golden/make_golden_graph_v2.py: (file, model)
+    ('reference_graph_v2_b0.npz', 'efficientnetv2-b0'),
+    ('reference_graph_v2_s.npz', 'efficientnetv2-s'),
+    ('reference_graph_v1_b1.npz', 'efficientnet-b1'),
+]
+V2_GRAPH_ENDPOINTS = ['reduction_%d' % i for i in range(1, 6)] + ['pooled_features']
+
+
+def _load_v2_graph(fixture, model_name):
+  import os
+  from tests.golden.name_values import value_for
+  g = np.load(os.path.join(os.path.dirname(__file__), 'golden', fixture))
+  shapes = {str(n): tuple(int(d) for d in str(s).split(',') if d) for n, s in zip(g['var_names'], g['var_shapes'])}
+  vals = {n: value_for(n, shp) for n, shp in shapes.items()}
+  spec = effnetv2_model.V2Spec(effnetv2_configs.model_config(model_name, 'dropout_rate=0'))
+  return g, shapes, vals, spec
+
+
+def _v2_graph_drop_scales(g, spec):
+  """Recorded tf.random.uniform draws (one row per utils.drop_connect call = per residual block with a survival
+  probability, in block order) -> the oracle's block scope -> [B] scale input."""
+  scopes = [('%s/blocks_%d' % (spec.name, b.index), p) for b, p in zip(spec.blocks, spec.survival_probs)
+            if b.has_residual and p]
+  assert len(scopes) == len(g['drop_draws'])
+  return {s: torch.floor(torch.tensor(p, dtype=torch.float32) + torch.from_numpy(u)) / p
+          for (s, p), u in zip(scopes, g['drop_draws'])}
+
+
+@pytest.mark.parametrize('fixture,model_name', V2_GRAPH_CASES)
+def test_oracle_and_inventory_equal_the_executed_reference_model(fixture, model_name):
+  """tests/golden/reference_graph_v*.npz come from EXECUTING the reference's own efficientnetv2/effnetv2_model.
+  EffNetV2Model (Stem, MBConvBlock, FusedMBConvBlock, SE, Head, utils.drop_connect -- unmodified) on the torch-backed
+  tf.keras stand-in tests/golden/mini_keras.py, weights a function of the variable name.  Checked: the variable
+  inventory (names and shapes) equals V2Spec's, and the oracle reproduces logits, pooled features and the five
+  reduction endpoints -- inference BatchNorm to 1e-5 of each tensor's range, training BatchNorm (with the recorded
+  stochastic-depth draws) to 1e-3 (measured <= 8e-5).  This pins the wiring
+  against the reference's Python, not the layer arithmetic against the TensorFlow binary."""
+  g, shapes, vals, spec = _load_v2_graph(fixture, model_name)
+  mine = {p.name: tuple(p.shape) for p in spec.params}
+  assert sorted(mine) == sorted(shapes)
+  assert mine == shapes
+  images = torch.from_numpy(g['images'])
+  for training, tol in ((False, 1e-5), (True, 1e-3)):
+    oracle = v2orc.V2Oracle(model_name, 'dropout_rate=0', params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
+    if training:
+      oracle.drop_scale = _v2_graph_drop_scales(g, spec)
+      assert oracle.drop_scale
+    with torch.no_grad():
+      ends = oracle.forward(images, training)
+    errs = {}
+    for nm, key in [('head', 'logits')] + [(e, e) for e in V2_GRAPH_ENDPOINTS]:
+      want = g['%s_%d' % (key, training)]
+      got = ends[nm].numpy().reshape(want.shape)
+      errs[nm] = float(np.abs(got - want).max()) / max(float(np.abs(want).max()), 1e-20)
+    print(fixture, training, {k: '%.1e' % v for k, v in errs.items()})
+    assert all(e <= tol for e in errs.values()), (training, errs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('fixture,model_name', V2_GRAPH_CASES)
+def test_device_outputs_equal_the_executed_reference_model(fixture, model_name):
+  """The HIP path (fp32 storage, inference BatchNorm) against the outputs of the executed reference model code,
+  without the oracle in between: every endpoint within 1e-3 of its range (north_star tolerance)."""
+  g, shapes, vals, spec = _load_v2_graph(fixture, model_name)
+  net = effnetv2_model.EffNetV2Model(model_name, 'dropout_rate=0', dtype='f32', params=vals)
+  outs = net(torch.from_numpy(g['images']), training=False, with_endpoints=True)
+  torch.cuda.synchronize()
+  got = dict(zip(['logits'] + ['reduction_%d' % i for i in range(1, 6)], outs))
+  got['pooled_features'] = net.endpoints['pooled_features']
+  errs = {}
+  for key, t in got.items():
+    want = g['%s_0' % key]
+    errs[key] = float(np.abs(t.float().cpu().numpy().reshape(want.shape) - want).max()) / float(np.abs(want).max())
+  print(fixture, {k: '%.1e' % v for k, v in errs.items()})
+  assert all(e <= 1e-3 for e in errs.values()), errs
