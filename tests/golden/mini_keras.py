@@ -25,6 +25,8 @@ from name_values import value_for   # noqa (same directory)
 
 
 SCOPE = []          # current Keras name-scope stack
+TRAINABLE = []      # trainable variables in creation order (one model per process)
+GRAD = [False]      # True: trainable variables require grad (make_golden_trainstep.py)
 DRAWS = []          # tf.random.uniform results, in call order
 DRAW_RNG = [np.random.default_rng(1234)]
 TRAINING = []       # `training` of the enclosing layer calls
@@ -49,6 +51,14 @@ class KT(torch.Tensor):
   def get_shape(self):
     return self.shape
 
+  @property
+  def name(self):            # variables: '<scope path>/<leaf>:0'
+    return getattr(self, '_vname', None)
+
+  @name.setter
+  def name(self, v):
+    self._vname = v
+
 
 def T(x):
   t = x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))
@@ -66,6 +76,10 @@ class Layer(object):
     full = '/'.join([s for s in SCOPE if s] + [name])
     assert full not in VARIABLES, 'variable created twice: ' + full
     t = T(torch.from_numpy(value_for(full, shape)))
+    t.name = full + ':0'
+    if trainable:
+      TRAINABLE.append(t)
+      t.requires_grad_(bool(GRAD[0]))
     VARIABLES[full] = t
     self._weights.append(t)
     return t
@@ -103,7 +117,9 @@ class Layer(object):
 
 
 class Model(Layer):
-  pass
+  @property
+  def trainable_variables(self):
+    return list(TRAINABLE)
 
 
 def _orc():
@@ -268,6 +284,45 @@ def build_tf():
     DRAWS.append(u.reshape(-1).numpy().copy())
     return T(u)
   tf.random = ns('random', uniform=uniform)
+
+  # -- the pieces tf2/train_lib.py's losses and train_step touch ---------------------------------------------
+  def one_hot(indices, depth, dtype=None, **kwargs):
+    idx = T(indices).long()
+    out = torch.zeros(tuple(idx.shape) + (int(depth),), dtype=dtype or torch.float32)
+    ok = (idx >= 0) & (idx < depth)                   # tf.one_hot: out-of-range indices give all-zero rows
+    out.scatter_(-1, idx.clamp(0, depth - 1).unsqueeze(-1), ok.unsqueeze(-1).to(out.dtype))
+    return T(out)
+  tf.one_hot = one_hot
+  tf.reshape = lambda x, shape, name=None: T(x).reshape([int(v) for v in shape])
+  tf.expand_dims = lambda x, axis=-1: T(x).unsqueeze(axis)
+  tf.not_equal = lambda a, b: T(a) != b
+  tf.cast = lambda x, dtype=None: T(x).to(dtype) if isinstance(dtype, torch.dtype) else T(x)
+  tf.convert_to_tensor = lambda x, dtype=None: T(torch.as_tensor(x, dtype=dtype) if isinstance(dtype, torch.dtype)
+                                                 else x)
+
+  def clip_by_norm(t, clip_norm):
+    return t * clip_norm / torch.clamp(t.norm(), min=clip_norm)
+
+  def global_norm(ts):
+    return torch.sqrt(sum((t * t).sum() for t in ts if t is not None))
+
+  def clip_by_global_norm(ts, clip_norm):
+    g = global_norm(ts)
+    scale = clip_norm * torch.minimum(1.0 / g, torch.tensor(1.0 / clip_norm))
+    return [t * scale if t is not None else None for t in ts], g
+  tf.clip_by_norm, tf.clip_by_global_norm = clip_by_norm, clip_by_global_norm
+  tf.linalg = ns('linalg', global_norm=global_norm)
+
+  class GradientTape(object):
+    def __enter__(self):
+      return self
+
+    def __exit__(self, *a):
+      return False
+
+    def gradient(self, loss, variables):
+      return list(torch.autograd.grad(loss, variables, allow_unused=True))
+  tf.GradientTape = GradientTape
   tf.convert_to_tensor = lambda x, dtype=None: T(x)
   tf.stop_gradient = lambda x: x
   tf.zeros_initializer = lambda *a, **k: 'zeros'
@@ -296,6 +351,9 @@ def build_tf():
   nn.sigmoid = torch.sigmoid
   nn.softmax = lambda x, axis=-1: torch.softmax(x, dim=axis)
   tf.nn = nn
+  tf.nn.l2_loss = lambda v: (v * v).sum() / 2
+  tf.nn.sigmoid_cross_entropy_with_logits = lambda labels=None, logits=None: (
+      torch.clamp(logits, min=0) - logits * labels + torch.log1p(torch.exp(-logits.abs())))   # TF's stable form
   tf.autograph = ns('autograph', experimental=ns('experimental', do_not_convert=lambda f: f))
 
   def resize_nearest(images, size, **kwargs):
@@ -310,6 +368,37 @@ def build_tf():
   keras.layers = layers
   keras.Model = Model
   tf.keras = keras
+
+  class Reduction(object):
+    NONE, AUTO, SUM, SUM_OVER_BATCH_SIZE = 'none', 'auto', 'sum', 'sum_over_batch_size'
+
+  class Loss(object):
+    """keras.losses.Loss.__call__: call() then the reduction; the reference builds its losses with Reduction.NONE
+    (tf2/train.py:115-140), which returns call()'s result as is."""
+
+    def __init__(self, reduction='auto', name=None, **kwargs):
+      self.reduction = reduction
+
+    def __call__(self, y_true, y_pred, sample_weight=None):
+      assert sample_weight is None
+      out = self.call(y_true, y_pred)
+      if self.reduction == Reduction.NONE:
+        return out
+      return out.sum() if self.reduction == Reduction.SUM else out.mean()
+
+  class Huber(Loss):
+    """keras.losses.Huber: 0.5 e^2 for |e| <= delta else delta |e| - 0.5 delta^2, mean over the LAST axis."""
+
+    def __init__(self, delta=1.0, **kwargs):
+      super().__init__(**kwargs)
+      self.delta = delta
+
+    def call(self, y_true, y_pred):
+      err = (y_pred - y_true).abs()
+      quad = torch.clamp(err, max=self.delta)
+      return (0.5 * quad * quad + self.delta * (err - quad)).mean(dim=-1)
+  keras.losses = ns('losses', Loss=Loss, Huber=Huber, Reduction=Reduction)
+  keras.mixed_precision = ns('mixed_precision', LossScaleOptimizer=type('LossScaleOptimizer', (), {}))
   tf.io = ns('io', gfile=ns('gfile', GFile=open, exists=lambda p: False))
   return tf
 

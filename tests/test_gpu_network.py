@@ -380,3 +380,34 @@ def test_device_outputs_equal_the_executed_reference_graph(fixture, model, overr
                    rel_err(b, torch.from_numpy(g['box_%d_%d' % (training, i)]))))
     print('reference graph %s training=%s: %s' % (fixture, training, errs))
     assert all(e[1] <= tol and e[2] <= tol for e in errs), errs
+
+
+def test_device_train_step_equals_the_executed_reference_train_step():
+  """The HIP train step (fp32 storage) against the reference's own train_step executed on the stand-in
+  (tests/golden/make_golden_trainstep.py -> reference_trainstep_d0.npz), without the oracle in between: loss values
+  to 1e-3, the clipped gradients handed to the optimizer to 1e-2 per tensor (norm, probe dot product, small tensors
+  element-wise; see tests/test_reference_kats.py::check_trainstep_gradients)."""
+  from tests.test_reference_kats import check_trainstep_gradients, load_trainstep_case
+  g, config, vals, labels = load_trainstep_case()
+  images = g['images']
+  batch, size = images.shape[0], images.shape[1]
+  net = train_lib.EfficientDetNetTrain(config=config, dtype='f32', params={k: v.copy() for k, v in vals.items()})
+  eng = net._ensure_engine(batch, size, size)
+  eng.forward(net._to_device_images(torch.from_numpy(images), eng), training=True)
+  eng.loss_backward(net._labels_to_device(labels, eng))
+  eng.optimizer_step(float(g['val/learning_rate']), None)
+  torch.cuda.synchronize()
+  got = eng.loss_values()
+  print('loss values', got)
+  for k in ('cls_loss', 'box_loss', 'det_loss', 'reg_l2_loss', 'loss', 'gradient_norm'):
+    want = float(g['val/' + k])
+    assert abs(got[k] - want) <= 1e-3 * abs(want), (k, got[k], want)
+  clipped = eng.grads_flat.cpu()
+  factor = eng.seg_factor.cpu()
+  grads = {}
+  for name in (str(n) for n in g['grad_names']):
+    off, n, shape, _ = eng.offsets[name]
+    grads[name] = (clipped[off:off + n] * factor[_seg_index(eng, name)]).numpy().reshape(shape)
+  bad = check_trainstep_gradients(g, grads, 1e-2)
+  print('worst', bad[:5])
+  assert not bad, (len(bad), bad[:8])

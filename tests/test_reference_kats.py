@@ -364,3 +364,59 @@ def test_oracle_outputs_equal_the_executed_reference_graph(fixture, model, overr
         assert tuple(got.shape) == want.shape
         err = np.abs(got.numpy() - want).max() / max(np.abs(want).max(), 1e-20)
         assert err < tol, (key, err)
+
+
+def load_trainstep_case():
+  from tests.golden.name_values import value_for
+  g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'reference_trainstep_d0.npz'))
+  config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  config.override('image_size=192')
+  shapes = {str(n): tuple(int(d) for d in str(s).split(',') if d) for n, s in zip(g['var_names'], g['var_shapes'])}
+  vals = {n: value_for(n, shp) for n, shp in shapes.items()}
+  labels = {k[len('label/'):]: g[k] for k in g.files if k.startswith('label/')}
+  return g, config, vals, labels
+
+
+def check_trainstep_gradients(g, grads, rtol):
+  """grads: name -> numpy clipped gradient.  Against the stored per-variable norm, probe dot product and (small
+  tensors) full values of the gradients the reference's train_step handed to optimizer.apply_gradients."""
+  from tests.golden.name_values import value_for
+  names = [str(n) for n in g['grad_names']]
+  assert sorted(names) == sorted(grads)
+  total = float(np.sqrt((g['grad_norms']**2).sum()))
+  bad = []
+  for name, norm, dot in zip(names, g['grad_norms'], g['grad_dots']):
+    mine = np.asarray(grads[name], np.float64)
+    probe = value_for('probe/' + name, mine.shape).astype(np.float64)
+    # tensors holding < 1e-3 of the whole gradient's norm are measured against that share: they include the
+    # mathematically zero gradients (a bias / beta feeding a 1x1 convolution + BatchNorm), which are rounding noise
+    floor = 1e-3 * total
+    e_norm = abs(np.sqrt((mine**2).sum()) - norm) / max(norm, floor)
+    e_dot = abs((mine * probe).sum() - dot) / max(norm * np.sqrt((probe**2).sum() / probe.size), floor)
+    e_full = 0.0
+    if 'grad/' + name in g.files:
+      want = g['grad/' + name]
+      e_full = float(np.abs(mine.reshape(want.shape) - want).max()) / max(float(np.abs(want).max()), floor)
+    if max(e_norm, e_dot, e_full) > rtol:
+      bad.append((name, e_norm, e_dot, e_full))
+  bad.sort(key=lambda t: -max(t[1:]))
+  return bad
+
+
+def test_oracle_train_step_equals_the_executed_reference_train_step():
+  """tests/golden/reference_trainstep_d0.npz: the reference's own EfficientDetNetTrain.train_step (_detection_loss,
+  _reg_l2_loss, FocalLoss, BoxLoss, per-variable + global clipping -- train_lib.py:357-437,486-684, unmodified) executed
+  on the torch-backed tf.keras stand-in (tests/golden/make_golden_trainstep.py), d0 at 192 px, batch 4.  The oracle's
+  train step must give the same loss values and hand the same clipped gradients to the optimizer."""
+  g, config, vals, labels = load_trainstep_case()
+  oracle = orc.Oracle(config=config, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
+  images = torch.from_numpy(g['images'])
+  with torch.no_grad():
+    oracle.forward(images, False)          # registers the trainable list
+  tl = {k: torch.from_numpy(v) for k, v in labels.items()}
+  got, grads = orc.train_step(oracle, images, tl, {}, float(g['val/learning_rate']), None)
+  for k in ('loss', 'det_loss', 'cls_loss', 'box_loss', 'reg_l2_loss', 'gradient_norm'):
+    want = float(g['val/' + k])
+    assert abs(got[k] - want) <= 2e-5 * abs(want), (k, got[k], want)
+  bad = check_trainstep_gradients(g, {k: v.detach().numpy() for k, v in grads.items()}, 2e-3)
+  assert not bad, (len(bad), bad[:8])
