@@ -34,6 +34,15 @@ class BwdEpi(ctypes.Structure):
               ('stat_partials', c_void_p), ('dgate', c_void_p)]
 
 
+class NmsCfg(ctypes.Structure):
+  _fields_ = [('method', c_int), ('convention', c_int), ('iou_thresh', c_float), ('score_thresh', c_float),
+              ('sigma', c_float), ('max_output_size', c_int)]
+
+
+NMS_HARD, NMS_GAUSSIAN, NMS_LINEAR = 0, 1, 2
+NMS_TF_V5, NMS_NUMPY = 0, 1
+NMS_PAD_INDEX0, NMS_PAD_ZERO, NMS_PAD_DUMMY = 0, 1, 2
+
 PT, PG, PE, PI = (ctypes.POINTER(TView), ctypes.POINTER(GView), ctypes.POINTER(BwdEpi),
                   ctypes.POINTER(c_int))
 
@@ -90,6 +99,16 @@ SIGNATURES = {
     'edet_opt_scale': [c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     'edet_opt_sgd_ema': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                          c_float, c_void_p],
+    'edet_pre_nms': [c_void_p, c_void_p, PI, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                     c_void_p, c_void_p],
+    'edet_pre_nms_topk_workspace_bytes': [c_int, c_int, ctypes.POINTER(ctypes.c_size_t)],
+    'edet_pre_nms_topk': [c_void_p, c_void_p, PI, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
+                          ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
+    'edet_nms_workspace_bytes': [c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_size_t)],
+    'edet_nms': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(NmsCfg), c_void_p,
+                 ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
+    'edet_nms_gather': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
+                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
 }
 
 _lib = None

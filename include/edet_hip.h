@@ -309,6 +309,59 @@ int edet_opt_sgd_ema(float* params, float* grads, float* velocity, float* ema,
                      const int64_t* seg_offsets, const float* seg_factor, int nseg,
                      const float* hyper_dev, float momentum, void* stream);
 
+/* ---- detection post-processing -------------------------------
+ * tf2/postprocess.py: merge_class_box_level_outputs :67-79, topk_class_boxes :82-117, pre_nms :120-157, nms :160-206,
+ * clip_boxes :61-64, postprocess_global :375-406, per_class_nms :409-467; nms_np.py: hard_nms :84-120, soft_nms
+ * :123-184, per_class_nms :214-265; tf2/anchors.py decode_box_outputs :30-58.
+ *
+ * edet_pre_nms: cls_levels[l] / box_levels[l] are the network outputs of level l, [batch][level_pixels[l]]
+ * [anchors_per_pixel * num_classes] and [...][anchors_per_pixel * 4] (HOST arrays of DEVICE pointers); anchor_boxes
+ * = the [N][4] fp32 anchors (ymin, xmin, ymax, xmax) in the order of anchors.Anchors.boxes.  Per anchor: the first
+ * maximum class, sigmoid of its logit, the decoded box.  Outputs boxes [batch][N][4], scores [batch][N] fp32,
+ * classes [batch][N] int32.
+ * edet_pre_nms_topk: the nms_configs.max_nms_inputs = k > 0 branch: the k largest (anchor, class) logits of every
+ * image in descending order (ties: lower flat index), outputs [batch][k]...; k <= 8192.  */
+int edet_pre_nms(const void* const* cls_levels, const void* const* box_levels, const int* level_pixels,
+                 int nlevels, int batch, int anchors_per_pixel, int num_classes, const float* anchor_boxes,
+                 int dtype, float* boxes, float* scores, int* classes, void* stream);
+int edet_pre_nms_topk_workspace_bytes(int batch, int k, size_t* bytes);
+int edet_pre_nms_topk(const void* const* cls_levels, const void* const* box_levels, const int* level_pixels,
+                      int nlevels, int batch, int anchors_per_pixel, int num_classes, const float* anchor_boxes,
+                      int dtype, int k, void* workspace, size_t workspace_bytes, float* boxes, float* scores,
+                      int* classes, void* stream);
+
+#define EDET_NMS_HARD 0
+#define EDET_NMS_GAUSSIAN 1
+#define EDET_NMS_LINEAR 2      /* nms_np.py only */
+#define EDET_NMS_TF_V5 0       /* tf.raw_ops.NonMaxSuppressionV5: IoU on the corner extents, `score > score_thresh`
+                                  filter up front, a decayed score <= score_thresh drops the candidate, sigma =
+                                  soft_nms_sigma (= nms_configs.sigma / 2, postprocess.py:193-201) */
+#define EDET_NMS_NUMPY 1       /* nms_np.py: pixel-inclusive extents (+1), no filter up front, a decayed score
+                                  < score_thresh drops the candidate, weight exp(-iou^2 / sigma); hard = hard_nms */
+typedef struct edet_nms_cfg {
+  int method, convention;
+  float iou_thresh, score_thresh, sigma;
+  int max_output_size;
+} edet_nms_cfg_t;
+/* boxes [batch][n][4], scores [batch][n], classes [batch][n] (may be NULL when segments == 1).  segments == 1:
+ * one suppression per image over all candidates (postprocess_global); segments == num_classes: one per (image,
+ * class), merged per image to the max_output_size best by score (postprocess.per_class_nms, nms_np.per_class_nms).
+ * out_index [batch][max_output_size]: index of the selected candidate or -1 (padding row), out_score: its decayed
+ * score (0 for padding), out_valid [batch]: number of selected rows.  */
+int edet_nms_workspace_bytes(int batch, int n, int segments, int max_output_size, size_t* bytes);
+int edet_nms(const float* boxes, const float* scores, const int* classes, int batch, int n, int segments,
+             const edet_nms_cfg_t* cfg, void* workspace, size_t workspace_bytes, int* out_index,
+             float* out_score, int* out_valid, void* stream);
+#define EDET_NMS_PAD_INDEX0 0  /* padding rows gather candidate 0 (tf.gather on the zero-padded indices), score 0 */
+#define EDET_NMS_PAD_ZERO 1    /* padding rows are zeros (tf.pad in per_class_nms) */
+#define EDET_NMS_PAD_DUMMY 2   /* padding rows are zeros with score -1e5 (nms_np._generate_dummy_detections) */
+/* nms_boxes [batch][M][4] = boxes of the selected candidates, clipped to [0, clip_h] x [0, clip_w] when clip_h > 0
+ * and multiplied by image_scales[b] when given; nms_classes = class + 1 (CLASS_OFFSET) as float.  */
+int edet_nms_gather(const float* boxes, const int* classes, const int* out_index, const float* out_score,
+                    int batch, int n, int max_output_size, int pad_mode, float clip_h, float clip_w,
+                    const float* image_scales, float* nms_boxes, float* nms_scores, float* nms_classes,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif
