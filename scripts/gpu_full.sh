@@ -1,5 +1,5 @@
 # Full GPU evidence pass: parity tests, smoke, bench (with cpu_baseline), rocprof kernel stats, HBM PMC passes.
-# usage (via gpurun): bash scripts/gpu_full.sh TAG
+# usage (via gpurun): [SKIP_PMC=1] bash scripts/gpu_full.sh TAG
 mkdir -p gpurun_out
 T=${1:-full}
 STEPS_IN_PMC_RUN=6
@@ -14,6 +14,8 @@ run() {
   python scripts/pmc_agg.py gpurun_out/${T}_$1 > gpurun_out/${T}_pmc_$1.txt 2>&1
   rm -rf gpurun_out/${T}_$1
 }
+if [ -z "$SKIP_PMC" ]; then
 run fetch "FETCH_SIZE"
 run write "WRITE_SIZE"
+fi
 tail -6 gpurun_out/${T}_pytest_gpu.log; cat gpurun_out/${T}_smoke.log; cut -c1-900 gpurun_out/${T}_bench_b128.log; head -5 gpurun_out/${T}_pmc_fetch.txt
