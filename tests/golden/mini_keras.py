@@ -39,6 +39,13 @@ class Shape(tuple):
   def as_list(self):
     return list(self)
 
+  def is_fully_defined(self):
+    return True
+
+  @property
+  def ndims(self):
+    return len(self)
+
 
 class KT(torch.Tensor):
   """torch.Tensor whose .shape answers as_list() (the reference reads static shapes that way); results of torch
@@ -50,6 +57,9 @@ class KT(torch.Tensor):
 
   def get_shape(self):
     return self.shape
+
+  def set_shape(self, shape):
+    assert list(shape) == list(self.shape), (shape, self.shape)
 
   @property
   def name(self):            # variables: '<scope path>/<leaf>:0'
