@@ -25,6 +25,11 @@ class EfficientDetNet(object):
     config = config or hparams_config.get_efficientdet_config(model_name)
     if 'object_detection' not in config.heads or len(config.heads) != 1:
       raise ValueError('No valid head found: {}'.format(config.heads))
+    if getattr(config, 'survival_prob', None):
+      # efficientdet_keras.py:434-436 / :612-614: stochastic depth with residual connections inside the class / box
+      # towers; no d0..d7x configuration sets it (the backbone's own survival_prob 0.8 is independent of this key)
+      raise ValueError('config.survival_prob=%r (stochastic depth in the class/box towers) is not built' %
+                       config.survival_prob)
     self.config = config
     self.name = name
     self._dtype, self._device, self._seed = dtype, device, seed
