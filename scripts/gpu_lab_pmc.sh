@@ -14,6 +14,7 @@ run() {
 run sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES"
 run sq2 "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT"
 run mfma "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA"
-run hbm "FETCH_SIZE WRITE_SIZE"
+run fetch "FETCH_SIZE"
+run write "WRITE_SIZE"
 tail -4 gpurun_out/${T}_sq1.log | cut -c1-160
-for p in sq1 sq2 mfma hbm; do head -6 gpurun_out/${T}_${p}_agg.txt | cut -c1-220; done
+for p in sq1 sq2 mfma fetch write; do head -6 gpurun_out/${T}_${p}_agg.txt | cut -c1-220; done
