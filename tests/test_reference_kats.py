@@ -99,6 +99,13 @@ def test_activation_values():
   x = torch.tensor([1.0, 10.0, -3.0])
   np.testing.assert_allclose(orc.swish(x).numpy(), (x * torch.sigmoid(x)).numpy())
   np.testing.assert_allclose(orc.swish(torch.tensor([1.0])).numpy(), [0.7310586], rtol=1e-6)
+  # utils_test.py:113-143: the reference's expected values for every activation type
+  features = torch.tensor([.5, 10.])
+  for act, want in (('swish', [0.311, 10]), ('swish_native', [0.311, 10]), ('hswish', [0.29166667, 10.0]),
+                    ('relu', [0.5, 10]), ('relu6', [0.5, 6]), ('mish', [0.37524524, 10.0])):
+    np.testing.assert_allclose(orc.activation_fn(features, act).numpy(), want, rtol=2e-3, err_msg=act)
+  with pytest.raises(ValueError):
+    orc.activation_fn(features, 'bogus')
 
 
 def test_feat_sizes():
