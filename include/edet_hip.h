@@ -362,6 +362,18 @@ int edet_nms_gather(const float* boxes, const int* classes, const int* out_index
                     const float* image_scales, float* nms_boxes, float* nms_scores, float* nms_classes,
                     void* stream);
 
+/* ---- anchor labelling -------------------------------------------
+ * tf2/anchors.py AnchorLabeler.label_anchors :215-250 for a batch of images.  anchor_boxes [N][4] as for
+ * edet_pre_nms; level_anchors[l] = anchors of level l (H_l * W_l * A); gt_boxes [batch][max_gt][4] (ymin, xmin, ymax,
+ * xmax), gt_labels [batch][max_gt] (1-based class ids), gt_count [batch] valid rows per image (device arrays).
+ * Outputs per level (HOST arrays of DEVICE pointers): cls_targets[l] int32 [batch][H_l][W_l][A] (class - 1, -1 =
+ * background), box_targets[l] fp32 [batch][H_l][W_l][4A]; num_positives fp32 [batch].  */
+int edet_label_anchors_workspace_bytes(int batch, int num_anchors, size_t* bytes);
+int edet_label_anchors(const float* anchor_boxes, const int* level_anchors, int nlevels, const float* gt_boxes,
+                       const int* gt_labels, const int* gt_count, int batch, int max_gt, float match_threshold,
+                       void* workspace, size_t workspace_bytes, int* const* cls_targets, float* const* box_targets,
+                       float* num_positives, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
