@@ -25,6 +25,11 @@ class EfficientDetNet(object):
     config = config or hparams_config.get_efficientdet_config(model_name)
     if 'object_detection' not in config.heads or len(config.heads) != 1:
       raise ValueError('No valid head found: {}'.format(config.heads))
+    if getattr(config, 'survival_prob', None):
+      # efficientdet_keras.py:434-436 / :612-614: stochastic depth with residual connections inside the class / box
+      # towers; no d0..d7x configuration sets it (the backbone's own survival_prob 0.8 is independent of this key)
+      raise ValueError('config.survival_prob=%r (stochastic depth in the class/box towers) is not built' %
+                       config.survival_prob)
     self.config = config
     self.name = name
     self._dtype, self._device, self._seed = dtype, device, seed
@@ -76,3 +81,37 @@ class EfficientDetNet(object):
     size = image_size if image_size is not None else c.image_size
     return anchors_lib.Anchors(c.min_level, c.max_level, c.num_scales, c.aspect_ratios, c.anchor_scale,
                                size)
+
+
+class EfficientDetModel(EfficientDetNet):
+  """EfficientDet full model with post-processing: ``efficientdet_keras.EfficientDetModel`` (:917-1000).
+
+  ``model(inputs, training=False, pre_mode='infer', post_mode='global')``.  Image preprocessing is
+  not built: ``pre_mode`` must be None / '' and ``inputs`` the normalised [B, H, W, 3] batch at ``config.image_size``;
+  the default 'infer' of the reference signature raises.  ``post_mode``: 'global' / 'per_class' run on the GPU
+  (automl_amd/postprocess.py) and return (boxes, scores, classes, valid_len); None returns the raw level outputs.
+  """
+
+  def _postprocess(self, cls_outputs, box_outputs, scales, mode='global'):
+    """Postprocess class and box predictions (efficientdet_keras.py:953-976)."""
+    if not mode:
+      return cls_outputs, box_outputs
+    from automl_amd import postprocess
+    if mode == 'global':
+      return postprocess.postprocess_global(self.config.as_dict(), cls_outputs, box_outputs, scales)
+    if mode == 'per_class':
+      return postprocess.postprocess_per_class(self.config.as_dict(), cls_outputs, box_outputs, scales)
+    if mode in ('combined', 'tflite'):
+      raise ValueError('postprocess mode {} is not built'.format(mode))
+    raise ValueError('Unsupported postprocess mode {}'.format(mode))
+
+  def __call__(self, inputs, training=False, pre_mode='infer', post_mode='global'):
+    if pre_mode:
+      raise ValueError('image preprocessing (pre_mode=%r) is not built: pass normalised images of config.image_size '
+                       'with pre_mode=None' % (pre_mode,))
+    cls_outputs, box_outputs = EfficientDetNet.__call__(self, inputs, training)
+    if post_mode:
+      return self._postprocess(cls_outputs, box_outputs, None, post_mode)
+    return cls_outputs, box_outputs
+
+  call = __call__

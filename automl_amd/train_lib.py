@@ -126,6 +126,7 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
     rate / EMA decay / loss normalizer travel through a small device vector.  With data parallelism the
     gradient all-reduce stays an eager RCCL call between two captured halves."""
     super().__init__(*args, **kwargs)
+    self._check_training_options(self.config)
     # sync_bn: cross-replica BatchNorm statistics (the reference's --strategy=gpus / tpu BatchNorm classes,
     # utils.py:166-266): two small all-reduces per BatchNorm layer and step, eager launches only.
     self.sync_bn = sync_bn
@@ -137,6 +138,24 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
     self.use_dist = use_dist or process_group is not None
     self._lr_fn = None
     self.iterations = 0
+
+  @staticmethod
+  def _check_training_options(c):
+    """The train step here is the reference's default one (train_lib.py:606-684 with the d0..d7x settings); options
+    that would change its arithmetic and are not built raise instead of being ignored."""
+    unsupported = []
+    if getattr(c, 'iou_loss_type', None):
+      unsupported.append('iou_loss_type=%r (BoxIouLoss, train_lib.py:440-466)' % c.iou_loss_type)
+    if getattr(c, 'label_smoothing', 0.0):
+      unsupported.append('label_smoothing=%r (FocalLoss, train_lib.py:400-401)' % c.label_smoothing)
+    if getattr(c, 'positives_momentum', None):
+      unsupported.append('positives_momentum=%r (moving normalizer, train_lib.py:519-534)' % c.positives_momentum)
+    if getattr(c, 'var_freeze_expr', None):
+      unsupported.append('var_freeze_expr=%r (train_lib.py:478-484)' % c.var_freeze_expr)
+    if str(getattr(c, 'optimizer', 'sgd')).lower() != 'sgd':
+      unsupported.append('optimizer=%r (only SGD momentum, train_lib.py:183-185)' % c.optimizer)
+    if unsupported:
+      raise ValueError('training options that are not built: ' + '; '.join(unsupported))
 
   def _lr(self, batch):
     if self._lr_fn is None:

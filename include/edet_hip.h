@@ -318,7 +318,9 @@ int edet_opt_sgd_ema(float* params, float* grads, float* velocity, float* ema,
  * [anchors_per_pixel * num_classes] and [...][anchors_per_pixel * 4] (HOST arrays of DEVICE pointers); anchor_boxes
  * = the [N][4] fp32 anchors (ymin, xmin, ymax, xmax) in the order of anchors.Anchors.boxes.  Per anchor: the first
  * maximum class, sigmoid of its logit, the decoded box.  Outputs boxes [batch][N][4], scores [batch][N] fp32,
- * classes [batch][N] int32.
+ * classes [batch][N] int32.  The first call for a given pyramid geometry uploads a (level, first anchor) table of a
+ * few KB that stays cached on the device for the life of the process (one hipMalloc + one stream synchronisation);
+ * every later call only launches.
  * edet_pre_nms_topk: the nms_configs.max_nms_inputs = k > 0 branch: the k largest (anchor, class) logits of every
  * image in descending order (ties: lower flat index), outputs [batch][k]...; k <= 8192.  */
 int edet_pre_nms(const void* const* cls_levels, const void* const* box_levels, const int* level_pixels,

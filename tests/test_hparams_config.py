@@ -89,3 +89,21 @@ def test_override_strings_equal_reference():
     c = hparams_config.get_efficientdet_config('efficientdet-d0')
     c.override(case['str'])
     assert json.loads(json.dumps(c.as_dict())) == case['result'], case['str']
+
+
+def test_unbuilt_options_raise_instead_of_being_ignored():
+  """Options of the reference that would change the arithmetic of the network / train step and are not built must
+  fail loudly (constructing the host objects needs no GPU)."""
+  import pytest
+  from automl_amd import efficientdet_net, train_lib
+  for override in ('iou_loss_type=ciou', 'label_smoothing=0.1', 'positives_momentum=0.9', 'var_freeze_expr=.*bn.*',
+                   'optimizer=adam', 'survival_prob=0.8'):
+    config = hparams_config.get_efficientdet_config('efficientdet-d0')
+    config.override(override)
+    with pytest.raises(ValueError, match='not built'):
+      train_lib.EfficientDetNetTrain(config=config)
+  config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  config.override('survival_prob=0.8')
+  with pytest.raises(ValueError, match='not built'):
+    efficientdet_net.EfficientDetNet(config=config)
+  train_lib.EfficientDetNetTrain(config=hparams_config.get_efficientdet_config('efficientdet-d0'))   # defaults pass

@@ -228,3 +228,46 @@ def test_device_properties_at_d0_640_batch_8():
     for p in range(v):
       for q in range(p):
         assert porc._iou_tf(raw[i], p, q) <= 0.5 + 1e-6
+
+
+def test_model_wrapper_dispatch(monkeypatch):
+  """EfficientDetModel (efficientdet_keras.py:917-1000): argument handling without a GPU -- the network call and the
+  post-processing functions are replaced by recorders."""
+  from automl_amd import efficientdet_net, hparams_config, postprocess as pp
+  config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  model = efficientdet_net.EfficientDetModel(config=config)
+  calls = []
+  monkeypatch.setattr(efficientdet_net.EfficientDetNet, '__call__', lambda self, x, training=False: (['c'], ['b']))
+  monkeypatch.setattr(pp, 'postprocess_global', lambda p, c, b, s=None: calls.append(('global', p['name'], c, b, s)) or 'G')
+  monkeypatch.setattr(pp, 'postprocess_per_class', lambda p, c, b, s=None: calls.append(('per_class', c, b, s)) or 'P')
+  with pytest.raises(ValueError, match='preprocessing'):
+    model(None)                                            # the reference default pre_mode='infer'
+  assert model(None, pre_mode=None) == 'G' and calls[-1] == ('global', 'efficientdet-d0', ['c'], ['b'], None)
+  assert model(None, pre_mode=None, post_mode='per_class') == 'P'
+  assert model(None, pre_mode=None, post_mode=None) == (['c'], ['b'])
+  for mode in ('combined', 'tflite'):
+    with pytest.raises(ValueError, match='not built'):
+      model(None, pre_mode=None, post_mode=mode)
+  with pytest.raises(ValueError, match='Unsupported postprocess mode'):
+    model(None, pre_mode=None, post_mode='bogus')
+
+
+@pytest.mark.gpu
+def test_model_wrapper_equals_network_plus_postprocess():
+  """EfficientDetModel(post_mode=...) == postprocess_*() of the level outputs of that very forward pass (two forward
+  passes are not bit-identical: the SE pooling sums are fp32 atomics), fp32 storage."""
+  from automl_amd import efficientdet_net, hparams_config, postprocess as pp
+  config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  config.override('image_size=128')
+  rng = np.random.default_rng(9)
+  images = torch.from_numpy(rng.standard_normal((2, 128, 128, 3)).astype(np.float32))
+  model = efficientdet_net.EfficientDetModel(config=config, dtype='f32', seed=3)
+  for mode, fn in (('global', pp.postprocess_global), ('per_class', pp.postprocess_per_class)):
+    got = model(images, training=False, pre_mode=None, post_mode=mode)
+    cls, box = model.engine.outputs()                       # the logits that call has just post-processed
+    want = fn(config.as_dict(), [c.clone() for c in cls], [b.clone() for b in box])
+    assert len(got) == 4 and tuple(got[0].shape) == (2, 100, 4) and tuple(got[3].shape) == (2,)
+    for g, w in zip(got, want):
+      assert torch.equal(g, w), mode
+  raw = model(images, pre_mode=None, post_mode=None)
+  assert len(raw[0]) == 5 and tuple(raw[0][0].shape) == (2, 16, 16, 810) and tuple(raw[1][4].shape) == (2, 1, 1, 36)
