@@ -35,11 +35,16 @@ def apply_view(x, scale, shift, act, gate):
   return z
 
 
-@pytest.fixture(params=['auto', 'big'])
+@pytest.fixture(params=['auto', 'big', 'big_balanced'])
 def pw_impl(request, monkeypatch):
-  """EDET_PW_IMPL (read per call by the library): 'big' forces the workgroup-tiled kernels of pw_big.hip."""
+  """EDET_PW_IMPL (read per call by the library): 'big' forces the workgroup-tiled kernels of pw_big.hip;
+  'big_balanced' additionally selects the balanced-staging weight-gradient kernel (EDET_WG_BALANCED=1)."""
   if request.param != 'auto':
-    monkeypatch.setenv('EDET_PW_IMPL', request.param)
+    monkeypatch.setenv('EDET_PW_IMPL', 'big')
+  if request.param == 'big_balanced':
+    if 'bwd_weight' not in request.node.name:
+      pytest.skip('EDET_WG_BALANCED only changes the weight gradient')
+    monkeypatch.setenv('EDET_WG_BALANCED', '1')
   return request.param
 
 
