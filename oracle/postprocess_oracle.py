@@ -27,11 +27,11 @@ DUMMY_DETECTION_SCORE = -1e5   # nms_np.py:22
 
 
 def parse_image_size(image_size):
-  """utils.parse_image_size (utils.py:484-506): int, 'WxH'-style 'HxW' string or pair -> (height, width)."""
+  """utils.parse_image_size (utils.py:484-506): int, 'WxH' string or (height, width) pair -> (height, width)."""
   if isinstance(image_size, int):
     return (image_size, image_size)
   if isinstance(image_size, str):
-    h, w = image_size.lower().split('x')
+    w, h = image_size.lower().split('x')       # the string form is WIDTH x HEIGHT (utils.py:497-499)
     return (int(h), int(w))
   return tuple(int(v) for v in image_size)
 
