@@ -110,6 +110,8 @@ SIGNATURES = {
     'edet_label_anchors_workspace_bytes': [c_int, c_int, ctypes.POINTER(ctypes.c_size_t)],
     'edet_label_anchors': [c_void_p, PI, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p,
                            ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
+    'edet_preprocess_infer': [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_int, c_void_p],
     'edet_nms_gather': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
 }

@@ -376,6 +376,15 @@ int edet_label_anchors(const float* anchor_boxes, const int* level_anchors, int 
                        void* workspace, size_t workspace_bytes, int* const* cls_targets, float* const* box_targets,
                        float* num_positives, void* stream);
 
+/* ---- inference image preprocessing ----------------------------------
+ * efficientdet_keras.py:920-951 (mode 'infer'): raw_images [batch][height][width][3] uint8 (raw_is_float = 0) or
+ * float32 (1) on the device, all of one size; out [batch][out_height][out_width][3] in `dtype`: normalised with
+ * mean_rgb / stddev_rgb (HOST arrays of 3), aspect-preserving bilinear resize into the top-left corner, zero padding.
+ * *image_scale_to_original (HOST) = 1 / scale, the factor that maps detections back to the raw image.  */
+int edet_preprocess_infer(const void* raw_images, int raw_is_float, int batch, int height, int width,
+                          int out_height, int out_width, const float* mean_rgb, const float* stddev_rgb, void* out,
+                          float* image_scale_to_original, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
