@@ -53,8 +53,11 @@ CASES = [   # (model, override, image size, batch, seed, file)
     ('efficientdet-d0', 'image_size=64', 64, 2, 5, 'reference_graph_d0.npz'),
     ('efficientdet-d1', 'image_size=64', 64, 2, 6, 'reference_graph_d1.npz'),
     ('efficientdet-d0', 'image_size=128,max_level=8,fpn_weight_method=sum', 128, 1, 7, 'reference_graph_d0_l8sum.npz'),
+    ('efficientdet-d0', 'image_size=64,act_type=hswish', 64, 2, 8, 'reference_graph_d0_hswish.npz'),
 ]
 
 if __name__ == '__main__':
+  only = sys.argv[1:]
   for case in CASES:
-    run(*case)
+    if not only or case[5] in only:
+      run(*case)

@@ -358,6 +358,7 @@ def build_tf():
   nn.swish = lambda x: x * torch.sigmoid(x)
   nn.silu = nn.swish
   nn.relu = torch.relu
+  nn.relu6 = lambda x: torch.clamp(x, 0, 6)
   nn.sigmoid = torch.sigmoid
   nn.softmax = lambda x, axis=-1: torch.softmax(x, dim=axis)
   tf.nn = nn

@@ -99,6 +99,13 @@ def test_activation_values():
   x = torch.tensor([1.0, 10.0, -3.0])
   np.testing.assert_allclose(orc.swish(x).numpy(), (x * torch.sigmoid(x)).numpy())
   np.testing.assert_allclose(orc.swish(torch.tensor([1.0])).numpy(), [0.7310586], rtol=1e-6)
+  # utils_test.py:113-143: the reference's expected values for every activation type
+  features = torch.tensor([.5, 10.])
+  for act, want in (('swish', [0.311, 10]), ('swish_native', [0.311, 10]), ('hswish', [0.29166667, 10.0]),
+                    ('relu', [0.5, 10]), ('relu6', [0.5, 6]), ('mish', [0.37524524, 10.0])):
+    np.testing.assert_allclose(orc.activation_fn(features, act).numpy(), want, rtol=2e-3, err_msg=act)
+  with pytest.raises(ValueError):
+    orc.activation_fn(features, 'bogus')
 
 
 def test_feat_sizes():
@@ -420,3 +427,22 @@ def test_oracle_train_step_equals_the_executed_reference_train_step():
     assert abs(got[k] - want) <= 2e-5 * abs(want), (k, got[k], want)
   bad = check_trainstep_gradients(g, {k: v.detach().numpy() for k, v in grads.items()}, 2e-3)
   assert not bad, (len(bad), bad[:8])
+
+
+def test_oracle_other_activation_equals_the_executed_reference_graph():
+  """act_type=hswish (x * relu6(x + 3) / 6, utils.py:36-53) through the whole executed reference graph: the oracle side
+  of SURVEY row B6 beyond swish.  The product builds swish only and NetSpec says so."""
+  g, config, shapes, params = load_graph_case('reference_graph_d0_hswish.npz', 'efficientdet-d0',
+                                              'image_size=64,act_type=hswish')
+  with pytest.raises(ValueError, match='swish only'):
+    netspec.NetSpec(config)
+  images = torch.from_numpy(g['images'])
+  for training, tol in ((False, 5e-6), (True, 2e-2)):
+    oracle = orc.Oracle(config=config, params={k: v.clone() for k, v in params.items()})
+    with torch.no_grad():
+      cls, box = oracle.forward(images, training=training)
+    for i, (c, b) in enumerate(zip(cls, box)):
+      for got, key in ((c, 'cls_%d_%d' % (training, i)), (b, 'box_%d_%d' % (training, i))):
+        want = g[key]
+        err = np.abs(got.numpy() - want).max() / max(np.abs(want).max(), 1e-20)
+        assert err < tol, (key, err)
