@@ -36,6 +36,10 @@ extern "C" {
 
 #define EDET_ACT_NONE 0
 #define EDET_ACT_SWISH 1
+/* utils.activation_fn (utils.py:36-53) beyond swish: value and derivative at every activated view */
+#define EDET_ACT_RELU 2
+#define EDET_ACT_RELU6 3
+#define EDET_ACT_HSWISH 4   /* x * relu6(x + 3) / 6 */
 
 /* resample modes of one BiFPN fusion input */
 #define EDET_RS_IDENTITY 0
@@ -220,19 +224,19 @@ int edet_add(void* dst, const void* src, int64_t rows, int c, int ld, int beta,
              int dtype, void* stream);
 
 /* ---- squeeze-and-excitation --------------------------------------------------
- * efficientnet_model.py:153-195: mean over H,W -> 1x1 (+bias) -> swish -> 1x1
- * (+bias) -> sigmoid.  pooled [n,c] must be zero before edet_se_pool (atomics).  */
+ * efficientnet_model.py:153-195: mean over H,W -> 1x1 (+bias) -> act (the model's relu_fn, an EDET_ACT_* code)
+ * -> 1x1 (+bias) -> sigmoid.  pooled [n,c] must be zero before edet_se_pool (atomics).  */
 int edet_se_pool(const edet_tview_t* in, float* pooled_sum, int dtype, void* stream);
 int edet_se_fc(const float* pooled_sum, int n, int c, int se, float inv_hw,
                const float* w1, const float* b1, const float* w2, const float* b2,
-               float* hidden_pre, float* gate, void* stream);
+               float* hidden_pre, float* gate, int act, void* stream);
 /* dgate [n,c] -> dpool [n,c] (already divided by H*W), parameter gradients.
  * scratch: caller-owned fp32 workspace of n*(c + 2*se) elements.  */
 int edet_se_fc_bwd(const float* pooled_sum, const float* hidden_pre, const float* gate,
                    const float* dgate, int n, int c, int se, float inv_hw,
                    const float* w1, const float* w2,
                    float* dw1, float* db1, float* dw2, float* db2,
-                   float* dpool, float* scratch, void* stream);
+                   float* dpool, float* scratch, int act, void* stream);
 /* in place on g (holding the gated gradient D): dz = (D*gate + dpool)*act'(z);
  * writes BN backward partials for `in`'s BatchNorm.  */
 int edet_se_gate_bwd(const edet_tview_t* in, void* g, const float* dpool,
