@@ -10,7 +10,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libedet_hip.so')
 
 EDET_F32, EDET_BF16 = 0, 1
-ACT_NONE, ACT_SWISH = 0, 1
+ACT_NONE, ACT_SWISH, ACT_RELU, ACT_RELU6, ACT_HSWISH = 0, 1, 2, 3, 4
+ACT_CODES = {'swish': ACT_SWISH, 'silu': ACT_SWISH, 'swish_native': ACT_SWISH, 'relu': ACT_RELU, 'relu6': ACT_RELU6,
+             'hswish': ACT_HSWISH}
 RS_IDENTITY, RS_UP2, RS_POOL = 0, 1, 2
 MAX_PARTS = 1024
 OPT_SPLIT = 16   # EDET_OPT_SPLIT: partial squared norms per tensor segment
@@ -76,9 +78,9 @@ SIGNATURES = {
     'edet_add': [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
     'edet_se_pool': [PT, c_void_p, c_int, c_void_p],
     'edet_se_fc': [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
-                   c_void_p, c_void_p, c_void_p],
+                   c_void_p, c_void_p, c_int, c_void_p],
     'edet_se_fc_bwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
-                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     'edet_se_gate_bwd': [PT, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, PI, c_int, c_void_p],
     'edet_fuse_weights': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p],
     'edet_fuse_fwd': [PT, PT, PT, PI, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
@@ -107,6 +109,11 @@ SIGNATURES = {
     'edet_nms_workspace_bytes': [c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_size_t)],
     'edet_nms': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(NmsCfg), c_void_p,
                  ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
+    'edet_label_anchors_workspace_bytes': [c_int, c_int, ctypes.POINTER(ctypes.c_size_t)],
+    'edet_label_anchors': [c_void_p, PI, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p,
+                           ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
+    'edet_preprocess_infer': [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_int, c_void_p],
     'edet_nms_gather': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
 }

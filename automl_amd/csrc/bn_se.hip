@@ -241,7 +241,7 @@ __global__ __launch_bounds__(THREADS) void k_se_pool(const edet_tview_t in, floa
 constexpr int SE_FC_THREADS = 1024;
 __global__ __launch_bounds__(SE_FC_THREADS) void k_se_fc(const float* __restrict__ pooled, int c, int se, float inv_hw,
                                                         const float* w1, const float* b1, const float* w2,
-                                                        const float* b2, float* hidden_pre, float* gate) {
+                                                        const float* b2, float* hidden_pre, float* gate, int act) {
   extern __shared__ float sm[];  // p[c], h[se]
   float* p = sm;
   float* h = sm + c;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(SE_FC_THREADS) void k_se_fc(const float* __restrict
   for (int j = tid; j < se; j += nthr) {
     const float acc = h[j] + b1[j];
     hidden_pre[(size_t)n * se + j] = acc;
-    h[j] = swishf_(acc);
+    h[j] = act_apply_(act, acc);
   }
   __syncthreads();
   for (int i = tid; i < c; i += nthr) {
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(SE_FC_THREADS) void k_se_fc_bwd_img(const float* __
                                                           const float* __restrict__ gate,
                                                           const float* __restrict__ dgate, int nimg, int c,
                                                           int se, float inv_hw, const float* w1,
-                                                          const float* w2, float* dpool, float* scratch) {
+                                                          const float* w2, float* dpool, float* scratch, int act) {
   extern __shared__ float sm[];  // dpre2[c], dpre1[se]
   float* d2 = sm;
   float* d1 = sm + c;
@@ -321,10 +321,10 @@ __global__ __launch_bounds__(SE_FC_THREADS) void k_se_fc_bwd_img(const float* __
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if (lane == 0) {
       const float hp = hidden_pre[(size_t)n * se + j];
-      const float v = acc * swish_gradf_(hp);
+      const float v = acc * act_grad_(act, hp);
       d1[j] = v;
       dpre1_g[j] = v;
-      hact_g[j] = swishf_(hp);
+      hact_g[j] = act_apply_(act, hp);
     }
   }
   __syncthreads();
@@ -403,8 +403,9 @@ __global__ __launch_bounds__(THREADS) void k_se_fc_bwd_par(const float* __restri
   }
 }
 
-// g (in place, holds D) -> dz = (D*gate + dpool)*act'(z); BN backward stat partials
-template <typename T>
+// g (in place, holds D) -> dz = (D*gate + dpool)*act'(z); BN backward stat partials.  OTHER: an activation beyond
+// swish (its own instantiation: the extra selects cost the swish kernel three VGPRs and one occupancy step)
+template <typename T, bool OTHER>
 __global__ __launch_bounds__(THREADS) void k_se_gate_bwd(const edet_tview_t in, T* g, const float* dpool,
                                                         const float* mean, const float* rstd,
                                                         float* partials, int wg_per_img, RowMap m) {
@@ -437,7 +438,8 @@ __global__ __launch_bounds__(THREADS) void k_se_gate_bwd(const edet_tview_t in, 
       for (int e = 0; e < 8; ++e) {
         const float z = fmaf(x[e], sc[e], sh[e]);
         const float da = fmaf(d[e], gt[e], dp[e]);
-        d[e] = in.act == EDET_ACT_SWISH ? da * swish_gradf_(z) : da;
+        if (OTHER) d[e] = da * act_other_grad_(in.act, z);
+        else d[e] = in.act == EDET_ACT_SWISH ? da * swish_gradf_(z) : da;
         s1[e] += d[e];
         s2[e] += d[e] * (x[e] - mu[e]) * rs[e];
       }
@@ -593,10 +595,11 @@ extern "C" int edet_se_pool(const edet_tview_t* in, float* pooled_sum, int dtype
 
 extern "C" int edet_se_fc(const float* pooled_sum, int n, int c, int se, float inv_hw,
                           const float* w1, const float* b1, const float* w2, const float* b2,
-                          float* hidden_pre, float* gate, void* stream) {
+                          float* hidden_pre, float* gate, int act, void* stream) {
   EDET_CHECK(pooled_sum && w1 && b1 && w2 && b2 && hidden_pre && gate, "edet_se_fc: null pointer");
+  EDET_CHECK(act >= EDET_ACT_NONE && act <= EDET_ACT_HSWISH, "edet_se_fc: activation %d", act);
   const int fc_threads = c >= 512 ? SE_FC_THREADS : THREADS;
-  k_se_fc<<<n, fc_threads, (size_t)(c + se) * sizeof(float), to_stream(stream)>>>(pooled_sum, c, se, inv_hw, w1, b1, w2, b2, hidden_pre, gate);
+  k_se_fc<<<n, fc_threads, (size_t)(c + se) * sizeof(float), to_stream(stream)>>>(pooled_sum, c, se, inv_hw, w1, b1, w2, b2, hidden_pre, gate, act);
   EDET_LAUNCH_CHECK("edet_se_fc");
   return 0;
 }
@@ -605,10 +608,11 @@ extern "C" int edet_se_fc_bwd(const float* pooled_sum, const float* hidden_pre, 
                               const float* dgate, int n, int c, int se, float inv_hw,
                               const float* w1, const float* w2,
                               float* dw1, float* db1, float* dw2, float* db2,
-                              float* dpool, float* scratch, void* stream) {
+                              float* dpool, float* scratch, int act, void* stream) {
+  EDET_CHECK(act >= EDET_ACT_NONE && act <= EDET_ACT_HSWISH, "edet_se_fc_bwd: activation %d", act);
   EDET_CHECK(pooled_sum && hidden_pre && gate && dgate && w1 && w2 && dw1 && db1 && dw2 && db2 && dpool && scratch,
              "edet_se_fc_bwd: null pointer");
-  k_se_fc_bwd_img<<<n, c >= 512 ? SE_FC_THREADS : THREADS, (size_t)(c + se) * sizeof(float), to_stream(stream)>>>(hidden_pre, gate, dgate, n, c, se, inv_hw, w1, w2, dpool, scratch);
+  k_se_fc_bwd_img<<<n, c >= 512 ? SE_FC_THREADS : THREADS, (size_t)(c + se) * sizeof(float), to_stream(stream)>>>(hidden_pre, gate, dgate, n, c, se, inv_hw, w1, w2, dpool, scratch, act);
   const int nsplit = n >= 2 * SE_SPLIT ? SE_SPLIT : 1;
   const int per_split = cdiv(n, nsplit);
   k_se_fc_bwd_par<<<dim3(cdiv(c, 64), cdiv(n, per_split), cdiv(se, SE_JB)), THREADS,
@@ -629,8 +633,11 @@ extern "C" int edet_se_gate_bwd(const edet_tview_t* in, void* g, const float* dp
   EDET_CHECK(in->n * wpi <= EDET_MAX_PARTS, "edet_se_gate_bwd: batch %d exceeds %d partial rows", in->n, EDET_MAX_PARTS);
   if (nparts_out) *nparts_out = in->n * wpi;
   const size_t lds = (size_t)2 * in->c * sizeof(float);
-  if (dtype == EDET_BF16) k_se_gate_bwd<bf16_t><<<in->n * wpi, THREADS, lds, to_stream(stream)>>>(*in, (bf16_t*)g, dpool, mean, rstd, stat_partials, wpi, m);
-  else if (dtype == EDET_F32) k_se_gate_bwd<float><<<in->n * wpi, THREADS, lds, to_stream(stream)>>>(*in, (float*)g, dpool, mean, rstd, stat_partials, wpi, m);
+  const bool other = in->act > EDET_ACT_SWISH;
+  if (dtype == EDET_BF16 && !other) k_se_gate_bwd<bf16_t, false><<<in->n * wpi, THREADS, lds, to_stream(stream)>>>(*in, (bf16_t*)g, dpool, mean, rstd, stat_partials, wpi, m);
+  else if (dtype == EDET_BF16) k_se_gate_bwd<bf16_t, true><<<in->n * wpi, THREADS, lds, to_stream(stream)>>>(*in, (bf16_t*)g, dpool, mean, rstd, stat_partials, wpi, m);
+  else if (dtype == EDET_F32 && !other) k_se_gate_bwd<float, false><<<in->n * wpi, THREADS, lds, to_stream(stream)>>>(*in, (float*)g, dpool, mean, rstd, stat_partials, wpi, m);
+  else if (dtype == EDET_F32) k_se_gate_bwd<float, true><<<in->n * wpi, THREADS, lds, to_stream(stream)>>>(*in, (float*)g, dpool, mean, rstd, stat_partials, wpi, m);
   else EDET_CHECK(false, "edet_se_gate_bwd: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_se_gate_bwd");
   return 0;

@@ -111,6 +111,26 @@ __device__ __forceinline__ float swish_gradf_(float x) {
   return s * (1.0f + x * (1.0f - s));
 }
 
+// The other activation types of utils.activation_fn (act > EDET_ACT_SWISH): relu, relu6, hswish.  Derivatives as
+// TensorFlow's gradient kernels define them at the kinks (ReluGrad: x > 0; Relu6Grad: 0 < x < 6).
+__device__ __forceinline__ float act_other_(int act, float z) {
+  if (act == EDET_ACT_RELU) return fmaxf(z, 0.f);
+  if (act == EDET_ACT_RELU6) return fminf(fmaxf(z, 0.f), 6.f);
+  return z * fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f;
+}
+__device__ __forceinline__ float act_other_grad_(int act, float z) {
+  if (act == EDET_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == EDET_ACT_RELU6) return (z > 0.f && z < 6.f) ? 1.f : 0.f;
+  return z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) / 6.f);
+}
+// any activation code (kernel-uniform): value and derivative
+__device__ __forceinline__ float act_apply_(int act, float z) {
+  return act == EDET_ACT_SWISH ? swishf_(z) : (act == EDET_ACT_NONE ? z : act_other_(act, z));
+}
+__device__ __forceinline__ float act_grad_(int act, float z) {
+  return act == EDET_ACT_SWISH ? swish_gradf_(z) : (act == EDET_ACT_NONE ? 1.f : act_other_grad_(act, z));
+}
+
 // Activated-view element transform for 8 consecutive channels starting at c0.
 // img = image index of the row (only used when gate != NULL).
 struct ViewCoef {
@@ -132,6 +152,9 @@ __device__ __forceinline__ void view_apply(const edet_tview_t& v, const ViewCoef
   if (v.act == EDET_ACT_SWISH) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = swishf_(x[e]);
+  } else if (v.act > EDET_ACT_SWISH) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = act_other_(v.act, x[e]);
   }
   if (v.gate) {
     float g[8];

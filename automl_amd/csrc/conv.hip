@@ -66,7 +66,7 @@ __global__ __launch_bounds__(DTHREADS) void k_conv_direct(const ConvArgs a) {
           for (int c = 0; c < cin; ++c) {
             float x = to_f<T>(xp[c]);
             if (a.in.scale) x = fmaf(x, a.in.scale[c], a.in.shift[c]);
-            if (a.in.act == EDET_ACT_SWISH) x = swishf_(x);
+            x = act_apply_(a.in.act, x);
             if (a.in.gate) x *= a.in.gate[img * cin + c];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(DTHREADS) void k_conv_wgrad_direct(const ConvBwdArg
         if (ix < 0 || ix >= a.in.w) continue;
         float x = to_f<T>(X[((size_t)(img * a.in.h + iy) * a.in.w + ix) * a.in.ld + c]);
         if (a.in.scale) x = fmaf(x, a.in.scale[c], a.in.shift[c]);
-        if (a.in.act == EDET_ACT_SWISH) x = swishf_(x);
+        x = act_apply_(a.in.act, x);
         if (a.in.gate) x *= a.in.gate[(size_t)img * cin + c];
         acc = fmaf(x, conv_dy<T>(a.gy, ((size_t)(img * a.oh + oy) * a.ow + ox) * a.gy.ld + co, co), acc);
       }

@@ -1394,6 +1394,7 @@ inline bool dw_lx_enabled() {
 // return 1 = handled, 0 = not applicable (caller falls back), < 0 = error
 int dwm_try_fwd(const edet_tview_t* in, const float* weight, int k, int s, void* out, int ldo,
                 float* stat_partials, int* nparts_out, hipStream_t st) {
+  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace dwm;
   if (in->gate || in->c % 8 != 0) return 0;
   Args a;
@@ -1429,6 +1430,7 @@ int dwm_try_fwd(const edet_tview_t* in, const float* weight, int k, int s, void*
 
 int dwm_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, float* dweight, void* workspace,
                   size_t workspace_bytes, hipStream_t st) {
+  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace dwm;
   if (in->gate || in->c % 8 != 0 || !workspace) return 0;
   Args a;
@@ -1469,6 +1471,7 @@ int dwm_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, 
 
 int dwm_try_dgrad(const edet_gview_t* dy, const float* weight, int k, int s, const edet_tview_t* in,
                   const edet_bwd_epi_t* epi, int* nparts_out, hipStream_t st) {
+  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace dwm;
   if (in->gate || epi->dgate || in->c % 8 != 0) return 0;
   Args a;
@@ -1508,6 +1511,7 @@ int dwm_try_dgrad(const edet_gview_t* dy, const float* weight, int k, int s, con
 int dwm_try_bwd_fused(const edet_gview_t* dy, const float* weight, int k, int s, const edet_tview_t* in,
                       const edet_bwd_epi_t* epi, int* nparts_out, float* dweight, void* workspace,
                       size_t workspace_bytes, hipStream_t st) {
+  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace dwm;
   static const bool enabled = !(getenv("EDET_DW_FUSED") && getenv("EDET_DW_FUSED")[0] == '0');
   // k = 3: 4 channels per thread (8-byte loads, 2 waves/SIMD) wins on the large maps, 2 channels per thread

@@ -251,9 +251,9 @@ __global__ __launch_bounds__(THREADS) void k_dw_bwd_data(const DwArgs a) {
         float g[4] = {acc[pp][0], acc[pp][1], acc[pp][2], acc[pp][3]};
         float x[4] = {0, 0, 0, 0};
         if (a.in.act != EDET_ACT_NONE || want_stats) load4<T>(reinterpret_cast<const T*>(a.in.data) + off, x);
-        if (a.in.act == EDET_ACT_SWISH) {
+        if (a.in.act != EDET_ACT_NONE) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) g[e] *= swish_gradf_(fmaf(x[e], sc[e], sh[e]));
+          for (int e = 0; e < 4; ++e) g[e] *= act_grad_(a.in.act, fmaf(x[e], sc[e], sh[e]));
         }
         if (a.epi.beta) {
           float old[4];

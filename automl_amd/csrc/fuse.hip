@@ -140,6 +140,9 @@ __global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restric
       if (a.act == EDET_ACT_SWISH) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] = swishf_(s[e]);
+      } else if (a.act > EDET_ACT_SWISH) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = act_other_(a.act, s[e]);
       }
       store8<T>(out + off, s);
     } else {
@@ -148,6 +151,9 @@ __global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restric
       if (a.act == EDET_ACT_SWISH) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) d[e] *= swish_gradf_(s[e]);
+      } else if (a.act > EDET_ACT_SWISH) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] *= act_other_grad_(a.act, s[e]);
       }
       store8<T>(ds + off, d);
       for (int i = 0; i < a.nin; ++i) {

@@ -657,6 +657,157 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_wgrad(const WgArgs a) {
     }
 }
 
+// ---- balanced staging variant (EDET_WG_BALANCED=1; UNVERIFIED ON HARDWARE, branch wip/round2-prep) --------------
+// In k_big_wgrad waves 0-1 stage X (BatchNorm + swish + gate: ~10 issue slots per element) while waves 2-3 stage dY
+// (BatchNorm backward: ~3), and all four meet at the barrier: the r01g SQ counters show the step time tracking the
+// X waves.  Here every thread stages one 4-row x 8-channel block of X AND one of dY (256 blocks each per 64-row
+// step), so the four waves carry equal work; LDS writes become 8-byte (4 rows) instead of 16-byte.
+// p[r] = 8 bf16 channels of row r (4 rows)  ->  LDS rows (cb + e), 4 consecutive row indices starting at rb
+__device__ __forceinline__ void store_transposed4(unsigned char* tile, int cb, int rb, const uint4 (&p)[4]) {
+  const uint32_t w[4][4] = {{p[0].x, p[0].y, p[0].z, p[0].w}, {p[1].x, p[1].y, p[1].z, p[1].w},
+                            {p[2].x, p[2].y, p[2].z, p[2].w}, {p[3].x, p[3].y, p[3].z, p[3].w}};
+#pragma unroll
+  for (int c2 = 0; c2 < 4; ++c2) {
+    uint2 lo, hi;
+    lo.x = perm_lo(w[0][c2], w[1][c2]); lo.y = perm_lo(w[2][c2], w[3][c2]);
+    hi.x = perm_hi(w[0][c2], w[1][c2]); hi.y = perm_hi(w[2][c2], w[3][c2]);
+    *reinterpret_cast<uint2*>(tile + (cb + 2 * c2) * LDT + rb * 2) = lo;
+    *reinterpret_cast<uint2*>(tile + (cb + 2 * c2 + 1) * LDT + rb * 2) = hi;
+  }
+}
+
+template <bool GBN>
+__global__ __launch_bounds__(THREADS, 2) void k_big_wgrad_bal(const WgArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave & 1, wj = wave >> 1;
+  const int ntile = a.ntk * a.ntn;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int tile = q % ntile;
+  const int split = (q / ntile) * 8 + xcd;
+  if (split >= a.S) return;
+  const int kt0 = (tile / a.ntn) * 128, nt0 = (tile % a.ntn) * 128;
+  const int m_begin = split * a.rows_per_split;
+  const int m_end = min(a.M, m_begin + a.rows_per_split);
+
+  // staging tasks of this thread: rows rg*4 .. rg*4+3 of the 64-row step, channel chunk cchunk of BOTH operands
+  const int rg = lane & 15;
+  const int cchunk = (lane >> 4) + 4 * wave;        // 0..15
+  const int cb = cchunk * 8;
+  const int xglob = kt0 + cb, dglob = nt0 + cb;
+  const bool x_ok = xglob < a.K, d_ok = dglob < a.N;
+  const bf16_t* XS = reinterpret_cast<const bf16_t*>(a.tv.data);
+  const bf16_t* DZ = reinterpret_cast<const bf16_t*>(a.gv.dz);
+  const bf16_t* DY = reinterpret_cast<const bf16_t*>(a.gv.y);
+  const bool swish = a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr, gated = a.tv.gate != nullptr;
+  float xs[8], xt[8], ga[8], gb[8], gc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { xs[e] = 1.f; xt[e] = 0.f; ga[e] = 1.f; gb[e] = 0.f; gc[e] = 0.f; }
+  if (x_ok && affine) { loadf8(a.tv.scale + xglob, xs); loadf8(a.tv.shift + xglob, xt); }
+  if (d_ok && GBN) { loadf8(a.gv.a + dglob, ga); loadf8(a.gv.b + dglob, gb); loadf8(a.gv.cc + dglob, gc); }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[x][y][e] = 0.f;
+
+  uint4 rx[4], rz[4], ry[GBN ? 4 : 1];
+  auto issue = [&](int mb) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = mb + rg * 4 + r;
+      rx[r] = make_uint4(0, 0, 0, 0);
+      rz[r] = make_uint4(0, 0, 0, 0);
+      if (GBN) ry[r] = make_uint4(0, 0, 0, 0);
+      if (m < m_end) {
+        if (x_ok) rx[r] = *reinterpret_cast<const uint4*>(XS + (size_t)m * a.tv.ld + xglob);
+        if (d_ok) {
+          rz[r] = *reinterpret_cast<const uint4*>(DZ + (size_t)m * a.gv.ld + dglob);
+          if (GBN) ry[r] = *reinterpret_cast<const uint4*>(DY + (size_t)m * a.gv.ld + dglob);
+        }
+      }
+    }
+  };
+  auto commit = [&](int mb, unsigned char* stage) {
+    uint4 px[4], pd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = mb + rg * 4 + r;
+      px[r] = make_uint4(0, 0, 0, 0);       // rows past the split / channels past K, N contribute zero
+      pd[r] = make_uint4(0, 0, 0, 0);
+      if (m < m_end) {
+        if (x_ok) {
+          px[r] = rx[r];
+          if (affine || swish || gated) {
+            float x[8];
+            unpack8(rx[r], x);
+            if (affine) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], xs[e], xt[e]);
+            }
+            if (swish) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[e] = swishf_(x[e]);
+            }
+            if (gated) {
+              float gt[8];
+              loadf8(a.tv.gate + (size_t)(m / a.hw) * a.K + xglob, gt);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[e] *= gt[e];
+            }
+            px[r] = pack8(x);
+          }
+        }
+        if (d_ok) {
+          pd[r] = rz[r];
+          if (GBN) {
+            float x[8], y[8];
+            unpack8(rz[r], x);
+            unpack8(ry[r], y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = fmaf(ga[e], x[e], fmaf(gb[e], y[e], gc[e]));
+            pd[r] = pack8(x);
+          }
+        }
+      }
+    }
+    store_transposed4(stage, cb, rg * 4, px);                  // X^T tile
+    store_transposed4(stage + TILE_BYTES, cb, rg * 4, pd);     // dY^T tile
+  };
+
+  const int nst = (m_end - m_begin + BK - 1) / BK;
+  if (nst > 0) {
+    issue(m_begin);
+    commit(m_begin, smem);
+    if (nst > 1) issue(m_begin + BK);
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+      unsigned char* cur = smem + (st & 1) * STAGE_BYTES;
+      unsigned char* nxt = smem + ((st + 1) & 1) * STAGE_BYTES;
+      if (st + 1 < nst) commit(m_begin + (st + 1) * BK, nxt);
+      if (st + 2 < nst) issue(m_begin + (st + 2) * BK);
+      mma_stage(cur + TILE_BYTES, cur, wj, wm, lane, BK / 16, acc);
+      __syncthreads();
+    }
+  }
+  float* dst = a.ws + (size_t)split * a.K * a.N;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) {
+      const int n = nt0 + wj * 64 + nn * 32 + r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int k = kt0 + wm * 64 + kk * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (k < a.K && n < a.N) dst[(size_t)k * a.N + n] = acc[kk][nn][e];
+      }
+    }
+}
+
 inline bool big_lds_ok(const void* kern) {
   return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES) == hipSuccess;
 }
@@ -666,6 +817,7 @@ inline bool big_lds_ok(const void* kern) {
 // return 1 = handled, 0 = shape outside the envelope (caller falls back), < 0 = error
 int pwb_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bias, void* out, int cout,
                 int ldo, float* stat_partials, int* nparts_out, hipStream_t st) {
+  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace pwb;
   const int K = in->c, N = cout;
   if (K % 8 != 0 || in->ld % 8 != 0 || ldw % 8 != 0 || ldo % 8 != 0 || ldo < (N + 7) / 8 * 8) return 0;
@@ -691,6 +843,7 @@ int pwb_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
 // (ky*k + kx)*cin + c contiguous.  return 1 = handled, 0 = shape outside the envelope, < 0 = error
 int pwb_try_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, int k, int s, const float* bias, void* out,
                      int cout, int ldo, float* stat_partials, int* nparts_out, hipStream_t st) {
+  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace pwb;
   const int cin = in->c, N = cout;
   if (cin % 8 != 0 || in->ld % 8 != 0 || ldw % 8 != 0 || ldo % 8 != 0 || ldo < (N + 7) / 8 * 8) return 0;
@@ -717,6 +870,7 @@ int pwb_try_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, int k, int
 
 int pwb_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tview_t* in,
                   const edet_bwd_epi_t* epi, int* nparts_out, hipStream_t st) {
+  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace pwb;
   const int R = dy->c, KO = in->c;
   if (KO % 8 != 0 || in->ld % 8 != 0 || dy->ld % 8 != 0 || ldw % 8 != 0 || R % 8 != 0) return 0;
@@ -742,6 +896,7 @@ int pwb_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tvi
 
 int pwb_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight, void* workspace,
                   size_t workspace_bytes, hipStream_t st) {
+  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace pwb;
   const int K = in->c, N = dy->c;
   if (!workspace || K % 8 != 0 || N % 8 != 0 || dy->ld % 8 != 0 || in->ld % 8 != 0) return 0;
@@ -765,8 +920,18 @@ int pwb_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight
   static const bool ok2 = big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad<true>));
   if (!ok1 || !ok2) return 0;
   const int grid = (a.S + 7) / 8 * 8 * ntile;
-  if (dy->a) k_big_wgrad<true><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
-  else k_big_wgrad<false><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+  const char* bal = getenv("EDET_WG_BALANCED");        // read per call (A/B with scripts/kernel_lab.py)
+  if (bal && bal[0] == '1') {
+    static const bool ok3 = big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad_bal<false>));
+    static const bool ok4 = big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad_bal<true>));
+    if (!ok3 || !ok4) return 0;
+    if (dy->a) k_big_wgrad_bal<true><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+    else k_big_wgrad_bal<false><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+  } else if (dy->a) {
+    k_big_wgrad<true><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+  } else {
+    k_big_wgrad<false><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+  }
   EDET_LAUNCH_CHECK("edet_pw_bwd_weight(big)");
   if (edet_reduce_partials(a.ws, a.S, kn, dweight, st) != 0) return -2;
   return 1;
@@ -776,6 +941,7 @@ int pwb_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight
 // data gradient: w_t [cin][ldw] with the reduction index (ky*k + kx)*cout + co contiguous; rows = input pixels
 int pwb_try_conv_dgrad(const edet_gview_t* dy, const void* w_t, int ldw, int k, int s, const edet_tview_t* in,
                        const edet_bwd_epi_t* epi, int* nparts_out, hipStream_t st) {
+  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace pwb;
   const int cout = dy->c, cin = in->c;
   if (cout % 8 != 0 || cin % 8 != 0 || in->ld % 8 != 0 || dy->ld % 8 != 0 || ldw % 8 != 0) return 0;
@@ -806,6 +972,7 @@ int pwb_try_conv_dgrad(const edet_gview_t* dy, const void* w_t, int ldw, int k, 
 // weight gradient: dweight fp32 HWIO [k][k][cin][cout] += gathered(in)^T dy
 int pwb_try_conv_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, float* dweight, void* workspace,
                        size_t workspace_bytes, hipStream_t st) {
+  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace pwb;
   const int cin = in->c, N = dy->c, K = k * k * cin;
   if (!workspace || cin % 8 != 0 || N % 8 != 0 || dy->ld % 8 != 0 || in->ld % 8 != 0) return 0;

@@ -338,13 +338,13 @@ __global__ __launch_bounds__(THREADS) void k_gemm(const GemmArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                   const float z = fmaf(x[e], sc8[e], sh8[e]);
-                  const float av = a.tv.act == EDET_ACT_SWISH ? swishf_(z) : z;
+                  const float av = act_apply_(a.tv.act, z);
                   gp[e] += v[e] * av;
                   g[e] = v[e];
                 }
-              } else if (a.tv.act == EDET_ACT_SWISH) {
+              } else if (a.tv.act != EDET_ACT_NONE) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) g[e] = v[e] * swish_gradf_(fmaf(x[e], sc8[e], sh8[e]));
+                for (int e = 0; e < 8; ++e) g[e] = v[e] * act_grad_(a.tv.act, fmaf(x[e], sc8[e], sh8[e]));
               } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) g[e] = v[e];

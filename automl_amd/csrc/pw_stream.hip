@@ -843,6 +843,7 @@ inline bool allow_big_lds(KernelT kern, size_t lds) {
 // (the caller then falls back to the tiled kernel in pw_gemm.hip), negative on error.
 int pws_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bias, void* out, int cout,
                 int ldo, float* stat_partials, int* nparts_out, hipStream_t st) {
+  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace pws;
   const int K = in->c, N = cout;
   if (K > 256 || K % 8 != 0) return 0;
@@ -898,6 +899,7 @@ int pws_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
 
 int pws_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tview_t* in,
                   const edet_bwd_epi_t* epi, int* nparts_out, hipStream_t st) {
+  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace pws;
   const int R = dy->c, KO = in->c;
   if (R > 128 || KO > 512 || KO % 8 != 0 || dy->ld % 8 != 0) return 0;
@@ -947,6 +949,7 @@ int pws_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tvi
 
 int pws_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight, void* workspace,
                   size_t workspace_bytes, hipStream_t st) {
+  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace pws;
   const int K = in->c, N = dy->c;
   if (!workspace || K % 8 != 0 || dy->ld % 8 != 0 || in->ld % 8 != 0) return 0;

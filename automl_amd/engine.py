@@ -95,6 +95,7 @@ class Engine(object):
     _lib.load()
     self.config = config
     self.spec = spec if spec is not None else netspec_lib.NetSpec(config)
+    self.act = getattr(self.spec, 'act_code', ACT_SWISH)     # the model's activation (config.act_type)
     self.bn_momentum = getattr(self.spec, 'bn_momentum', netspec_lib.BN_MOMENTUM)
     self.bn_epsilon = getattr(self.spec, 'bn_epsilon', netspec_lib.BN_EPSILON)
     self.device = torch.device(device)
@@ -477,7 +478,7 @@ class Engine(object):
     call('edet_se_pool', ctypes.byref(v.tview()), ptr(pooled), self.dtype, self.stream,
          nbytes=r.rows * c * self.esize)
     call('edet_se_fc', ptr(pooled), n, c, se_filters, inv_hw, ptr(self.param(w1)), ptr(self.param(b1)),
-         ptr(self.param(w2)), ptr(self.param(b2)), ptr(hidden), ptr(gate), self.stream)
+         ptr(self.param(w2)), ptr(self.param(b2)), ptr(hidden), ptr(gate), v.act, self.stream)
     vg = View(r, v.bn, v.act, gate)
     vg.dgate = self.zbuf(key + ':dgate', (n, c)) if self.training else None
     v.consumers += 1
@@ -488,7 +489,7 @@ class Engine(object):
       def bwd():
         call('edet_se_fc_bwd', ptr(pooled), ptr(hidden), ptr(gate), ptr(vg.dgate), n, c, se_filters, inv_hw,
              ptr(self.param(w1)), ptr(self.param(w2)), ptr(self.grad(w1)), ptr(self.grad(b1)),
-             ptr(self.grad(w2)), ptr(self.grad(b2)), ptr(dpool), ptr(scratch), self.stream)
+             ptr(self.grad(w2)), ptr(self.grad(b2)), ptr(dpool), ptr(scratch), v.act, self.stream)
         call('edet_se_gate_bwd', ctypes.byref(vg.tview()), ptr(r.grad), ptr(dpool), ptr(v.bn.mean),
              ptr(v.bn.rstd), ptr(self.partials), ctypes.byref(self._nparts), self.dtype, self.stream,
              nbytes=2 * r.rows * c * self.esize)
@@ -670,7 +671,7 @@ class Engine(object):
          ptr(self.partials) if training else None, ctypes.byref(self._nparts), self.dtype, self.stream,
          nbytes=(n * h * w * 3 + y0.rows * y0.c) * self.esize)
     self._bn_forward(bn0, y0.rows, self._nparts.value)
-    x = View(y0, bn0, ACT_SWISH)
+    x = View(y0, bn0, self.act)
     if training:
       v0 = x
 
@@ -718,11 +719,11 @@ class Engine(object):
     x = xin
     if b.expand_ratio != 1:
       x = self.pw(scope + ':exp', x, '%s/%s/kernel' % (scope, conv_names[ci]), cexp,
-                  bn='%s/%s' % (scope, bn_names[bi]), act=ACT_SWISH)
+                  bn='%s/%s' % (scope, bn_names[bi]), act=self.act)
       ci += 1
       bi += 1
     x = self.dw(scope + ':dw', x, scope + '/depthwise_conv2d/depthwise_kernel', b.kernel_size, b.stride,
-                bn='%s/%s' % (scope, bn_names[bi]), act=ACT_SWISH)
+                bn='%s/%s' % (scope, bn_names[bi]), act=self.act)
     bi += 1
     if b.se_filters:
       x = self.se(scope + ':se', x, scope, b.se_filters)
@@ -762,7 +763,7 @@ class Engine(object):
       wnames = []
       if fpn.weight_method in ('fastattn', 'attn', 'channel_fastattn', 'channel_attn'):
         wnames = [scope + '/WSM' + ('' if i == 0 else '_%d' % i) for i in range(len(ins))]
-      x = self.fuse(scope + ':fuse', ins, modes, wnames, th, tw, act=ACT_SWISH)
+      x = self.fuse(scope + ':fuse', ins, modes, wnames, th, tw, act=self.act)
       oc = '%s/op_after_combine%d' % (scope, len(feats))
       d = self.dw(oc + ':dw', x, oc + '/conv/depthwise_kernel', 3, 1)
       y = self.pw(oc + ':pw', d, oc + '/conv/pointwise_kernel', wf, bias=oc + '/conv/bias', bn=oc + '/bn')
@@ -788,7 +789,7 @@ class Engine(object):
         key = '%s:l%d' % (s, level)
         d = self.dw(key + ':dw', x, s + '/depthwise_kernel', 3, 1)
         x = self.pw(key + ':pw', d, s + '/pointwise_kernel', wf, bias=s + '/bias',
-                    bn='%s/%s-%d-bn-%d' % (net, prefix, i, level), act=ACT_SWISH)
+                    bn='%s/%s-%d-bn-%d' % (net, prefix, i, level), act=self.act)
       s = '%s/%s-predict' % (net, prefix)
       key = '%s:l%d' % (s, level)
       d = self.dw(key + ':dw', x, s + '/depthwise_kernel', 3, 1)

@@ -33,8 +33,11 @@ class NetSpec(object):
     c = config
     if not c.backbone_name.startswith('efficientnet-b'):
       raise ValueError('backbone %r is out of scope (efficientnet-b0..b7 are built)' % c.backbone_name)
-    if c.act_type not in ('swish', 'silu'):
-      raise ValueError('act_type %r is out of scope (swish only)' % c.act_type)
+    # utils.activation_fn (utils.py:36-53): codes of include/edet_hip.h; mish / srelu are not built
+    codes = {'swish': 1, 'silu': 1, 'swish_native': 1, 'relu': 2, 'relu6': 3, 'hswish': 4}
+    if c.act_type not in codes:
+      raise ValueError('act_type %r is not built (swish, relu, relu6, hswish are)' % c.act_type)
+    self.act_code = codes[c.act_type]
     if not c.separable_conv or c.conv_bn_act_pattern or c.conv_after_downsample or \
         not c.apply_bn_for_resampling:
       raise ValueError('only the default separable_conv / conv-bn ordering of the d0..d7x configs is built')

@@ -36,6 +36,10 @@ extern "C" {
 
 #define EDET_ACT_NONE 0
 #define EDET_ACT_SWISH 1
+/* utils.activation_fn (utils.py:36-53) beyond swish: value and derivative at every activated view */
+#define EDET_ACT_RELU 2
+#define EDET_ACT_RELU6 3
+#define EDET_ACT_HSWISH 4   /* x * relu6(x + 3) / 6 */
 
 /* resample modes of one BiFPN fusion input */
 #define EDET_RS_IDENTITY 0
@@ -220,19 +224,19 @@ int edet_add(void* dst, const void* src, int64_t rows, int c, int ld, int beta,
              int dtype, void* stream);
 
 /* ---- squeeze-and-excitation --------------------------------------------------
- * efficientnet_model.py:153-195: mean over H,W -> 1x1 (+bias) -> swish -> 1x1
- * (+bias) -> sigmoid.  pooled [n,c] must be zero before edet_se_pool (atomics).  */
+ * efficientnet_model.py:153-195: mean over H,W -> 1x1 (+bias) -> act (the model's relu_fn, an EDET_ACT_* code)
+ * -> 1x1 (+bias) -> sigmoid.  pooled [n,c] must be zero before edet_se_pool (atomics).  */
 int edet_se_pool(const edet_tview_t* in, float* pooled_sum, int dtype, void* stream);
 int edet_se_fc(const float* pooled_sum, int n, int c, int se, float inv_hw,
                const float* w1, const float* b1, const float* w2, const float* b2,
-               float* hidden_pre, float* gate, void* stream);
+               float* hidden_pre, float* gate, int act, void* stream);
 /* dgate [n,c] -> dpool [n,c] (already divided by H*W), parameter gradients.
  * scratch: caller-owned fp32 workspace of n*(c + 2*se) elements.  */
 int edet_se_fc_bwd(const float* pooled_sum, const float* hidden_pre, const float* gate,
                    const float* dgate, int n, int c, int se, float inv_hw,
                    const float* w1, const float* w2,
                    float* dw1, float* db1, float* dw2, float* db2,
-                   float* dpool, float* scratch, void* stream);
+                   float* dpool, float* scratch, int act, void* stream);
 /* in place on g (holding the gated gradient D): dz = (D*gate + dpool)*act'(z);
  * writes BN backward partials for `in`'s BatchNorm.  */
 int edet_se_gate_bwd(const edet_tview_t* in, void* g, const float* dpool,
@@ -363,6 +367,27 @@ int edet_nms_gather(const float* boxes, const int* classes, const int* out_index
                     int batch, int n, int max_output_size, int pad_mode, float clip_h, float clip_w,
                     const float* image_scales, float* nms_boxes, float* nms_scores, float* nms_classes,
                     void* stream);
+
+/* ---- anchor labelling -------------------------------------------
+ * tf2/anchors.py AnchorLabeler.label_anchors :215-250 for a batch of images.  anchor_boxes [N][4] as for
+ * edet_pre_nms; level_anchors[l] = anchors of level l (H_l * W_l * A); gt_boxes [batch][max_gt][4] (ymin, xmin, ymax,
+ * xmax), gt_labels [batch][max_gt] (1-based class ids), gt_count [batch] valid rows per image (device arrays).
+ * Outputs per level (HOST arrays of DEVICE pointers): cls_targets[l] int32 [batch][H_l][W_l][A] (class - 1, -1 =
+ * background), box_targets[l] fp32 [batch][H_l][W_l][4A]; num_positives fp32 [batch].  */
+int edet_label_anchors_workspace_bytes(int batch, int num_anchors, size_t* bytes);
+int edet_label_anchors(const float* anchor_boxes, const int* level_anchors, int nlevels, const float* gt_boxes,
+                       const int* gt_labels, const int* gt_count, int batch, int max_gt, float match_threshold,
+                       void* workspace, size_t workspace_bytes, int* const* cls_targets, float* const* box_targets,
+                       float* num_positives, void* stream);
+
+/* ---- inference image preprocessing ----------------------------------
+ * efficientdet_keras.py:920-951 (mode 'infer'): raw_images [batch][height][width][3] uint8 (raw_is_float = 0) or
+ * float32 (1) on the device, all of one size; out [batch][out_height][out_width][3] in `dtype`: normalised with
+ * mean_rgb / stddev_rgb (HOST arrays of 3), aspect-preserving bilinear resize into the top-left corner, zero padding.
+ * *image_scale_to_original (HOST) = 1 / scale, the factor that maps detections back to the raw image.  */
+int edet_preprocess_infer(const void* raw_images, int raw_is_float, int batch, int height, int width,
+                          int out_height, int out_width, const float* mean_rgb, const float* stddev_rgb, void* out,
+                          float* image_scale_to_original, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

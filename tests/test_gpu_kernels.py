@@ -35,11 +35,16 @@ def apply_view(x, scale, shift, act, gate):
   return z
 
 
-@pytest.fixture(params=['auto', 'big'])
+@pytest.fixture(params=['auto', 'big', 'big_balanced'])
 def pw_impl(request, monkeypatch):
-  """EDET_PW_IMPL (read per call by the library): 'big' forces the workgroup-tiled kernels of pw_big.hip."""
+  """EDET_PW_IMPL (read per call by the library): 'big' forces the workgroup-tiled kernels of pw_big.hip;
+  'big_balanced' additionally selects the balanced-staging weight-gradient kernel (EDET_WG_BALANCED=1)."""
   if request.param != 'auto':
-    monkeypatch.setenv('EDET_PW_IMPL', request.param)
+    monkeypatch.setenv('EDET_PW_IMPL', 'big')
+  if request.param == 'big_balanced':
+    if 'bwd_weight' not in request.node.name:
+      pytest.skip('EDET_WG_BALANCED only changes the weight gradient')
+    monkeypatch.setenv('EDET_WG_BALANCED', '1')
   return request.param
 
 
@@ -482,7 +487,7 @@ def test_squeeze_excite(dt, shape):
   w1d, b1d, w2d, b2d = (gu.fdev(t) for t in (w1, b1, w2, b2))
   call('edet_se_pool', ctypes.byref(tv), ptr(pd), edt, gu.stream())
   call('edet_se_fc', ptr(pd), n, c, se, 1.0 / (h * w), ptr(w1d), ptr(b1d), ptr(w2d), ptr(b2d), ptr(hd), ptr(gd),
-       gu.stream())
+       ACT_SWISH, gu.stream())
   torch.cuda.synchronize()
   gu.check(pd / (h * w), pooled.detach(), 'f32', 'se pooled', rtol=1e-3, atol=1e-4)
   gu.check(gd, gate.detach(), 'f32', 'se gate', rtol=1e-3, atol=1e-4)
@@ -493,7 +498,7 @@ def test_squeeze_excite(dt, shape):
   dpool = torch.zeros(n, c, dtype=torch.float32, device=gu.DEV)
   scratch = torch.zeros(n * (c + 2 * se), dtype=torch.float32, device=gu.DEV)
   call('edet_se_fc_bwd', ptr(pd), ptr(hd), ptr(gd), ptr(dgate), n, c, se, 1.0 / (h * w), ptr(w1d), ptr(w2d),
-       ptr(grads[0]), ptr(grads[1]), ptr(grads[2]), ptr(grads[3]), ptr(dpool), ptr(scratch), gu.stream())
+       ptr(grads[0]), ptr(grads[1]), ptr(grads[2]), ptr(grads[3]), ptr(dpool), ptr(scratch), ACT_SWISH, gu.stream())
   parts = partial_buf(c)
   npart = NP(0)
   tvg = gu.tview(xd, c, sc, sh, gd, ACT_SWISH)

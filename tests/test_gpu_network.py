@@ -75,6 +75,8 @@ CASES = [
     ('efficientdet-d1', '', 96, 1),
     ('efficientdet-d0', 'fpn_weight_method=attn', 128, 2),                # softmax fusion weights
     ('efficientdet-d0', 'fpn_weight_method=channel_fastattn', 128, 2),    # per-channel weight vectors
+    ('efficientdet-d0', 'act_type=hswish', 128, 2),   # utils.activation_fn beyond swish: the generic kernels
+    ('efficientdet-d0', 'act_type=relu6', 128, 2),
     ('efficientdet-d7x', '', 256, 1),     # BASELINE configs[4] at a small image: b7 backbone (55 blocks, SE up to
                                           # 160 units, 3840 channels), levels 3-8, 8 BiFPN cells of 384 filters, 'sum'
 ]
@@ -121,7 +123,8 @@ def test_forward_matches_oracle(case, training, dtype, tol):
     assert worst <= (1e-3 if dtype == 'f32' else 0.2), 'moving statistics differ: %g' % worst
 
 
-@pytest.mark.parametrize('case', CASES[:2] + [('efficientdet-d1', '', 96, 3), CASES[3], ('efficientdet-d7x', '', 384, 2), CASES[4]],
+@pytest.mark.parametrize('case', CASES[:2] + [('efficientdet-d1', '', 96, 3), CASES[3], ('efficientdet-d7x', '', 384, 2), CASES[4],
+                                               CASES[5], CASES[6]],
                          ids=lambda c: '%s[%s]@%d' % (c[0], c[1], c[2]))
 def test_train_step_matches_oracle_fp32(case):
   """loss values, clipped gradients of every variable, and the updated variables after one step."""
@@ -353,6 +356,7 @@ def test_two_replicas_equal_one_big_batch(tmp_path):
     ('reference_graph_d0.npz', 'efficientdet-d0', 'image_size=64'),
     ('reference_graph_d1.npz', 'efficientdet-d1', 'image_size=64'),
     ('reference_graph_d0_l8sum.npz', 'efficientdet-d0', 'image_size=128,max_level=8,fpn_weight_method=sum'),
+    ('reference_graph_d0_hswish.npz', 'efficientdet-d0', 'image_size=64,act_type=hswish'),
 ])
 def test_device_outputs_equal_the_executed_reference_graph(fixture, model, override):
   """The HIP path against outputs of the reference's OWN graph code (tests/golden/make_golden_graph.py executed

@@ -49,3 +49,50 @@ def test_matcher_properties():
   pos = match >= 0
   decoded = anchors.decode_box_outputs(reg[pos], an[pos])
   assert np.abs(np.asarray(decoded) - gt[match[pos]]).max() <= 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_device_equals_the_executed_reference_labeler(name):
+  """edet_label_anchors against the fixtures of the executed reference code: class targets and positives exactly,
+  box targets to 1e-6."""
+  import torch
+  from automl_amd import labeling
+  g = np.load(GOLDEN)
+  size, lo, hi = CASES[name]
+  a = anchors.Anchors(lo, hi, 3, [1.0, 2.0, 0.5], 4.0, size)
+  cls, box, npos = labeling.AnchorLabeler(a, 90).label_anchors(g[name + '/gt_boxes'], g[name + '/gt_labels'])
+  torch.cuda.synchronize()
+  assert float(npos) == float(g[name + '/num_positives'])
+  for level in range(lo, hi + 1):
+    assert np.array_equal(cls[level].cpu().numpy(), g['%s/cls_%d' % (name, level)]), level
+    assert np.abs(box[level].cpu().numpy() - g['%s/box_%d' % (name, level)]).max() <= 1e-6, level
+
+
+@pytest.mark.gpu
+def test_device_batch_matches_oracle_d0_640():
+  """BASELINE geometry (76,725 anchors), batch 16 with 0..100 boxes per image, against the oracle."""
+  import torch
+  from automl_amd import labeling
+  rng = np.random.default_rng(21)
+  size, lo, hi, b, mmax = 640, 3, 7, 16, 100
+  a = anchors.Anchors(lo, hi, 3, [1.0, 2.0, 0.5], 4.0, size)
+  an = np.asarray(a.boxes, np.float32)
+  feat = [(a.feat_sizes[l]['height'], a.feat_sizes[l]['width']) for l in range(lo, hi + 1)]
+  counts = rng.integers(0, mmax + 1, b)
+  counts[0], counts[1] = 0, mmax
+  gt = np.zeros((b, mmax, 4), np.float32) - 1
+  labels = np.zeros((b, mmax), np.int32) - 1
+  for i in range(b):
+    ctr = rng.uniform(0.05, 0.95, (counts[i], 2)) * size
+    hw = np.exp(rng.uniform(np.log(0.02), np.log(0.7), (counts[i], 2))) * size
+    gt[i, :counts[i]] = np.clip(np.concatenate([ctr - hw / 2, ctr + hw / 2], 1), 0, size)
+    labels[i, :counts[i]] = rng.integers(1, 91, counts[i])
+  cls, box, npos = labeling.AnchorLabeler(a, 90).label_anchors_batch(gt, labels, counts)
+  torch.cuda.synchronize()
+  for i in range(b):
+    wc, wb, wn = lorc.label_anchors(an, feat, 9, gt[i, :counts[i]], labels[i, :counts[i]])
+    assert float(npos[i]) == float(wn), i
+    for j, level in enumerate(range(lo, hi + 1)):
+      assert np.array_equal(cls[level][i].cpu().numpy(), wc[j]), (i, level)
+      assert np.abs(box[level][i].cpu().numpy() - wb[j]).max() <= 1e-6, (i, level)

@@ -63,3 +63,37 @@ def test_resize_bilinear_identity_and_constant():
   x = np.random.default_rng(1).standard_normal((7, 9, 3)).astype(np.float32)
   assert np.array_equal(porc.resize_bilinear(x, 7, 9), x)
   assert np.allclose(porc.resize_bilinear(np.full((5, 4, 1), 3.0, np.float32), 11, 13), 3.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['infer_wide', 'infer_tall'])
+def test_device_equals_the_executed_reference_infer_preprocessing(name):
+  """edet_preprocess_infer against the fixtures of the executed reference InputProcessor (fp32 output, 1e-4)."""
+  import torch
+  from automl_amd import preprocess
+  g = np.load(GOLDEN)
+  osize = CASES[name][0]
+  out, scales = preprocess.preprocess_infer(torch.from_numpy(g[name + '/raw'])[None], osize, MEAN, STD)
+  torch.cuda.synchronize()
+  want = g[name + '/image']
+  assert tuple(out.shape) == (1,) + want.shape and np.abs(out[0].cpu().numpy() - want).max() <= 1e-4
+  assert abs(float(scales[0]) - 1.0 / float(g[name + '/image_scale'])) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_device_infer_preprocessing_matches_oracle_batch(dtype):
+  """A batch of 1080p-like frames down to 640x640 and an upscaling case, uint8 and float inputs."""
+  import torch
+  from automl_amd import preprocess
+  tdt = torch.float32 if dtype == 'f32' else torch.bfloat16
+  rng = np.random.default_rng(4)
+  for (h, w, osize, as_float) in ((270, 480, (160, 160), False), (45, 80, (128, 96), True)):
+    raw = rng.integers(0, 256, (3, h, w, 3)).astype(np.uint8)
+    t = torch.from_numpy(raw.astype(np.float32)) if as_float else torch.from_numpy(raw)
+    out, scales = preprocess.preprocess_infer(t, osize, MEAN, STD, dtype=tdt)
+    want, wscales = porc.preprocess_infer(list(raw), osize, MEAN, STD)
+    torch.cuda.synchronize()
+    tol = 1e-4 if dtype == 'f32' else 2e-2
+    assert np.abs(out.float().cpu().numpy() - want).max() <= tol
+    assert np.allclose(scales.cpu().numpy(), wscales, rtol=1e-6)

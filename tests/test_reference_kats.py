@@ -431,11 +431,14 @@ def test_oracle_train_step_equals_the_executed_reference_train_step():
 
 def test_oracle_other_activation_equals_the_executed_reference_graph():
   """act_type=hswish (x * relu6(x + 3) / 6, utils.py:36-53) through the whole executed reference graph: the oracle side
-  of SURVEY row B6 beyond swish.  The product builds swish only and NetSpec says so."""
+  of SURVEY row B6 beyond swish (the device side: tests/test_gpu_network.py)."""
   g, config, shapes, params = load_graph_case('reference_graph_d0_hswish.npz', 'efficientdet-d0',
                                               'image_size=64,act_type=hswish')
-  with pytest.raises(ValueError, match='swish only'):
-    netspec.NetSpec(config)
+  assert netspec.NetSpec(config).act_code == 4
+  bad = hparams_config.get_efficientdet_config('efficientdet-d0')
+  bad.override('act_type=mish')
+  with pytest.raises(ValueError, match='not built'):
+    netspec.NetSpec(bad)
   images = torch.from_numpy(g['images'])
   for training, tol in ((False, 5e-6), (True, 2e-2)):
     oracle = orc.Oracle(config=config, params={k: v.clone() for k, v in params.items()})
