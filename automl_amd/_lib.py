@@ -67,7 +67,7 @@ SIGNATURES = {
     'edet_dw_bwd_data': [PG, c_void_p, c_int, c_int, PT, PE, PI, c_int, c_void_p],
     'edet_dw_bwd_weight': [PT, PG, c_int, c_int, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],
     'edet_dw_bwd': [PG, c_void_p, c_int, c_int, PT, PE, PI, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],
-    'edet_bn_finalize': [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_float, c_float,
+    'edet_bn_finalize': [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_float, c_float, c_int,
                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     'edet_bn_eval': [c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     'edet_bn_bwd_reduce': [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, PI,

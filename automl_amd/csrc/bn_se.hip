@@ -66,7 +66,7 @@ __device__ __forceinline__ void partial_colsum(const float* __restrict__ partial
 
 __global__ __launch_bounds__(FIN_CH * FIN_SL) void k_bn_finalize(
     const float* __restrict__ partials, int nparts, int c, double count, const float* gamma, const float* beta,
-    float eps, float momentum, float* moving_mean, float* moving_var, float* scale, float* shift,
+    float eps, float momentum, int bessel, float* moving_mean, float* moving_var, float* scale, float* shift,
     float* mean_out, float* rstd_out) {
   const int ch = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
   const int slice = threadIdx.x / FIN_CH;
@@ -83,8 +83,9 @@ __global__ __launch_bounds__(FIN_CH * FIN_SL) void k_bn_finalize(
   mean_out[ch] = (float)mean;
   rstd_out[ch] = rstd;
   if (momentum >= 0.f && moving_mean) {
-    // Keras fused BatchNorm: moving variance is updated with the Bessel-corrected batch variance
-    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    // Keras fused BatchNorm (the single-replica classes): moving variance is updated with the Bessel-corrected batch
+    // variance; SyncBatchNormalization / TpuBatchNormalization run un-fused (utils.py:172,211): biased variance
+    const double unbiased = (bessel && count > 1.0) ? var * count / (count - 1.0) : var;
     moving_mean[ch] = moving_mean[ch] * momentum + (float)mean * (1.f - momentum);
     moving_var[ch] = moving_var[ch] * momentum + (float)unbiased * (1.f - momentum);
   }
@@ -497,11 +498,11 @@ int edet_reduce_partials(const float* ws, int P, int64_t n, float* dst, hipStrea
 
 extern "C" int edet_bn_finalize(const float* partials, int nparts, int c, double count,
                                 const float* gamma, const float* beta, float eps, float momentum,
-                                float* moving_mean, float* moving_var, float* scale, float* shift,
+                                int bessel, float* moving_mean, float* moving_var, float* scale, float* shift,
                                 float* mean, float* rstd, void* stream) {
   EDET_CHECK(partials && gamma && beta && scale && shift && mean && rstd, "edet_bn_finalize: null pointer");
   k_bn_finalize<<<cdiv(c, FIN_CH), FIN_CH * FIN_SL, 0, to_stream(stream)>>>(partials, nparts, c, count, gamma, beta, eps,
-                                                            momentum, moving_mean, moving_var, scale, shift,
+                                                            momentum, bessel, moving_mean, moving_var, scale, shift,
                                                             mean, rstd);
   EDET_LAUNCH_CHECK("edet_bn_finalize");
   return 0;

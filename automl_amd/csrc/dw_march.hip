@@ -1,5 +1,5 @@
 // Depthwise k x k convolution (k in {3,5}, stride in {1,2}, TF 'SAME') for the bf16 path: row-marching
-// kernels without LDS staging.
+// kernels with an LDS row exchange.
 //
 // A depthwise conv moves ~4 bytes per output element and does k*k FMAs on it: pure HBM streaming.  Each
 // thread owns one output column and CPT consecutive channels and marches DOWN the image: per input row it
@@ -149,403 +149,6 @@ __device__ __forceinline__ void block_channel_sums(const Args& a, const Lane& l,
       if (c < C) dst_rows[((size_t)l.p * NROW + r) * C + c] = out[threadIdx.x];
     }
   }
-}
-
-// ------------------------------------------------------------------------------------ forward
-template <int K, int S, int CPT>
-__global__ __launch_bounds__(THREADS) void k_fwd(const Args a) {
-  constexpr int NSL = (K + S - 1) / S;   // output rows in flight
-  constexpr int U = S * NSL;             // static unroll of the row loop
-  extern __shared__ float red[];
-  const int C = a.in.c, H = a.in.h, W = a.in.w;
-  const Lane l = lane_setup<CPT>(a, C);
-  const bf16_t* IN = reinterpret_cast<const bf16_t*>(a.in.data);
-  float w[K * K][CPT], sc[CPT], sh[CPT];
-  float st[2][CPT];
-#pragma unroll
-  for (int e = 0; e < CPT; ++e) { sc[e] = 1.f; sh[e] = 0.f; st[0][e] = st[1][e] = 0.f; }
-#pragma unroll
-  for (int t = 0; t < K * K; ++t)
-#pragma unroll
-    for (int e = 0; e < CPT; ++e) w[t][e] = l.active ? a.w[(size_t)t * C + l.c + e] : 0.f;
-  if (l.active && a.in.scale) { loadf<CPT>(a.in.scale + l.c, sc); loadf<CPT>(a.in.shift + l.c, sh); }
-  const bool want_stats = a.stat_partials != nullptr;
-
-  for (int tile = l.p; tile < a.ntiles; tile += a.P) {
-    const int per_img = a.tiles_y * a.tiles_x;
-    const int n = tile / per_img, rr = tile - n * per_img;
-    const int ty = rr / a.tiles_x, tx = rr - ty * a.tiles_x;
-    const int oy0 = ty * a.TY, oy1 = min(a.oh, oy0 + a.TY);
-    const int ox = tx * a.TX + l.px;
-    const bool xok = l.active && ox < a.ow;
-    const int ix0 = ox * S - a.pad_l;
-    unsigned xmask = 0;
-#pragma unroll
-    for (int kx = 0; kx < K; ++kx)
-      if (xok && ix0 + kx >= 0 && ix0 + kx < W) xmask |= 1u << kx;
-    const bf16_t* ibase = IN + (((int64_t)n * H * W + ix0) * a.in.ld + l.c);   // ix0 may be -pad
-    bf16_t* obase = a.out + ((size_t)n * a.oh * a.ow + ox) * a.ldo + l.c;
-    float acc[NSL][CPT];
-#pragma unroll
-    for (int s = 0; s < NSL; ++s)
-#pragma unroll
-      for (int e = 0; e < CPT; ++e) acc[s][e] = 0.f;
-
-    const int t0 = (oy0 * S / U) * U, t_last = (oy1 - 1) * S + K - 1;   // t = input row + pad_t
-    Raw<CPT> cur[K], n1[K], n2[K];
-    auto load_row = [&](int t, Raw<CPT> (&dst)[K]) {
-      const int r = t - a.pad_t;
-      if (t <= t_last && r >= 0 && r < H) {
-        const bf16_t* rp = ibase + (int64_t)r * W * a.in.ld;
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx)
-          dst[kx] = (xmask >> kx) & 1u ? raw_load<CPT>(rp + (int64_t)kx * a.in.ld) : raw_zero<CPT>();
-      }
-    };
-    load_row(t0, cur);
-    load_row(t0 + 1, n1);
-    for (int tb = t0; tb <= t_last; tb += U) {
-#pragma unroll
-      for (int tt = 0; tt < U; ++tt) {
-        const int t = tb + tt;
-        load_row(t + 2, n2);                               // two input rows in flight per thread
-        const int r = t - a.pad_t;
-        if (t <= t_last && r >= 0 && r < H) {
-#pragma unroll
-          for (int kx = 0; kx < K; ++kx) {
-            float x[CPT];
-            raw_unpack<CPT>(cur[kx], x);
-            view_act<CPT>(a.in, sc, sh, x);
-            if (!((xmask >> kx) & 1u)) {
-#pragma unroll
-              for (int e = 0; e < CPT; ++e) x[e] = 0.f;   // 'SAME' padding is zero in the activated domain
-            }
-#pragma unroll
-            for (int ky = 0; ky < K; ++ky) {
-              if ((tt - ky) % S == 0) {                    // static: this input row feeds output (t - ky) / S
-                const int sl = slot_of((tt - ky) / S, NSL);
-#pragma unroll
-                for (int e = 0; e < CPT; ++e) acc[sl][e] = fmaf(w[ky * K + kx][e], x[e], acc[sl][e]);
-              }
-            }
-          }
-        }
-        if ((tt - (K - 1)) % S == 0) {                     // static: output row (t - K + 1) / S is complete
-          const int sl = slot_of((tt - (K - 1)) / S, NSL);
-          const int oy = (t - (K - 1)) / S;
-          if (t <= t_last && t >= K - 1 && oy >= oy0 && oy < oy1 && xok) {
-            store_bf<CPT>(obase + (size_t)oy * a.ow * a.ldo, acc[sl]);
-            if (want_stats) {
-#pragma unroll
-              for (int e = 0; e < CPT; ++e) {
-                const float v = bf2f(f2bf(acc[sl][e]));
-                st[0][e] += v;
-                st[1][e] = fmaf(v, v, st[1][e]);
-              }
-            }
-          }
-#pragma unroll
-          for (int e = 0; e < CPT; ++e) acc[sl][e] = 0.f;
-        }
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx) { cur[kx] = n1[kx]; n1[kx] = n2[kx]; }
-      }
-    }
-  }
-  if (want_stats) block_channel_sums<CPT, 2>(a, l, C, st, a.stat_partials, red);
-}
-
-// ---------------------------------------------------------------------------- weight gradient
-// dW[ky][kx][c] = sum over (n, oy, ox) of act(in)[oy*S+ky-pt][ox*S+kx-pl][c] * dy[oy][ox][c].
-// Marches over the input rows; the dy rows an input row pairs with are kept in a rotating register window.
-template <int K, int S, int CPT, bool GBN>
-__global__ __launch_bounds__(THREADS) void k_wgrad(const Args a) {
-  constexpr int NSL = (K + S - 1) / S;
-  constexpr int U = S * NSL;
-  extern __shared__ float red[];
-  const int C = a.in.c, H = a.in.h, W = a.in.w;
-  const Lane l = lane_setup<CPT>(a, C);
-  const bf16_t* IN = reinterpret_cast<const bf16_t*>(a.in.data);
-  const bf16_t* DZ = reinterpret_cast<const bf16_t*>(a.gy.dz);
-  const bf16_t* YY = reinterpret_cast<const bf16_t*>(a.gy.y);
-  float wacc[K * K][CPT], sc[CPT], sh[CPT], ga[CPT], gb[CPT], gc[CPT];
-#pragma unroll
-  for (int e = 0; e < CPT; ++e) { sc[e] = 1.f; sh[e] = 0.f; ga[e] = 1.f; gb[e] = 0.f; gc[e] = 0.f; }
-#pragma unroll
-  for (int t = 0; t < K * K; ++t)
-#pragma unroll
-    for (int e = 0; e < CPT; ++e) wacc[t][e] = 0.f;
-  if (l.active) {
-    if (a.in.scale) { loadf<CPT>(a.in.scale + l.c, sc); loadf<CPT>(a.in.shift + l.c, sh); }
-    if (GBN) { loadf<CPT>(a.gy.a + l.c, ga); loadf<CPT>(a.gy.b + l.c, gb); loadf<CPT>(a.gy.cc + l.c, gc); }
-  }
-
-  for (int tile = l.p; tile < a.ntiles; tile += a.P) {
-    const int per_img = a.tiles_y * a.tiles_x;
-    const int n = tile / per_img, rr = tile - n * per_img;
-    const int ty = rr / a.tiles_x, tx = rr - ty * a.tiles_x;
-    const int oy0 = ty * a.TY, oy1 = min(a.oh, oy0 + a.TY);
-    const int ox = tx * a.TX + l.px;
-    const bool xok = l.active && ox < a.ow;
-    const int ix0 = ox * S - a.pad_l;
-    unsigned xmask = 0;
-#pragma unroll
-    for (int kx = 0; kx < K; ++kx)
-      if (xok && ix0 + kx >= 0 && ix0 + kx < W) xmask |= 1u << kx;
-    const bf16_t* ibase = IN + (((int64_t)n * H * W + ix0) * a.in.ld + l.c);   // ix0 may be -pad
-    const size_t gbase = ((size_t)n * a.oh * a.ow + ox) * a.gy.ld + l.c;
-    float dyw[NSL][CPT];                       // dy rows in flight, slot = oy mod NSL
-#pragma unroll
-    for (int s = 0; s < NSL; ++s)
-#pragma unroll
-      for (int e = 0; e < CPT; ++e) dyw[s][e] = 0.f;
-
-    const int t0 = (oy0 * S / U) * U, t_last = (oy1 - 1) * S + K - 1;
-    Raw<CPT> cur[K], n1[K], n2[K], gz, gyr;
-    auto load_row = [&](int t, Raw<CPT> (&dst)[K]) {
-      const int r = t - a.pad_t;
-      if (t <= t_last && r >= 0 && r < H) {
-        const bf16_t* rp = ibase + (int64_t)r * W * a.in.ld;
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx)
-          dst[kx] = (xmask >> kx) & 1u ? raw_load<CPT>(rp + (int64_t)kx * a.in.ld) : raw_zero<CPT>();
-      }
-    };
-    auto load_dy = [&](int oy) {                       // raw dy row oy (zero outside the tile / image)
-      gz = raw_zero<CPT>();
-      gyr = raw_zero<CPT>();
-      if (oy >= oy0 && oy < oy1 && xok) {
-        const size_t off = gbase + (size_t)oy * a.ow * a.gy.ld;
-        gz = raw_load<CPT>(DZ + off);
-        if (GBN) gyr = raw_load<CPT>(YY + off);
-      }
-    };
-    load_row(t0, cur);
-    load_row(t0 + 1, n1);
-    load_dy(t0 / S);
-    for (int tb = t0; tb <= t_last; tb += U) {
-#pragma unroll
-      for (int tt = 0; tt < U; ++tt) {
-        const int t = tb + tt;
-        load_row(t + 2, n2);
-        if (tt % S == 0) {                     // static: dy row oy = t / S enters the window at ky = 0
-          const int sl = slot_of(tt / S, NSL);
-          const int oy = t / S;
-          float g[CPT];
-          raw_unpack<CPT>(gz, g);
-          if (GBN) {
-            float y[CPT];
-            raw_unpack<CPT>(gyr, y);
-            const bool in_tile = oy >= oy0 && oy < oy1 && xok;
-#pragma unroll
-            for (int e = 0; e < CPT; ++e) g[e] = in_tile ? fmaf(ga[e], g[e], fmaf(gb[e], y[e], gc[e])) : 0.f;
-          }
-#pragma unroll
-          for (int e = 0; e < CPT; ++e) dyw[sl][e] = g[e];
-          load_dy(oy + 1);                     // next dy row flies while this input row is processed
-        }
-        const int r = t - a.pad_t;
-        if (t <= t_last && r >= 0 && r < H) {
-#pragma unroll
-          for (int kx = 0; kx < K; ++kx) {
-            float x[CPT];
-            raw_unpack<CPT>(cur[kx], x);
-            view_act<CPT>(a.in, sc, sh, x);
-            if (!((xmask >> kx) & 1u)) {
-#pragma unroll
-              for (int e = 0; e < CPT; ++e) x[e] = 0.f;
-            }
-#pragma unroll
-            for (int ky = 0; ky < K; ++ky) {
-              if ((tt - ky) % S == 0) {
-                const int sl = slot_of((tt - ky) / S, NSL);
-#pragma unroll
-                for (int e = 0; e < CPT; ++e) wacc[ky * K + kx][e] = fmaf(x[e], dyw[sl][e], wacc[ky * K + kx][e]);
-              }
-            }
-          }
-        }
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx) { cur[kx] = n1[kx]; n1[kx] = n2[kx]; }
-      }
-    }
-  }
-  block_channel_sums<CPT, K * K>(a, l, C, wacc, a.ws, red);
-}
-
-// ------------------------------------------------------------------------------ data gradient
-// d in[iy][ix] = sum over (ky, kx) with (iy+pt-ky) % S == 0, (ix+pl-kx) % S == 0 of
-//                w[ky][kx] * dy[(iy+pt-ky)/S][(ix+pl-kx)/S].
-// With ty = iy + pt and tx = ix + pl, thread q owns the S columns tx = S*q + u (u < S) and marches over the
-// dy rows: row oy feeds ty = oy*S + ky, so K (+S-1) input rows are in flight; after dy row oy the rows
-// ty = oy*S .. oy*S + S-1 are complete and go through the epilogue (act', accumulate, BN backward sums).
-template <int K, int S, int CPT, bool GBN>
-__global__ __launch_bounds__(THREADS, 3) void k_dgrad(const Args a) {
-  constexpr int D = (K + S - 1) / S;          // dy columns / rows a thread needs per step
-  constexpr int RS = S * D;                   // ring of in-flight ty rows (>= K), divisible by S
-  extern __shared__ float red[];
-  const int C = a.in.c, H = a.in.h, W = a.in.w;
-  const Lane l = lane_setup<CPT>(a, C);
-  const bf16_t* X = reinterpret_cast<const bf16_t*>(a.in.data);
-  const bf16_t* DZ = reinterpret_cast<const bf16_t*>(a.gy.dz);
-  const bf16_t* YY = reinterpret_cast<const bf16_t*>(a.gy.y);
-  bf16_t* GO = reinterpret_cast<bf16_t*>(a.epi.gout);
-  float w[K * K][CPT], sc[CPT], sh[CPT], ga[CPT], gb[CPT], gc[CPT], mu[CPT], rs[CPT];
-  float st[2][CPT];
-#pragma unroll
-  for (int e = 0; e < CPT; ++e) {
-    sc[e] = 1.f; sh[e] = 0.f; ga[e] = 1.f; gb[e] = 0.f; gc[e] = 0.f; mu[e] = 0.f; rs[e] = 1.f;
-    st[0][e] = st[1][e] = 0.f;
-  }
-#pragma unroll
-  for (int t = 0; t < K * K; ++t)
-#pragma unroll
-    for (int e = 0; e < CPT; ++e) w[t][e] = l.active ? a.w[(size_t)t * C + l.c + e] : 0.f;
-  const bool want_stats = a.epi.stat_partials != nullptr;
-  const bool swish = a.in.act == EDET_ACT_SWISH;
-  if (l.active) {
-    if (a.in.scale) { loadf<CPT>(a.in.scale + l.c, sc); loadf<CPT>(a.in.shift + l.c, sh); }
-    if (GBN) { loadf<CPT>(a.gy.a + l.c, ga); loadf<CPT>(a.gy.b + l.c, gb); loadf<CPT>(a.gy.cc + l.c, gc); }
-    if (want_stats) { loadf<CPT>(a.epi.mean + l.c, mu); loadf<CPT>(a.epi.rstd + l.c, rs); }
-  }
-
-  // tiles are over (q, oy): q in [0, QW), QW = ceil((W + pad_l) / S); oy-space rows [qy0, qy1) with
-  // QH = ceil((H + pad_t) / S): step oy completes ty = oy*S + u
-  const int QW = (W + a.pad_l + S - 1) / S, QH = (H + a.pad_t + S - 1) / S;
-  for (int tile = l.p; tile < a.ntiles; tile += a.P) {
-    const int per_img = a.tiles_y * a.tiles_x;
-    const int n = tile / per_img, rr = tile - n * per_img;
-    const int ty_ = rr / a.tiles_x, tx_ = rr - ty_ * a.tiles_x;
-    const int q = tx_ * a.TX + l.px;
-    const bool qok = l.active && q < QW;
-    const int qy0 = ty_ * a.TY, qy1 = min(QH, qy0 + a.TY);
-    // dy column q - d (d < D) valid?
-    unsigned dmask = 0;
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-      if (qok && q - d >= 0 && q - d < a.ow) dmask |= 1u << d;
-    float acc[RS][S][CPT];
-#pragma unroll
-    for (int s = 0; s < RS; ++s)
-#pragma unroll
-      for (int u = 0; u < S; ++u)
-#pragma unroll
-        for (int e = 0; e < CPT; ++e) acc[s][u][e] = 0.f;
-    const size_t gimg = (size_t)n * a.oh * a.ow;
-    // dy rows needed for ty rows [qy0*S, qy1*S): oy from qy0 - (D-1) to qy1 - 1; start aligned to D steps
-    const int o_begin = ((qy0 - (D - 1)) >= 0 ? (qy0 - (D - 1)) / D : -((D - 1 - (qy0 - (D - 1))) / D)) * D;
-    Raw<CPT> cz[D], cy[GBN ? D : 1], nz[D], ny[GBN ? D : 1];
-    auto load_dyrow = [&](int oy, Raw<CPT> (&z)[D], Raw<CPT> (&y)[GBN ? D : 1]) {
-      if (oy < qy1 && oy >= 0 && oy < a.oh) {             // uniform
-        const size_t rowoff = (gimg + (size_t)oy * a.ow) * a.gy.ld + l.c;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          z[d] = raw_zero<CPT>();
-          if (GBN) y[d] = raw_zero<CPT>();
-          if ((dmask >> d) & 1u) {
-            const size_t off = rowoff + (size_t)(q - d) * a.gy.ld;
-            z[d] = raw_load<CPT>(DZ + off);
-            if (GBN) y[d] = raw_load<CPT>(YY + off);
-          }
-        }
-      }
-    };
-    load_dyrow(o_begin, cz, cy);
-    for (int ob = o_begin; ob < qy1; ob += D) {
-#pragma unroll
-      for (int oo = 0; oo < D; ++oo) {
-        const int oy = ob + oo;
-        load_dyrow(oy + 1, nz, ny);                        // next dy row in flight during this step
-        // saved conv input of the S x S pixels this step completes (needed for act' / BN backward sums)
-        Raw<CPT> xr[S][S];
-#pragma unroll
-        for (int v = 0; v < S; ++v) {
-          const int iy = oy * S + v - a.pad_t;
-#pragma unroll
-          for (int u = 0; u < S; ++u) {
-            const int ix = q * S + u - a.pad_l;
-            xr[v][u] = raw_zero<CPT>();
-            if ((swish || want_stats) && oy >= qy0 && oy < qy1 && iy >= 0 && iy < H && qok && ix >= 0 && ix < W)
-              xr[v][u] = raw_load<CPT>(X + ((size_t)(n * H + iy) * W + ix) * a.in.ld + l.c);
-          }
-        }
-        if (oy < qy1 && oy >= 0 && oy < a.oh) {            // uniform
-#pragma unroll
-          for (int d = 0; d < D; ++d) {
-            float g[CPT];
-            raw_unpack<CPT>(cz[d], g);
-            if (GBN) {
-              float y[CPT];
-              raw_unpack<CPT>(cy[d], y);
-              const bool ok = (dmask >> d) & 1u;
-#pragma unroll
-              for (int e = 0; e < CPT; ++e) g[e] = ok ? fmaf(ga[e], g[e], fmaf(gb[e], y[e], gc[e])) : 0.f;
-            }
-            // dy[oy][q-d] feeds tx = S*q + u with kx = u + S*d, and ty = oy*S + ky
-#pragma unroll
-            for (int u = 0; u < S; ++u) {
-              if (u + S * d < K) {
-#pragma unroll
-                for (int ky = 0; ky < K; ++ky) {
-                  const int sl = slot_of(oo * S + ky, RS);     // (oy*S + ky) mod RS, ob*S = 0 mod RS
-#pragma unroll
-                  for (int e = 0; e < CPT; ++e)
-                    acc[sl][u][e] = fmaf(w[ky * K + u + S * d][e], g[e], acc[sl][u][e]);
-                }
-              }
-            }
-          }
-        }
-        // rows ty = oy*S + v (v < S) are complete
-#pragma unroll
-        for (int v = 0; v < S; ++v) {
-          const int sl = slot_of(oo * S + v, RS);
-          const int iy = oy * S + v - a.pad_t;
-          if (oy >= qy0 && oy < qy1 && iy >= 0 && iy < H) {   // uniform
-#pragma unroll
-            for (int u = 0; u < S; ++u) {
-              const int ix = q * S + u - a.pad_l;
-              if (qok && ix >= 0 && ix < W) {
-                const size_t off = ((size_t)(n * H + iy) * W + ix) * a.in.ld + l.c;
-                float g[CPT], x[CPT];
-#pragma unroll
-                for (int e = 0; e < CPT; ++e) g[e] = acc[sl][u][e];
-                raw_unpack<CPT>(xr[v][u], x);
-                if (swish) {
-#pragma unroll
-                  for (int e = 0; e < CPT; ++e) g[e] *= swish_gradf_(fmaf(x[e], sc[e], sh[e]));
-                }
-                if (a.epi.beta) {
-                  float old[CPT];
-                  raw_unpack<CPT>(raw_load<CPT>(GO + off), old);
-#pragma unroll
-                  for (int e = 0; e < CPT; ++e) g[e] += old[e];
-                }
-                store_bf<CPT>(GO + off, g);
-                if (want_stats) {
-#pragma unroll
-                  for (int e = 0; e < CPT; ++e) {
-                    st[0][e] += g[e];
-                    st[1][e] = fmaf(g[e], (x[e] - mu[e]) * rs[e], st[1][e]);
-                  }
-                }
-              }
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < S; ++u)
-#pragma unroll
-            for (int e = 0; e < CPT; ++e) acc[sl][u][e] = 0.f;
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          cz[d] = nz[d];
-          if (GBN) cy[d] = ny[d];
-        }
-      }
-    }
-  }
-  if (want_stats) block_channel_sums<CPT, 2>(a, l, C, st, a.epi.stat_partials, red);
 }
 
 // =====================================================================================================
@@ -1383,12 +986,6 @@ inline void plan(Args& a, int C, int n, int space_w, int space_h, int max_p) {
   a.P = P;
 }
 
-// EDET_DW_LX=0 selects the register-only variants (A/B measurements)
-inline bool dw_lx_enabled() {
-  const char* e = getenv("EDET_DW_LX");
-  return !(e && e[0] == '0');
-}
-
 }  // namespace dwm
 
 // return 1 = handled, 0 = not applicable (caller falls back), < 0 = error
@@ -1402,22 +999,14 @@ int dwm_try_fwd(const edet_tview_t* in, const float* weight, int k, int s, void*
   a.in = *in; a.w = weight; a.out = reinterpret_cast<bf16_t*>(out); a.ldo = ldo; a.stat_partials = stat_partials;
   a.oh = same_out(in->h, s); a.ow = same_out(in->w, s);
   a.pad_t = same_pad_before(in->h, k, s); a.pad_l = same_pad_before(in->w, k, s);
-  static const bool lx = dw_lx_enabled();
 #define DWM_FWD(K_, S_, CPT_)                                                             \
   do {                                                                                    \
     plan<CPT_>(a, in->c, in->n, a.ow, a.oh, EDET_MAX_PARTS);                              \
     const size_t lds0 = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                  \
-    if (lx) {                                                                             \
-      const size_t ring = (size_t)2 * (a.TX * S_ + K_ - S_) * a.nch * CPT_ * sizeof(float); \
-      k_fwd_lx<K_, S_, CPT_><<<dim3(a.P * a.ngroups), dim3(THREADS), lds0 + ring, st>>>(a); \
-    } else {                                                                              \
-      k_fwd<K_, S_, CPT_><<<dim3(a.P * a.ngroups), dim3(THREADS), lds0, st>>>(a);         \
-    }                                                                                     \
+    const size_t ring = (size_t)2 * (a.TX * S_ + K_ - S_) * a.nch * CPT_ * sizeof(float); \
+    k_fwd_lx<K_, S_, CPT_><<<dim3(a.P * a.ngroups), dim3(THREADS), lds0 + ring, st>>>(a); \
   } while (0)
-  static const bool cpt8 = getenv("EDET_DW_CPT8") && getenv("EDET_DW_CPT8")[0] == '1';
-  if (k == 3 && s == 1 && cpt8 && lx) DWM_FWD(3, 1, 8);
-  else if (k == 3 && s == 2 && cpt8 && lx) DWM_FWD(3, 2, 8);
-  else if (k == 3 && s == 1) DWM_FWD(3, 1, 4);
+  if (k == 3 && s == 1) DWM_FWD(3, 1, 4);
   else if (k == 3 && s == 2) DWM_FWD(3, 2, 4);
   else if (k == 5 && s == 1) DWM_FWD(5, 1, 2);
   else if (k == 5 && s == 2) DWM_FWD(5, 2, 2);
@@ -1443,20 +1032,14 @@ int dwm_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, 
   if (max_p < 1) return 0;
   if (max_p > 1024) max_p = 1024;
   const bool gbn = dy->a != nullptr;
-  static const bool lx = dw_lx_enabled();
 #define DWM_WG(K_, S_, CPT_)                                                              \
   do {                                                                                    \
     plan<CPT_>(a, in->c, in->n, a.ow, a.oh, max_p);                                       \
     const size_t lds = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                   \
     const size_t ring = (size_t)2 * (a.TX * S_ + K_ - S_) * a.nch * CPT_ * sizeof(float); \
     const dim3 grid(a.P * a.ngroups), block(THREADS);                                     \
-    if (lx) {                                                                             \
-      if (gbn) k_wgrad_lx<K_, S_, CPT_, true><<<grid, block, lds + ring, st>>>(a);        \
-      else k_wgrad_lx<K_, S_, CPT_, false><<<grid, block, lds + ring, st>>>(a);           \
-    } else {                                                                              \
-      if (gbn) k_wgrad<K_, S_, CPT_, true><<<grid, block, lds, st>>>(a);                  \
-      else k_wgrad<K_, S_, CPT_, false><<<grid, block, lds, st>>>(a);                     \
-    }                                                                                     \
+    if (gbn) k_wgrad_lx<K_, S_, CPT_, true><<<grid, block, lds + ring, st>>>(a);          \
+    else k_wgrad_lx<K_, S_, CPT_, false><<<grid, block, lds + ring, st>>>(a);             \
   } while (0)
   if (k == 3 && s == 1) DWM_WG(3, 1, 4);
   else if (k == 3 && s == 2) DWM_WG(3, 2, 4);
@@ -1481,20 +1064,14 @@ int dwm_try_dgrad(const edet_gview_t* dy, const float* weight, int k, int s, con
   a.pad_t = same_pad_before(in->h, k, s); a.pad_l = same_pad_before(in->w, k, s);
   const int QW = (in->w + a.pad_l + s - 1) / s, QH = (in->h + a.pad_t + s - 1) / s;
   const bool gbn = dy->a != nullptr;
-  static const bool lx = dw_lx_enabled();
 #define DWM_DG(K_, S_, CPT_)                                                              \
   do {                                                                                    \
     plan<CPT_>(a, in->c, in->n, QW, QH, EDET_MAX_PARTS);                                  \
     const size_t lds = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                   \
     const size_t ring = (size_t)2 * (a.TX + (K_ + S_ - 1) / S_ - 1) * a.nch * CPT_ * sizeof(float); \
     const dim3 grid(a.P * a.ngroups), block(THREADS);                                     \
-    if (lx) {                                                                             \
-      if (gbn) k_dgrad_lx<K_, S_, CPT_, true><<<grid, block, lds + ring, st>>>(a);        \
-      else k_dgrad_lx<K_, S_, CPT_, false><<<grid, block, lds + ring, st>>>(a);           \
-    } else {                                                                              \
-      if (gbn) k_dgrad<K_, S_, CPT_, true><<<grid, block, lds, st>>>(a);                  \
-      else k_dgrad<K_, S_, CPT_, false><<<grid, block, lds, st>>>(a);                     \
-    }                                                                                     \
+    if (gbn) k_dgrad_lx<K_, S_, CPT_, true><<<grid, block, lds + ring, st>>>(a);          \
+    else k_dgrad_lx<K_, S_, CPT_, false><<<grid, block, lds + ring, st>>>(a);             \
   } while (0)
   if (k == 3 && s == 1) DWM_DG(3, 1, 4);
   else if (k == 3 && s == 2) DWM_DG(3, 2, 4);
@@ -1513,12 +1090,10 @@ int dwm_try_bwd_fused(const edet_gview_t* dy, const float* weight, int k, int s,
                       size_t workspace_bytes, hipStream_t st) {
   if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace dwm;
-  static const bool enabled = !(getenv("EDET_DW_FUSED") && getenv("EDET_DW_FUSED")[0] == '0');
   // k = 3: 4 channels per thread (8-byte loads, 2 waves/SIMD) wins on the large maps, 2 channels per thread
   // (3-4 waves/SIMD) on the small ones (measured: 320x320x32 1.08 vs 1.55 ms, 40x40x64 1.25 vs 1.05 ms)
-  const char* c4env = getenv("EDET_DW_FUSED_C4");
-  const bool k3c4 = c4env ? c4env[0] == '1' : (int64_t)in->h * in->w >= 128 * 128;
-  if (!enabled || s != 1 || (k != 3 && k != 5) || in->gate || epi->dgate || in->c % 8 != 0 || !workspace) return 0;
+  const bool k3c4 = (int64_t)in->h * in->w >= 128 * 128;
+  if (s != 1 || (k != 3 && k != 5) || in->gate || epi->dgate || in->c % 8 != 0 || !workspace) return 0;
   Args a;
   memset(&a, 0, sizeof(a));
   a.in = *in; a.gy = *dy; a.w = weight; a.epi = *epi; a.ws = reinterpret_cast<float*>(workspace);

@@ -648,9 +648,8 @@ int pwb_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight
 
 // Which bf16 implementation serves a (rows, cin, cout) pointwise layer.  The streaming kernels own the
 // HBM-bound layers (few channels, many rows); the tiled kernels own the layers whose weight matrix is large
-// (cin*cout >= EDET_PW_BIG_MINKN, default 24576: from 80x480 / 112x672 upwards).  EDET_PW_IMPL = stream | big |
-// tiled forces one implementation where its envelope allows (parity tests, A/B timing); both variables are
-// read per call.
+// (thresholds below).  EDET_PW_IMPL = stream | big | tiled forces one implementation where its envelope allows
+// (every value is exercised by the parity tests); it is read per call.
 enum { PW_AUTO = 0, PW_STREAM = 1, PW_BIG = 2, PW_TILED = 3 };
 static int pw_impl_env() {
   const char* e = getenv("EDET_PW_IMPL");
@@ -663,13 +662,11 @@ static int pw_impl_env() {
 // Which implementation goes first: the workgroup-tiled kernels (pw_big.hip) once cin*cout reaches a threshold,
 // else the wave-private streaming kernels.  Thresholds from A/B runs of the D0 640x640 step (r01g, per-op
 // totals in ms at threshold 2048 / 4096 / 8192 / 24576: forward 8.54 / 7.98 / 7.87 / 8.05, data gradient
-// 12.15 / 12.85 / 12.88 / 13.4, weight gradient 14.21 / 14.26 / 14.51 / 14.4); EDET_PW_BIG_MINKN overrides all.
+// 12.15 / 12.85 / 12.88 / 13.4, weight gradient 14.21 / 14.26 / 14.51 / 14.4).
 enum { PW_OP_FWD = 0, PW_OP_DGRAD = 1, PW_OP_WGRAD = 2 };
 static bool pw_prefers_big(int op, int64_t rows, int cin, int cout) {
-  static const int64_t defaults[3] = {8192, 2048, 4096};
-  const char* e = getenv("EDET_PW_BIG_MINKN");
-  const int64_t minkn = e && *e ? atoll(e) : defaults[op];
-  return (int64_t)cin * cout >= minkn && rows >= 1024;
+  static const int64_t minkn[3] = {8192, 2048, 4096};
+  return (int64_t)cin * cout >= minkn[op] && rows >= 1024;
 }
 
 // streaming bf16 kernels (pw_stream.hip); return 1 = handled, 0 = shape outside their envelope

@@ -138,11 +138,11 @@ class V2Engine(engine_lib.Engine):
   """Launch plan of one EffNetV2Model on one MI355X (buffers, BatchNorm plumbing and the layer
   primitives come from engine.Engine)."""
 
-  def __init__(self, spec, batch_size, image_size, dtype='bf16', device='cuda:0', seed=0, params=None):
-    if params is None:
+  def __init__(self, spec, batch_size, image_size, dtype='bf16', device='cuda:0', seed=0, params=None, arena=None):
+    if params is None and arena is None:
       params = init_params(spec, seed)
     super().__init__(spec.mconfig, batch_size, image_size, dtype=dtype, device=device, seed=seed,
-                     params=params, spec=spec)
+                     params=params, spec=spec, arena=arena)
 
   def forward(self, images, training=False, update_moving=True):
     """images: device tensor [B,H,W,3] in the engine dtype.  Fills self.endpoints / self.outputs."""
@@ -301,9 +301,9 @@ class EffNetV2Model(object):
   def _ensure_engine(self, batch, height, width):
     e = self.engine
     if e is None or e.batch != batch or e.image_size != (height, width):
-      params = self._init_params if e is None else e.get_params()
+      # a new shape gets new buffers; the variables stay in the arena the previous executor used
       self.engine = V2Engine(self.spec, batch, (height, width), dtype=self._dtype, device=self._device,
-                             seed=self._seed, params=params)
+                             seed=self._seed, params=self._init_params, arena=None if e is None else e.arena)
     return self.engine
 
   def backward(self, d_outputs):

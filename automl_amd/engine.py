@@ -85,11 +85,112 @@ class View(object):
                  r.n, r.h, r.w, r.c, r.ld)
 
 
+class ParamArena(object):
+  """The model's variables on the device, independent of batch and image size: one flat fp32 master arena of the
+  trainable variables (+ gradient, momentum and EMA arenas of the same layout), one of the BatchNorm moving
+  statistics, the segment table for per-tensor clipping, and the optimizer's iteration count.  Every Engine of a
+  model (one per batch / image shape) works on the SAME arena, so a shape change keeps the optimizer slots, as the
+  reference's Keras variables do (train_lib.py:176-199)."""
+
+  def __init__(self, spec, device, values):
+    train = [p for p in spec.params if p.trainable]
+    state = [p for p in spec.params if not p.trainable]
+    self.offsets = {}
+    off = 0
+    seg = [0]
+    flags = []
+    for p in train:
+      n = int(np.prod(p.shape)) if p.shape else 1
+      self.offsets[p.name] = (off, n, p.shape, True)
+      off += n
+      off_al = (off + 3) // 4 * 4  # keep every tensor 16-byte aligned
+      seg.append(off)
+      flags.append(1 if netspec_lib.is_l2_regularised(p.name) else 0)
+      if off_al != off:
+        seg.append(off_al)  # padding segment (zeros, never regularised)
+        flags.append(0)
+        off = off_al
+    self.n_train_elems = off
+    self.seg_names = [p.name for p in train]
+    soff = 0
+    for p in state:
+      n = int(np.prod(p.shape))
+      self.offsets[p.name] = (soff, n, p.shape, False)
+      soff = (soff + n + 3) // 4 * 4
+    dev = self.device = torch.device(device)
+    self.params_flat = torch.zeros(off, dtype=torch.float32, device=dev)
+    self.grads_flat = torch.zeros(off, dtype=torch.float32, device=dev)
+    self.velocity = torch.zeros(off, dtype=torch.float32, device=dev)
+    self.ema = torch.zeros(off, dtype=torch.float32, device=dev)
+    self.state_flat = torch.zeros(max(soff, 4), dtype=torch.float32, device=dev)
+    self.seg_offsets = torch.tensor(seg, dtype=torch.int64, device=dev)
+    self.seg_flags = torch.tensor(flags, dtype=torch.int32, device=dev)
+    self.nseg = len(flags)
+    self.seg_sqnorm = torch.zeros(self.nseg * _lib.OPT_SPLIT, dtype=torch.float32, device=dev)
+    self.seg_factor = torch.ones(self.nseg, dtype=torch.float32, device=dev)
+    self.version = 0          # bumped whenever a variable changes: engines re-make their compute copies
+    self.step_count = 0       # optimizer iterations applied to this arena
+    self.set_params(values)
+
+  def _slice(self, flat_train, flat_state, name):
+    off, n, _, tr = self.offsets[name]
+    return (flat_train if tr else flat_state)[off:off + n]
+
+  def param(self, name):
+    return self._slice(self.params_flat, self.state_flat, name)
+
+  def grad(self, name):
+    off, n, _, tr = self.offsets[name]
+    assert tr, name
+    return self.grads_flat[off:off + n]
+
+  def set_params(self, values):
+    """values: name -> array-like in reference layouts.  Until the first optimizer step the EMA shadow follows the
+    variables (TFA MovingAverage seeds the average with the variable's value at its first apply)."""
+    for name, v in values.items():
+      if name not in self.offsets:
+        raise KeyError('unknown variable %s' % name)
+      off, n, shape, tr = self.offsets[name]
+      t = torch.as_tensor(np.asarray(v, dtype=np.float32)).reshape(-1)
+      if t.numel() != n:
+        raise ValueError('variable %s: expected %d elements, got %d' % (name, n, t.numel()))
+      self.param(name).copy_(t)
+      if self.step_count == 0 and tr:
+        self._slice(self.ema, None, name).copy_(t)
+    self.version += 1
+
+  def _export(self, flat_train, flat_state, names):
+    out = {}
+    for name in (names or self.offsets.keys()):
+      shape = self.offsets[name][2]
+      out[name] = self._slice(flat_train, flat_state, name).detach().cpu().numpy().reshape(shape)
+    return out
+
+  def get_params(self, names=None):
+    return self._export(self.params_flat, self.state_flat, names)
+
+  def get_ema_params(self, names=None):
+    """The variables as an EMA evaluation would load them: the TFA MovingAverage shadow of every trainable variable
+    (train_lib.py:193-197 wraps the optimizer, which averages the variables it updates) and the BatchNorm moving
+    statistics as they are (they have no shadow in the Keras train step)."""
+    return self._export(self.ema, self.state_flat, names)
+
+  def get_optimizer_state(self):
+    """Host copy of the optimizer slots: momentum, EMA shadows, iteration count."""
+    return {'velocity': self.velocity.cpu().numpy().copy(), 'ema': self.ema.cpu().numpy().copy(),
+            'iterations': self.step_count}
+
+  def set_optimizer_state(self, state):
+    self.velocity.copy_(torch.as_tensor(state['velocity']))
+    self.ema.copy_(torch.as_tensor(state['ema']))
+    self.step_count = int(state['iterations'])
+
+
 class Engine(object):
   """Builds buffers for (config, batch, image size, dtype) and runs forward / backward / update."""
 
   def __init__(self, config, batch_size, image_size=None, dtype='bf16', device='cuda:0', seed=0,
-               params=None, spec=None, stochastic_depth=True):
+               params=None, spec=None, stochastic_depth=True, arena=None):
     if not torch.cuda.is_available():
       raise _lib.EdetError('no HIP device visible: the EfficientDet engine has no CPU path')
     _lib.load()
@@ -108,9 +209,9 @@ class Engine(object):
     self._zero_list = []
     self.tape = []
     self.training = False
-    self.step_count = 0
     self._nparts = ctypes.c_int(0)
-    self._build_params(params, seed)
+    self._cast_version = -1
+    self._build_params(params, seed, arena)
     cmax = max([p.shape[0] for p in self.spec.params if len(p.shape) == 1] + [64])
     self.partials = torch.empty(_lib.MAX_PARTS * 2 * cmax, dtype=torch.float32, device=self.device)
     self.workspace = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=self.device)  # 64 MiB scratch
@@ -119,15 +220,16 @@ class Engine(object):
     self.loss_sums = self.zbuf('loss_sums', (4,))
     self.hyper = torch.zeros(4, dtype=torch.float32, device=self.device)   # lr, ema decay, 1/normalizer, -
     self.gnorm = torch.zeros(1, dtype=torch.float32, device=self.device)
-    self.pool_argmax = os.environ.get('EDET_POOL_ARGMAX', '1') != '0'
+    self.pool_argmax = True      # max-pool backward through the recorded winning tap (edet_fuse_bwd_pre)
     self.stochastic_depth = stochastic_depth
     self._cast_items = {}      # weight name -> descriptors of its compute copies (filled by the first pass)
     self._cast_table = None
-    self.batched_casts = os.environ.get('EDET_BATCHED_CASTS', '1') != '0'
-    self.fused_dw_bwd = os.environ.get('EDET_DW_BWD_ENTRY', '1') != '0'   # one edet_dw_bwd call per stride-1 layer
+    self.batched_casts = True    # every compute copy of a step in one edet_cast_batch launch
+    self.fused_dw_bwd = True     # one edet_dw_bwd call per stride-1 layer
     # cross-replica BatchNorm (utils.SyncBatchNormalization / TpuBatchNormalization, utils.py:166-241):
     # (all_reduce_fn, world_size) or None.  Set by train_lib when sync_bn=True.
     self.sync_bn = None
+    self.bn_bessel = True        # Keras fused BatchNorm: Bessel-corrected batch variance into moving_variance
     self.drop_masks = {}      # block scope -> (mask [n,c] fp32 = floor(p + u_n) / p, survival probability p)
     self._rng = torch.Generator(device=self.device)
     self._rng.manual_seed(1000003 * seed + 17)
@@ -158,75 +260,35 @@ class Engine(object):
       self._zero_list.append(t)
     return t
 
-  def _build_params(self, params, seed):
-    spec = self.spec
-    values = params if params is not None else netspec_lib.init_params(spec, seed)
-    train = [p for p in spec.params if p.trainable]
-    state = [p for p in spec.params if not p.trainable]
-    self.offsets = {}
-    off = 0
-    seg = [0]
-    flags = []
-    for p in train:
-      n = int(np.prod(p.shape)) if p.shape else 1
-      self.offsets[p.name] = (off, n, p.shape, True)
-      off += n
-      off_al = (off + 3) // 4 * 4  # keep every tensor 16-byte aligned
-      seg.append(off)
-      flags.append(1 if netspec_lib.is_l2_regularised(p.name) else 0)
-      if off_al != off:
-        seg.append(off_al)  # padding segment (zeros, never regularised)
-        flags.append(0)
-        off = off_al
-    self.n_train_elems = off
-    self.seg_names = [p.name for p in train]
-    soff = 0
-    for p in state:
-      n = int(np.prod(p.shape))
-      self.offsets[p.name] = (soff, n, p.shape, False)
-      soff = (soff + n + 3) // 4 * 4
-    dev = self.device
-    self.params_flat = torch.zeros(off, dtype=torch.float32, device=dev)
-    self.grads_flat = torch.zeros(off, dtype=torch.float32, device=dev)
-    self.velocity = torch.zeros(off, dtype=torch.float32, device=dev)
-    self.ema = torch.zeros(off, dtype=torch.float32, device=dev)
-    self.state_flat = torch.zeros(max(soff, 4), dtype=torch.float32, device=dev)
-    self.seg_offsets = torch.tensor(seg, dtype=torch.int64, device=dev)
-    self.seg_flags = torch.tensor(flags, dtype=torch.int32, device=dev)
-    self.nseg = len(flags)
-    self.seg_sqnorm = torch.zeros(self.nseg * _lib.OPT_SPLIT, dtype=torch.float32, device=dev)
-    self.seg_factor = torch.ones(self.nseg, dtype=torch.float32, device=dev)
-    self.set_params(values)
-    self.ema.copy_(self.params_flat)
+  def _build_params(self, params, seed, arena):
+    if arena is None:
+      values = params if params is not None else netspec_lib.init_params(self.spec, seed)
+      arena = ParamArena(self.spec, self.device, values)
+    self.arena = arena
+    for k in ('offsets', 'n_train_elems', 'seg_names', 'params_flat', 'grads_flat', 'velocity', 'ema', 'state_flat',
+              'seg_offsets', 'seg_flags', 'nseg', 'seg_sqnorm', 'seg_factor'):
+      setattr(self, k, getattr(arena, k))
+
+  @property
+  def step_count(self):
+    return self.arena.step_count
+
+  @property
+  def _cast_dirty(self):
+    return self._cast_version != self.arena.version
 
   def param(self, name):
-    off, n, shape, tr = self.offsets[name]
-    base = self.params_flat if tr else self.state_flat
-    return base[off:off + n]
+    return self.arena.param(name)
 
   def grad(self, name):
-    off, n, shape, tr = self.offsets[name]
-    assert tr, name
-    return self.grads_flat[off:off + n]
+    return self.arena.grad(name)
 
   def set_params(self, values):
     """values: name -> array-like in reference layouts."""
-    for name, v in values.items():
-      if name not in self.offsets:
-        raise KeyError('unknown variable %s' % name)
-      off, n, shape, tr = self.offsets[name]
-      t = torch.as_tensor(np.asarray(v, dtype=np.float32)).reshape(-1)
-      if t.numel() != n:
-        raise ValueError('variable %s: expected %d elements, got %d' % (name, n, t.numel()))
-      self.param(name).copy_(t)
-    self._cast_dirty = True
+    self.arena.set_params(values)
 
   def get_params(self, names=None):
-    out = {}
-    for name in (names or self.offsets.keys()):
-      off, n, shape, tr = self.offsets[name]
-      out[name] = self.param(name).detach().cpu().numpy().reshape(shape)
-    return out
+    return self.arena.get_params(names)
 
   def get_grads(self):
     return {name: self.grad(name).detach().cpu().numpy().reshape(self.offsets[name][2])
@@ -288,11 +350,11 @@ class Engine(object):
         nparts, count = 1, count * self.sync_bn[1]
       bn.count = count
       call('edet_bn_finalize', ptr(self.partials), nparts, bn.c, float(count), ptr(bn.gamma), ptr(bn.beta),
-           self.bn_epsilon, self.bn_momentum if self.update_moving else -1.0,
+           self.bn_epsilon, self.bn_momentum if self.update_moving else -1.0, 1 if (self.bn_bessel and self.sync_bn is None) else 0,
            ptr(bn.mm), ptr(bn.mv), ptr(bn.scale), ptr(bn.shift), ptr(bn.mean), ptr(bn.rstd), self.stream)
       bn.bwd_ready = False
       bn.eval_done = False
-      self._cast_dirty = True          # moving statistics (and soon the weights) change
+      self.arena.version += 1          # moving statistics (and soon the weights) change
     elif not bn.eval_done:
       call('edet_bn_eval', bn.c, ptr(bn.gamma), ptr(bn.beta), self.bn_epsilon, ptr(bn.mm), ptr(bn.mv),
            ptr(bn.scale), ptr(bn.shift), self.stream)
@@ -641,7 +703,7 @@ class Engine(object):
         self._cast_all()
       for bn in self.bns.values():
         bn.eval_done = False
-      self._cast_dirty = False
+      self._cast_version = self.arena.version
     for bn in self.bns.values():
       bn.bwd_ready = False
     for t in self._zero_list:      # atomic accumulation targets (SE pooled sums, ...) start every pass at zero
@@ -874,8 +936,8 @@ class Engine(object):
          ptr(self.ema) if use_ema else None, ptr(self.seg_offsets),
          None if already_scaled else ptr(self.seg_factor), self.nseg, ptr(self.hyper),
          float(self.config.momentum), self.stream)
-    self._cast_dirty = True
-    self.step_count += 1
+    self.arena.version += 1
+    self.arena.step_count += 1
 
   def optimizer_step(self, lr, ema_decay=None, all_reduce=None):
     """L2 + clip (local, before the reduce) + [all-reduce SUM] + SGD momentum + EMA."""

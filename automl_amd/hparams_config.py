@@ -13,139 +13,162 @@ from collections import abc
 import yaml
 
 
-def eval_str_fn(val):
-  """'true'/'false' -> bool, python literals -> value, anything else stays str."""
-  if val in ('true', 'false'):
-    return val == 'true'
+def _scalar_from_text(text):
+  """Value of one override token: true / false, a Python literal (int, float, tuple ...), else the text itself
+  (so that '640x640' or 'ss' stay strings)."""
+  lowered = {'true': True, 'false': False}
+  if text in lowered:
+    return lowered[text]
   try:
-    return ast.literal_eval(val)
+    return ast.literal_eval(text)
   except (ValueError, SyntaxError):
-    return val
+    return text
+
+
+eval_str_fn = _scalar_from_text      # the reference's public name for the same conversion
+
+
+def parse_override_string(text):
+  """'a=1,b.c=x,d=1*2*3' -> {'a': 1, 'b': {'c': 'x'}, 'd': [1, 2, 3]}.
+
+  Grammar of the reference's command-line overrides (hparams_config.py:127-157): comma-separated ``key=value``
+  pairs, empty pairs ignored, dots in the key open nested tables, ``*`` separates list elements.  Anything that is
+  not exactly one ``key=value`` raises ValueError('Invalid config_str: ...').
+  """
+  tree = {}
+  for item in (text or '').split(','):
+    if not item:
+      continue
+    if item.count('=') != 1:
+      raise ValueError('Invalid config_str: {}'.format(text))
+    dotted, raw = item.split('=')
+    path = dotted.strip().split('.')
+    value = [_scalar_from_text(piece) for piece in raw.split('*')] if '*' in raw else _scalar_from_text(raw)
+    node = tree
+    for part in path[:-1]:
+      child = node.get(part)
+      if not isinstance(child, dict):
+        child = node[part] = {}
+      node = child
+    leaf = path[-1]
+    if isinstance(value, dict) and isinstance(node.get(leaf), dict):
+      node[leaf].update(value)
+    else:
+      node[leaf] = value
+  return tree
 
 
 class Config(object):
-  """Nested attribute dictionary with string / dict / yaml overrides."""
+  """Attribute-style table of hyper-parameters; nested tables are Configs themselves.
+
+  The fields live in one ordered mapping (``_fields``) instead of the instance ``__dict__``; values are stored by
+  copy, mappings are wrapped on the way in.  Public surface = the reference's: attribute get / set, ``update``
+  (new keys allowed), ``override`` (dict, ``k=v`` string or ``*.yaml`` path; unknown keys raise KeyError unless
+  ``allow_new_keys``), ``get``, ``keys``, ``as_dict``, yaml load / save.
+  """
+
+  __slots__ = ('_fields',)
 
   def __init__(self, config_dict=None):
+    object.__setattr__(self, '_fields', {})
     self.update(config_dict)
 
-  def __setattr__(self, k, v):
-    self.__dict__[k] = Config(v) if isinstance(v, dict) else copy.deepcopy(v)
+  # ---- element access
+  @staticmethod
+  def _wrap(value):
+    if isinstance(value, Config):
+      return Config(value.as_dict())
+    if isinstance(value, abc.Mapping):
+      return Config(dict(value))
+    return copy.deepcopy(value)
 
-  def __getattr__(self, k):
-    try:
-      return self.__dict__[k]
-    except KeyError:
-      raise AttributeError(k)
+  def __setattr__(self, key, value):
+    self._fields[key] = self._wrap(value)
 
-  def __getitem__(self, k):
-    return self.__dict__[k]
+  def __getattr__(self, key):
+    fields = object.__getattribute__(self, '_fields')
+    if key in fields:
+      return fields[key]
+    raise AttributeError(key)
 
-  def __contains__(self, k):
-    return k in self.__dict__
+  def __getitem__(self, key):
+    return self._fields[key]
 
-  def __repr__(self):
-    return repr(self.as_dict())
+  def __contains__(self, key):
+    return key in self._fields
 
-  def __deepcopy__(self, memodict):
-    return type(self)(self.as_dict())
+  def __iter__(self):
+    return iter(self._fields)
 
-  def __str__(self):
-    try:
-      return yaml.dump(self.as_dict(), indent=4)
-    except TypeError:
-      return str(self.as_dict())
-
-  def _update(self, config_dict, allow_new_keys=True):
-    if not config_dict:
-      return
-    for k, v in config_dict.items():
-      if k not in self.__dict__:
-        if not allow_new_keys:
-          raise KeyError('Key `{}` does not exist for overriding. '.format(k))
-        self.__setattr__(k, v)
-      else:
-        cur = self.__dict__[k]
-        if isinstance(cur, Config) and isinstance(v, dict):
-          cur._update(v, allow_new_keys)
-        elif isinstance(cur, Config) and isinstance(v, Config):
-          cur._update(v.as_dict(), allow_new_keys)
-        else:
-          self.__setattr__(k, v)
-
-  def get(self, k, default_value=None):
-    return self.__dict__.get(k, default_value)
-
-  def update(self, config_dict):
-    """Update members, new keys allowed."""
-    self._update(config_dict, allow_new_keys=True)
+  def get(self, key, default_value=None):
+    return self._fields.get(key, default_value)
 
   def keys(self):
-    return self.__dict__.keys()
+    return self._fields.keys()
+
+  # ---- conversion
+  def as_dict(self):
+    return {k: (v.as_dict() if isinstance(v, Config) else copy.deepcopy(v)) for k, v in self._fields.items()}
+
+  def __deepcopy__(self, memo):
+    return type(self)(self.as_dict())
+
+  def __repr__(self):
+    return 'Config(%r)' % (self.as_dict(),)
+
+  def __str__(self):
+    plain = self.as_dict()
+    try:
+      return yaml.dump(plain, indent=4)
+    except TypeError:
+      return str(plain)
+
+  # ---- merging
+  def _merge(self, mapping, strict):
+    """Recursive merge of `mapping` into this table; strict: a key that does not exist yet is an error."""
+    if isinstance(mapping, Config):
+      mapping = mapping.as_dict()
+    for key, value in (mapping or {}).items():
+      present = key in self._fields
+      if not present and strict:
+        raise KeyError('Key `{}` does not exist for overriding. '.format(key))
+      current = self._fields.get(key)
+      if present and isinstance(current, Config) and isinstance(value, (abc.Mapping, Config)):
+        current._merge(value, strict)
+      else:
+        setattr(self, key, value)
+
+  def update(self, config_dict):
+    """Merge, creating keys that do not exist yet."""
+    self._merge(config_dict, strict=False)
 
   def override(self, config_dict_or_str, allow_new_keys=False):
-    """Update members; unknown keys raise KeyError unless allow_new_keys."""
-    if isinstance(config_dict_or_str, str):
-      if not config_dict_or_str:
+    """Merge a dict, a 'k=v,k2.sub=v' string or the contents of a .yaml file."""
+    source = config_dict_or_str
+    if isinstance(source, str):
+      if source == '':
         return
-      if '=' in config_dict_or_str:
-        config_dict = self.parse_from_str(config_dict_or_str)
-      elif config_dict_or_str.endswith('.yaml'):
-        config_dict = self.parse_from_yaml(config_dict_or_str)
+      if '=' in source:
+        source = self.parse_from_str(source)
+      elif source.endswith('.yaml'):
+        source = self.parse_from_yaml(source)
       else:
-        raise ValueError(
-            'Invalid string {}, must end with .yaml or contains "=".'.format(
-                config_dict_or_str))
-    elif isinstance(config_dict_or_str, dict):
-      config_dict = config_dict_or_str
-    else:
-      raise ValueError('Unknown value type: {}'.format(config_dict_or_str))
-    self._update(config_dict, allow_new_keys)
+        raise ValueError('Invalid string {}, must end with .yaml or contains "=".'.format(source))
+    elif not isinstance(source, (dict, Config)):
+      raise ValueError('Unknown value type: {}'.format(source))
+    self._merge(source, strict=not allow_new_keys)
+
+  # ---- text forms
+  def parse_from_str(self, config_str):
+    return parse_override_string(config_str)
 
   def parse_from_yaml(self, yaml_file_path):
-    with open(yaml_file_path, 'r') as f:
-      return yaml.load(f, Loader=yaml.FullLoader)
+    with open(yaml_file_path, 'r') as stream:
+      return yaml.load(stream, Loader=yaml.FullLoader)
 
   def save_to_yaml(self, yaml_file_path):
-    with open(yaml_file_path, 'w') as f:
-      yaml.dump(self.as_dict(), f, default_flow_style=False)
-
-  def parse_from_str(self, config_str):
-    """'x.y=1,x.z=2' -> {x: {y: 1, z: 2}}; '*' splits lists; 'WxH' stays str."""
-    if not config_str:
-      return {}
-    out = {}
-
-    def nest(key, val):
-      if '.' not in key:
-        if '*' in val:
-          return {key: [eval_str_fn(v) for v in val.split('*')]}
-        return {key: eval_str_fn(val)}
-      head, rest = key.split('.', 1)
-      return {head: nest(rest, val)}
-
-    def merge(dst, src):
-      for k in src:
-        if k in dst and isinstance(dst[k], dict) and isinstance(src[k], abc.Mapping):
-          merge(dst[k], src[k])
-        else:
-          dst[k] = src[k]
-
-    try:
-      for pair in config_str.split(','):
-        if not pair:
-          continue
-        key, val = pair.split('=')
-        merge(out, nest(key.strip(), val))
-      return out
-    except ValueError:
-      raise ValueError('Invalid config_str: {}'.format(config_str))
-
-  def as_dict(self):
-    d = {}
-    for k, v in self.__dict__.items():
-      d[k] = v.as_dict() if isinstance(v, Config) else copy.deepcopy(v)
-    return d
+    with open(yaml_file_path, 'w') as stream:
+      yaml.dump(self.as_dict(), stream, default_flow_style=False)
 
 
 # defaults of the detection path (values of reference hparams_config.py:170-298, pinned by

@@ -160,7 +160,14 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
   def _lr(self, batch):
     if self._lr_fn is None:
       p = self.config.as_dict()
-      p['batch_size'] = self.global_batch_size or batch
+      gbs = self.global_batch_size
+      if gbs is None:
+        # the reference scales by the GLOBAL batch (train_lib.py:41); per replica batch x number of replicas
+        gbs = batch
+        if self.use_dist:
+          import torch.distributed as dist
+          gbs = batch * dist.get_world_size(self.process_group)
+      p['batch_size'] = gbs
       p['steps_per_epoch'] = self.steps_per_epoch
       self._lr_fn = learning_rate_schedule(p)
     return self._lr_fn(self.iterations)
@@ -198,7 +205,12 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
       if labels[k].data_ptr() != buf.data_ptr():
         buf.copy_(labels[k], non_blocking=True)
     eng.set_hyper(lr, decay)
-    eng.set_normalizer(g['labels']['mean_num_positives'])
+    if 'normalizer' in labels:                         # host value supplied by the caller
+      eng.hyper[2:3].copy_(torch.tensor([1.0 / float(labels['normalizer'])], dtype=torch.float32), non_blocking=True)
+    elif 'mean_num_positives' in g['labels']:
+      eng.set_normalizer(g['labels']['mean_num_positives'])
+    else:
+      raise KeyError("labels need 'mean_num_positives' (dataloader.py:393) or a host 'normalizer'")
     glabels = dict(g['labels'])
     glabels['normalizer'] = 'device'
     reduce_fn = make_grad_all_reduce(self.process_group) if self.use_dist else None
@@ -238,6 +250,8 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
       if gb is not None:
         reduce_fn(eng.grads_flat)
         gb.replay()
+      eng.arena.version += 1        # what optimizer_apply does on the host when it is not replayed
+      eng.arena.step_count += 1
     g['steps'] += 1
 
   def train_step(self, data, sync_loss=True):

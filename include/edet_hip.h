@@ -193,9 +193,12 @@ int edet_dw_bwd(const edet_gview_t* dy, const float* weight, int k, int stride,
 /* ---- BatchNorm statistics --------------------------------------------------
  * utils.py:244-266 / util_keras.py:29-66 (eps 1e-3, momentum 0.99).
  * finalize: partial sums -> batch mean / biased variance -> scale, shift, mean,
- * rstd; moving statistics updated in place when momentum >= 0.  */
+ * rstd; moving statistics updated in place when momentum >= 0: moving_var with the Bessel-corrected batch
+ * variance when bessel != 0 (Keras' fused BatchNormalization, the single-replica classes of utils.py:244-266),
+ * with the biased one when bessel == 0 (SyncBatchNormalization / TpuBatchNormalization force fused=False,
+ * utils.py:166-213).  */
 int edet_bn_finalize(const float* partials, int nparts, int c, double count,
-                     const float* gamma, const float* beta, float eps, float momentum,
+                     const float* gamma, const float* beta, float eps, float momentum, int bessel,
                      float* moving_mean, float* moving_var,
                      float* scale, float* shift, float* mean, float* rstd, void* stream);
 /* inference: scale/shift from the moving statistics */

@@ -420,7 +420,7 @@ def test_batchnorm_train_fwd_bwd(dt, shape):
   mm = torch.zeros(c, dtype=torch.float32, device=gu.DEV)
   mv = torch.ones(c, dtype=torch.float32, device=gu.DEV)
   gd, bd = gu.fdev(gamma), gu.fdev(beta)
-  call('edet_bn_finalize', ptr(parts), 1, c, float(cnt), ptr(gd), ptr(bd), 1e-3, 0.99, ptr(mm), ptr(mv),
+  call('edet_bn_finalize', ptr(parts), 1, c, float(cnt), ptr(gd), ptr(bd), 1e-3, 0.99, 1, ptr(mm), ptr(mv),
        ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), gu.stream())
   yd, rd = gu.to_dev(y, tdt), gu.to_dev(res, tdt)
   od = torch.empty_like(yd)
@@ -430,6 +430,13 @@ def test_batchnorm_train_fwd_bwd(dt, shape):
   gu.check(od, out.detach() + res, name, 'bn_res %s' % (shape,))
   gu.check(mm, 0.01 * mean.detach(), 'f32', 'moving_mean', rtol=1e-4, atol=1e-6)
   gu.check(mv, 0.99 + 0.01 * var.detach() * cnt / (cnt - 1), 'f32', 'moving_var', rtol=1e-4, atol=1e-6)
+  # un-fused BatchNorm of the cross-replica classes (utils.py:166-213): biased variance into the moving average
+  mv.fill_(1.0)
+  mm.zero_()
+  call('edet_bn_finalize', ptr(parts), 1, c, float(cnt), ptr(gd), ptr(bd), 1e-3, 0.99, 0, ptr(mm), ptr(mv),
+       ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), gu.stream())
+  torch.cuda.synchronize()
+  gu.check(mv, 0.99 + 0.01 * var.detach(), 'f32', 'moving_var (biased)', rtol=1e-4, atol=1e-6)
   # backward
   dzd = gu.to_dev(dz, tdt)
   p2 = partial_buf(c)
