@@ -51,6 +51,8 @@ PT, PG, PE, PI = (ctypes.POINTER(TView), ctypes.POINTER(GView), ctypes.POINTER(B
 # name -> argtypes; every function returns int.  Must list EVERY symbol of include/edet_hip.h
 # (tests/test_abi.py checks the header against this table and the built library).
 SIGNATURES = {
+    'edet_debug_launch_log': [c_int],
+    'edet_debug_launch_names': [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)],
     'edet_cast': [c_void_p, c_void_p, c_int64, c_int, c_void_p],
     'edet_cast_matrix': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'edet_cast_batch': [c_void_p, c_int, c_int, c_int, c_void_p],
@@ -198,6 +200,25 @@ def call(name, *args, nbytes=0, tag=''):
     rc = getattr(lib, name)(*args)
   if rc != 0:
     raise EdetError('%s failed (%d): %s' % (name, rc, lib.edet_last_error().decode()))
+
+
+def launch_log_start():
+  """Clears and starts the library's debug launch log (kernel symbol -> launches)."""
+  call('edet_debug_launch_log', 1)
+
+
+def launch_log_stop():
+  """Stops the log and returns {demangled kernel name: launches}."""
+  call('edet_debug_launch_log', 0)
+  need = ctypes.c_size_t(0)
+  call('edet_debug_launch_names', None, 0, ctypes.byref(need))
+  buf = ctypes.create_string_buffer(need.value + 1)
+  call('edet_debug_launch_names', buf, need.value + 1, ctypes.byref(need))
+  out = {}
+  for line in buf.value.decode().splitlines():
+    count, name = line.split('\t', 1)
+    out[name] = int(count)
+  return out
 
 
 def ptr(t):

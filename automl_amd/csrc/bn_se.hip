@@ -491,7 +491,7 @@ inline int ew_grid(int64_t total) {
 }  // namespace
 
 int edet_reduce_partials(const float* ws, int P, int64_t n, float* dst, hipStream_t st) {
-  k_reduce_partials<<<dim3((unsigned)((n + 15) / 16)), dim3(16 * RED_SL), 0, st>>>(ws, P, n, dst);
+  edet_launch(k_reduce_partials, dim3((unsigned)((n + 15) / 16)), dim3(16 * RED_SL), 0, st, ws, P, n, dst);
   EDET_LAUNCH_CHECK("edet_reduce_partials");
   return 0;
 }
@@ -501,7 +501,7 @@ extern "C" int edet_bn_finalize(const float* partials, int nparts, int c, double
                                 int bessel, float* moving_mean, float* moving_var, float* scale, float* shift,
                                 float* mean, float* rstd, void* stream) {
   EDET_CHECK(partials && gamma && beta && scale && shift && mean && rstd, "edet_bn_finalize: null pointer");
-  k_bn_finalize<<<cdiv(c, FIN_CH), FIN_CH * FIN_SL, 0, to_stream(stream)>>>(partials, nparts, c, count, gamma, beta, eps,
+  edet_launch(k_bn_finalize, dim3(cdiv(c, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, to_stream(stream), partials, nparts, c, count, gamma, beta, eps,
                                                             momentum, bessel, moving_mean, moving_var, scale, shift,
                                                             mean, rstd);
   EDET_LAUNCH_CHECK("edet_bn_finalize");
@@ -512,7 +512,7 @@ extern "C" int edet_bn_eval(int c, const float* gamma, const float* beta, float 
                             const float* moving_mean, const float* moving_var, float* scale, float* shift,
                             void* stream) {
   EDET_CHECK(gamma && beta && moving_mean && moving_var && scale && shift, "edet_bn_eval: null pointer");
-  k_bn_eval<<<cdiv(c, 128), 128, 0, to_stream(stream)>>>(c, gamma, beta, eps, moving_mean, moving_var, scale, shift);
+  edet_launch(k_bn_eval, dim3(cdiv(c, 128)), dim3(128), 0, to_stream(stream), c, gamma, beta, eps, moving_mean, moving_var, scale, shift);
   EDET_LAUNCH_CHECK("edet_bn_eval");
   return 0;
 }
@@ -527,9 +527,9 @@ extern "C" int edet_bn_bwd_reduce(const void* dz, const void* y, int64_t rows, i
   if (nparts_out) *nparts_out = grid;
   const size_t lds = (size_t)2 * c * sizeof(float);
   if (dtype == EDET_BF16)
-    k_bn_bwd_reduce<bf16_t><<<grid, THREADS, lds, to_stream(stream)>>>((const bf16_t*)dz, (const bf16_t*)y, rows, c, ld, mean, rstd, stat_partials, m);
+    edet_launch(k_bn_bwd_reduce<bf16_t>, grid, dim3(THREADS), lds, to_stream(stream), (const bf16_t*)dz, (const bf16_t*)y, rows, c, ld, mean, rstd, stat_partials, m);
   else if (dtype == EDET_F32)
-    k_bn_bwd_reduce<float><<<grid, THREADS, lds, to_stream(stream)>>>((const float*)dz, (const float*)y, rows, c, ld, mean, rstd, stat_partials, m);
+    edet_launch(k_bn_bwd_reduce<float>, grid, dim3(THREADS), lds, to_stream(stream), (const float*)dz, (const float*)y, rows, c, ld, mean, rstd, stat_partials, m);
   else EDET_CHECK(false, "edet_bn_bwd_reduce: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_bn_bwd_reduce");
   return 0;
@@ -541,7 +541,7 @@ extern "C" int edet_bn_bwd_finalize(const float* partials, int nparts, int c, do
                                     float* a, float* b, float* cc, void* stream) {
   EDET_CHECK(partials && gamma && mean && rstd && a && b && cc, "edet_bn_bwd_finalize: null pointer");
   (void)dbias;  // d(bias before BatchNorm) is analytically zero: BN removes the mean
-  k_bn_bwd_finalize<<<cdiv(c, FIN_CH), FIN_CH * FIN_SL, 0, to_stream(stream)>>>(partials, nparts, c, count, gamma, mean, rstd,
+  edet_launch(k_bn_bwd_finalize, dim3(cdiv(c, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, to_stream(stream), partials, nparts, c, count, gamma, mean, rstd,
                                                                 dgamma, dbeta, a, b, cc);
   EDET_LAUNCH_CHECK("edet_bn_bwd_finalize");
   return 0;
@@ -553,8 +553,8 @@ extern "C" int edet_bn_res(const edet_tview_t* y, const void* residual, void* ou
   EDET_CHECK(y->c % 8 == 0 && y->ld % 8 == 0 && ldo % 8 == 0, "edet_bn_res: c/ld % 8");
   const int64_t rows = (int64_t)y->n * y->h * y->w;
   const int grid = ew_grid(rows * (y->c / 8));
-  if (dtype == EDET_BF16) k_bn_res<bf16_t><<<grid, THREADS, 0, to_stream(stream)>>>(*y, (const bf16_t*)residual, (bf16_t*)out, ldo, rows);
-  else if (dtype == EDET_F32) k_bn_res<float><<<grid, THREADS, 0, to_stream(stream)>>>(*y, (const float*)residual, (float*)out, ldo, rows);
+  if (dtype == EDET_BF16) edet_launch(k_bn_res<bf16_t>, grid, dim3(THREADS), 0, to_stream(stream), *y, (const bf16_t*)residual, (bf16_t*)out, ldo, rows);
+  else if (dtype == EDET_F32) edet_launch(k_bn_res<float>, grid, dim3(THREADS), 0, to_stream(stream), *y, (const float*)residual, (float*)out, ldo, rows);
   else EDET_CHECK(false, "edet_bn_res: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_bn_res");
   return 0;
@@ -565,8 +565,8 @@ extern "C" int edet_add(void* dst, const void* src, int64_t rows, int c, int ld,
   EDET_CHECK(dst && src, "edet_add: null pointer");
   EDET_CHECK(c % 8 == 0 && ld % 8 == 0, "edet_add: c/ld % 8");
   const int grid = ew_grid(rows * (c / 8));
-  if (dtype == EDET_BF16) k_add<bf16_t><<<grid, THREADS, 0, to_stream(stream)>>>((bf16_t*)dst, (const bf16_t*)src, rows, c, ld, beta);
-  else if (dtype == EDET_F32) k_add<float><<<grid, THREADS, 0, to_stream(stream)>>>((float*)dst, (const float*)src, rows, c, ld, beta);
+  if (dtype == EDET_BF16) edet_launch(k_add<bf16_t>, grid, dim3(THREADS), 0, to_stream(stream), (bf16_t*)dst, (const bf16_t*)src, rows, c, ld, beta);
+  else if (dtype == EDET_F32) edet_launch(k_add<float>, grid, dim3(THREADS), 0, to_stream(stream), (float*)dst, (const float*)src, rows, c, ld, beta);
   else EDET_CHECK(false, "edet_add: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_add");
   return 0;
@@ -587,8 +587,8 @@ extern "C" int edet_se_pool(const edet_tview_t* in, float* pooled_sum, int dtype
   const RowMap m = row_map(in->c);
   const int wpi = se_wg_per_img(in->n, in->h * in->w, m.rpp);
   const size_t lds = (size_t)in->c * sizeof(float);
-  if (dtype == EDET_BF16) k_se_pool<bf16_t><<<in->n * wpi, THREADS, lds, to_stream(stream)>>>(*in, pooled_sum, wpi, m);
-  else if (dtype == EDET_F32) k_se_pool<float><<<in->n * wpi, THREADS, lds, to_stream(stream)>>>(*in, pooled_sum, wpi, m);
+  if (dtype == EDET_BF16) edet_launch(k_se_pool<bf16_t>, dim3(in->n * wpi), dim3(THREADS), lds, to_stream(stream), *in, pooled_sum, wpi, m);
+  else if (dtype == EDET_F32) edet_launch(k_se_pool<float>, dim3(in->n * wpi), dim3(THREADS), lds, to_stream(stream), *in, pooled_sum, wpi, m);
   else EDET_CHECK(false, "edet_se_pool: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_se_pool");
   return 0;
@@ -600,7 +600,7 @@ extern "C" int edet_se_fc(const float* pooled_sum, int n, int c, int se, float i
   EDET_CHECK(pooled_sum && w1 && b1 && w2 && b2 && hidden_pre && gate, "edet_se_fc: null pointer");
   EDET_CHECK(act >= EDET_ACT_NONE && act <= EDET_ACT_HSWISH, "edet_se_fc: activation %d", act);
   const int fc_threads = c >= 512 ? SE_FC_THREADS : THREADS;
-  k_se_fc<<<n, fc_threads, (size_t)(c + se) * sizeof(float), to_stream(stream)>>>(pooled_sum, c, se, inv_hw, w1, b1, w2, b2, hidden_pre, gate, act);
+  edet_launch(k_se_fc, dim3(n), dim3(fc_threads), (size_t)(c + se) * sizeof(float), to_stream(stream), pooled_sum, c, se, inv_hw, w1, b1, w2, b2, hidden_pre, gate, act);
   EDET_LAUNCH_CHECK("edet_se_fc");
   return 0;
 }
@@ -613,11 +613,10 @@ extern "C" int edet_se_fc_bwd(const float* pooled_sum, const float* hidden_pre, 
   EDET_CHECK(act >= EDET_ACT_NONE && act <= EDET_ACT_HSWISH, "edet_se_fc_bwd: activation %d", act);
   EDET_CHECK(pooled_sum && hidden_pre && gate && dgate && w1 && w2 && dw1 && db1 && dw2 && db2 && dpool && scratch,
              "edet_se_fc_bwd: null pointer");
-  k_se_fc_bwd_img<<<n, c >= 512 ? SE_FC_THREADS : THREADS, (size_t)(c + se) * sizeof(float), to_stream(stream)>>>(hidden_pre, gate, dgate, n, c, se, inv_hw, w1, w2, dpool, scratch, act);
+  edet_launch(k_se_fc_bwd_img, dim3(n), dim3(c >= 512 ? SE_FC_THREADS : THREADS), (size_t)(c + se) * sizeof(float), to_stream(stream), hidden_pre, gate, dgate, n, c, se, inv_hw, w1, w2, dpool, scratch, act);
   const int nsplit = n >= 2 * SE_SPLIT ? SE_SPLIT : 1;
   const int per_split = cdiv(n, nsplit);
-  k_se_fc_bwd_par<<<dim3(cdiv(c, 64), cdiv(n, per_split), cdiv(se, SE_JB)), THREADS,
-                    (size_t)2 * SE_NB * SE_JB * sizeof(float), to_stream(stream)>>>(
+  edet_launch(k_se_fc_bwd_par, dim3(cdiv(c, 64), cdiv(n, per_split), cdiv(se, SE_JB)), dim3(THREADS), (size_t)2 * SE_NB * SE_JB * sizeof(float), to_stream(stream), 
       pooled_sum, scratch, n, c, se, inv_hw, dw1, db1, dw2, db2, per_split);
   EDET_LAUNCH_CHECK("edet_se_fc_bwd");
   return 0;
@@ -635,10 +634,10 @@ extern "C" int edet_se_gate_bwd(const edet_tview_t* in, void* g, const float* dp
   if (nparts_out) *nparts_out = in->n * wpi;
   const size_t lds = (size_t)2 * in->c * sizeof(float);
   const bool other = in->act > EDET_ACT_SWISH;
-  if (dtype == EDET_BF16 && !other) k_se_gate_bwd<bf16_t, false><<<in->n * wpi, THREADS, lds, to_stream(stream)>>>(*in, (bf16_t*)g, dpool, mean, rstd, stat_partials, wpi, m);
-  else if (dtype == EDET_BF16) k_se_gate_bwd<bf16_t, true><<<in->n * wpi, THREADS, lds, to_stream(stream)>>>(*in, (bf16_t*)g, dpool, mean, rstd, stat_partials, wpi, m);
-  else if (dtype == EDET_F32 && !other) k_se_gate_bwd<float, false><<<in->n * wpi, THREADS, lds, to_stream(stream)>>>(*in, (float*)g, dpool, mean, rstd, stat_partials, wpi, m);
-  else if (dtype == EDET_F32) k_se_gate_bwd<float, true><<<in->n * wpi, THREADS, lds, to_stream(stream)>>>(*in, (float*)g, dpool, mean, rstd, stat_partials, wpi, m);
+  if (dtype == EDET_BF16 && !other) edet_launch(k_se_gate_bwd<bf16_t, false>, dim3(in->n * wpi), dim3(THREADS), lds, to_stream(stream), *in, (bf16_t*)g, dpool, mean, rstd, stat_partials, wpi, m);
+  else if (dtype == EDET_BF16) edet_launch(k_se_gate_bwd<bf16_t, true>, dim3(in->n * wpi), dim3(THREADS), lds, to_stream(stream), *in, (bf16_t*)g, dpool, mean, rstd, stat_partials, wpi, m);
+  else if (dtype == EDET_F32 && !other) edet_launch(k_se_gate_bwd<float, false>, dim3(in->n * wpi), dim3(THREADS), lds, to_stream(stream), *in, (float*)g, dpool, mean, rstd, stat_partials, wpi, m);
+  else if (dtype == EDET_F32) edet_launch(k_se_gate_bwd<float, true>, dim3(in->n * wpi), dim3(THREADS), lds, to_stream(stream), *in, (float*)g, dpool, mean, rstd, stat_partials, wpi, m);
   else EDET_CHECK(false, "edet_se_gate_bwd: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_se_gate_bwd");
   return 0;

@@ -30,6 +30,31 @@ void edet_set_error(const char* fmt, ...);
     }                                                                    \
   } while (0)
 
+// ---------------------------------------------------------------- kernel launches
+// Every kernel of the library is launched through edet_launch, so that the debug launch log
+// (edet_debug_launch_log / edet_debug_launch_names in include/edet_hip.h) can name the kernel symbols a run
+// used: the parity tests assert that every symbol of the full-size benchmark step is also launched by a
+// test that checks results against the oracle.  With the log off the cost is one predictable branch.
+#include <tuple>
+#include <utility>
+extern int g_edet_launch_log_on;
+void edet_log_launch(const void* host_fn);
+template <typename Tuple, size_t... I>
+inline hipError_t edet_launch_impl(const void* fn, dim3 grid, dim3 block, size_t lds, hipStream_t st, Tuple& params,
+                                   std::index_sequence<I...>) {
+  void* ptrs[] = {static_cast<void*>(&std::get<I>(params))..., nullptr};
+  return hipLaunchKernel(fn, grid, block, ptrs, lds, st);
+}
+// kern<<<grid, block, lds, st>>>(args...) with the arguments converted to the kernel's parameter types
+template <typename... KArgs, typename... Args>
+inline void edet_launch(void (*kern)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args&&... args) {
+  static_assert(sizeof...(KArgs) == sizeof...(Args), "edet_launch: wrong number of kernel arguments");
+  const void* fn = reinterpret_cast<const void*>(kern);
+  if (g_edet_launch_log_on) edet_log_launch(fn);
+  std::tuple<typename std::decay<KArgs>::type...> params(static_cast<KArgs>(args)...);
+  (void)edet_launch_impl(fn, grid, block, lds, st, params, std::index_sequence_for<KArgs...>{});
+}
+
 // ---------------------------------------------------------------- scalar conversions
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // round-to-nearest-even fp32 -> bf16: gfx950 has v_cvt_pk_bf16_f32, which the compiler selects for a

@@ -216,8 +216,8 @@ extern "C" int edet_conv_bwd_data(const edet_gview_t* dy, const void* w_t, int l
   a.w = w_t; a.ldw = ldw; a.gout = epi->gout; a.beta = epi->beta;
   const int64_t total = (int64_t)in->n * in->h * in->w * in->c;
   const int grid = (int)((total + DTHREADS - 1) / DTHREADS < 8192 ? (total + DTHREADS - 1) / DTHREADS : 8192);
-  if (dtype == EDET_BF16) k_conv_dgrad_direct<bf16_t><<<grid, DTHREADS, 0, st>>>(a);
-  else k_conv_dgrad_direct<float><<<grid, DTHREADS, 0, st>>>(a);
+  if (dtype == EDET_BF16) edet_launch(k_conv_dgrad_direct<bf16_t>, grid, dim3(DTHREADS), 0, st, a);
+  else edet_launch(k_conv_dgrad_direct<float>, grid, dim3(DTHREADS), 0, st, a);
   if (nparts_out) *nparts_out = 0;
   EDET_LAUNCH_CHECK("edet_conv_bwd_data");
   return 0;
@@ -237,8 +237,8 @@ extern "C" int edet_conv_bwd_weight(const edet_tview_t* in, const edet_gview_t* 
   }
   a.dweight = dweight;
   const int total = k * k * in->c * dy->c;
-  if (dtype == EDET_BF16) k_conv_wgrad_direct<bf16_t><<<(total + DTHREADS - 1) / DTHREADS, DTHREADS, 0, st>>>(a);
-  else k_conv_wgrad_direct<float><<<(total + DTHREADS - 1) / DTHREADS, DTHREADS, 0, st>>>(a);
+  if (dtype == EDET_BF16) edet_launch(k_conv_wgrad_direct<bf16_t>, dim3((total + DTHREADS - 1) / DTHREADS), dim3(DTHREADS), 0, st, a);
+  else edet_launch(k_conv_wgrad_direct<float>, dim3((total + DTHREADS - 1) / DTHREADS), dim3(DTHREADS), 0, st, a);
   EDET_LAUNCH_CHECK("edet_conv_bwd_weight");
   return 0;
 }
@@ -271,8 +271,8 @@ extern "C" int edet_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, in
   a.P = (int)P;
   if (nparts_out) *nparts_out = a.P;
   const size_t lds = 2 * (size_t)cout * sizeof(float);
-  if (dtype == EDET_BF16) k_conv_direct<bf16_t><<<dim3(a.P), dim3(DTHREADS), lds, st>>>(a);
-  else k_conv_direct<float><<<dim3(a.P), dim3(DTHREADS), lds, st>>>(a);
+  if (dtype == EDET_BF16) edet_launch(k_conv_direct<bf16_t>, dim3(a.P), dim3(DTHREADS), lds, st, a);
+  else edet_launch(k_conv_direct<float>, dim3(a.P), dim3(DTHREADS), lds, st, a);
   EDET_LAUNCH_CHECK("edet_conv_fwd");
   return 0;
 }

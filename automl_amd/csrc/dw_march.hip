@@ -1004,7 +1004,7 @@ int dwm_try_fwd(const edet_tview_t* in, const float* weight, int k, int s, void*
     plan<CPT_>(a, in->c, in->n, a.ow, a.oh, EDET_MAX_PARTS);                              \
     const size_t lds0 = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                  \
     const size_t ring = (size_t)2 * (a.TX * S_ + K_ - S_) * a.nch * CPT_ * sizeof(float); \
-    k_fwd_lx<K_, S_, CPT_><<<dim3(a.P * a.ngroups), dim3(THREADS), lds0 + ring, st>>>(a); \
+    edet_launch(k_fwd_lx<K_, S_, CPT_>, dim3(a.P * a.ngroups), dim3(THREADS), lds0 + ring, st, a); \
   } while (0)
   if (k == 3 && s == 1) DWM_FWD(3, 1, 4);
   else if (k == 3 && s == 2) DWM_FWD(3, 2, 4);
@@ -1038,8 +1038,8 @@ int dwm_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, 
     const size_t lds = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                   \
     const size_t ring = (size_t)2 * (a.TX * S_ + K_ - S_) * a.nch * CPT_ * sizeof(float); \
     const dim3 grid(a.P * a.ngroups), block(THREADS);                                     \
-    if (gbn) k_wgrad_lx<K_, S_, CPT_, true><<<grid, block, lds + ring, st>>>(a);          \
-    else k_wgrad_lx<K_, S_, CPT_, false><<<grid, block, lds + ring, st>>>(a);             \
+    if (gbn) edet_launch(k_wgrad_lx<K_, S_, CPT_, true>, grid, block, lds + ring, st, a);          \
+    else edet_launch(k_wgrad_lx<K_, S_, CPT_, false>, grid, block, lds + ring, st, a);             \
   } while (0)
   if (k == 3 && s == 1) DWM_WG(3, 1, 4);
   else if (k == 3 && s == 2) DWM_WG(3, 2, 4);
@@ -1070,8 +1070,8 @@ int dwm_try_dgrad(const edet_gview_t* dy, const float* weight, int k, int s, con
     const size_t lds = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                   \
     const size_t ring = (size_t)2 * (a.TX + (K_ + S_ - 1) / S_ - 1) * a.nch * CPT_ * sizeof(float); \
     const dim3 grid(a.P * a.ngroups), block(THREADS);                                     \
-    if (gbn) k_dgrad_lx<K_, S_, CPT_, true><<<grid, block, lds + ring, st>>>(a);          \
-    else k_dgrad_lx<K_, S_, CPT_, false><<<grid, block, lds + ring, st>>>(a);             \
+    if (gbn) edet_launch(k_dgrad_lx<K_, S_, CPT_, true>, grid, block, lds + ring, st, a);          \
+    else edet_launch(k_dgrad_lx<K_, S_, CPT_, false>, grid, block, lds + ring, st, a);             \
   } while (0)
   if (k == 3 && s == 1) DWM_DG(3, 1, 4);
   else if (k == 3 && s == 2) DWM_DG(3, 2, 4);
@@ -1110,8 +1110,8 @@ int dwm_try_bwd_fused(const edet_gview_t* dy, const float* weight, int k, int s,
     const size_t lds = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                   \
     const size_t ring = (size_t)2 * (a.TX + K_ - 1) * a.nch * CPT_ * sizeof(float);       \
     const dim3 grid(a.P * a.ngroups), block(THREADS);                                     \
-    if (gbn) k_bwd_fused<K_, CPT_, true><<<grid, block, lds + ring, st>>>(a);             \
-    else k_bwd_fused<K_, CPT_, false><<<grid, block, lds + ring, st>>>(a);                \
+    if (gbn) edet_launch(k_bwd_fused<K_, CPT_, true>, grid, block, lds + ring, st, a);             \
+    else edet_launch(k_bwd_fused<K_, CPT_, false>, grid, block, lds + ring, st, a);                \
   } while (0)
   if (k == 3 && k3c4) DWM_FUSED(3, 4);
   else if (k == 3) DWM_FUSED(3, 2);

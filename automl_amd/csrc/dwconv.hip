@@ -429,9 +429,9 @@ size_t plan(DwArgs& a, int which, int k, int s, int n, int space_h, int space_w,
 template <typename T, int K, int S>
 void launch(int which, const DwArgs& a, size_t ldsb, hipStream_t st) {
   const dim3 grid(a.P * a.nchunks), block(THREADS);
-  if (which == DW_FWD) k_dw_fwd<T, K, S><<<grid, block, ldsb, st>>>(a);
-  else if (which == DW_BWD_DATA) k_dw_bwd_data<T, K, S><<<grid, block, ldsb, st>>>(a);
-  else k_dw_bwd_weight<T, K, S><<<grid, block, ldsb, st>>>(a);
+  if (which == DW_FWD) edet_launch(k_dw_fwd<T, K, S>, grid, block, ldsb, st, a);
+  else if (which == DW_BWD_DATA) edet_launch(k_dw_bwd_data<T, K, S>, grid, block, ldsb, st, a);
+  else edet_launch(k_dw_bwd_weight<T, K, S>, grid, block, ldsb, st, a);
 }
 
 template <typename T>

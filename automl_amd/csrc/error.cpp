@@ -1,6 +1,14 @@
-// Thread-local error message of the C ABI (edet_last_error).
+// Thread-local error message of the C ABI (edet_last_error) and the debug launch log.
+#include <cxxabi.h>
+#include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
 
 #include "../../include/edet_hip.h"
 
@@ -14,4 +22,52 @@ void edet_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* edet_last_error(void) { return g_err; }
-extern "C" int edet_version(void) { return 1; }
+extern "C" int edet_version(void) { return 2; }
+
+// ---- debug launch log: host function pointer of every kernel launched while the log is on -> count
+int g_edet_launch_log_on = 0;
+static std::mutex g_log_mu;
+static std::map<const void*, long> g_log_counts;
+
+void edet_log_launch(const void* host_fn) {
+  std::lock_guard<std::mutex> lock(g_log_mu);
+  ++g_log_counts[host_fn];
+}
+
+extern "C" int edet_debug_launch_log(int enable) {
+  std::lock_guard<std::mutex> lock(g_log_mu);
+  if (enable) g_log_counts.clear();
+  g_edet_launch_log_on = enable ? 1 : 0;
+  return 0;
+}
+
+extern "C" int edet_debug_launch_names(char* buf, size_t capacity, size_t* needed) {
+  std::string text;
+  {
+    std::lock_guard<std::mutex> lock(g_log_mu);
+    std::map<std::string, long> by_name;
+    for (const auto& kv : g_log_counts) {
+      const char* mangled = hipKernelNameRefByPtr(kv.first, nullptr);
+      std::string name;
+      if (mangled) {
+        int status = 0;
+        char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+        name = (status == 0 && dem) ? dem : mangled;
+        free(dem);
+      } else {
+        char tmp[32];
+        snprintf(tmp, sizeof(tmp), "kernel@%p", kv.first);
+        name = tmp;
+      }
+      by_name[name] += kv.second;
+    }
+    for (const auto& kv : by_name) text += std::to_string(kv.second) + "\t" + kv.first + "\n";
+  }
+  if (needed) *needed = text.size() + 1;
+  if (buf && capacity) {
+    const size_t n = text.size() < capacity - 1 ? text.size() : capacity - 1;
+    memcpy(buf, text.data(), n);
+    buf[n] = 0;
+  }
+  return 0;
+}

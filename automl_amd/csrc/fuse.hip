@@ -406,7 +406,7 @@ int fill_args(FuseArgs& a, const edet_tview_t* in0, const edet_tview_t* in1, con
 extern "C" int edet_fuse_weights(const float* w0, const float* w1, const float* w2, int nin,
                                  int method, float* wn, int wc, void* stream) {
   EDET_CHECK(wn && (method == 1 || w0) && wc >= 1, "edet_fuse_weights: bad arguments");
-  k_fuse_weights<<<(wc + 63) / 64, 64, 0, to_stream(stream)>>>(w0, w1, w2, nin, method, wn, wc);
+  edet_launch(k_fuse_weights, dim3((wc + 63) / 64), dim3(64), 0, to_stream(stream), w0, w1, w2, nin, method, wn, wc);
   EDET_LAUNCH_CHECK("edet_fuse_weights");
   return 0;
 }
@@ -416,7 +416,7 @@ extern "C" int edet_fuse_weights_bwd(const float* w0, const float* w1, const flo
                                      int wc, void* stream) {
   if (method == 1) return 0;
   EDET_CHECK(w0 && dwn && dw0 && wc >= 1, "edet_fuse_weights_bwd: bad arguments");
-  k_fuse_weights_bwd<<<(wc + 63) / 64, 64, 0, to_stream(stream)>>>(w0, w1, w2, nin, method, dwn, dw0, dw1, dw2, wc);
+  edet_launch(k_fuse_weights_bwd, dim3((wc + 63) / 64), dim3(64), 0, to_stream(stream), w0, w1, w2, nin, method, dwn, dw0, dw1, dw2, wc);
   EDET_LAUNCH_CHECK("edet_fuse_weights_bwd");
   return 0;
 }
@@ -428,8 +428,8 @@ extern "C" int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, c
   if (int rc = fill_args(a, in0, in1, in2, modes, nin, wn, wc, act, oh, ow, ldo)) return rc;
   EDET_CHECK(out, "edet_fuse_fwd: null output");
   const int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8));
-  if (dtype == EDET_BF16) k_fuse<bf16_t, false><<<grid, THREADS, 0, to_stream(stream)>>>(a, (bf16_t*)out, nullptr, nullptr, nullptr, nullptr);
-  else if (dtype == EDET_F32) k_fuse<float, false><<<grid, THREADS, 0, to_stream(stream)>>>(a, (float*)out, nullptr, nullptr, nullptr, nullptr);
+  if (dtype == EDET_BF16) edet_launch(k_fuse<bf16_t, false>, grid, dim3(THREADS), 0, to_stream(stream), a, (bf16_t*)out, nullptr, nullptr, nullptr, nullptr);
+  else if (dtype == EDET_F32) edet_launch(k_fuse<float, false>, grid, dim3(THREADS), 0, to_stream(stream), a, (float*)out, nullptr, nullptr, nullptr, nullptr);
   else EDET_CHECK(false, "edet_fuse_fwd: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_fuse_fwd");
   return 0;
@@ -444,8 +444,8 @@ extern "C" int edet_fuse_bwd_pre(const edet_tview_t* in0, const edet_tview_t* in
   EDET_CHECK(dout && ds, "edet_fuse_bwd_pre: null pointer");
   const int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8));
   const size_t lds = wc > 1 ? (size_t)3 * a.c * sizeof(float) : 0;
-  if (dtype == EDET_BF16) k_fuse<bf16_t, true><<<grid, THREADS, lds, to_stream(stream)>>>(a, nullptr, (const bf16_t*)dout, (bf16_t*)ds, dwn, (unsigned char*)pool_argmax);
-  else if (dtype == EDET_F32) k_fuse<float, true><<<grid, THREADS, lds, to_stream(stream)>>>(a, nullptr, (const float*)dout, (float*)ds, dwn, (unsigned char*)pool_argmax);
+  if (dtype == EDET_BF16) edet_launch(k_fuse<bf16_t, true>, grid, dim3(THREADS), lds, to_stream(stream), a, nullptr, (const bf16_t*)dout, (bf16_t*)ds, dwn, (unsigned char*)pool_argmax);
+  else if (dtype == EDET_F32) edet_launch(k_fuse<float, true>, grid, dim3(THREADS), lds, to_stream(stream), a, nullptr, (const float*)dout, (float*)ds, dwn, (unsigned char*)pool_argmax);
   else EDET_CHECK(false, "edet_fuse_bwd_pre: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_fuse_bwd_pre");
   return 0;
@@ -467,8 +467,8 @@ extern "C" int edet_fuse_bwd_input(const edet_tview_t* in, int mode, const float
   }
   const int grid = ew_grid((int64_t)in->n * in->h * in->w * (in->c / 8));
   const unsigned char* am = mode == EDET_RS_POOL ? reinterpret_cast<const unsigned char*>(pool_argmax) : nullptr;
-  if (dtype == EDET_BF16) k_fuse_bwd_input<bf16_t><<<grid, THREADS, 0, to_stream(stream)>>>(a, (const bf16_t*)ds, (bf16_t*)gout, am);
-  else if (dtype == EDET_F32) k_fuse_bwd_input<float><<<grid, THREADS, 0, to_stream(stream)>>>(a, (const float*)ds, (float*)gout, am);
+  if (dtype == EDET_BF16) edet_launch(k_fuse_bwd_input<bf16_t>, grid, dim3(THREADS), 0, to_stream(stream), a, (const bf16_t*)ds, (bf16_t*)gout, am);
+  else if (dtype == EDET_F32) edet_launch(k_fuse_bwd_input<float>, grid, dim3(THREADS), 0, to_stream(stream), a, (const float*)ds, (float*)gout, am);
   else EDET_CHECK(false, "edet_fuse_bwd_input: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_fuse_bwd_input");
   return 0;

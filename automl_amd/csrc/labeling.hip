@@ -173,9 +173,9 @@ extern "C" int edet_label_anchors(const float* anchor_boxes, const int* level_an
   a.num_positives = num_positives;
   hipStream_t st = to_stream(stream);
   const int64_t total = (int64_t)batch * a.N;
-  k_label_init<<<cdiv(total, 256), 256, 0, st>>>(a.force, num_positives, total, batch);
-  k_label_force<<<dim3(max_gt, batch), LB_THREADS, 0, st>>>(a);
-  k_label_assign<<<dim3(cdiv(a.N, LB_THREADS), batch), LB_THREADS, 0, st>>>(a);
+  edet_launch(k_label_init, dim3(cdiv(total, 256)), dim3(256), 0, st, a.force, num_positives, total, batch);
+  edet_launch(k_label_force, dim3(max_gt, batch), dim3(LB_THREADS), 0, st, a);
+  edet_launch(k_label_assign, dim3(cdiv(a.N, LB_THREADS), batch), dim3(LB_THREADS), 0, st, a);
   EDET_LAUNCH_CHECK("edet_label_anchors");
   return 0;
 }

@@ -326,7 +326,7 @@ extern "C" int edet_focal_loss(const void* logits, int ld, const int32_t* cls_ta
   const size_t lds = (size_t)ld * sizeof(float);
   const bool g15 = gamma == 1.5f;
 #define FOCAL_LAUNCH(T, G)                                                                            \
-  k_focal<T, G><<<(int)g, THREADS, lds, to_stream(stream)>>>((const T*)logits, ld, cls_targets, positions, \
+  edet_launch(k_focal<T, G>, dim3((int)g), dim3(THREADS), lds, to_stream(stream), (const T*)logits, ld, cls_targets, positions, \
       num_anchors, num_classes, alpha, gamma, inv_normalizer, norm_scale_dev, (T*)dlogits, dbias, sums, m)
   if (dtype == EDET_BF16) { if (g15) FOCAL_LAUNCH(bf16_t, true); else FOCAL_LAUNCH(bf16_t, false); }
   else if (dtype == EDET_F32) { if (g15) FOCAL_LAUNCH(float, true); else FOCAL_LAUNCH(float, false); }
@@ -349,9 +349,9 @@ extern "C" int edet_box_loss(const void* box_out, int ld, const float* box_targe
   if (g < 1) g = 1;
   const size_t lds = (size_t)ld * sizeof(float);
   if (dtype == EDET_BF16)
-    k_box<bf16_t><<<(int)g, THREADS, lds, to_stream(stream)>>>((const bf16_t*)box_out, ld, box_targets, positions, nch, delta, inv_normalizer, grad_scale, norm_scale_dev, (bf16_t*)dbox, dbias, sums, m);
+    edet_launch(k_box<bf16_t>, dim3((int)g), dim3(THREADS), lds, to_stream(stream), (const bf16_t*)box_out, ld, box_targets, positions, nch, delta, inv_normalizer, grad_scale, norm_scale_dev, (bf16_t*)dbox, dbias, sums, m);
   else if (dtype == EDET_F32)
-    k_box<float><<<(int)g, THREADS, lds, to_stream(stream)>>>((const float*)box_out, ld, box_targets, positions, nch, delta, inv_normalizer, grad_scale, norm_scale_dev, (float*)dbox, dbias, sums, m);
+    edet_launch(k_box<float>, dim3((int)g), dim3(THREADS), lds, to_stream(stream), (const float*)box_out, ld, box_targets, positions, nch, delta, inv_normalizer, grad_scale, norm_scale_dev, (float*)dbox, dbias, sums, m);
   else EDET_CHECK(false, "edet_box_loss: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_box_loss");
   return 0;
@@ -361,7 +361,7 @@ extern "C" int edet_opt_l2_norms(float* grads, const float* params, const int64_
                                  const int32_t* seg_flags, int nseg, float weight_decay,
                                  float* seg_sqnorm, float* l2_sum, void* stream) {
   EDET_CHECK(grads && params && seg_offsets && seg_flags && seg_sqnorm && nseg > 0, "edet_opt_l2_norms: bad arguments");
-  k_l2_norms<<<dim3(nseg, OPT_SPLIT), THREADS, 0, to_stream(stream)>>>(grads, params, seg_offsets, seg_flags, weight_decay, seg_sqnorm, l2_sum);
+  edet_launch(k_l2_norms, dim3(nseg, OPT_SPLIT), dim3(THREADS), 0, to_stream(stream), grads, params, seg_offsets, seg_flags, weight_decay, seg_sqnorm, l2_sum);
   EDET_LAUNCH_CHECK("edet_opt_l2_norms");
   return 0;
 }
@@ -369,7 +369,7 @@ extern "C" int edet_opt_l2_norms(float* grads, const float* params, const int64_
 extern "C" int edet_opt_clip_factors(const float* seg_sqnorm, int nseg, float clip_norm,
                                      float* seg_factor, float* global_norm_out, void* stream) {
   EDET_CHECK(seg_sqnorm && seg_factor && nseg > 0, "edet_opt_clip_factors: bad arguments");
-  k_clip_factors<<<1, THREADS, 0, to_stream(stream)>>>(seg_sqnorm, nseg, clip_norm, seg_factor, global_norm_out);
+  edet_launch(k_clip_factors, dim3(1), dim3(THREADS), 0, to_stream(stream), seg_sqnorm, nseg, clip_norm, seg_factor, global_norm_out);
   EDET_LAUNCH_CHECK("edet_opt_clip_factors");
   return 0;
 }
@@ -377,7 +377,7 @@ extern "C" int edet_opt_clip_factors(const float* seg_sqnorm, int nseg, float cl
 extern "C" int edet_opt_scale(float* grads, const int64_t* seg_offsets, const float* seg_factor,
                               int nseg, void* stream) {
   EDET_CHECK(grads && seg_offsets && seg_factor && nseg > 0, "edet_opt_scale: bad arguments");
-  k_scale<<<dim3(nseg, OPT_SPLIT), THREADS, 0, to_stream(stream)>>>(grads, seg_offsets, seg_factor);
+  edet_launch(k_scale, dim3(nseg, OPT_SPLIT), dim3(THREADS), 0, to_stream(stream), grads, seg_offsets, seg_factor);
   EDET_LAUNCH_CHECK("edet_opt_scale");
   return 0;
 }
@@ -386,7 +386,7 @@ extern "C" int edet_opt_sgd_ema(float* params, float* grads, float* velocity, fl
                                 const int64_t* seg_offsets, const float* seg_factor, int nseg,
                                 const float* hyper_dev, float momentum, void* stream) {
   EDET_CHECK(params && grads && velocity && seg_offsets && hyper_dev && nseg > 0, "edet_opt_sgd_ema: bad arguments");
-  k_sgd_ema<<<dim3(nseg, OPT_SPLIT), THREADS, 0, to_stream(stream)>>>(params, grads, velocity, ema, seg_offsets, seg_factor, hyper_dev, momentum);
+  edet_launch(k_sgd_ema, dim3(nseg, OPT_SPLIT), dim3(THREADS), 0, to_stream(stream), params, grads, velocity, ema, seg_offsets, seg_factor, hyper_dev, momentum);
   EDET_LAUNCH_CHECK("edet_opt_sgd_ema");
   return 0;
 }

@@ -758,7 +758,7 @@ extern "C" int edet_pre_nms(const void* const* cls_levels, const void* const* bo
     if (lds > 48 * 1024)                                                                                       \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pre_nms<T, VB>),                                     \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
-    k_pre_nms<T, VB><<<grid, 64, lds, st>>>(a, table, table + ngroups);                                        \
+    edet_launch(k_pre_nms<T, VB>, grid, dim3(64), lds, st, a, table, table + ngroups);                                        \
   } while (0)
   if (dtype == EDET_BF16) {
     if (vb == 16) PRE_CASE(bf16_t, 16); else if (vb == 4) PRE_CASE(bf16_t, 4); else PRE_CASE(bf16_t, 2);
@@ -803,25 +803,25 @@ extern "C" int edet_pre_nms_topk(const void* const* cls_levels, const void* cons
   a.sel_val = reinterpret_cast<float*>(w); w += (size_t)batch * a.Kpad * 4;
   a.eq_count = reinterpret_cast<uint32_t*>(w); w += (size_t)batch * TOPK_BLOCKS * 4;
   a.eq_base = reinterpret_cast<uint32_t*>(w);
-  k_topk_init<<<batch, 256, 0, st>>>(a);
+  edet_launch(k_topk_init, dim3(batch), dim3(256), 0, st, a);
   const int blocks = (int)std::min<int64_t>((a.total + 255) / 256, TOPK_BLOCKS);
   const dim3 grid(blocks, batch);
   const int shifts[3] = {20, 8, 0}, nbits[3] = {12, 12, 8};
   for (int pass = 0; pass < 3; ++pass) {
     a.shift = shifts[pass];
     a.bits = nbits[pass];
-    if (dtype == EDET_BF16) k_topk_hist<bf16_t><<<grid, 256, 0, st>>>(a);
-    else k_topk_hist<float><<<grid, 256, 0, st>>>(a);
-    k_topk_pick<<<batch, 256, 0, st>>>(a);
+    if (dtype == EDET_BF16) edet_launch(k_topk_hist<bf16_t>, grid, dim3(256), 0, st, a);
+    else edet_launch(k_topk_hist<float>, grid, dim3(256), 0, st, a);
+    edet_launch(k_topk_pick, dim3(batch), dim3(256), 0, st, a);
   }
-  if (dtype == EDET_BF16) k_topk_collect<bf16_t, false><<<grid, 256, 0, st>>>(a);
-  else k_topk_collect<float, false><<<grid, 256, 0, st>>>(a);
-  k_topk_eq_prefix<<<cdiv(batch, 64), 64, 0, st>>>(a, blocks);
-  if (dtype == EDET_BF16) k_topk_collect<bf16_t, true><<<grid, 256, 0, st>>>(a);
-  else k_topk_collect<float, true><<<grid, 256, 0, st>>>(a);
-  k_topk_sort_decode<<<batch, 1024, (size_t)a.Kpad * 8, st>>>(a);
-  if (dtype == EDET_BF16) k_topk_boxes<bf16_t><<<dim3(cdiv(k, 256), batch), 256, 0, st>>>(a);
-  else k_topk_boxes<float><<<dim3(cdiv(k, 256), batch), 256, 0, st>>>(a);
+  if (dtype == EDET_BF16) edet_launch(k_topk_collect<bf16_t, false>, grid, dim3(256), 0, st, a);
+  else edet_launch(k_topk_collect<float, false>, grid, dim3(256), 0, st, a);
+  edet_launch(k_topk_eq_prefix, dim3(cdiv(batch, 64)), dim3(64), 0, st, a, blocks);
+  if (dtype == EDET_BF16) edet_launch(k_topk_collect<bf16_t, true>, grid, dim3(256), 0, st, a);
+  else edet_launch(k_topk_collect<float, true>, grid, dim3(256), 0, st, a);
+  edet_launch(k_topk_sort_decode, dim3(batch), dim3(1024), (size_t)a.Kpad * 8, st, a);
+  if (dtype == EDET_BF16) edet_launch(k_topk_boxes<bf16_t>, dim3(cdiv(k, 256), batch), dim3(256), 0, st, a);
+  else edet_launch(k_topk_boxes<float>, dim3(cdiv(k, 256), batch), dim3(256), 0, st, a);
   EDET_LAUNCH_CHECK("edet_pre_nms_topk");
   return 0;
 }
@@ -865,15 +865,15 @@ extern "C" int edet_nms(const float* boxes, const float* scores, const int* clas
   a.sel_index = reinterpret_cast<int*>(w); w += (size_t)batch * segments * M * 4;
   a.sel_score = reinterpret_cast<float*>(w); w += (size_t)batch * segments * M * 4;
   a.sel_count = reinterpret_cast<int*>(w);
-  if (segments > 1) k_class_offsets<<<batch, NMS_THREADS, (size_t)segments * 4, st>>>(a);
+  if (segments > 1) edet_launch(k_class_offsets, dim3(batch), dim3(NMS_THREADS), (size_t)segments * 4, st, a);
   const dim3 grid(segments, batch);
-  if (cfg->convention == EDET_NMS_TF_V5) k_nms_segment<EDET_NMS_TF_V5><<<grid, NMS_THREADS, 0, st>>>(a);
-  else k_nms_segment<EDET_NMS_NUMPY><<<grid, NMS_THREADS, 0, st>>>(a);
+  if (cfg->convention == EDET_NMS_TF_V5) edet_launch(k_nms_segment<EDET_NMS_TF_V5>, grid, dim3(NMS_THREADS), 0, st, a);
+  else edet_launch(k_nms_segment<EDET_NMS_NUMPY>, grid, dim3(NMS_THREADS), 0, st, a);
   MergeArgs m;
   m.sel_index = a.sel_index; m.sel_score = a.sel_score; m.sel_count = a.sel_count;
   m.S = segments; m.M = M;
   m.out_index = out_index; m.out_score = out_score; m.out_valid = out_valid;
-  k_nms_merge<<<batch, NMS_THREADS, (size_t)segments * M, st>>>(m);
+  edet_launch(k_nms_merge, dim3(batch), dim3(NMS_THREADS), (size_t)segments * M, st, m);
   EDET_LAUNCH_CHECK("edet_nms");
   return 0;
 }
@@ -891,7 +891,7 @@ extern "C" int edet_nms_gather(const float* boxes, const int* classes, const int
   g.K = n; g.M = max_output_size; g.pad_mode = pad_mode;
   g.clip_h = clip_h; g.clip_w = clip_w; g.scales = image_scales;
   g.nms_boxes = nms_boxes; g.nms_scores = nms_scores; g.nms_classes = nms_classes;
-  k_nms_gather<<<dim3(cdiv(max_output_size, 128), batch), 128, 0, to_stream(stream)>>>(g);
+  edet_launch(k_nms_gather, dim3(cdiv(max_output_size, 128), batch), dim3(128), 0, to_stream(stream), g);
   EDET_LAUNCH_CHECK("edet_nms_gather");
   return 0;
 }

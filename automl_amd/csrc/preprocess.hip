@@ -81,8 +81,8 @@ extern "C" int edet_preprocess_infer(const void* raw_images, int raw_is_float, i
   a.out = out;
   *image_scale_to_original = 1.0f / scale;       // HOST output: the same scale for every image of the batch
   const dim3 grid(cdiv(out_width, 64), cdiv(out_height, 4), batch);
-  if (dtype == EDET_BF16) k_preprocess_infer<bf16_t><<<grid, 256, 0, to_stream(stream)>>>(a);
-  else k_preprocess_infer<float><<<grid, 256, 0, to_stream(stream)>>>(a);
+  if (dtype == EDET_BF16) edet_launch(k_preprocess_infer<bf16_t>, grid, dim3(256), 0, to_stream(stream), a);
+  else edet_launch(k_preprocess_infer<float>, grid, dim3(256), 0, to_stream(stream), a);
   EDET_LAUNCH_CHECK("edet_preprocess_infer");
   return 0;
 }

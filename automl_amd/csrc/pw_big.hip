@@ -834,7 +834,7 @@ int pwb_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
   static const bool ok = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<false, false>));
   if (!ok) return 0;
   const int grid = (a.ngrp + 7) / 8 * 8 * a.ntj;
-  k_big_gemm<false, false><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+  edet_launch(k_big_gemm<false, false>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
   EDET_LAUNCH_CHECK("edet_pw_fwd(big)");
   return 1;
 }
@@ -863,7 +863,7 @@ int pwb_try_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, int k, int
   static const bool ok = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<false, false, true>));
   if (!ok) return 0;
   const int grid = (a.ngrp + 7) / 8 * 8 * a.ntj;
-  k_big_gemm<false, false, true><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+  edet_launch(k_big_gemm<false, false, true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
   EDET_LAUNCH_CHECK("edet_conv_fwd(big)");
   return 1;
 }
@@ -888,8 +888,8 @@ int pwb_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tvi
   static const bool ok2 = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<true, true>));
   if (!ok1 || !ok2) return 0;
   const int grid = (a.ngrp + 7) / 8 * 8 * a.ntj;
-  if (dy->a) k_big_gemm<true, true><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
-  else k_big_gemm<true, false><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+  if (dy->a) edet_launch(k_big_gemm<true, true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
+  else edet_launch(k_big_gemm<true, false>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
   EDET_LAUNCH_CHECK("edet_pw_bwd_data(big)");
   return 1;
 }
@@ -925,12 +925,12 @@ int pwb_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight
     static const bool ok3 = big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad_bal<false>));
     static const bool ok4 = big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad_bal<true>));
     if (!ok3 || !ok4) return 0;
-    if (dy->a) k_big_wgrad_bal<true><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
-    else k_big_wgrad_bal<false><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+    if (dy->a) edet_launch(k_big_wgrad_bal<true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
+    else edet_launch(k_big_wgrad_bal<false>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
   } else if (dy->a) {
-    k_big_wgrad<true><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+    edet_launch(k_big_wgrad<true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
   } else {
-    k_big_wgrad<false><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+    edet_launch(k_big_wgrad<false>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
   }
   EDET_LAUNCH_CHECK("edet_pw_bwd_weight(big)");
   if (edet_reduce_partials(a.ws, a.S, kn, dweight, st) != 0) return -2;
@@ -963,8 +963,8 @@ int pwb_try_conv_dgrad(const edet_gview_t* dy, const void* w_t, int ldw, int k, 
   static const bool ok2 = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<true, true, true>));
   if (!ok1 || !ok2) return 0;
   const int grid = (a.ngrp + 7) / 8 * 8 * a.ntj;
-  if (dy->a) k_big_gemm<true, true, true><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
-  else k_big_gemm<true, false, true><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+  if (dy->a) edet_launch(k_big_gemm<true, true, true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
+  else edet_launch(k_big_gemm<true, false, true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
   EDET_LAUNCH_CHECK("edet_conv_bwd_data(big)");
   return 1;
 }
@@ -997,8 +997,8 @@ int pwb_try_conv_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, in
   static const bool ok2 = big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad<true, true>));
   if (!ok1 || !ok2) return 0;
   const int grid = (a.S + 7) / 8 * 8 * ntile;
-  if (dy->a) k_big_wgrad<true, true><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
-  else k_big_wgrad<false, true><<<dim3(grid), dim3(THREADS), SMEM_BYTES, st>>>(a);
+  if (dy->a) edet_launch(k_big_wgrad<true, true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
+  else edet_launch(k_big_wgrad<false, true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
   EDET_LAUNCH_CHECK("edet_conv_bwd_weight(big)");
   if (edet_reduce_partials(a.ws, a.S, kn, dweight, st) != 0) return -2;
   return 1;

@@ -412,11 +412,11 @@ int launch_gemm(GemmArgs& a, int* nparts_out, hipStream_t st) {
   const size_t extra = (size_t)(gate ? 4 : 2) * a.Jp * sizeof(float);
   if (nparts_out) *nparts_out = grid;
   if (a.J <= 32) {
-    k_gemm<T, 2, BWD><<<dim3(grid), dim3(THREADS), GemmCfg<T, 2>::TILE_BYTES + extra, st>>>(a);
+    edet_launch(k_gemm<T, 2, BWD>, dim3(grid), dim3(THREADS), GemmCfg<T, 2>::TILE_BYTES + extra, st, a);
   } else if (a.J <= 64) {
-    k_gemm<T, 4, BWD><<<dim3(grid), dim3(THREADS), GemmCfg<T, 4>::TILE_BYTES + extra, st>>>(a);
+    edet_launch(k_gemm<T, 4, BWD>, dim3(grid), dim3(THREADS), GemmCfg<T, 4>::TILE_BYTES + extra, st, a);
   } else {
-    k_gemm<T, 8, BWD><<<dim3(grid), dim3(THREADS), GemmCfg<T, 8>::TILE_BYTES + extra, st>>>(a);
+    edet_launch(k_gemm<T, 8, BWD>, dim3(grid), dim3(THREADS), GemmCfg<T, 8>::TILE_BYTES + extra, st, a);
   }
   EDET_LAUNCH_CHECK(BWD ? "edet_pw_bwd_data" : "edet_pw_fwd");
   return 0;
@@ -606,7 +606,7 @@ void launch_wgrad_nj(const WgradArgs& a, int grid, hipStream_t st) {
       attr_set = true;
     }
   }
-  k_wgrad<T, NJ><<<dim3(grid), dim3(THREADS), lds, st>>>(a);
+  edet_launch(k_wgrad<T, NJ>, dim3(grid), dim3(THREADS), lds, st, a);
 }
 
 template <typename T>

@@ -888,10 +888,10 @@ int pws_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
   if (nparts_out) *nparts_out = grid;
   if (NS == 8) {
     if (!allow_big_lds(&k_pw_fwd<8>, lds)) return 0;
-    k_pw_fwd<8><<<dim3(grid), dim3(THREADS), lds, st>>>(a);
+    edet_launch(k_pw_fwd<8>, dim3(grid), dim3(THREADS), lds, st, a);
   } else {
     if (!allow_big_lds(&k_pw_fwd<16>, lds)) return 0;
-    k_pw_fwd<16><<<dim3(grid), dim3(THREADS), lds, st>>>(a);
+    edet_launch(k_pw_fwd<16>, dim3(grid), dim3(THREADS), lds, st, a);
   }
   EDET_LAUNCH_CHECK("edet_pw_fwd(stream)");
   return 1;
@@ -939,7 +939,7 @@ int pws_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tvi
 #define PWS_DGRAD(NS_, GBN_)                                                    \
   do {                                                                          \
     if (!allow_big_lds(&k_pw_dgrad<NS_, GBN_>, lds)) return 0;                  \
-    k_pw_dgrad<NS_, GBN_><<<dim3(grid), dim3(THREADS), lds, st>>>(a);           \
+    edet_launch(k_pw_dgrad<NS_, GBN_>, dim3(grid), dim3(THREADS), lds, st, a);           \
   } while (0)
   if (gbn) PWS_DGRAD(8, true); else PWS_DGRAD(8, false);
 #undef PWS_DGRAD
@@ -979,7 +979,7 @@ int pws_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight
   int grid;
   if (a.nus >= 3) grid = ((a.nus + 3) / 4) * a.S;
   else grid = (a.S + WAVES / a.nus - 1) / (WAVES / a.nus);
-#define PWS_WG(UG_, GBN_) k_pw_wgrad<UG_, GBN_><<<dim3(grid), dim3(THREADS), 0, st>>>(a)
+#define PWS_WG(UG_, GBN_) edet_launch(k_pw_wgrad<UG_, GBN_>, dim3(grid), dim3(THREADS), 0, st, a)
   if (ug) { if (gbn) PWS_WG(true, true); else PWS_WG(true, false); }
   else { if (gbn) PWS_WG(false, true); else PWS_WG(false, false); }
 #undef PWS_WG

@@ -380,8 +380,8 @@ int stem_launch(bool fwd, StemArgs& a, hipStream_t st) {
     a.nsp = a.n * a.tiles_y * a.tiles_x;
     a.P = a.nsp < EDET_MAX_PARTS ? a.nsp : EDET_MAX_PARTS;
     EDET_CHECK(a.cout <= 64, "stem: cout %d unsupported (need <= 64)", a.cout);
-    if (a.cout <= 32) k_stem_fwd_mfma<1><<<dim3(a.P), dim3(THREADS), 0, st>>>(a);
-    else k_stem_fwd_mfma<2><<<dim3(a.P), dim3(THREADS), 0, st>>>(a);
+    if (a.cout <= 32) edet_launch(k_stem_fwd_mfma<1>, dim3(a.P), dim3(THREADS), 0, st, a);
+    else edet_launch(k_stem_fwd_mfma<2>, dim3(a.P), dim3(THREADS), 0, st, a);
     EDET_LAUNCH_CHECK("edet_stem_fwd");
     return 0;
   }
@@ -393,9 +393,9 @@ int stem_launch(bool fwd, StemArgs& a, hipStream_t st) {
 #define STEM_CASE(CV)                                                   \
   case CV:                                                              \
     if (fwd) {                                                          \
-      if constexpr (sizeof(T) == 4) k_stem_fwd<T, CV><<<grid, block, 0, st>>>(a); \
+      if constexpr (sizeof(T) == 4) edet_launch(k_stem_fwd<T, CV>, grid, block, 0, st, a); \
     } else {                                                            \
-      k_stem_bwd_weight<T, CV><<<grid, block, 0, st>>>(a);              \
+      edet_launch(k_stem_bwd_weight<T, CV>, grid, block, 0, st, a);              \
     }                                                                   \
     break;
   switch (a.cout / 8) {
@@ -452,8 +452,8 @@ extern "C" int edet_cast(const float* src, void* dst, int64_t count, int dtype, 
   EDET_CHECK(src && dst, "edet_cast: null pointer");
   if (count <= 0) return 0;
   const int grid = (int)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
-  if (dtype == EDET_BF16) k_cast<bf16_t><<<grid, 256, 0, to_stream(stream)>>>(src, (bf16_t*)dst, count);
-  else if (dtype == EDET_F32) k_cast<float><<<grid, 256, 0, to_stream(stream)>>>(src, (float*)dst, count);
+  if (dtype == EDET_BF16) edet_launch(k_cast<bf16_t>, grid, dim3(256), 0, to_stream(stream), src, (bf16_t*)dst, count);
+  else if (dtype == EDET_F32) edet_launch(k_cast<float>, grid, dim3(256), 0, to_stream(stream), src, (float*)dst, count);
   else EDET_CHECK(false, "edet_cast: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_cast");
   return 0;
@@ -466,9 +466,9 @@ extern "C" int edet_cast_matrix(const float* src, void* dst, int rows, int cols,
   const int64_t total = (int64_t)(transpose ? cols : rows) * ld_out;
   const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   if (dtype == EDET_BF16)
-    k_cast_matrix<bf16_t><<<grid, 256, 0, to_stream(stream)>>>(src, (bf16_t*)dst, rows, cols, ld_out, transpose);
+    edet_launch(k_cast_matrix<bf16_t>, grid, dim3(256), 0, to_stream(stream), src, (bf16_t*)dst, rows, cols, ld_out, transpose);
   else if (dtype == EDET_F32)
-    k_cast_matrix<float><<<grid, 256, 0, to_stream(stream)>>>(src, (float*)dst, rows, cols, ld_out, transpose);
+    edet_launch(k_cast_matrix<float>, grid, dim3(256), 0, to_stream(stream), src, (float*)dst, rows, cols, ld_out, transpose);
   else EDET_CHECK(false, "edet_cast_matrix: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_cast_matrix");
   return 0;
@@ -478,8 +478,8 @@ extern "C" int edet_cast_batch(const edet_cast_item_t* items_dev, int count, int
                                void* stream) {
   EDET_CHECK(items_dev && count > 0 && max_blocks_per_item > 0, "edet_cast_batch: bad arguments");
   const dim3 grid(max_blocks_per_item, count);
-  if (dtype == EDET_BF16) k_cast_batch<bf16_t><<<grid, 256, 0, to_stream(stream)>>>(items_dev);
-  else if (dtype == EDET_F32) k_cast_batch<float><<<grid, 256, 0, to_stream(stream)>>>(items_dev);
+  if (dtype == EDET_BF16) edet_launch(k_cast_batch<bf16_t>, grid, dim3(256), 0, to_stream(stream), items_dev);
+  else if (dtype == EDET_F32) edet_launch(k_cast_batch<float>, grid, dim3(256), 0, to_stream(stream), items_dev);
   else EDET_CHECK(false, "edet_cast_batch: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_cast_batch");
   return 0;

@@ -104,6 +104,16 @@ typedef struct edet_bwd_epi {
 const char* edet_last_error(void);
 int edet_version(void);
 
+/* ---- debug launch log ----------------------------------------------------------
+ * Test infrastructure on the product side of the boundary: while the log is on, the library counts every
+ * kernel launch by kernel symbol.  edet_debug_launch_log(1) clears the log and starts it, (0) stops it;
+ * edet_debug_launch_names writes "count<TAB>demangled kernel name<NEWLINE>" lines (NUL terminated, truncated
+ * to `capacity`; *needed = bytes for the whole text).  tests/test_gpu_bench_shapes.py uses it to assert that
+ * every kernel symbol of the full-size benchmark step is also launched by a test that checks results
+ * against the oracle.  The reference has no counterpart (TensorFlow picks its kernels internally).  */
+int edet_debug_launch_log(int enable);
+int edet_debug_launch_names(char* buf, size_t capacity, size_t* needed);
+
 /* ---- parameter preparation ------------------------------------------------
  * fp32 master -> compute copy (dtype), optionally transposed [rows][cols] ->
  * [cols][ld_out].  Replaces the Keras mixed-precision variable cast

@@ -1,0 +1,360 @@
+"""-m gpu: parity of the bf16 throughput path AT THE SHAPES AND SIZES OF THE BASELINE CONFIGURATIONS.
+
+tests/test_gpu_kernels.py checks every entry point on small ragged maps; the kernel variants that bench.py runs are
+chosen by shape (rows, map size, channel counts, workspace size), so this module repeats the checks where the
+benchmark lives (BASELINE.json configs[0] / configs[2]):
+
+  1. every C-ABI entry point of the hot path at the real EfficientDet-D0 640x640 layer shapes (two images), bf16,
+     against the CPU oracle -- same bodies as tests/test_gpu_kernels.py, engine-sized workspace;
+  2. the whole network: d0 512x512 batch 1 forward (configs[0]) and d0 640x640 batch 2 training-mode forward + full
+     train step (configs[2] at a batch the CPU oracle finishes in seconds), bf16 AND fp32 storage, against the fp32
+     oracle (tolerance stated in TOL) and against the bf16-storage-emulating oracle (tighter);
+  3. the full benchmark size, 640x640 batch 128, through a size-independent property: a batch made of 64 copies of
+     the 2 oracle-checked images must reproduce the 2-image step -- same activations, same losses, gradients and
+     updated variables (BatchNorm statistics of a tiled batch equal those of the tile; the loss normalizer is
+     scaled by 64).  This runs every kernel at its benchmark grid, on tensors beyond 2^31 bytes;
+  4. coverage: every kernel SYMBOL launched by the batch-128 step must also have been launched by a test of (1) or
+     by the oracle-checked 2-image step of (2) (the library's debug launch log, include/edet_hip.h).
+
+Tolerances.  fp32 storage: 1e-3 of the level's max |logit| (BASELINE.json north_star).  bf16 storage vs the fp32
+oracle: TOL['bf16_vs_f32'] -- the accumulated storage rounding of ~100 layers; vs the emulating oracle (rounds where
+the engine stores): TOL['bf16_vs_emu'] -- a few bf16 ulps, what is left are 1-ulp flips from fp32 summation order.
+"""
+import ctypes
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from automl_amd import _lib, hparams_config, train_lib
+from oracle import efficientdet_oracle as orc
+from tests import gpu_util as gu
+from tests import test_gpu_kernels as tk
+from tests.test_gpu_network import _seg_index, make_labels, perturbed_params, rel_err
+
+pytestmark = pytest.mark.gpu
+
+BF16 = gu.DTYPES[1]
+TOL = {'f32': 1e-3, 'bf16_vs_f32': 3e-2, 'bf16_vs_emu': 1e-2}
+ENGINE_WS_MIB = 64          # automl_amd/engine.py: the weight-gradient workspace the benchmark step hands over
+COVERED = {}                # kernel symbol -> launches, accumulated over the oracle-checked tests of this module
+
+
+@pytest.fixture(autouse=True)
+def _log_kernel_symbols():
+  _lib.launch_log_start()
+  yield
+  for k, v in _lib.launch_log_stop().items():
+    COVERED[k] = COVERED.get(k, 0) + v
+
+
+# ------------------------------------------------------------------ 1. entry points at the D0 640x640 layer shapes
+# (H = W, cin, cout, view of the conv input): 'plain' = a stored block output / depthwise output, 'gate' = BatchNorm +
+# swish + SE gate (the project convolutions), as engine.py builds them
+PW_LAYERS = [
+    (320, 32, 16, 'gate'), (320, 16, 96, 'plain'), (160, 96, 24, 'gate'), (160, 24, 144, 'plain'),
+    (160, 144, 24, 'gate'), (80, 144, 40, 'gate'), (80, 40, 240, 'plain'), (80, 240, 40, 'gate'),
+    (40, 240, 80, 'gate'), (40, 80, 480, 'plain'), (40, 480, 80, 'gate'), (40, 480, 112, 'gate'),
+    (40, 112, 672, 'plain'), (40, 672, 112, 'gate'), (20, 672, 192, 'gate'), (20, 192, 1152, 'plain'),
+    (20, 1152, 192, 'gate'), (20, 1152, 320, 'gate'),
+    (80, 40, 64, 'plain'), (40, 112, 64, 'plain'), (20, 320, 64, 'plain'),      # BiFPN resample 1x1
+    (80, 64, 64, 'plain'), (40, 64, 64, 'plain'), (20, 64, 64, 'plain'), (10, 64, 64, 'plain'), (5, 64, 64, 'plain'),
+    (80, 64, 810, 'plain'), (80, 64, 36, 'plain'), (40, 64, 810, 'plain'),      # class / box predict
+]
+DW_LAYERS = [   # (H = W of the input, channels, k, stride)
+    (320, 32, 3, 1), (320, 96, 3, 2), (160, 144, 3, 1), (160, 144, 5, 2), (80, 240, 5, 1), (80, 240, 3, 2),
+    (40, 480, 3, 1), (40, 480, 5, 1), (40, 672, 5, 1), (40, 672, 5, 2), (20, 1152, 5, 1), (20, 1152, 3, 1),
+    (80, 64, 3, 1), (40, 64, 3, 1), (20, 64, 3, 1), (10, 64, 3, 1), (5, 64, 3, 1),
+]
+N_IMG = 2
+
+
+def _pw_id(l):
+  return '%dx%dx%d->%d' % (l[0], l[0], l[1], l[2])
+
+
+def _dw_id(l):
+  return '%dx%dx%d_k%ds%d' % (l[0], l[0], l[1], l[2], l[3])
+
+
+@pytest.mark.parametrize('layer', PW_LAYERS, ids=_pw_id)
+def test_pw_fwd_at_d0_640_shapes(layer):
+  h, cin, cout, view = layer
+  tk.test_pw_fwd(BF16, (N_IMG, h, h, cin, cout), 'bn_swish_gate' if view == 'gate' else 'plain', 'auto')
+
+
+@pytest.mark.parametrize('layer', PW_LAYERS, ids=_pw_id)
+def test_pw_bwd_data_at_d0_640_shapes(layer):
+  """The epilogues the network uses: project layers chain into the SE-gated view ('gate'), expand / BiFPN / head
+  layers into a stored tensor ('plain'; 'plain_beta' where a residual or a second consumer already wrote the
+  gradient); dy carries the BatchNorm backward on load except for the predict layers."""
+  h, cin, cout, view = layer
+  predict = cout in (810, 36)
+  tk.test_pw_bwd_data(BF16, (N_IMG, h, h, cin, cout), 'gate' if view == 'gate' else 'plain', not predict, 'auto')
+  if view == 'plain' and cout > cin and not predict:
+    tk.test_pw_bwd_data(BF16, (N_IMG, h, h, cin, cout), 'plain_beta', True, 'auto')
+  if cin == 64 and cout == 64:
+    tk.test_pw_bwd_data(BF16, (N_IMG, h, h, cin, cout), 'bn_swish_stats', True, 'auto')
+
+
+@pytest.mark.parametrize('layer', PW_LAYERS, ids=_pw_id)
+def test_pw_bwd_weight_at_d0_640_shapes(layer):
+  h, cin, cout, view = layer
+  tk.test_pw_bwd_weight(BF16, (N_IMG, h, h, cin, cout), 'bn_swish_gate' if view == 'gate' else 'plain', True, 'auto',
+                        ws_mib=ENGINE_WS_MIB)
+
+
+@pytest.mark.parametrize('layer', DW_LAYERS, ids=_dw_id)
+def test_dw_fwd_at_d0_640_shapes(layer):
+  h, c, k, s = layer
+  tk.test_dw_fwd(BF16, (N_IMG, h, h, c), (k, s), 'bn_swish' if c != 64 else 'plain')
+
+
+@pytest.mark.parametrize('layer', DW_LAYERS, ids=_dw_id)
+def test_dw_bwd_at_d0_640_shapes(layer):
+  """edet_dw_bwd as the engine calls it (stride 1: the fused kernel, 4 channels per thread on the 320x320 / 160x160
+  maps; stride 2: the two separate kernels), BatchNorm backward on dy, BatchNorm-backward sums in the epilogue."""
+  h, c, k, s = layer
+  tk.test_dw_bwd(BF16, (N_IMG, h, h, c), (k, s), 'bn_swish_stats', 'one_call', ws_mib=ENGINE_WS_MIB)
+  if c == 64:    # BiFPN / head depthwise layers read a stored (fused / activated) tensor that has other consumers
+    tk.test_dw_bwd(BF16, (N_IMG, h, h, c), (k, s), 'plain_beta', 'one_call', ws_mib=ENGINE_WS_MIB)
+
+
+def test_stem_se_bn_fuse_at_d0_640_shapes():
+  tk.test_stem(BF16, (N_IMG, 640, 640, 32))
+  for shape in ((N_IMG, 320, 320, 32, 8), (N_IMG, 160, 160, 96, 4), (N_IMG, 40, 40, 672, 28), (N_IMG, 20, 20, 1152, 48)):
+    tk.test_squeeze_excite(BF16, shape)
+  for shape in ((N_IMG, 320, 320, 16), (N_IMG, 160, 160, 24), (N_IMG, 40, 40, 112)):
+    tk.test_batchnorm_train_fwd_bwd(BF16, shape)
+  for case in (((N_IMG, 80, 80, 64), [(_lib.RS_IDENTITY, 80, 80), (_lib.RS_UP2, 40, 40)], 'fastattn'),
+               ((N_IMG, 40, 40, 64), [(_lib.RS_IDENTITY, 40, 40), (_lib.RS_IDENTITY, 40, 40), (_lib.RS_POOL, 80, 80)],
+                'fastattn'),
+               ((N_IMG, 10, 10, 64), [(_lib.RS_POOL, 20, 20)], 'none')):
+    tk.test_fuse(BF16, case)
+
+
+# ------------------------------------------------------------------ 2. the whole network against the two oracles
+def _problem(size, batch, seed):
+  config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  config.override('image_size=%d' % size)
+  vals = perturbed_params(config, seed)
+  rng = np.random.default_rng(seed + 100)
+  images = torch.from_numpy(rng.standard_normal((batch, size, size, 3)).astype(np.float32)).to(torch.bfloat16).float()
+  return config, vals, images
+
+
+def _oracle(config, vals, storage):
+  return orc.Oracle(config=config, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()}, storage=storage)
+
+
+def _level_errs(got, want):
+  return [round(rel_err(g, w), 5) for g, w in zip(got, want)]
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_d0_512_batch1_forward_equals_oracle(dtype):
+  """BASELINE.json configs[0]: efficientdet-d0, 512x512, batch 1, inference forward; 49,104 anchors."""
+  config, vals, images = _problem(512, 1, 11)
+  net = train_lib.EfficientDetNetTrain(config=config, dtype=dtype, params=vals)
+  cls, box = net(images, training=False)
+  torch.cuda.synchronize()
+  assert [tuple(c.shape) for c in cls] == [(1, s, s, 810) for s in (64, 32, 16, 8, 4)]
+  assert sum(int(np.prod(c.shape[1:3])) * 9 for c in cls) == 49104
+  with torch.no_grad():
+    cref, bref = _oracle(config, vals, 'f32').forward(images, False)
+  e32 = _level_errs(cls, cref) + _level_errs(box, bref)
+  print('d0-512 forward %s vs fp32 oracle: %s' % (dtype, e32))
+  assert max(e32) <= (TOL['f32'] if dtype == 'f32' else TOL['bf16_vs_f32']), e32
+  if dtype == 'bf16':
+    with torch.no_grad():
+      cemu, bemu = _oracle(config, vals, 'bf16').forward(images, False)
+    eemu = _level_errs(cls, cemu) + _level_errs(box, bemu)
+    print('d0-512 forward bf16 vs emulating oracle: %s' % (eemu,))
+    assert max(eemu) <= TOL['bf16_vs_emu'], eemu
+
+
+class _Step(object):
+  """One train step of d0 at 640x640 on the device, with everything the comparisons need kept."""
+
+  def __init__(self, dtype, batch, tile_of=None):
+    self.config, self.vals, images2 = _problem(640, 2, 13)
+    labels2 = make_labels(self.config, 2, 640, 19)
+    self.images2, self.labels2 = images2, labels2
+    reps = batch // 2
+    images = images2.repeat(reps, 1, 1, 1)
+    labels = {k: np.tile(v, (reps,) + (1,) * (v.ndim - 1)) for k, v in labels2.items()}
+    # the loss normalizer sum(mean_num_positives) + 1 of the 2-image problem, times the number of copies: the loss
+    # and every variable's gradient are then those of the 2-image step
+    labels['normalizer'] = reps * (float(labels2['mean_num_positives'].sum()) + 1.0)
+    self.lr, self.decay = 0.02, 0.9
+    net = train_lib.EfficientDetNetTrain(config=self.config, dtype=dtype, params=self.vals)
+    eng = self.eng = net._ensure_engine(batch, 640, 640)
+    _lib.launch_log_start()
+    eng.forward(net._to_device_images(images, eng), training=True)
+    torch.cuda.synchronize()
+    self.cls = [c.float().cpu() for c in eng.outputs()[0]]
+    self.box = [b.float().cpu() for b in eng.outputs()[1]]
+    eng.loss_backward(net._labels_to_device(labels, eng))
+    eng.optimizer_step(self.lr, self.decay)
+    torch.cuda.synchronize()
+    self.kernels = _lib.launch_log_stop()
+    _lib.launch_log_start()       # the autouse fixture's log continues
+    self.losses = eng.loss_values()
+    self.grads = {name: (eng.grad(name).cpu() * eng.seg_factor.cpu()[_seg_index(eng, name)]).reshape(
+        eng.offsets[name][2]) for name in eng.seg_names}
+    self.new_params = eng.get_params()
+
+
+_STEPS = {}
+
+
+def _step(dtype, batch):
+  key = (dtype, batch)
+  if key not in _STEPS:
+    _STEPS[key] = _Step(dtype, batch)
+  return _STEPS[key]
+
+
+_ORACLE_STEPS = {}
+
+
+def _oracle_step(storage):
+  """The same 2-image step on the CPU oracle -> (cls, box, loss values, clipped gradients, updated variables)."""
+  if storage not in _ORACLE_STEPS:
+    config, vals, images = _problem(640, 2, 13)
+    labels = {k: torch.from_numpy(v) for k, v in make_labels(config, 2, 640, 19).items()}
+    o = _oracle(config, vals, storage)
+    with torch.no_grad():
+      cls, box = o.forward(images, True)
+    o = _oracle(config, vals, storage)
+    with torch.no_grad():
+      o.forward(images[:1, :64, :64], False)       # registers the trainable list
+    loss_vals, grads = orc.train_step(o, images, labels, {}, 0.02, 0.9)
+    _ORACLE_STEPS[storage] = (cls, box, loss_vals, {k: g.detach() for k, g in grads.items()},
+                              {k: v.detach().numpy() for k, v in o.params().items()})
+  return _ORACLE_STEPS[storage]
+
+
+def _grad_report(step, ref_grads):
+  """-> (cosine of the whole clipped gradient, worst per-tensor error relative to the tensor's max)."""
+  num = na = nb = 0.0
+  worst = (0.0, '')
+  gmax = max(float(g.abs().max()) for g in ref_grads.values())
+  for name, g in ref_grads.items():
+    mine = step.grads[name].double()
+    g = g.double()
+    num += float((mine * g).sum())
+    na += float((mine * mine).sum())
+    nb += float((g * g).sum())
+    e = float((mine - g).abs().max()) / max(float(g.abs().max()), 1e-3 * gmax)
+    if e > worst[0]:
+      worst = (e, name)
+  return num / np.sqrt(na * nb + 1e-300), worst
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_d0_640_batch2_train_step_equals_oracle(dtype):
+  """BASELINE.json configs[2] at two images: training-mode forward (batch statistics), focal + Huber loss, backward,
+  L2, clipping, SGD / EMA update -- logits per level, the six loss values, the clipped gradient of every variable
+  and the updated variables."""
+  step = _step(dtype, 2)
+  cref, bref, lref, gref, pref = _oracle_step('f32')
+  e32 = _level_errs(step.cls, cref) + _level_errs(step.box, bref)
+  tol = TOL['f32'] if dtype == 'f32' else TOL['bf16_vs_f32']
+  print('d0-640 B=2 training forward %s vs fp32 oracle: %s' % (dtype, e32))
+  assert max(e32) <= tol, e32
+  loss_tol = 2e-3 if dtype == 'f32' else 1e-2
+  for k in ('cls_loss', 'box_loss', 'det_loss', 'reg_l2_loss', 'loss', 'gradient_norm'):
+    assert abs(step.losses[k] - lref[k]) <= loss_tol * abs(lref[k]) + 1e-6, (k, step.losses[k], lref[k])
+  cos, worst = _grad_report(step, gref)
+  print('d0-640 B=2 %s: gradient cosine vs fp32 oracle %.6f, worst tensor %s' % (dtype, cos, worst))
+  if dtype == 'f32':
+    assert cos >= 0.99999 and worst[0] <= 1e-2, (cos, worst)
+  else:
+    assert cos >= 0.995, cos
+    cemu, bemu, lemu, gemu, pemu = _oracle_step('bf16')
+    eemu = _level_errs(step.cls, cemu) + _level_errs(step.box, bemu)
+    print('d0-640 B=2 training forward bf16 vs emulating oracle: %s' % (eemu,))
+    assert max(eemu) <= TOL['bf16_vs_emu'], eemu
+    for k in ('cls_loss', 'box_loss', 'loss'):
+      assert abs(step.losses[k] - lemu[k]) <= 3e-3 * abs(lemu[k]) + 1e-6, (k, step.losses[k], lemu[k])
+    cos_e, worst_e = _grad_report(step, gemu)
+    print('d0-640 B=2 bf16: gradient cosine vs emulating oracle %.6f, worst tensor %s' % (cos_e, worst_e))
+    assert cos_e >= 0.999, cos_e
+  upd = max(float(np.abs(step.new_params[n] - (pref if dtype == 'f32' else pemu)[n]).max()) /
+            max(float(np.abs(pref[n]).max()), 1e-6) for n in gref)
+  assert upd <= (1e-4 if dtype == 'f32' else 2e-3), 'updated variables differ: %g' % upd
+
+
+# ------------------------------------------------------------------ 3. the full benchmark size
+def test_d0_640_batch128_step_equals_the_tiled_2_image_step():
+  """BASELINE.json configs[2] at full size (128 images, 36 GB of activations, tensors up to 2.5 GB): 64 copies of
+  the 2 oracle-checked images.  Every stored activation and gradient buffer of the batch-128 executor must equal the
+  2-image executor's (each copy), the losses must agree, and so must the clipped gradients and updated variables."""
+  small, big = _step('bf16', 2), _step('bf16', 128)
+  reps = 64
+  worst_act, worst_grad = (0.0, ''), (0.0, '')
+  for key, t2 in small.eng._bufs.items():
+    t128 = big.eng._bufs.get(key)
+    if t128 is None or t2.dim() != 4 or t2.shape[0] != 2 or t128.shape[0] != 128 or t2.dtype != torch.bfloat16:
+      continue
+    a = t128.view((reps, 2) + tuple(t2.shape[1:])).float()
+    b = t2.float().unsqueeze(0)
+    is_grad = key.endswith('#grad') or key.endswith(':ds') or key.endswith(':dcg')
+    if is_grad:
+      a = a * reps          # per-image loss terms are 1/64 of the 2-image problem's
+    ref = float(b.abs().max())
+    if not np.isfinite(ref) or ref == 0.0:
+      continue
+    err = float((a - b).abs().max()) / ref
+    assert np.isfinite(err), key
+    if is_grad and err > worst_grad[0]:
+      worst_grad = (err, key)
+    if not is_grad and err > worst_act[0]:
+      worst_act = (err, key)
+    del a
+  print('batch 128 vs tiled batch 2: worst activation buffer %s, worst gradient buffer %s' % (worst_act, worst_grad))
+  assert worst_act[0] <= 2e-2, worst_act
+  assert worst_grad[0] <= 6e-2, worst_grad
+  for c128, c2 in zip(big.cls + big.box, small.cls + small.box):
+    assert rel_err(c128.view((reps, 2) + tuple(c2.shape[1:]))[reps - 1], c2) <= 2e-2
+  for k in ('cls_loss', 'box_loss', 'det_loss', 'reg_l2_loss', 'loss', 'gradient_norm'):
+    assert abs(big.losses[k] - small.losses[k]) <= 2e-3 * abs(small.losses[k]) + 1e-6, (k, big.losses[k], small.losses[k])
+  cos, worst = _grad_report(big, small.grads)
+  print('batch 128 vs tiled batch 2: gradient cosine %.6f, worst tensor %s' % (cos, worst))
+  assert cos >= 0.9995 and worst[0] <= 5e-2, (cos, worst)
+  upd = max(float(np.abs(big.new_params[n] - small.new_params[n]).max()) / max(float(np.abs(small.new_params[n]).max()), 1e-6)
+            for n in small.grads)
+  assert upd <= 1e-3, 'updated variables differ: %g' % upd
+
+
+# ------------------------------------------------------------------ 4. coverage of the benchmark's kernel symbols
+def _norm(name):
+  return name.replace('void ', '').replace(' ', '')
+
+
+def test_every_kernel_symbol_of_the_benchmark_step_is_parity_checked():
+  """Kernel symbols of the batch-128 step (debug launch log) and of the newest committed rocprofv3 kernel statistics of
+  bench.py (profiles/CURRENT names the file that belongs to this tree) must all have been launched by an
+  oracle-checked test: the entry-point cases above or the 2-image 640x640 step."""
+  big = _step('bf16', 128)
+  checked = dict(COVERED)
+  for k, v in _step('bf16', 2).kernels.items():
+    checked[k] = checked.get(k, 0) + v
+  have = {_norm(k) for k in checked}
+  missing = sorted(k for k in big.kernels if _norm(k) not in have)
+  print('batch-128 step: %d kernel symbols, %d launches; oracle-checked symbols: %d' % (
+      len(big.kernels), sum(big.kernels.values()), len(have)))
+  assert not missing, 'kernel symbols of the benchmark step that no parity test launches: %s' % missing
+  cur = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'CURRENT')
+  if not os.path.exists(cur):
+    pytest.skip('profiles/CURRENT not present: no rocprof statistics tied to this tree')
+  csv_path = os.path.join(os.path.dirname(cur), open(cur).read().strip())
+  import csv
+  names = [row['Name'] for row in csv.DictReader(open(csv_path))]
+  ours = [n for n in names if '::k_' in n or n.startswith('k_') or n.startswith('void k_')]
+  assert len(ours) >= 20, 'no library kernels in %s' % csv_path
+  missing = sorted(n for n in ours if _norm(n) not in have)
+  assert not missing, 'kernels of %s that no parity test launches: %s' % (os.path.basename(csv_path), missing)

@@ -2,7 +2,8 @@
 
 Tolerances (stated per BASELINE.json north_star): fp32 storage mode -- class/box logits within
 1e-3 relative (of the level's max |logit|) of the oracle; bf16 storage mode (the throughput
-configuration) -- within 6e-2, the accumulated effect of ~100 layers of 2^-8 storage rounding.
+configuration) -- within 6e-2 of the fp32 oracle, the accumulated effect of ~100 layers of 2^-8 storage
+rounding, and within 1.5e-2 of the oracle that emulates the bf16 storage points (oracle storage='bf16').
 Gradients (fp32 mode) within 1e-2 of each tensor's max |grad| (observed: 3 of 493 tensors above
 2e-3, worst 4e-3 -- fp32 summation-order noise through ~100 layers; losses agree to 7 digits).
 """
@@ -82,15 +83,21 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize('case', CASES, ids=lambda c: '%s[%s]@%d' % (c[0], c[1], c[2]))
-@pytest.mark.parametrize('training', [False, True])
-@pytest.mark.parametrize('dtype,tol', [('f32', 1e-3), ('bf16', 6e-2)])
-def test_forward_matches_oracle(case, training, dtype, tol):
-  if training and dtype == 'bf16':
-    # Batch statistics over the 2..32 samples that the top pyramid levels of a 128-pixel test image
-    # hold amplify bf16 storage noise by 1/sqrt(eps) ~ 30x (x_hat = (a-b)/sqrt((a-b)^2/4+eps) for 2
-    # samples); the fp32 run of the same kernels pins the logic at 1e-3, bf16 is checked loosely here.
-    tol = 0.5
+# bf16 storage, training-mode BatchNorm: batch statistics over the 2..8 samples that the top pyramid levels of a
+# 128-pixel image hold amplify ANY perturbation by 1/sqrt(eps) ~ 30x (x_hat = (a-b)/sqrt((a-b)^2/4+eps) for two
+# samples), so that mode is checked on images large enough for every BatchNorm layer to see >= 18 samples.
+BF16_TRAIN_CASES = [
+    ('efficientdet-d0', '', 384, 2),
+    ('efficientdet-d0', 'max_level=8,fpn_weight_method=sum', 768, 1),
+    ('efficientdet-d1', '', 384, 2),
+    ('efficientdet-d0', 'fpn_weight_method=channel_fastattn', 384, 2),
+    ('efficientdet-d0', 'act_type=relu6', 384, 2),
+]
+TOL_F32, TOL_BF16_VS_F32, TOL_BF16_VS_EMU = 1e-3, 6e-2, 1.5e-2
+
+
+def _forward_case(case, training, dtype):
+  """-> (per-level errors vs the fp32 oracle, vs the bf16-storage-emulating oracle or None, moving-stat error)."""
   model, override, size, batch = case
   config = hparams_config.get_efficientdet_config(model)
   config.override(override)
@@ -102,25 +109,53 @@ def test_forward_matches_oracle(case, training, dtype, tol):
   net = efficientdet_net.EfficientDetNet(config=config, dtype=dtype, params=vals)
   cls, box = net(torch.from_numpy(images), training=training)
   torch.cuda.synchronize()
-  oracle = orc.Oracle(config=config, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
-  oracle.drop_scale = drop_scales(net.engine)     # d1: 16 residual blocks with survival_prob < 1
-  assert bool(oracle.drop_scale) == (training and model != 'efficientdet-d0')
-  with torch.no_grad():
-    cls_ref, box_ref = oracle.forward(torch.from_numpy(images), training)
-  errs = []
-  for lvl, (c, cr, b, br) in enumerate(zip(cls, cls_ref, box, box_ref)):
-    assert tuple(c.shape) == tuple(cr.shape) and tuple(b.shape) == tuple(br.shape)
-    errs.append((lvl, rel_err(c, cr), rel_err(b, br)))
-  print('forward %s training=%s %s: per-level rel err (cls, box) = %s' % (case, training, dtype, errs))
+  out = []
+  for storage in (('f32', 'bf16') if dtype == 'bf16' else ('f32',)):
+    oracle = orc.Oracle(config=config, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()},
+                        storage=storage)
+    oracle.drop_scale = drop_scales(net.engine)     # d1: 16 residual blocks with survival_prob < 1
+    assert bool(oracle.drop_scale) == (training and model != 'efficientdet-d0')
+    with torch.no_grad():
+      cls_ref, box_ref = oracle.forward(torch.from_numpy(images), training)
+    errs = []
+    for lvl, (c, cr, b, br) in enumerate(zip(cls, cls_ref, box, box_ref)):
+      assert tuple(c.shape) == tuple(cr.shape) and tuple(b.shape) == tuple(br.shape)
+      errs.append((lvl, round(rel_err(c, cr), 5), round(rel_err(b, br), 5)))
+    out.append(errs)
+    if storage == 'f32':
+      moving = 0.0
+      if training:
+        new = net.get_weights()
+        for k, v in oracle.new_moving.items():
+          moving = max(moving, float(np.abs(new[k] - v.numpy()).max()) / max(float(v.abs().max()), 1e-6))
+  return out[0], (out[1] if len(out) > 1 else None), moving
+
+
+def _assert_levels(errs, tol, what):
   bad = [e for e in errs if not (e[1] <= tol and e[2] <= tol)]
-  assert not bad, 'logits differ from the oracle beyond %g: %s' % (tol, errs)
-  if training:
-    new = net.get_weights()
-    worst = 0.0
-    for k, v in oracle.new_moving.items():
-      d = float(np.abs(new[k] - v.numpy()).max()) / max(float(v.abs().max()), 1e-6)
-      worst = max(worst, d)
-    assert worst <= (1e-3 if dtype == 'f32' else 0.2), 'moving statistics differ: %g' % worst
+  assert not bad, '%s: logits differ beyond %g: %s' % (what, tol, errs)
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: '%s[%s]@%d' % (c[0], c[1], c[2]))
+@pytest.mark.parametrize('training', [False, True])
+def test_forward_matches_oracle_fp32(case, training):
+  """fp32 storage: the north_star tolerance, 1e-3 of each level's max |logit|, both BatchNorm modes."""
+  e32, _, moving = _forward_case(case, training, 'f32')
+  print('forward %s training=%s f32: per-level rel err (cls, box) = %s' % (case, training, e32))
+  _assert_levels(e32, TOL_F32, 'fp32 vs oracle')
+  assert moving <= 1e-3, 'moving statistics differ: %g' % moving
+
+
+@pytest.mark.parametrize('case,training', [(c, False) for c in CASES] + [(c, True) for c in BF16_TRAIN_CASES],
+                         ids=lambda v: ('%s[%s]@%d' % (v[0], v[1], v[2])) if isinstance(v, tuple) else str(v))
+def test_forward_matches_oracle_bf16(case, training):
+  """bf16 storage (the throughput path): within TOL_BF16_VS_F32 of the fp32 oracle -- the accumulated storage
+  rounding of ~100 layers -- and within TOL_BF16_VS_EMU of the oracle that rounds where the engine stores."""
+  e32, eemu, moving = _forward_case(case, training, 'bf16')
+  print('forward %s training=%s bf16: vs fp32 oracle %s\n   vs emulating oracle %s' % (case, training, e32, eemu))
+  _assert_levels(e32, TOL_BF16_VS_F32, 'bf16 vs fp32 oracle')
+  _assert_levels(eemu, TOL_BF16_VS_EMU, 'bf16 vs emulating oracle')
+  assert moving <= 2e-2, 'moving statistics differ: %g' % moving
 
 
 @pytest.mark.parametrize('case', CASES[:2] + [('efficientdet-d1', '', 96, 3), CASES[3], ('efficientdet-d7x', '', 384, 2), CASES[4],
@@ -202,19 +237,16 @@ def _seg_index(eng, name):
   return int((eng.seg_offsets.cpu() == off).nonzero()[0][0])
 
 
-def test_train_step_bf16_runs_and_tracks_oracle():
-  """bf16 storage: losses within 3 %, global gradient direction (cosine) > 0.85 vs the fp32 oracle."""
+def test_train_step_bf16_tracks_both_oracles():
+  """bf16 storage, one full step of d0 at 384 px (every BatchNorm layer sees >= 18 samples): loss values and the
+  direction of the whole clipped gradient against the fp32 oracle (storage rounding of ~100 layers, both ways) and
+  against the oracle that emulates the bf16 storage points (tight)."""
   config = hparams_config.get_efficientdet_config('efficientdet-d0')
-  size, batch = 128, 2
+  size, batch = 384, 2
   vals = perturbed_params(config, 7)
   rng = np.random.default_rng(31)
   images = torch.from_numpy(rng.standard_normal((batch, size, size, 3)).astype(np.float32)).to(torch.bfloat16).float()
   labels = make_labels(config, batch, size, 37)
-  oracle = orc.Oracle(config=config, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
-  with torch.no_grad():
-    oracle.forward(images, False)
-  ref_vals, ref_grads = orc.train_step(oracle, images, {k: torch.from_numpy(v) for k, v in labels.items()},
-                                       {}, 0.02, 0.9)
   net = train_lib.EfficientDetNetTrain(config=config, dtype='bf16', params=vals)
   eng = net._ensure_engine(batch, size, size)
   eng.forward(net._to_device_images(images, eng), training=True)
@@ -222,19 +254,26 @@ def test_train_step_bf16_runs_and_tracks_oracle():
   eng.optimizer_step(0.02, 0.9)
   torch.cuda.synchronize()
   got = eng.loss_values()
-  print('bf16 loss values: got %s\n ref %s' % (got, ref_vals))
-  for k in ('cls_loss', 'box_loss', 'loss'):
-    assert abs(got[k] - ref_vals[k]) <= 3e-2 * abs(ref_vals[k]) + 1e-4, (k, got[k], ref_vals[k])
-  num = den_a = den_b = 0.0
-  for name, g in ref_grads.items():
-    off, n, shape, _ = eng.offsets[name]
-    mine = (eng.grads_flat[off:off + n].cpu() * eng.seg_factor.cpu()[_seg_index(eng, name)]).double()
-    num += float((mine * g.reshape(-1).double()).sum())
-    den_a += float((mine**2).sum())
-    den_b += float((g.double()**2).sum())
-  cos = num / (np.sqrt(den_a * den_b) + 1e-30)
-  print('bf16 gradient cosine vs fp32 oracle: %.5f' % cos)
-  assert cos > 0.85, cos    # tiny-pyramid BN noise amplification, see test_forward_matches_oracle
+  for storage, loss_tol, cos_min in (('f32', 2e-2, 0.99), ('bf16', 5e-3, 0.998)):
+    oracle = orc.Oracle(config=config, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()},
+                        storage=storage)
+    with torch.no_grad():
+      oracle.forward(images[:1, :64, :64], False)
+    ref_vals, ref_grads = orc.train_step(oracle, images, {k: torch.from_numpy(v) for k, v in labels.items()},
+                                         {}, 0.02, 0.9)
+    print('bf16 loss values: got %s\n %s oracle %s' % (got, storage, ref_vals))
+    for k in ('cls_loss', 'box_loss', 'loss'):
+      assert abs(got[k] - ref_vals[k]) <= loss_tol * abs(ref_vals[k]) + 1e-4, (storage, k, got[k], ref_vals[k])
+    num = den_a = den_b = 0.0
+    for name, g in ref_grads.items():
+      off, n, shape, _ = eng.offsets[name]
+      mine = (eng.grads_flat[off:off + n].cpu() * eng.seg_factor.cpu()[_seg_index(eng, name)]).double()
+      num += float((mine * g.reshape(-1).double()).sum())
+      den_a += float((mine**2).sum())
+      den_b += float((g.double()**2).sum())
+    cos = num / (np.sqrt(den_a * den_b) + 1e-30)
+    print('bf16 gradient cosine vs the %s oracle: %.5f' % (storage, cos))
+    assert cos >= cos_min, (storage, cos)
 
 
 def test_two_steps_decrease_loss_and_are_deterministic_in_shape():
