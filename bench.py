@@ -1,7 +1,8 @@
 """Headline benchmark: EfficientDet-D0 640x640 forward+backward (one full train_step) images/sec.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: launched by torch.distributed.run with one rank per GPU; started WITHOUT it, `--gpus N` spawns the N ranks
+  itself through `python -m torch.distributed.run --standalone`-style arguments on 127.0.0.1)
 
 One step = forward (training BatchNorm), focal+Huber loss, backward, L2, clip, [gradient all-reduce
 SUM over RCCL], SGD-momentum + EMA update on a synthetic COCO-shaped batch already resident in HBM
@@ -90,31 +91,157 @@ def synth_batch(config, batch, size, seed, device, tdtype):
   return images, labels
 
 
-def cpu_baseline(config, size, seconds_budget=25.0):
-  """fp32 CPU oracle train step (forward+backward+update) on a bounded sample of the same workload."""
+def physical_cores():
+  """Distinct (socket, core) pairs of /proc/cpuinfo; falls back to the logical count."""
+  try:
+    pairs, phys, core = set(), None, None
+    for line in open('/proc/cpuinfo'):
+      if line.startswith('physical id'):
+        phys = line.split(':')[1].strip()
+      elif line.startswith('core id'):
+        core = line.split(':')[1].strip()
+      elif not line.strip():
+        if phys is not None and core is not None:
+          pairs.add((phys, core))
+        phys = core = None
+    return len(pairs) or os.cpu_count()
+  except OSError:
+    return os.cpu_count()
+
+
+def cpu_baseline(config, size, seconds_budget=28.0):
+  """The fp32 CPU oracle on the host cores, timed with the reference's recipe (tf2/infer_lib.py:181-207: warm-up
+  runs, then the mean of timed runs), on a bounded sample of the workloads SURVEY.md section 8d names:
+  (i) efficientdet-d0 512x512 batch 1 inference forward (BASELINE configs[0]), (ii) efficientdet-d0 at the
+  benchmark image size, batch 8, one full train step (forward + backward + update).  `value` is (ii)."""
   from oracle import efficientdet_oracle as orc
   threads = torch.get_num_threads()
-  batch = 2
   spec = netspec.NetSpec(config)
   vals = netspec.init_params(spec, 0)
-  oracle = orc.Oracle(config=config, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
+
+  def fresh(cfg):
+    return orc.Oracle(config=cfg, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
+
+  # (i) forward, 512x512, batch 1
+  c512 = hparams_config.get_efficientdet_config('efficientdet-d0')
+  o = fresh(c512)
+  x = torch.from_numpy(np.random.default_rng(1).standard_normal((1, 512, 512, 3)).astype(np.float32))
+  with torch.no_grad():
+    for _ in range(3):
+      o.forward(x, False)
+    n_fwd, t0 = 0, time.perf_counter()
+    while n_fwd < 10 and (n_fwd == 0 or time.perf_counter() - t0 < 0.25 * seconds_budget):
+      o.forward(x, False)
+      n_fwd += 1
+    fwd_dt = (time.perf_counter() - t0) / n_fwd
+  # (ii) train step, batch 8: one warm-up step on 2 images, then timed steps inside the budget
+  batch = 8
+  oracle = fresh(config)
   images, labels = synth_batch(config, batch, size, 3, 'cpu', torch.float32)
   labels = {k: v for k, v in labels.items() if k != 'normalizer'}
   with torch.no_grad():
     oracle.forward(images[:1, :64, :64], False)       # registers the variable list
   state = {}
-  t0 = time.perf_counter()
-  orc.train_step(oracle, images, labels, state, 0.01, 0.9)     # warm-up
-  warm = time.perf_counter() - t0
-  iters = max(1, min(4, int(seconds_budget / max(warm, 1e-3)) - 1))
-  t0 = time.perf_counter()
-  for _ in range(iters):
+  orc.train_step(oracle, images[:2], {k: v[:2] for k, v in labels.items()}, state, 0.01, 0.9)     # warm-up
+  n_step, t0 = 0, time.perf_counter()
+  while n_step < 10 and (n_step == 0 or time.perf_counter() - t0 < 0.6 * seconds_budget):
     orc.train_step(oracle, images, labels, state, 0.01, 0.9)
-  dt = (time.perf_counter() - t0) / iters
-  return {'value': batch / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-          'sample': 'fp32 PyTorch-CPU oracle (restatement of the reference graph; the reference TF binary '
-                    'is not installable), efficientdet-d0 %dx%d batch %d train_step, 1 warm-up + %d timed'
-                    % (size, size, batch, iters)}
+    n_step += 1
+  dt = (time.perf_counter() - t0) / n_step
+  return {'value': batch / dt, 'unit': 'images/sec', 'cores': threads, 'physical_cores': physical_cores(),
+          'kind': 'port',
+          'forward_d0_512_b1_images_per_sec': 1.0 / fwd_dt,
+          'sample': 'fp32 PyTorch-CPU oracle (a restatement of the reference graph: the reference\'s TensorFlow '
+                    'binary is not installable here) on %d threads; value = efficientdet-d0 %dx%d batch %d full '
+                    'train step, 1 warm-up (2 images) + %d timed; also d0 512x512 batch 1 inference forward, '
+                    '3 warm-up + %d timed' % (threads, size, size, batch, n_step, n_fwd)}
+
+
+def parity_block(config, size):
+  """One bf16 training-mode forward of the benchmark network on 2 images against the fp32 oracle and against the
+  oracle that emulates the bf16 storage points: per-level max |logit error| / max |logit| (class, box).  Checker
+  only -- the measured path above never touches the oracle."""
+  from oracle import efficientdet_oracle as orc
+  spec = netspec.NetSpec(config)
+  vals = netspec.init_params(spec, 0)
+  rng = np.random.default_rng(5)
+  images = torch.from_numpy(rng.standard_normal((2, size, size, 3)).astype(np.float32)).to(torch.bfloat16).float()
+  net = train_lib.EfficientDetNetTrain(config=config, dtype='bf16', params=vals)
+  cls, box = net(images, training=True)
+  torch.cuda.synchronize()
+  out = {'workload': 'efficientdet-d0 %dx%d batch 2 bf16 training-mode forward, per level (class, box)' % (size, size)}
+  for storage in ('f32', 'bf16'):
+    o = orc.Oracle(config=config, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()}, storage=storage)
+    with torch.no_grad():
+      cr, br = o.forward(images, True)
+    errs = []
+    for c, r, b, q in zip(cls, cr, box, br):
+      errs.append([float((c.float().cpu() - r).abs().max() / r.abs().max()),
+                   float((b.float().cpu() - q).abs().max() / q.abs().max())])
+    out['vs_fp32_oracle' if storage == 'f32' else 'vs_bf16_storage_emulating_oracle'] = errs
+  return out
+
+
+def other_configs():
+  """The two other single-GPU BASELINE configurations, measured with the same recipe (not the headline value):
+  configs[1] efficientnetv2-s backbone 224x224 batch 256 bf16 forward; the per-GPU leg of configs[4]
+  efficientdet-d7x 1536x1536 batch 8 full train step."""
+  from automl_amd import effnetv2_model
+  out = {}
+  net = effnetv2_model.EffNetV2Model('efficientnetv2-s', include_top=False, dtype='bf16')
+  images = torch.from_numpy(np.random.default_rng(2).standard_normal((256, 224, 224, 3)).astype(np.float32))
+  images = images.to('cuda:0', torch.bfloat16).contiguous()
+  eng = net._ensure_engine(256, 224, 224)
+  for _ in range(3):
+    eng.forward(images, training=False)
+  torch.cuda.synchronize()
+  g = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(g):
+    eng.forward(images, training=False)
+  g.replay()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(20):
+    g.replay()
+  torch.cuda.synchronize()
+  dt = (time.perf_counter() - t0) / 20
+  out['efficientnetv2-s 224x224 batch 256 bf16 forward (BASELINE configs[1])'] = {
+      'images_per_sec': 256 / dt, 'ms_per_step': dt * 1e3, 'steps': 20,
+      'hbm_frac': 49.0e6 * 256 / dt / 1e9 / HBM_PEAK_GBS}        # SURVEY 8d: 49.0 MB / image forward
+  del net, eng, g, images
+  torch.cuda.empty_cache()
+  config = hparams_config.get_efficientdet_config('efficientdet-d7x')
+  net = train_lib.EfficientDetNetTrain(config=config, dtype='bf16', seed=0, global_batch_size=8, steps_per_epoch=1000,
+                                       use_graph=True)
+  eng = net._ensure_engine(8, 1536, 1536)
+  images, labels = synth_batch(config, 8, 1536, 3, 'cuda:0', eng.tdtype)
+  labels.pop('normalizer')
+  for _ in range(3):
+    net.train_step((images, labels), sync_loss=False)
+  images, labels = net.input_buffers()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(5):
+    net.train_step((images, labels), sync_loss=False)
+  torch.cuda.synchronize()
+  dt = (time.perf_counter() - t0) / 5
+  out['efficientdet-d7x 1536x1536 batch 8 bf16 train step, stochastic depth on (BASELINE configs[4], per-GPU leg)'] = {
+      'images_per_sec': 8 / dt, 'ms_per_step': dt * 1e3, 'steps': 5,
+      'hbm_frac': 38630.0e6 * 8 / dt / 1e9 / HBM_PEAK_GBS}      # SURVEY 8d: 38,630 MB / image fwd+bwd
+  return out
+
+
+def spawn_ranks(args):
+  """`python bench.py --gpus N` started by hand: run the N ranks through torch.distributed.run on 127.0.0.1 and
+  pass rank 0's JSON line through."""
+  import socket
+  import subprocess
+  with socket.socket() as sk:
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+         '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  raise SystemExit(subprocess.call(cmd, env=dict(os.environ, EDET_BENCH_SPAWNED='1')))
 
 
 def main():
@@ -126,7 +253,9 @@ def main():
   ap.add_argument('--image_size', type=int, default=640)
   ap.add_argument('--model', default='efficientdet-d0')
   ap.add_argument('--dtype', default='bf16')
-  ap.add_argument('--no_cpu_baseline', action='store_true')
+  ap.add_argument('--no_cpu_baseline', action='store_true', help='skip the cpu_baseline and parity legs')
+  ap.add_argument('--no_other_configs', action='store_true',
+                  help='skip the V2-S / D7x side measurements (they run at N = 1 on the headline workload only)')
   ap.add_argument('--dump_launches', default='', help='write the per-(kernel, shape) launch table of one step here')
   ap.add_argument('--graph', type=int, default=int(os.environ.get('EDET_GRAPH', '1')),
                   help='1: the timed steps replay the step captured as a hipGraph; 0: eager launches')
@@ -135,8 +264,10 @@ def main():
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   world = int(os.environ.get('WORLD_SIZE', '1'))
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    spawn_ranks(args)
   if args.gpus > 1 and world != args.gpus:
-    raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+    raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
   # EDET_BENCH_SAME_DEVICE=1 + EDET_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a 1-GPU box (all ranks
   # on cuda:0, gloo between them); never set for a measurement
   if os.environ.get('EDET_BENCH_SAME_DEVICE') == '1':
@@ -218,10 +349,14 @@ def main():
     eager_ms_per_step = (time.perf_counter() - t1) / args.steps * 1e3
   prof = _lib.profiler.summary()
   _lib.profiler = None
+  ranks_seen = 1
   if dist is not None:
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    ones = torch.ones(1, dtype=torch.float32, device=device)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)          # through the same RCCL communicator as the gradients
+    ranks_seen = int(ones.item())
   losses = eng.loss_values()
 
   if rank == 0:
@@ -243,7 +378,7 @@ def main():
                                    args.model, args.image_size, args.image_size, args.batch,
                                    'BASELINE configs[2]' if is_headline else
                                    ('BASELINE configs[4] per-GPU leg' if 'd7x' in args.model else 'not a BASELINE config')),
-                   'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
+                   'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'ranks_seen': ranks_seen,
                    'loss': losses.get('loss'),
                    'launch': 'hipGraph replay of the captured step' if args.graph else 'eager',
                    'host_enqueue_ms_per_step': host_enqueue / args.steps * 1e3,
@@ -266,6 +401,14 @@ def main():
     }
     if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
       out['cpu_baseline'] = cpu_baseline(config, args.image_size)
+      if is_headline:
+        out['parity'] = parity_block(config, args.image_size)
+    if is_headline and world == 1 and not args.no_other_configs:
+      net._graph, net.engine = None, None      # release the headline workload's 36 GB of activation buffers
+      net._engines.clear()
+      eng._bufs.clear()
+      torch.cuda.empty_cache()
+      out['other_configs'] = other_configs()
     print(json.dumps(out))
   if dist is not None:
     dist.barrier()

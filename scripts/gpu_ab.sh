@@ -8,7 +8,7 @@ if [ -n "$K" ]; then
 fi
 for v in "$@"; do
   name=${v%%:*}; envs=${v#*:}
-  (env $envs timeout 600 python bench.py --steps 5 --warmup 2 --no_cpu_baseline --dump_launches gpurun_out/${T}_${name}_launches.txt 2>&1 | tail -1) > gpurun_out/${T}_${name}_bench.log
+  (env $envs timeout 600 python bench.py --steps 5 --warmup 2 --no_cpu_baseline --no_other_configs --dump_launches gpurun_out/${T}_${name}_launches.txt 2>&1 | tail -1) > gpurun_out/${T}_${name}_bench.log
   echo "$name: $(python -c "
 import json,sys
 try:

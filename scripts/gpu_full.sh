@@ -7,10 +7,10 @@ export TMPDIR=/tmp
 (timeout 900 python -m pytest tests -m gpu -q --durations=5 2>&1 | tail -25) > gpurun_out/${T}_pytest_gpu.log
 (timeout 300 python __graft_entry__.py smoke 2>&1 | tail -4) > gpurun_out/${T}_smoke.log
 (timeout 600 python bench.py --steps 10 --warmup 3 --dump_launches gpurun_out/${T}_launches.txt 2>&1 | tail -3) > gpurun_out/${T}_bench_b128.log
-(timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${T} -o ${T} --output-format csv -- python bench.py --steps 3 --warmup 1 --no_cpu_baseline 2>&1 | tail -3) > gpurun_out/${T}_prof.log
+(timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${T} -o ${T} --output-format csv -- python bench.py --steps 3 --warmup 1 --no_cpu_baseline --no_other_configs 2>&1 | tail -3) > gpurun_out/${T}_prof.log
 rm -f gpurun_out/prof_${T}/*kernel_trace.csv gpurun_out/prof_${T}/*/*kernel_trace.csv
 run() {
-  timeout 600 rocprofv3 --kernel-trace --pmc $2 -d gpurun_out/${T}_$1 -o $1 --output-format csv -- python bench.py --steps 1 --warmup 1 --no_cpu_baseline > gpurun_out/${T}_$1.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $2 -d gpurun_out/${T}_$1 -o $1 --output-format csv -- python bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_other_configs > gpurun_out/${T}_$1.log 2>&1
   python scripts/pmc_agg.py gpurun_out/${T}_$1 > gpurun_out/${T}_pmc_$1.txt 2>&1
   rm -rf gpurun_out/${T}_$1
 }

@@ -4,7 +4,7 @@ T=${1:-pmc}
 export TMPDIR=/tmp
 rocprofv3 -L 2>/dev/null | grep -E "^\s*(Name|gpu-agent|.*SQ_WAIT|.*SQ_ACTIVE_INST|.*SQ_INSTS_V|.*SQ_BUSY_CY|.*SQ_WAVE_CY|.*FETCH_SIZE|.*WRITE_SIZE|.*TA_BUSY|.*TCP_|.*GRBM_GUI)" | head -80 > gpurun_out/${T}_counters.txt
 run() {
-  timeout 600 rocprofv3 --kernel-trace --pmc $2 -d gpurun_out/${T}_$1 -o $1 --output-format csv -- python bench.py --steps 1 --warmup 1 --no_cpu_baseline > gpurun_out/${T}_$1.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $2 -d gpurun_out/${T}_$1 -o $1 --output-format csv -- python bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_other_configs > gpurun_out/${T}_$1.log 2>&1
   python scripts/pmc_agg.py gpurun_out/${T}_$1 > gpurun_out/${T}_$1_agg.txt 2>&1
   rm -rf gpurun_out/${T}_$1
 }
