@@ -1,5 +1,5 @@
-// Anchor labelling on device -- UNVERIFIED ON HARDWARE (written without GPU time left in the
-// round; lives on the branch wip/labeling-device until `pytest -m gpu tests/test_labeling.py` has passed).
+// Anchor labelling on device.
+//
 //
 //   edet_label_anchors   tf2/anchors.py AnchorLabeler.label_anchors :215-250 for a batch: IoU of every groundtruth
 //                        box with every anchor (object_detection/region_similarity_calculator.py:42-88), ArgMaxMatcher

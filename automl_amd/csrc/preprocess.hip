@@ -1,4 +1,4 @@
-// Inference image preprocessing on device -- UNVERIFIED ON HARDWARE (branch wip/round2-prep).
+// Inference image preprocessing on device.
 //
 //   edet_preprocess_infer   efficientdet_keras.EfficientDetModel._preprocessing(mode='infer') :920-951 =
 //                           dataloader.InputProcessor.normalize_image :58-64, set_scale_factors_to_output_size

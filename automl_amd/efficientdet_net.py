@@ -116,11 +116,26 @@ class EfficientDetNet(object):
 class EfficientDetModel(EfficientDetNet):
   """EfficientDet full model with post-processing: ``efficientdet_keras.EfficientDetModel`` (:917-1000).
 
-  ``model(inputs, training=False, pre_mode='infer', post_mode='global')``.  Image preprocessing is
-  not built: ``pre_mode`` must be None / '' and ``inputs`` the normalised [B, H, W, 3] batch at ``config.image_size``;
-  the default 'infer' of the reference signature raises.  ``post_mode``: 'global' / 'per_class' run on the GPU
-  (automl_amd/postprocess.py) and return (boxes, scores, classes, valid_len); None returns the raw level outputs.
+  ``model(inputs, training=False, pre_mode='infer', post_mode='global')``.  ``pre_mode='infer'`` (the reference's
+  default): ``inputs`` are raw [B, H, W, 3] images (uint8 or float, 0..255) of one size; they are normalised with
+  config.mean_rgb / stddev_rgb, resized with the aspect ratio kept into the top-left corner of config.image_size
+  and zero padded on the GPU (automl_amd/preprocess.py), and the detections come back in the pixels of the raw
+  images.  ``pre_mode`` None / '': ``inputs`` is the normalised batch at config.image_size.  ``post_mode``: 'global' /
+  'per_class' run on the GPU (automl_amd/postprocess.py) and return (boxes, scores, classes, valid_len); None returns
+  the raw level outputs.
   """
+
+  def _preprocessing(self, raw_images, image_size, mean_rgb, stddev_rgb, mode=None):
+    """Preprocess images before feeding to the network (efficientdet_keras.py:920-951)."""
+    if not mode:
+      return raw_images, None
+    if mode != 'infer':
+      raise ValueError('preprocessing must be infer or empty')
+    from automl_amd import preprocess
+    if isinstance(raw_images, np.ndarray):
+      raw_images = torch.from_numpy(raw_images)
+    tdt = torch.bfloat16 if self._dtype in ('bf16', 1) else torch.float32
+    return preprocess.preprocess_infer(raw_images, image_size, mean_rgb, stddev_rgb, dtype=tdt)
 
   def _postprocess(self, cls_outputs, box_outputs, scales, mode='global'):
     """Postprocess class and box predictions (efficientdet_keras.py:953-976)."""
@@ -136,12 +151,11 @@ class EfficientDetModel(EfficientDetNet):
     raise ValueError('Unsupported postprocess mode {}'.format(mode))
 
   def __call__(self, inputs, training=False, pre_mode='infer', post_mode='global'):
-    if pre_mode:
-      raise ValueError('image preprocessing (pre_mode=%r) is not built: pass normalised images of config.image_size '
-                       'with pre_mode=None' % (pre_mode,))
+    config = self.config
+    inputs, scales = self._preprocessing(inputs, config.image_size, config.mean_rgb, config.stddev_rgb, pre_mode)
     cls_outputs, box_outputs = EfficientDetNet.__call__(self, inputs, training)
     if post_mode:
-      return self._postprocess(cls_outputs, box_outputs, None, post_mode)
+      return self._postprocess(cls_outputs, box_outputs, scales, post_mode)
     return cls_outputs, box_outputs
 
   call = __call__

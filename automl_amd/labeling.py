@@ -4,8 +4,6 @@
 ``(cls_targets_dict, box_targets_dict, num_positives)`` keyed by level, as the reference does per image;
 ``label_anchors_batch`` does a padded batch in one call (the layout the train step consumes: dataloader.py:365-394).
 Everything runs in the HIP library (edet_label_anchors); there is no CPU path.
-
-UNVERIFIED ON HARDWARE: written at the end of round 1 without GPU time left (branch wip/labeling-device).
 """
 import collections
 import ctypes

@@ -1,7 +1,8 @@
 """Inference image preprocessing on the GPU: ``EfficientDetModel._preprocessing(mode='infer')``
-(efficientdet_keras.py:920-951).  UNVERIFIED ON HARDWARE (branch wip/round2-prep)."""
+(efficientdet_keras.py:920-951)."""
 import ctypes
 
+import numpy as np
 import torch
 
 from automl_amd import _lib
@@ -21,8 +22,9 @@ def preprocess_infer(raw_images, image_size, mean_rgb, stddev_rgb, dtype=torch.f
   oh, ow = utils.parse_image_size(image_size)
   b, h, w, _ = raw.shape
   out = torch.empty((b, oh, ow, 3), dtype=dtype, device=raw.device)
-  mean = (ctypes.c_float * 3)(*[float(v) for v in mean_rgb])
-  std = (ctypes.c_float * 3)(*[float(v) for v in stddev_rgb])
+  # per-channel lists, or one scalar for all channels (the efficientdet-lite configurations: 127.0 / 128.0)
+  mean = (ctypes.c_float * 3)(*[float(v) for v in np.broadcast_to(np.asarray(mean_rgb, np.float32).reshape(-1), (3,))])
+  std = (ctypes.c_float * 3)(*[float(v) for v in np.broadcast_to(np.asarray(stddev_rgb, np.float32).reshape(-1), (3,))])
   scale = ctypes.c_float(0.0)
   _lib.call('edet_preprocess_infer', raw.data_ptr(), 1 if raw.dtype == torch.float32 else 0, b, h, w, oh, ow, mean,
             std, out.data_ptr(), ctypes.byref(scale), _lib.EDET_BF16 if dtype == torch.bfloat16 else _lib.EDET_F32,

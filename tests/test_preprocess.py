@@ -97,3 +97,27 @@ def test_device_infer_preprocessing_matches_oracle_batch(dtype):
     tol = 1e-4 if dtype == 'f32' else 2e-2
     assert np.abs(out.float().cpu().numpy() - want).max() <= tol
     assert np.allclose(scales.cpu().numpy(), wscales, rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_model_call_with_infer_preprocessing_equals_preprocessed_call():
+  """EfficientDetModel(raw images, pre_mode='infer', post_mode='global') (efficientdet_keras.py:978-1000) = the same
+  model on the oracle-preprocessed batch with pre_mode=None, boxes scaled back by image_scale_to_original."""
+  import torch
+  from automl_amd import efficientdet_net, hparams_config
+  config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  config.override('image_size=256')
+  rng = np.random.default_rng(8)
+  raw = rng.integers(0, 256, (2, 300, 420, 3)).astype(np.uint8)
+  model = efficientdet_net.EfficientDetModel(config=config, dtype='f32')
+  boxes, scores, classes, valid = model(torch.from_numpy(raw), training=False, pre_mode='infer', post_mode='global')
+  images, scales = porc.preprocess_infer(list(raw), (256, 256), config.mean_rgb, config.stddev_rgb)
+  b2, s2, c2, v2 = model(torch.from_numpy(images), training=False, pre_mode=None, post_mode='global')
+  torch.cuda.synchronize()
+  assert np.array_equal(valid.cpu().numpy(), v2.cpu().numpy())
+  assert np.allclose(scores.cpu().numpy(), s2.cpu().numpy(), atol=2e-4)
+  assert np.array_equal(classes.cpu().numpy(), c2.cpu().numpy())
+  want = b2.cpu().numpy() * scales[:, None, None]
+  assert np.abs(boxes.cpu().numpy() - want).max() <= 2e-3 * 420
+  with pytest.raises(ValueError):
+    model(torch.from_numpy(raw), pre_mode='train')
