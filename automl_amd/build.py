@@ -10,6 +10,10 @@ LIB_PATH = os.path.join(_HERE, 'libedet_hip.so')
 SOURCES = ['pw_gemm.hip', 'pw_stream.hip', 'pw_big.hip', 'conv.hip', 'dwconv.hip', 'dw_march.hip', 'stem.hip', 'bn_se.hip', 'fuse.hip', 'loss_opt.hip', 'postprocess.hip', 'labeling.hip', 'preprocess.hip', 'error.cpp']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
+# files that restate float32 numpy / TensorFlow expressions operation by operation (argmax ties, 1e-6 parities):
+# no fused multiply-add contraction (hipcc's default is -ffp-contract=fast, and HIP's __fmul_rn / __fadd_rn are
+# plain operators, not contraction barriers)
+EXTRA_FLAGS = {'labeling.hip': ['-ffp-contract=off'], 'preprocess.hip': ['-ffp-contract=off']}
 
 
 def _stale(target, deps):
@@ -29,7 +33,7 @@ def build_library(force=False, verbose=False):
     s = os.path.join(CSRC, src)
     o = os.path.join(objdir, os.path.splitext(src)[0] + '.o')
     if force or _stale(o, [s] + hdrs):
-      cmd = [HIPCC] + FLAGS + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', s, '-o', o]
+      cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', s, '-o', o]
       jobs.append(cmd)
 
   def run(cmd):

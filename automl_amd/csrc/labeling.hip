@@ -15,6 +15,11 @@
 
 #include "common.h"
 
+// The arithmetic below restates float32 numpy / TensorFlow expressions operation by operation (argmax ties and
+// 1e-6 parities depend on it): this file is compiled with -ffp-contract=off (automl_amd/build.py) -- hipcc
+// contracts a*b+c into an FMA by default, and __fmul_rn / __fadd_rn are plain operators in HIP, not the
+// contraction barriers they are in CUDA.
+
 namespace {
 
 constexpr int MAX_LEVELS = 8;

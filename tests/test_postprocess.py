@@ -240,8 +240,11 @@ def test_model_wrapper_dispatch(monkeypatch):
   monkeypatch.setattr(efficientdet_net.EfficientDetNet, '__call__', lambda self, x, training=False: (['c'], ['b']))
   monkeypatch.setattr(pp, 'postprocess_global', lambda p, c, b, s=None: calls.append(('global', p['name'], c, b, s)) or 'G')
   monkeypatch.setattr(pp, 'postprocess_per_class', lambda p, c, b, s=None: calls.append(('per_class', c, b, s)) or 'P')
-  with pytest.raises(ValueError, match='preprocessing'):
-    model(None)                                            # the reference default pre_mode='infer'
+  from automl_amd import preprocess
+  monkeypatch.setattr(preprocess, 'preprocess_infer', lambda raw, size, mean, std, dtype=None: ('prep', 'scales'))
+  assert model('raw') == 'G' and calls[-1][-1] == 'scales'      # the reference default pre_mode='infer'
+  with pytest.raises(ValueError, match='preprocessing must be infer or empty'):
+    model(None, pre_mode='train')
   assert model(None, pre_mode=None) == 'G' and calls[-1] == ('global', 'efficientdet-d0', ['c'], ['b'], None)
   assert model(None, pre_mode=None, post_mode='per_class') == 'P'
   assert model(None, pre_mode=None, post_mode=None) == (['c'], ['b'])
