@@ -657,7 +657,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_wgrad(const WgArgs a) {
     }
 }
 
-// ---- balanced staging variant (EDET_WG_BALANCED=1; UNVERIFIED ON HARDWARE, branch wip/round2-prep) --------------
+// ---- balanced staging variant (the pointwise weight gradient's default since r02a) ---------------------------------
 // In k_big_wgrad waves 0-1 stage X (BatchNorm + swish + gate: ~10 issue slots per element) while waves 2-3 stage dY
 // (BatchNorm backward: ~3), and all four meet at the barrier: the r01g SQ counters show the step time tracking the
 // X waves.  Here every thread stages one 4-row x 8-channel block of X AND one of dY (256 blocks each per 64-row
@@ -916,22 +916,14 @@ int pwb_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight
   if (S < 1) return 0;
   a.rows_per_split = ((a.M + S - 1) / S + BK - 1) / BK * BK;
   a.S = (a.M + a.rows_per_split - 1) / a.rows_per_split;
-  static const bool ok1 = big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad<false>));
-  static const bool ok2 = big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad<true>));
+  // the balanced-staging kernel (r02a, 17 mid-size layers of D0 at batch 128: 6.03 ms against 6.53 ms for the
+  // two-waves-per-operand staging of k_big_wgrad, which remains for the dense-convolution variant)
+  static const bool ok1 = big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad_bal<false>));
+  static const bool ok2 = big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad_bal<true>));
   if (!ok1 || !ok2) return 0;
   const int grid = (a.S + 7) / 8 * 8 * ntile;
-  const char* bal = getenv("EDET_WG_BALANCED");        // read per call (A/B with scripts/kernel_lab.py)
-  if (bal && bal[0] == '1') {
-    static const bool ok3 = big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad_bal<false>));
-    static const bool ok4 = big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad_bal<true>));
-    if (!ok3 || !ok4) return 0;
-    if (dy->a) edet_launch(k_big_wgrad_bal<true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
-    else edet_launch(k_big_wgrad_bal<false>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
-  } else if (dy->a) {
-    edet_launch(k_big_wgrad<true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
-  } else {
-    edet_launch(k_big_wgrad<false>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
-  }
+  if (dy->a) edet_launch(k_big_wgrad_bal<true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
+  else edet_launch(k_big_wgrad_bal<false>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
   EDET_LAUNCH_CHECK("edet_pw_bwd_weight(big)");
   if (edet_reduce_partials(a.ws, a.S, kn, dweight, st) != 0) return -2;
   return 1;

@@ -115,9 +115,26 @@ def cpu_baseline(config, size, seconds_budget=28.0):
   (i) efficientdet-d0 512x512 batch 1 inference forward (BASELINE configs[0]), (ii) efficientdet-d0 at the
   benchmark image size, batch 8, one full train step (forward + backward + update).  `value` is (ii)."""
   from oracle import efficientdet_oracle as orc
-  threads = torch.get_num_threads()
   spec = netspec.NetSpec(config)
   vals = netspec.init_params(spec, 0)
+  # thread count: the best of a few candidates on one 512x512 forward (oneDNN on all 128 threads of the GPU box's
+  # host is several times slower on these small convolutions than on 16-32)
+  probe = orc.Oracle(config=hparams_config.get_efficientdet_config('efficientdet-d0'),
+                     params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
+  xp = torch.from_numpy(np.random.default_rng(1).standard_normal((1, 512, 512, 3)).astype(np.float32))
+  all_threads = torch.get_num_threads()
+  best = (None, all_threads)
+  for cand in sorted({all_threads, min(all_threads, 64), min(all_threads, 32), min(all_threads, 16), min(all_threads, 8)}):
+    torch.set_num_threads(cand)
+    with torch.no_grad():
+      probe.forward(xp, False)
+      t0 = time.perf_counter()
+      probe.forward(xp, False)
+      dt = time.perf_counter() - t0
+    if best[0] is None or dt < best[0]:
+      best = (dt, cand)
+  threads = best[1]
+  torch.set_num_threads(threads)
 
   def fresh(cfg):
     return orc.Oracle(config=cfg, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
@@ -148,6 +165,7 @@ def cpu_baseline(config, size, seconds_budget=28.0):
     orc.train_step(oracle, images, labels, state, 0.01, 0.9)
     n_step += 1
   dt = (time.perf_counter() - t0) / n_step
+  torch.set_num_threads(all_threads)
   return {'value': batch / dt, 'unit': 'images/sec', 'cores': threads, 'physical_cores': physical_cores(),
           'kind': 'port',
           'forward_d0_512_b1_images_per_sec': 1.0 / fwd_dt,
@@ -158,27 +176,42 @@ def cpu_baseline(config, size, seconds_budget=28.0):
 
 
 def parity_block(config, size):
-  """One bf16 training-mode forward of the benchmark network on 2 images against the fp32 oracle and against the
-  oracle that emulates the bf16 storage points: per-level max |logit error| / max |logit| (class, box).  Checker
-  only -- the measured path above never touches the oracle."""
+  """The bf16 benchmark network on 2 images against the CPU oracles (checker only -- the measured path above never
+  touches the oracle): (a) inference-mode forward, per level max |logit error| / max |logit| (class, box) against the
+  fp32 oracle and against the oracle that emulates the bf16 storage points; (b) training-mode forward (batch
+  statistics), layer by layer with teacher forcing: the worst error of any stored tensor against the emulating
+  oracle's value computed from the device's own stored inputs (end to end that mode is ill conditioned in bf16:
+  tests/test_oracle_conditioning.py)."""
   from oracle import efficientdet_oracle as orc
+  from oracle import teacher_force
   spec = netspec.NetSpec(config)
   vals = netspec.init_params(spec, 0)
   rng = np.random.default_rng(5)
   images = torch.from_numpy(rng.standard_normal((2, size, size, 3)).astype(np.float32)).to(torch.bfloat16).float()
   net = train_lib.EfficientDetNetTrain(config=config, dtype='bf16', params=vals)
-  cls, box = net(images, training=True)
+  cls, box = net(images, training=False)
   torch.cuda.synchronize()
-  out = {'workload': 'efficientdet-d0 %dx%d batch 2 bf16 training-mode forward, per level (class, box)' % (size, size)}
+  out = {'workload': 'efficientdet-d0 %dx%d batch 2 bf16' % (size, size)}
+
+  def fresh(storage):
+    return orc.Oracle(config=config, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()}, storage=storage)
   for storage in ('f32', 'bf16'):
-    o = orc.Oracle(config=config, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()}, storage=storage)
     with torch.no_grad():
-      cr, br = o.forward(images, True)
+      cr, br = fresh(storage).forward(images, False)
     errs = []
     for c, r, b, q in zip(cls, cr, box, br):
       errs.append([float((c.float().cpu() - r).abs().max() / r.abs().max()),
                    float((b.float().cpu() - q).abs().max() / q.abs().max())])
-    out['vs_fp32_oracle' if storage == 'f32' else 'vs_bf16_storage_emulating_oracle'] = errs
+    out['inference_forward_vs_' + ('fp32_oracle' if storage == 'f32' else 'bf16_storage_emulating_oracle')] = errs
+  net(images, training=True)
+  torch.cuda.synchronize()
+  o = fresh('bf16')
+  hook = o.hook = teacher_force.TeacherForce(net.engine)
+  with torch.no_grad():
+    o.forward(images, True)
+  out['training_forward_layer_by_layer'] = {'stored_tensors_checked': len(hook.fwd_err),
+                                            'worst_rel_err': max(hook.fwd_err.values()),
+                                            'worst_tensor': max(hook.fwd_err, key=hook.fwd_err.get)}
   return out
 
 

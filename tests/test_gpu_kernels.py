@@ -35,21 +35,16 @@ def apply_view(x, scale, shift, act, gate):
   return z
 
 
-@pytest.fixture(params=['auto', 'big', 'tiled', 'big_balanced'])
+@pytest.fixture(params=['auto', 'big', 'tiled'])
 def pw_impl(request, monkeypatch):
   """EDET_PW_IMPL (read per call by the library): 'big' forces the workgroup-tiled kernels of pw_big.hip, 'tiled'
-  the generic LDS-tiled kernels of pw_gemm.hip (the bf16 fallback of shapes outside the other two envelopes);
-  'big_balanced' additionally selects the balanced-staging weight-gradient kernel (EDET_WG_BALANCED=1)."""
+  the generic LDS-tiled kernels of pw_gemm.hip (the bf16 fallback of shapes outside the other two envelopes)."""
   if request.param == 'tiled':
     if sum(ord(ch) for ch in request.node.name) % 3:      # a third of the cases: the fallback is rarely reached
       pytest.skip('tiled fallback: sampled')
     monkeypatch.setenv('EDET_PW_IMPL', 'tiled')
   elif request.param != 'auto':
     monkeypatch.setenv('EDET_PW_IMPL', 'big')
-  if request.param == 'big_balanced':
-    if 'bwd_weight' not in request.node.name:
-      pytest.skip('EDET_WG_BALANCED only changes the weight gradient')
-    monkeypatch.setenv('EDET_WG_BALANCED', '1')
   return request.param
 
 
