@@ -321,6 +321,8 @@ def test_d0_640_batch2_bf16_train_step_layer_by_layer():
   for n in names:
     g = P[n].grad
     mine = step.eng.grad(n).cpu().reshape(g.shape)
+    if n.endswith('/bias') and float(mine.abs().max()) == 0.0 and float(g.abs().max()) <= 1e-3 * gmax:
+      continue      # a bias in front of a BatchNorm: its gradient is analytically zero (the device does not compute it)
     werr[n] = float((mine - g).abs().max()) / max(float(g.abs().max()), 1e-4 * gmax)
   print('teacher-forced variable gradients: %d tensors, worst %s' % (len(werr), gu.TeacherForce.worst(werr, 5)))
   assert max(werr.values()) <= TOL['layer_wgrad'], gu.TeacherForce.worst(werr, 8)
