@@ -62,6 +62,7 @@ SIGNATURES = {
     'edet_pw_fwd': [PT, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, PI, c_int, c_void_p],
     'edet_pw_bwd_data': [PG, c_void_p, c_int, PT, PE, PI, c_int, c_void_p],
     'edet_pw_bwd_weight': [PT, PG, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],
+    'edet_pw_bwd': [PG, c_void_p, c_int, PT, PE, PI, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],
     'edet_conv_fwd': [PT, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, PI, c_int, c_void_p],
     'edet_conv_bwd_data': [PG, c_void_p, c_int, c_int, c_int, PT, PE, PI, c_int, c_void_p],
     'edet_conv_bwd_weight': [PT, PG, c_int, c_int, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],

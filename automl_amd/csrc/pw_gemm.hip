@@ -763,3 +763,29 @@ extern "C" int edet_pw_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy
   if (dtype == EDET_F32) return launch_wgrad<float>(a, to_stream(stream));
   EDET_CHECK(false, "edet_pw_bwd_weight: bad dtype %d", dtype);
 }
+
+// streaming fused data + weight gradient (pw_stream.hip); return 1 = handled, 0 = shape outside its envelope
+int pws_try_bwd_fused(const edet_gview_t* dy, const void* w, int ldw, const edet_tview_t* in,
+                      const edet_bwd_epi_t* epi, int* nparts_out, float* dweight, void* workspace,
+                      size_t workspace_bytes, hipStream_t st);
+
+extern "C" int edet_pw_bwd(const edet_gview_t* dy, const void* w, int ldw, const edet_tview_t* in,
+                           const edet_bwd_epi_t* epi, int* nparts_out, float* dweight, void* workspace,
+                           size_t workspace_bytes, int dtype, void* stream) {
+  EDET_CHECK(dy && dy->dz && w && in && in->data && epi && epi->gout && dweight, "edet_pw_bwd: null pointer");
+  EDET_CHECK(in->c % 8 == 0 && in->ld % 8 == 0 && dy->ld % 8 == 0 && ldw % 8 == 0 && ldw >= dy->c,
+             "edet_pw_bwd: strides must be multiples of 8");
+  EDET_CHECK(!(epi->stat_partials && epi->beta), "edet_pw_bwd: fused stats need beta == 0");
+  EDET_CHECK(!(epi->dgate && !in->gate), "edet_pw_bwd: dgate given but input view has no gate");
+  if (dtype == EDET_BF16) {
+    const int impl = pw_impl_env();
+    if (impl == PW_AUTO || impl == PW_STREAM) {
+      const int rc = pws_try_bwd_fused(dy, w, ldw, in, epi, nparts_out, dweight, workspace, workspace_bytes,
+                                       to_stream(stream));
+      if (rc != 0) return rc < 0 ? rc : 0;
+    }
+  }
+  const int rc = edet_pw_bwd_weight(in, dy, dweight, workspace, workspace_bytes, dtype, stream);
+  if (rc != 0) return rc;
+  return edet_pw_bwd_data(dy, w, ldw, in, epi, nparts_out, dtype, stream);
+}

@@ -830,6 +830,389 @@ __global__ __launch_bounds__(THREADS, 2) void k_pw_wgrad(const WgArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ fused data + weight gradient
+// Both gradients of a pointwise convolution in ONE pass over (dz, y, x): the data-gradient kernel above and the
+// weight-gradient kernel each stream the gradient pair (2 N channels per row) and the saved input (K channels),
+// i.e. 7 tensor streams where one pass needs 4 (r01h PMC: 329 + 363 MB per launch pair against 194 MB
+// algorithmic each).  Here a wave owns a contiguous range of 32-row tiles; per tile
+//   * dz, y AND x are prefetched one tile ahead in whole 16-byte chunks (fixed column per lane: the BatchNorm
+//     backward coefficients stay in registers), dy = a*dz + b*y + c goes to the LDS tile Dt as bf16, x is parked raw
+//     in the LDS tile Xt;
+//   * D'[k][row] = W[k][:] . dy[row][:] on 32x32x16 MFMAs, through the fp32 C tile into the 8-channel-per-lane
+//     epilogue of k_pw_dgrad (act'(z), accumulate, BatchNorm-backward sums, SE dgate sums), which takes x from Xt
+//     and leaves the ACTIVATED operand act(bn(x)) * gate there as bf16;
+//   * dW[k][n] += sum_rows xa[row][k] * dy[row][n] on 16x16x32 MFMAs whose contraction runs over the tile's 32
+//     rows: fragments are gathered column-wise (8 consecutive rows of one channel per lane) from Xt and Dt; the dW
+//     block (<= 4 x 9 tiles of 16 x 16) stays in registers for the whole kernel.
+// One wave per SIMD (the accumulators and a whole tile of loads in flight take ~400 registers): latency is hidden
+// by the 14-21 KB every wave keeps in flight, not by occupancy.  At the end the four waves of a workgroup add their
+// dW blocks in LDS (fixed order) and write one partial per workgroup; edet_reduce_partials sums them.
+struct FusedArgs {
+  edet_gview_t gv;    // dy: R = gv.c channels (the convolution's output channels)
+  edet_tview_t tv;    // conv input view: raw x, scale, shift, gate, act; KO = tv.c channels
+  const bf16_t* W;    // [KO][ldw], n contiguous (compute copy of the kernel)
+  int ldw;
+  edet_bwd_epi_t epi;
+  float* ws;          // [grid][KO][R] fp32 partial weight gradients
+  int M, R, KO, hw;
+  ColMap cr, cx;      // load mappings of dy and of x (the passes per tile are template parameters)
+  int SA, SX, SC, SW; // LDS row strides in bytes: Dt, Xt, C tile, weights
+  int KOpad;          // KO rounded up to 32
+  int TK, TN;         // 16-wide tiles of dW along k and n
+  int tpw, ksteps;    // tiles per wave; ceil(R / 16)
+};
+
+// FT_S x FT_L = 16 x 16 tiles of dW kept per wave (min(TK, TN) <= FT_S, max(TK, TN) <= FT_L): 2 x 9 for the expand /
+// project layers (16..32 channels on one side, up to 144 on the other), 4 x 4 for the 64-channel BiFPN / head layers
+template <int NSR, int NSX, bool GBN, int FT_S, int FT_L>
+__global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const bool has_beta = a.epi.beta != 0;
+  unsigned char* Wl = smem;                                             // [KOpad][SW]
+  float* red = reinterpret_cast<float*>(Wl + (size_t)a.KOpad * a.SW);   // [2][KOpad] stats
+  float* coefS = red + 2 * a.KOpad;                                     // [KOpad] scale, [KOpad] shift of the view
+  float* coefH = coefS + a.KOpad;
+  const int d_alloc = NSR * a.cr.rp, x_alloc = NSX * a.cx.rp;           // >= 32 rows each (NSR / NSX load passes)
+  const size_t wave_bytes = (size_t)d_alloc * a.SA + (size_t)(has_beta ? 2 : 1) * x_alloc * a.SX +
+                            (size_t)TR * a.SC + (size_t)4 * a.KOpad * 4;
+  unsigned char* wbase = reinterpret_cast<unsigned char*>(coefH + a.KOpad) + (size_t)wave * wave_bytes;
+  unsigned char* Dt = wbase;                                            // [d_alloc][SA] bf16 dy
+  unsigned char* Xt = Dt + (size_t)d_alloc * a.SA;                      // [x_alloc][SX] bf16 x, then act(x)
+  unsigned char* Ot = Xt + (size_t)x_alloc * a.SX;                      // [x_alloc][SX] bf16 old gout (beta only)
+  unsigned char* Ct = Ot + (has_beta ? (size_t)x_alloc * a.SX : 0);     // [32][SC] fp32
+  float* wst = reinterpret_cast<float*>(Ct + TR * a.SC);                // [2][KOpad] sums (g, g*x) of this wave
+  float* wgt = wst + 2 * a.KOpad;                                       // [KOpad] dgate sums of the current image
+  float* gateL = wgt + a.KOpad;                                         // [KOpad] SE gate of the current image
+  const bool want_stats = a.epi.stat_partials != nullptr;
+  const bool want_gate = a.epi.dgate != nullptr;
+  const bool swish = a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr, gated = a.tv.gate != nullptr;
+
+  // Nothing inside the tile loop may wait on a global load other than the prefetched tile (vmcnt is in order: a
+  // wait for a later small load would drain the whole prefetch): per-channel vectors live in LDS.
+  for (int i = tid; i < 2 * a.KOpad; i += THREADS) red[i] = 0.f;
+  for (int i = tid; i < a.KOpad; i += THREADS) {
+    coefS[i] = (affine && i < a.KO) ? a.tv.scale[i] : 1.f;
+    coefH[i] = (affine && i < a.KO) ? a.tv.shift[i] : 0.f;
+  }
+  for (int i = lane; i < 3 * a.KOpad; i += 64) wst[i] = 0.f;
+  for (int i = lane; i < a.KOpad; i += 64) gateL[i] = 1.f;
+  for (int i = lane; i < (int)(((size_t)d_alloc * a.SA + (size_t)x_alloc * a.SX) / 16); i += 64)
+    reinterpret_cast<uint4*>(Dt)[i] = make_uint4(0, 0, 0, 0);
+  {  // weights -> LDS (zero-filled beyond KO and beyond R)
+    const int slots = a.SW / 16;
+    for (int q = tid; q < a.KOpad * slots; q += THREADS) {
+      const int r = q / slots, sl = q - r * slots;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (r < a.KO && sl * 8 < a.R) v = *reinterpret_cast<const uint4*>(a.W + (size_t)r * a.ldw + sl * 8);
+      *reinterpret_cast<uint4*>(Wl + (size_t)r * a.SW + sl * 16) = v;
+    }
+  }
+  __syncthreads();
+
+  // load mappings (lanes beyond nvec*rp duplicate the work of lane % (nvec*rp): no divergence)
+  const int lane_r = lane % (a.cr.nvec * a.cr.rp);
+  const int colR = lane_r % a.cr.nvec, rsubR = lane_r / a.cr.nvec;
+  const int kvalid = min(8, a.R - colR * 8);
+  const int lane_x = lane % (a.cx.nvec * a.cx.rp);
+  const int colX = lane_x % a.cx.nvec, rsubX = lane_x / a.cx.nvec;
+  const unsigned char* DZ = reinterpret_cast<const unsigned char*>(a.gv.dz);
+  const unsigned char* Y = reinterpret_cast<const unsigned char*>(a.gv.y);
+  const unsigned char* X = reinterpret_cast<const unsigned char*>(a.tv.data);
+  bf16_t* GO = reinterpret_cast<bf16_t*>(a.epi.gout);
+
+  const int ntile = (a.M + TR - 1) / TR;
+  const int gw = blockIdx.x * WAVES + wave;
+  const int t0 = min(ntile, gw * a.tpw), t1 = min(ntile, t0 + a.tpw);
+
+  // native vector types: a HIP uint4 struct copied whole from a register array to LDS is not promoted to registers
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  uint4 rz[NSR], ry[GBN ? NSR : 1];
+  u32x4 rx[NSX], ro[NSX];
+  auto issue = [&](int t) {
+    const int row0 = t * TR;
+#pragma unroll
+    for (int i = 0; i < NSR; ++i) {   // rows past M re-read row M-1 (finite values; zeroed when they are staged)
+      const size_t off = ((size_t)min(row0 + i * a.cr.rp + rsubR, a.M - 1) * a.gv.ld + colR * 8) * 2;
+      rz[i] = *reinterpret_cast<const uint4*>(DZ + off);
+      if (GBN) ry[i] = *reinterpret_cast<const uint4*>(Y + off);
+    }
+#pragma unroll
+    for (int i = 0; i < NSX; ++i) {
+      const size_t off = ((size_t)min(row0 + i * a.cx.rp + rsubX, a.M - 1) * a.tv.ld + colX * 8) * 2;
+      rx[i] = *reinterpret_cast<const u32x4*>(X + off);
+    }
+    if (has_beta) {       // the gradient already in gout (residual / second consumer) rides along with x
+#pragma unroll
+      for (int i = 0; i < NSX; ++i) {
+        const size_t off = ((size_t)min(row0 + i * a.cx.rp + rsubX, a.M - 1) * a.tv.ld + colX * 8) * 2;
+        ro[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(GO) + off);
+      }
+    }
+  };
+
+  // dW block of this wave: acc[s][l] is the 16 x 16 tile (s, l) of the (small side, large side) tile grid
+  const bool ksmall = a.TK <= a.TN;
+  const int TS = ksmall ? a.TK : a.TN, TL = ksmall ? a.TN : a.TK;
+  f32x4 acc[FT_S][FT_L];
+#pragma unroll
+  for (int s = 0; s < FT_S; ++s)
+#pragma unroll
+    for (int l = 0; l < FT_L; ++l)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[s][l][e] = 0.f;
+
+  float ga[8], gb[8], gc[8];
+  if (GBN) {
+    loadf8(a.gv.a + colR * 8, ga); loadf8(a.gv.b + colR * 8, gb); loadf8(a.gv.cc + colR * 8, gc);
+  }
+  const int ecol = lane & 7, erow = lane >> 3;     // epilogue mapping: 64-channel chunk, 8 lanes per row
+  const int fi = lane & 15, fq = lane >> 4;        // 16x16x32 fragment coordinates
+  int gate_img = -1;                               // image whose dgate sums are in wgt
+  int gateL_img = -1;                              // image whose SE gate is in gateL
+  if (t0 < t1) issue(t0);
+  for (int t = t0; t < t1; ++t) {
+    const int row0 = t * TR;
+    const int rows_valid = min(TR, a.M - row0);
+    // ---- stage dy = a*dz + b*y + c (bf16, zero beyond R and beyond M), raw x and the old gradient
+#pragma unroll
+    for (int i = 0; i < NSR; ++i) {
+      const int r = i * a.cr.rp + rsubR;
+      float x[8];
+      unpack8(rz[i], x);
+      if (GBN) {
+        float y[8];
+        unpack8(ry[i], y);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = fmaf(ga[e], x[e], fmaf(gb[e], y[e], gc[e]));
+      }
+      if (kvalid < 8 || r >= rows_valid) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (e >= kvalid || r >= rows_valid) x[e] = 0.f;
+      }
+      *reinterpret_cast<uint4*>(Dt + r * a.SA + colR * 16) = pack8(x);
+    }
+#pragma unroll
+    for (int i = 0; i < NSX; ++i)
+      *reinterpret_cast<u32x4*>(Xt + (i * a.cx.rp + rsubX) * a.SX + colX * 16) = rx[i];
+    if (has_beta) {
+#pragma unroll
+      for (int i = 0; i < NSX; ++i)
+        *reinterpret_cast<u32x4*>(Ot + (i * a.cx.rp + rsubX) * a.SX + colX * 16) = ro[i];
+    }
+    if (t + 1 < t1) issue(t + 1);
+    __builtin_amdgcn_wave_barrier();
+
+    const int img0 = row0 / a.hw, img1 = (row0 + rows_valid - 1) / a.hw;
+    const bool one_img = img0 == img1;
+    // SE gate of the tile's image -> LDS (once per image and wave: this load does wait behind the prefetch)
+    if (gated && one_img && img0 != gateL_img) {
+      for (int c = lane; c < a.KO; c += 64) gateL[c] = a.tv.gate[(size_t)img0 * a.KO + c];
+      gateL_img = img0;
+      __builtin_amdgcn_wave_barrier();
+    }
+    // dgate bookkeeping: the sums in wgt belong to one image; a tile that straddles two images goes straight to
+    // global atomics
+    bool gate_direct = false;
+    if (want_gate) {
+      gate_direct = !one_img;
+      if (gate_img >= 0 && (gate_direct || img0 != gate_img)) {
+        for (int c = lane; c < a.KO; c += 64) {
+          const float v = wgt[c];
+          if (v != 0.f) atomicAdd(&a.epi.dgate[(size_t)gate_img * a.KO + c], v);
+          wgt[c] = 0.f;
+        }
+        gate_img = -1;
+      }
+      if (!gate_direct) gate_img = img0;
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- data gradient, 64 input channels at a time, and the activated operand for the weight gradient
+    const unsigned char* arow = Dt + (size_t)j * a.SA + h * 16;
+    for (int c0 = 0; c0 < a.KOpad; c0 += ECC) {
+      const int ccols = min(ECC, a.KOpad - c0);                // 32 or 64
+      const int ch0 = c0 + ecol * 8;                           // this lane's 8 channels
+      const bool col_ok = ch0 < a.KO && ecol * 8 < ccols;
+      float sc[8], sh[8], gt[8], s1[8], s2[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; gt[e] = 1.f; s1[e] = s2[e] = 0.f; }
+      if (col_ok) {
+        loadf8(coefS + ch0, sc);
+        loadf8(coefH + ch0, sh);
+        if (gated && one_img) loadf8(gateL + ch0, gt);
+      }
+      for (int nt = 0; nt < ccols / 32; ++nt) {
+        const f32x16 d = mma_tile(Wl + (size_t)(c0 + nt * 32 + j) * a.SW + h * 16, arow, a.ksteps);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(Ct + j * a.SC + (nt * 32 + 8 * g + 4 * h) * 4) =
+              make_float4(d[4 * g + 0], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int r = p * 8 + erow;
+        if (col_ok) {
+          uint4* xslot = reinterpret_cast<uint4*>(Xt + r * a.SX + (c0 / 8 + ecol) * 16);
+          if (r < rows_valid) {
+            const float4 d0 = *reinterpret_cast<const float4*>(Ct + r * a.SC + ecol * 32);
+            const float4 d1 = *reinterpret_cast<const float4*>(Ct + r * a.SC + ecol * 32 + 16);
+            float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            float x[8], g[8], av[8];
+            unpack8(*xslot, x);
+            // z (pre-activation), its activation av and the chained gradient g
+            if (swish) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float z = fmaf(x[e], sc[e], sh[e]);
+                const float sg = sigmoidf_(z);
+                av[e] = z * sg;
+                g[e] = want_gate ? d[e] : d[e] * (sg * (1.0f + z * (1.0f - sg)));
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                av[e] = fmaf(x[e], sc[e], sh[e]);
+                g[e] = d[e];
+              }
+            }
+            if (want_gate) {
+              if (gate_direct) {
+                const int img = (row0 + r) / a.hw;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                  if (ch0 + e < a.KO) atomicAdd(&a.epi.dgate[(size_t)img * a.KO + ch0 + e], d[e] * av[e]);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s1[e] = fmaf(d[e], av[e], s1[e]);
+              }
+            }
+            if (gated) {
+              if (!one_img) loadf8(a.tv.gate + (size_t)((row0 + r) / a.hw) * a.KO + ch0, gt);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) av[e] *= gt[e];
+            }
+            if (has_beta) {
+              float old[8];
+              unpack8(*reinterpret_cast<const uint4*>(Ot + r * a.SX + (c0 / 8 + ecol) * 16), old);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) g[e] += old[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (ch0 + e >= a.KO) { g[e] = 0.f; av[e] = 0.f; }
+            *reinterpret_cast<uint4*>(GO + (size_t)(row0 + r) * a.tv.ld + ch0) = pack8(g);
+            *xslot = pack8(av);
+            if (want_stats) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                s1[e] += g[e];
+                s2[e] = fmaf(g[e], x[e], s2[e]);
+              }
+            }
+          } else {
+            *xslot = make_uint4(0, 0, 0, 0);          // rows past M do not contribute to dW
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      // chunk sums -> wave LDS accumulators (8 lanes share a column: LDS atomics); raw sums (g, g*x): the
+      // BatchNorm-backward form sum g*(x-mean)*rstd is taken from the totals at the end of the kernel
+      if (col_ok) {
+        if (want_stats) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (ch0 + e < a.KO) {
+              atomicAdd(&wst[ch0 + e], s1[e]);
+              atomicAdd(&wst[a.KOpad + ch0 + e], s2[e]);
+            }
+          }
+        }
+        if (want_gate && !gate_direct) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (ch0 + e < a.KO) atomicAdd(&wgt[ch0 + e], s1[e]);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- weight gradient: dW[k][n] += sum over the tile's 32 rows of xa[row][k] * dy[row][n]
+    {
+      const unsigned char* St = ksmall ? Xt : Dt;      // small side: fragments kept in registers
+      const unsigned char* Lt = ksmall ? Dt : Xt;
+      const int sS = ksmall ? a.SX : a.SA, sL = ksmall ? a.SA : a.SX;
+      bf16x8 sf[FT_S];
+#pragma unroll
+      for (int s = 0; s < FT_S; ++s)
+        if (s < TS) sf[s] = column_frag(St, sS, fq * 8, s * 16 + fi);
+#pragma unroll
+      for (int l = 0; l < FT_L; ++l) {
+        if (l < TL) {
+          const bf16x8 lf = column_frag(Lt, sL, fq * 8, l * 16 + fi);
+#pragma unroll
+          for (int s = 0; s < FT_S; ++s) {
+            if (s < TS) {
+              // A = the k side (rows of dW), B = the n side (columns of dW)
+              if (ksmall) acc[s][l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf[s], lf, acc[s][l], 0, 0, 0);
+              else acc[s][l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lf, sf[s], acc[s][l], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (want_gate && gate_img >= 0) {
+    for (int c = lane; c < a.KO; c += 64) {
+      const float v = wgt[c];
+      if (v != 0.f) atomicAdd(&a.epi.dgate[(size_t)gate_img * a.KO + c], v);
+    }
+  }
+  if (want_stats) {
+    for (int c = lane; c < a.KO; c += 64) {
+      atomicAdd(&red[c], wst[c]);
+      atomicAdd(&red[a.KOpad + c], wst[a.KOpad + c]);
+    }
+    __syncthreads();
+    float* dst = a.epi.stat_partials + (size_t)blockIdx.x * 2 * a.KO;
+    for (int c = tid; c < a.KO; c += THREADS) {
+      const float sg = red[c], sgx = red[a.KOpad + c];
+      dst[c] = sg;
+      dst[a.KO + c] = a.epi.rstd[c] * (sgx - a.epi.mean[c] * sg);      // sum g*(x-mean)*rstd
+    }
+  }
+  // ---- dW blocks of the four waves -> one partial per workgroup (fixed order: deterministic)
+  __syncthreads();
+  float* scratch = reinterpret_cast<float*>(smem);      // [KO][R] fp32; every LDS tile is dead by now
+  for (int w = 0; w < WAVES; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int s = 0; s < FT_S; ++s)
+#pragma unroll
+        for (int l = 0; l < FT_L; ++l) {
+          if (s < TS && l < TL) {
+            const int tk = ksmall ? s : l, tn = ksmall ? l : s;
+            const int n = tn * 16 + fi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int k = tk * 16 + fq * 4 + e;
+              if (k < a.KO && n < a.R) {
+                float* p = scratch + (size_t)k * a.R + n;
+                *p = (w == 0 ? 0.f : *p) + acc[s][l][e];
+              }
+            }
+          }
+        }
+    }
+    __syncthreads();
+  }
+  float* dstw = a.ws + (size_t)blockIdx.x * a.KO * a.R;
+  for (int i = tid; i < a.KO * a.R; i += THREADS) dstw[i] = scratch[i];
+}
+
 template <typename KernelT>
 inline bool allow_big_lds(KernelT kern, size_t lds) {
   if (lds <= 64 * 1024) return true;
@@ -985,5 +1368,83 @@ int pws_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight
 #undef PWS_WG
   EDET_LAUNCH_CHECK("edet_pw_bwd_weight(stream)");
   if (edet_reduce_partials(a.ws, a.S, kn, dweight, st) != 0) return -2;
+  return 1;
+}
+
+// Both gradients of one pointwise layer in one pass: 1 = handled, 0 = outside the envelope (the caller runs the two
+// separate kernels), < 0 = error.  dweight [KO][R] fp32 is accumulated into (edet_reduce_partials).
+int pws_try_bwd_fused(const edet_gview_t* dy, const void* w, int ldw, const edet_tview_t* in,
+                      const edet_bwd_epi_t* epi, int* nparts_out, float* dweight, void* workspace,
+                      size_t workspace_bytes, hipStream_t st) {
+  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
+  using namespace pws;
+  const int R = dy->c, KO = in->c;
+  if (!workspace || KO % 8 != 0 || dy->ld % 8 != 0 || in->ld % 8 != 0 || R > 160 || KO > 160) return 0;
+  FusedArgs a;
+  memset(&a, 0, sizeof(a));
+  a.gv = *dy; a.tv = *in; a.W = reinterpret_cast<const bf16_t*>(w); a.ldw = ldw; a.epi = *epi;
+  a.ws = reinterpret_cast<float*>(workspace);
+  a.M = in->n * in->h * in->w; a.R = R; a.KO = KO; a.hw = in->h * in->w;
+  a.TK = (KO + 15) / 16; a.TN = (R + 15) / 16;
+  const int ts = a.TK < a.TN ? a.TK : a.TN, tl = a.TK < a.TN ? a.TN : a.TK;
+  const bool wide = ts <= 2 && tl <= 9;          // accumulator shape 2 x 9, else 4 x 4
+  if (!wide && tl > 4) return 0;
+  a.cr = make_colmap(R);
+  a.cx = make_colmap(KO);
+  const int pstR = (TR + a.cr.rp - 1) / a.cr.rp, pstX = (TR + a.cx.rp - 1) / a.cx.rp;
+  // (load passes of dy, of x) per 32-row tile, rounded up to an instantiated pair: the loops over the passes carry
+  // no run-time guard (a guarded register array lands in scratch memory)
+  static const int pairs[6][2] = {{1, 2}, {2, 8}, {2, 12}, {4, 4}, {8, 1}, {12, 2}};
+  int nsr = 0, nsx = 0;
+  for (int i = 0; i < 6; ++i) {
+    if (pairs[i][0] >= pstR && pairs[i][1] >= pstX && (wide || (pairs[i][0] == 4 && pairs[i][1] == 4))) {
+      nsr = pairs[i][0]; nsx = pairs[i][1];
+      break;
+    }
+  }
+  if (!nsr) return 0;
+  const int Rp = (R + 7) / 8 * 8;
+  a.ksteps = (R + 15) / 16;
+  a.SA = frag_stride(Rp, Rp % 16 != 0);
+  a.SW = a.SA;
+  a.SX = frag_stride(KO, false);
+  a.KOpad = (KO + 31) / 32 * 32;
+  if (a.SX < a.KOpad * 2) a.SX = frag_stride(a.KOpad, false);     // the epilogue addresses whole 32-channel tiles
+  a.SC = ECC * 4 + 16;
+  const size_t lds = (size_t)a.KOpad * a.SW + (size_t)4 * a.KOpad * 4 +
+                     (size_t)WAVES * ((size_t)nsr * a.cr.rp * a.SA + (size_t)(epi->beta ? 2 : 1) * nsx * a.cx.rp * a.SX +
+                                      (size_t)TR * a.SC + (size_t)4 * a.KOpad * 4);
+  if (lds > 150 * 1024 || lds < (size_t)KO * R * 4) return 0;
+  const int ntile = (a.M + TR - 1) / TR;
+  // one workgroup per CU and wave (1 wave per SIMD); at least 4 tiles per wave, partials bounded by the workspace
+  int grid = 1024;
+  const int64_t max_by_ws = (int64_t)(workspace_bytes / sizeof(float)) / ((int64_t)KO * R);
+  if (grid > max_by_ws) grid = (int)max_by_ws;
+  if (grid > EDET_MAX_PARTS) grid = EDET_MAX_PARTS;
+  const int max_by_tiles = (ntile + WAVES * 4 - 1) / (WAVES * 4);
+  if (grid > max_by_tiles) grid = max_by_tiles;
+  if (grid < 1) return 0;
+  a.tpw = (ntile + grid * WAVES - 1) / (grid * WAVES);
+  grid = (ntile + a.tpw * WAVES - 1) / (a.tpw * WAVES);
+  if (nparts_out) *nparts_out = grid;
+  const bool gbn = dy->a != nullptr;
+#define PWS_FUSED(NSR_, NSX_, GBN_, FS_, FL_)                                                       \
+  do {                                                                                              \
+    if (!allow_big_lds(&k_pw_bwd_fused<NSR_, NSX_, GBN_, FS_, FL_>, lds)) return 0;                 \
+    edet_launch(k_pw_bwd_fused<NSR_, NSX_, GBN_, FS_, FL_>, dim3(grid), dim3(THREADS), lds, st, a); \
+  } while (0)
+#define PWS_FUSED_G(NSR_, NSX_, FS_, FL_) \
+  do { if (gbn) PWS_FUSED(NSR_, NSX_, true, FS_, FL_); else PWS_FUSED(NSR_, NSX_, false, FS_, FL_); } while (0)
+  if (!wide) PWS_FUSED_G(4, 4, 4, 4);
+  else if (nsr == 1) PWS_FUSED_G(1, 2, 2, 9);
+  else if (nsr == 2 && nsx == 8) PWS_FUSED_G(2, 8, 2, 9);
+  else if (nsr == 2) PWS_FUSED_G(2, 12, 2, 9);
+  else if (nsr == 4) PWS_FUSED_G(4, 4, 2, 9);
+  else if (nsr == 8) PWS_FUSED_G(8, 1, 2, 9);
+  else PWS_FUSED_G(12, 2, 2, 9);
+#undef PWS_FUSED_G
+#undef PWS_FUSED
+  EDET_LAUNCH_CHECK("edet_pw_bwd(fused)");
+  if (edet_reduce_partials(a.ws, grid, (int64_t)KO * R, dweight, st) != 0) return -2;
   return 1;
 }

@@ -226,6 +226,7 @@ class Engine(object):
     self._cast_table = None
     self.batched_casts = True    # every compute copy of a step in one edet_cast_batch launch
     self.fused_dw_bwd = True     # one edet_dw_bwd call per stride-1 layer
+    self.fused_pw_bwd = True     # one edet_pw_bwd call per pointwise layer whose input needs a gradient
     # cross-replica BatchNorm (utils.SyncBatchNormalization / TpuBatchNormalization, utils.py:166-241):
     # (all_reduce_fn, world_size) or None.  Set by train_lib when sync_bn=True.
     self.sync_bn = None
@@ -426,6 +427,17 @@ class Engine(object):
     g = self._gview(vout)
     nb = vin.raw.rows * (vin.raw.c + vout.raw.c) * self.esize
     tag = '%dx%dx%d->%d' % (vin.raw.h, vin.raw.w, vin.raw.c, vout.raw.c)
+    if vin.raw.needs_grad and self.fused_pw_bwd:
+      # both gradients in one call: one pass over (dz, y, x) where the layer fits the fused kernel
+      dgate = vin.dgate if vin.gate is not None else None
+      epi, fused = self._epi(vin, dgate)
+      call('edet_pw_bwd', ctypes.byref(g), ptr(w), ldn, ctypes.byref(vin.tview()), ctypes.byref(epi),
+           ctypes.byref(self._nparts), ptr(self.grad(wname)), ptr(self.workspace), self.workspace.numel() * 4,
+           self.dtype, self.stream, nbytes=2 * nb, tag=tag)
+      vin.raw.grad_written = True
+      if fused:
+        self._bn_bwd_finalize(vin.bn, self._nparts.value)
+      return
     call('edet_pw_bwd_weight', ctypes.byref(vin.tview()), ctypes.byref(g), ptr(self.grad(wname)),
          ptr(self.workspace), self.workspace.numel() * 4, self.dtype, self.stream, nbytes=nb, tag=tag)
     if vin.raw.needs_grad:

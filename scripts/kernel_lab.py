@@ -8,7 +8,7 @@ The whole-step bench (bench.py) costs ~40 s of GPU time per variant; a kernel-le
   python scripts/kernel_lab.py --entry dw_bwd --layers all --reps 5
   python scripts/kernel_lab.py --list                                      # the layer tables, no GPU needed
 
-Entries: pw_fwd, pw_bwd_data, pw_bwd_weight (1x1 convolutions; shape N x H x W x Cin x Cout), dw_fwd, dw_bwd
+Entries: pw_fwd, pw_bwd_data, pw_bwd_weight, pw_bwd (both gradients in one call) (1x1 convolutions; shape N x H x W x Cin x Cout), dw_fwd, dw_bwd
 (depthwise; shape N x H x W x C x K x S).  Views are the ones the network uses: forward inputs carry BatchNorm + swish
 (+ SE gate for the project layers) on load, gradients carry the BatchNorm backward on load and the statistic partials
 in the epilogue.  Prints one line per (layer, variant): ms per call, algorithmic MB (input + output elements x 2 B,
@@ -101,6 +101,17 @@ def build_case(entry, shape):
       keep = (wk, gout, mean, rstd)
       return (lambda: (keep, call('edet_pw_bwd_data', ctypes.byref(gv), ptr(wk), gu.pad8(cout), ctypes.byref(tv),
                                   ctypes.byref(epi), ctypes.byref(npart), edt, gu.stream()))), nbytes
+    if entry == 'pw_bwd':
+      tv = gu.tview(x, cin, vec(cin), vec(cin, -0.3, 0.3), None, _lib.ACT_SWISH)
+      wk = rand(cin, gu.pad8(cout)) * (1.0 / np.sqrt(cout))
+      gout = torch.empty(n, h, w, gu.pad8(cin), dtype=tdt, device=dev)
+      mean, rstd = vec(cin, -0.2, 0.2), vec(cin)
+      epi = BwdEpi(ptr(gout), 0, ptr(mean), ptr(rstd), ptr(parts), None)
+      dwt = torch.zeros(cin, cout, dtype=torch.float32, device=dev)
+      keep = (wk, gout, mean, rstd, dwt)
+      return (lambda: (keep, call('edet_pw_bwd', ctypes.byref(gv), ptr(wk), gu.pad8(cout), ctypes.byref(tv),
+                                  ctypes.byref(epi), ctypes.byref(npart), ptr(dwt), ptr(wsp), wsp.numel() * 4, edt,
+                                  gu.stream()))), 2 * nbytes
     if entry == 'pw_bwd_weight':
       dwt = torch.zeros(cin, cout, dtype=torch.float32, device=dev)
       return (lambda: call('edet_pw_bwd_weight', ctypes.byref(tv), ctypes.byref(gv), ptr(dwt), ptr(wsp),

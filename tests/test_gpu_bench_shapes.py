@@ -98,11 +98,27 @@ def test_pw_bwd_data_at_d0_640_shapes(layer):
   gradient); dy carries the BatchNorm backward on load except for the predict layers."""
   h, cin, cout, view = layer
   predict = cout in (810, 36)
-  tk.test_pw_bwd_data(BF16, (N_IMG, h, h, cin, cout), 'gate' if view == 'gate' else 'plain', not predict, 'auto')
+  shape = (N_IMG, h, h, cin, cout)
+  tk.test_pw_bwd_data(BF16, shape, 'gate' if view == 'gate' else 'plain', not predict, 'auto')
   if view == 'plain' and cout > cin and not predict:
-    tk.test_pw_bwd_data(BF16, (N_IMG, h, h, cin, cout), 'plain_beta', True, 'auto')
+    tk.test_pw_bwd_data(BF16, shape, 'plain_beta', True, 'auto')
   if cin == 64 and cout == 64:
-    tk.test_pw_bwd_data(BF16, (N_IMG, h, h, cin, cout), 'bn_swish_stats', True, 'auto')
+    tk.test_pw_bwd_data(BF16, shape, 'bn_swish_stats', True, 'auto')
+
+
+@pytest.mark.parametrize('layer', PW_LAYERS, ids=_pw_id)
+def test_pw_bwd_one_call_at_d0_640_shapes(layer):
+  """edet_pw_bwd as the engine calls it (the fused data + weight gradient kernel wherever the layer fits it), with
+  the engine's workspace: data gradient, epilogue sums AND weight gradient."""
+  h, cin, cout, view = layer
+  predict = cout in (810, 36)
+  shape = (N_IMG, h, h, cin, cout)
+  tk.test_pw_bwd_data(BF16, shape, 'gate' if view == 'gate' else 'plain', not predict, 'auto', one_call=True,
+                      ws_mib=ENGINE_WS_MIB)
+  if view == 'plain' and cout > cin and not predict:
+    tk.test_pw_bwd_data(BF16, shape, 'plain_beta', True, 'auto', one_call=True, ws_mib=ENGINE_WS_MIB)
+  if cin == 64 and cout == 64:
+    tk.test_pw_bwd_data(BF16, shape, 'bn_swish_stats', True, 'auto', one_call=True, ws_mib=ENGINE_WS_MIB)
 
 
 @pytest.mark.parametrize('layer', PW_LAYERS, ids=_pw_id)

@@ -125,7 +125,9 @@ def make_grad_view(rng, n, h, w, c, tdt, with_bn):
                                    (2, 9, 8, 384, 384)])
 @pytest.mark.parametrize('mode', ['plain', 'plain_beta', 'bn', 'bn_swish_stats', 'gate'])
 @pytest.mark.parametrize('gbn', [False, True])
-def test_pw_bwd_data(dt, shape, mode, gbn, pw_impl):
+def test_pw_bwd_data(dt, shape, mode, gbn, pw_impl, one_call=False, ws_mib=16):
+  """one_call: through edet_pw_bwd (both gradients in one call; bf16: the fused kernel where the layer fits it), which
+  must give the data gradient of edet_pw_bwd_data AND the weight gradient of edet_pw_bwd_weight."""
   name, edt, tdt = dt
   skip_f32_big(name, pw_impl)
   n, h, w, cin, cout = shape
@@ -178,8 +180,21 @@ def test_pw_bwd_data(dt, shape, mode, gbn, pw_impl):
   epi = BwdEpi(ptr(gout), 1 if old is not None else 0, ptr(md) if stats else None, ptr(rd) if stats else None,
                ptr(parts) if stats else None, ptr(dgate) if mode == 'gate' else None)
   npart = NP(0)
-  call('edet_pw_bwd_data', ctypes.byref(gv), ptr(wd), ldn, ctypes.byref(tv), ctypes.byref(epi),
-       ctypes.byref(npart), edt, gu.stream())
+  if one_call:
+    av = apply_view(x, scale, shift, act, gate)
+    if name == 'bf16':
+      av = av.to(torch.bfloat16).float()
+    dw0 = torch.from_numpy(rng.standard_normal((cin, cout)).astype(np.float32))   # dweight is accumulated into
+    want_dw = av.reshape(-1, cin).t() @ dyk.reshape(-1, cout) + dw0
+    dwd = dw0.to(gu.DEV)
+    wsp = torch.empty(ws_mib * 256 * 1024, dtype=torch.float32, device=gu.DEV)
+    call('edet_pw_bwd', ctypes.byref(gv), ptr(wd), ldn, ctypes.byref(tv), ctypes.byref(epi), ctypes.byref(npart),
+         ptr(dwd), ptr(wsp), ws_mib * 1024 * 1024, edt, gu.stream())
+    torch.cuda.synchronize()
+    gu.check(dwd, want_dw, name, 'pw_bwd dweight %s %s' % (shape, mode), rtol=2e-2 if name == 'bf16' else 1e-3)
+  else:
+    call('edet_pw_bwd_data', ctypes.byref(gv), ptr(wd), ldn, ctypes.byref(tv), ctypes.byref(epi),
+         ctypes.byref(npart), edt, gu.stream())
   torch.cuda.synchronize()
   gu.check(gout[..., :cin], want_g, name, 'pw_bwd_data g %s %s' % (shape, mode))
   if mode == 'gate':
@@ -190,6 +205,22 @@ def test_pw_bwd_data(dt, shape, mode, gbn, pw_impl):
     gq = want_g.to(tdt).float() if name == 'bf16' else want_g
     gu.check(s1, want_g.sum((0, 1, 2)), name, 'pw_bwd_data S1', rtol=3e-2 if name == 'bf16' else 1e-3)
     gu.check(s2, (gq * xh).sum((0, 1, 2)), name, 'pw_bwd_data S2', rtol=3e-2 if name == 'bf16' else 1e-3)
+
+
+PW_BWD_SHAPES = [(2, 9, 7, 24, 40), (3, 13, 11, 144, 24), (2, 12, 12, 96, 16), (4, 33, 31, 16, 96), (2, 8, 8, 64, 36),
+                 (2, 17, 19, 24, 144), (3, 9, 9, 64, 64), (1, 7, 7, 40, 64), (2, 10, 10, 32, 16), (2, 5, 5, 64, 810),
+                 (1, 20, 20, 1152, 192), (2, 6, 6, 112, 64)]
+
+
+@pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
+@pytest.mark.parametrize('shape', PW_BWD_SHAPES)
+@pytest.mark.parametrize('mode', ['plain', 'plain_beta', 'bn_swish_stats', 'gate'])
+@pytest.mark.parametrize('gbn', [False, True])
+def test_pw_bwd(dt, shape, mode, gbn):
+  """edet_pw_bwd: both gradients in one call.  The first shapes are inside the fused kernel's envelope (every
+  accumulator shape and load-pass pair it is instantiated for, ragged maps, tiles that straddle images, R % 8 != 0),
+  the last three outside (the entry point then runs the two separate kernels)."""
+  test_pw_bwd_data(dt, shape, mode, gbn, 'auto', one_call=True)
 
 
 @pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
