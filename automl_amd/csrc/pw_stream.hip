@@ -862,8 +862,8 @@ struct FusedArgs {
   int tpw, ksteps;    // tiles per wave; ceil(R / 16)
 };
 
-// FT_S x FT_L = 16 x 16 tiles of dW kept per wave (min(TK, TN) <= FT_S, max(TK, TN) <= FT_L): 2 x 9 for the expand /
-// project layers (16..32 channels on one side, up to 144 on the other), 4 x 4 for the 64-channel BiFPN / head layers
+// FT_S x FT_L = 16 x 16 tiles of dW kept per wave (min(TK, TN) <= FT_S, max(TK, TN) <= FT_L): 2 x 9 covers the expand
+// layers the host routes here (16..32 input channels, up to 144 output channels)
 template <int NSR, int NSX, bool GBN, int FT_S, int FT_L>
 __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -1386,23 +1386,21 @@ int pws_try_bwd_fused(const edet_gview_t* dy, const void* w, int ldw, const edet
   a.ws = reinterpret_cast<float*>(workspace);
   a.M = in->n * in->h * in->w; a.R = R; a.KO = KO; a.hw = in->h * in->w;
   a.TK = (KO + 15) / 16; a.TN = (R + 15) / 16;
-  const int ts = a.TK < a.TN ? a.TK : a.TN, tl = a.TK < a.TN ? a.TN : a.TK;
-  const bool wide = ts <= 2 && tl <= 9;          // accumulator shape 2 x 9, else 4 x 4
-  if (!wide && tl > 4) return 0;
+  // Envelope: the "expand" shape, few input channels and many output channels (R >= 2 KO, dW <= 2 x 9 tiles of
+  // 16 x 16).  r02d, D0 640x640 batch 128, both gradients: 320x320x16->96 2.44 -> 1.95 ms, 160x160x24->144 1.45 ->
+  // 0.73 ms.  With one wave per SIMD the kernel is epilogue-bound on the K-heavy project layers (160x160x144->24:
+  // 1.79 ms against 1.83 ms for the two kernels; 160x160x96->24 and the 64->64 BiFPN / head layers are slower
+  // fused), so those keep the two-kernel path.
+  if (R < 2 * KO || a.TK > 2 || a.TN > 9) return 0;
   a.cr = make_colmap(R);
   a.cx = make_colmap(KO);
   const int pstR = (TR + a.cr.rp - 1) / a.cr.rp, pstX = (TR + a.cx.rp - 1) / a.cx.rp;
   // (load passes of dy, of x) per 32-row tile, rounded up to an instantiated pair: the loops over the passes carry
   // no run-time guard (a guarded register array lands in scratch memory)
-  static const int pairs[6][2] = {{1, 2}, {2, 8}, {2, 12}, {4, 4}, {8, 1}, {12, 2}};
-  int nsr = 0, nsx = 0;
-  for (int i = 0; i < 6; ++i) {
-    if (pairs[i][0] >= pstR && pairs[i][1] >= pstX && (wide || (pairs[i][0] == 4 && pairs[i][1] == 4))) {
-      nsr = pairs[i][0]; nsx = pairs[i][1];
-      break;
-    }
-  }
-  if (!nsr) return 0;
+  int nsr, nsx;
+  if (pstR <= 8 && pstX <= 1) { nsr = 8; nsx = 1; }
+  else if (pstR <= 12 && pstX <= 2) { nsr = 12; nsx = 2; }
+  else return 0;
   const int Rp = (R + 7) / 8 * 8;
   a.ksteps = (R + 15) / 16;
   a.SA = frag_stride(Rp, Rp % 16 != 0);
@@ -1435,12 +1433,7 @@ int pws_try_bwd_fused(const edet_gview_t* dy, const void* w, int ldw, const edet
   } while (0)
 #define PWS_FUSED_G(NSR_, NSX_, FS_, FL_) \
   do { if (gbn) PWS_FUSED(NSR_, NSX_, true, FS_, FL_); else PWS_FUSED(NSR_, NSX_, false, FS_, FL_); } while (0)
-  if (!wide) PWS_FUSED_G(4, 4, 4, 4);
-  else if (nsr == 1) PWS_FUSED_G(1, 2, 2, 9);
-  else if (nsr == 2 && nsx == 8) PWS_FUSED_G(2, 8, 2, 9);
-  else if (nsr == 2) PWS_FUSED_G(2, 12, 2, 9);
-  else if (nsr == 4) PWS_FUSED_G(4, 4, 2, 9);
-  else if (nsr == 8) PWS_FUSED_G(8, 1, 2, 9);
+  if (nsr == 8) PWS_FUSED_G(8, 1, 2, 9);
   else PWS_FUSED_G(12, 2, 2, 9);
 #undef PWS_FUSED_G
 #undef PWS_FUSED

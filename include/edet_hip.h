@@ -161,10 +161,10 @@ int edet_pw_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy, float* dw
                        void* workspace, size_t workspace_bytes, int dtype, void* stream);
 /* both gradients of one layer in one call (TF's Conv2DBackpropInput + Conv2DBackpropFilter under the reference's
  * GradientTape, train_lib.py:623-669): the same result as edet_pw_bwd_weight followed by edet_pw_bwd_data with the
- * same arguments (workspace required).  In bf16, layers whose weight matrix fits a wave's registers (cin, cout <=
- * 160; min(ceil(cin/16), ceil(cout/16)) <= 4, max <= 9: every EfficientNet-B0 expand / project layer down to the
- * 80 x 80 maps, every 64-channel BiFPN / head layer) run ONE fused kernel that reads dy, the saved convolution
- * output behind it and the saved input once; other shapes run the two kernels.  */
+ * same arguments (workspace required).  In bf16, "expand"-shaped layers whose weight matrix fits a wave's registers
+ * (cout >= 2 cin, cin <= 32, cout <= 144: the first MBConv expansions, where the 6x expanded gradient pair
+ * dominates the traffic) run ONE fused kernel that reads dy, the saved convolution output behind it and the saved
+ * input once; other shapes run the two kernels.  */
 int edet_pw_bwd(const edet_gview_t* dy, const void* w, int ldw, const edet_tview_t* in,
                 const edet_bwd_epi_t* epi, int* nparts_out, float* dweight, void* workspace,
                 size_t workspace_bytes, int dtype, void* stream);

@@ -207,9 +207,9 @@ def test_pw_bwd_data(dt, shape, mode, gbn, pw_impl, one_call=False, ws_mib=16):
     gu.check(s2, (gq * xh).sum((0, 1, 2)), name, 'pw_bwd_data S2', rtol=3e-2 if name == 'bf16' else 1e-3)
 
 
-PW_BWD_SHAPES = [(2, 9, 7, 24, 40), (3, 13, 11, 144, 24), (2, 12, 12, 96, 16), (4, 33, 31, 16, 96), (2, 8, 8, 64, 36),
-                 (2, 17, 19, 24, 144), (3, 9, 9, 64, 64), (1, 7, 7, 40, 64), (2, 10, 10, 32, 16), (2, 5, 5, 64, 810),
-                 (1, 20, 20, 1152, 192), (2, 6, 6, 112, 64)]
+PW_BWD_SHAPES = [(4, 33, 31, 16, 96), (2, 17, 19, 24, 144), (3, 11, 13, 8, 16), (2, 9, 9, 32, 64), (1, 23, 5, 16, 36),
+                 (2, 9, 7, 24, 40), (3, 13, 11, 144, 24), (2, 12, 12, 96, 16), (3, 9, 9, 64, 64), (2, 5, 5, 64, 810),
+                 (1, 20, 20, 1152, 192)]
 
 
 @pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
@@ -217,9 +217,9 @@ PW_BWD_SHAPES = [(2, 9, 7, 24, 40), (3, 13, 11, 144, 24), (2, 12, 12, 96, 16), (
 @pytest.mark.parametrize('mode', ['plain', 'plain_beta', 'bn_swish_stats', 'gate'])
 @pytest.mark.parametrize('gbn', [False, True])
 def test_pw_bwd(dt, shape, mode, gbn):
-  """edet_pw_bwd: both gradients in one call.  The first shapes are inside the fused kernel's envelope (every
-  accumulator shape and load-pass pair it is instantiated for, ragged maps, tiles that straddle images, R % 8 != 0),
-  the last three outside (the entry point then runs the two separate kernels)."""
+  """edet_pw_bwd: both gradients in one call.  The first five shapes are inside the fused kernel's envelope (cout >=
+  2 cin: both load-pass instantiations, ragged maps, tiles that straddle images, cout % 8 != 0), the others outside
+  (the entry point then runs the two separate kernels)."""
   test_pw_bwd_data(dt, shape, mode, gbn, 'auto', one_call=True)
 
 
