@@ -34,6 +34,7 @@ class EfficientDetNet(object):
     self.name = name
     self._dtype, self._device, self._seed = dtype, device, seed
     self._init_params = params
+    self._init_ema = None
     self._stochastic_depth = stochastic_depth   # False: survival_prob off for every backbone (deterministic)
     self.engine = None
     self._engines = {}
@@ -52,6 +53,9 @@ class EfficientDetNet(object):
       e = engine_lib.Engine(self.config, batch, (height, width), dtype=self._dtype, device=self._device,
                             seed=self._seed, params=self._init_params, stochastic_depth=self._stochastic_depth,
                             arena=arena)
+      if self._init_ema and arena is None:
+        e.arena.set_ema_params(self._init_ema)      # shadows restored before the model was built (util_keras.restore_ckpt)
+        self._init_ema = None
       while len(self._engines) >= self.MAX_ENGINES:
         self._engines.pop(next(iter(self._engines)))          # least recently used shape
       self._engines[key] = e
@@ -93,6 +97,13 @@ class EfficientDetNet(object):
     if self.engine is None:
       raise RuntimeError('the network has not been built yet (call it once)')
     return self.engine.arena.get_ema_params()
+
+  def set_ema_weights(self, values):
+    """EMA shadows of trainable variables by name (the 'average' slots util_keras.restore_ckpt fills, :166-178)."""
+    if self.engine is None:
+      self._init_ema = dict(values) if self._init_ema is None else {**self._init_ema, **values}
+    else:
+      self.engine.arena.set_ema_params(values)
 
   def get_optimizer_state(self):
     """Momentum, EMA shadows and iteration count (host copies), for checkpointing."""

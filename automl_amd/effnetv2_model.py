@@ -359,7 +359,15 @@ class EffNetV2Model(object):
 
 
 def get_model(model_name, model_config=None, include_top=True, weights=None, **kwargs):
-  """effnetv2_model.get_model (:661-...): pretrained-weight download is unavailable offline."""
+  """effnetv2_model.get_model (:661-760).  ``weights``: None (random initialisation) or the path of a checkpoint /
+  checkpoint directory, as the reference's last branch (``tf.train.latest_checkpoint`` + ``load_weights``); the named
+  pretrained sets ('imagenet', 'imagenet21k', ...) are downloads and cannot be fetched offline."""
+  model = EffNetV2Model(model_name, model_config, include_top, **kwargs)
   if weights:
-    raise ValueError('pretrained weights cannot be fetched here; pass weights=None and set_weights()')
-  return EffNetV2Model(model_name, model_config, include_top, **kwargs)
+    import os
+    if weights in ('imagenet', 'imagenet21k', 'imagenet21k-ft1k', 'jft') or not (
+        os.path.isdir(weights) or os.path.exists(weights + '.index')):
+      raise ValueError('pretrained weights %r cannot be fetched here; pass a checkpoint path or set_weights()' % (weights,))
+    from automl_amd import util_keras
+    util_keras.restore_ckpt(model, weights, ema_decay=0, skip_mismatch=False)
+  return model

@@ -175,6 +175,19 @@ class ParamArena(object):
     statistics as they are (they have no shadow in the Keras train step)."""
     return self._export(self.ema, self.state_flat, names)
 
+  def set_ema_params(self, values):
+    """EMA shadows (the MovingAverage optimizer's 'average' slots) of trainable variables, by name."""
+    for name, v in values.items():
+      if name not in self.offsets:
+        raise KeyError('unknown variable %s' % name)
+      off, n, shape, tr = self.offsets[name]
+      if not tr:
+        raise KeyError('%s has no EMA shadow (not a trainable variable)' % name)
+      t = torch.as_tensor(np.asarray(v, dtype=np.float32)).reshape(-1)
+      if t.numel() != n:
+        raise ValueError('variable %s: expected %d elements, got %d' % (name, n, t.numel()))
+      self._slice(self.ema, None, name).copy_(t)
+
   def get_optimizer_state(self):
     """Host copy of the optimizer slots: momentum, EMA shadows, iteration count."""
     return {'velocity': self.velocity.cpu().numpy().copy(), 'ema': self.ema.cpu().numpy().copy(),
@@ -264,6 +277,9 @@ class Engine(object):
   def _build_params(self, params, seed, arena):
     if arena is None:
       values = params if params is not None else netspec_lib.init_params(self.spec, seed)
+      if any(p.name not in values for p in self.spec.params):
+        # a partial set (e.g. a checkpoint restored with skip_mismatch): the other variables keep their initial values
+        values = {**netspec_lib.init_params(self.spec, seed), **values}
       arena = ParamArena(self.spec, self.device, values)
     self.arena = arena
     for k in ('offsets', 'n_train_elems', 'seg_names', 'params_flat', 'grads_flat', 'velocity', 'ema', 'state_flat',

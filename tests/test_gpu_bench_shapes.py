@@ -43,7 +43,7 @@ from tests.test_gpu_network import _seg_index, make_labels, perturbed_params, re
 pytestmark = pytest.mark.gpu
 
 BF16 = gu.DTYPES[1]
-TOL = {'f32': 1e-3, 'bf16_vs_f32': 3e-2, 'bf16_vs_emu': 1e-2, 'layer': 1.2e-2, 'layer_grad': 3e-2, 'layer_wgrad': 3e-2}
+TOL = {'f32': 1e-3, 'bf16_vs_f32': 3e-2, 'bf16_vs_emu': 1e-2, 'layer': 1.2e-2, 'layer_grad': 3e-2, 'layer_wgrad': 2.5e-2}
 ENGINE_WS_MIB = 64          # automl_amd/engine.py: the weight-gradient workspace the benchmark step hands over
 COVERED = {}                # kernel symbol -> launches, accumulated over the oracle-checked tests of this module
 
@@ -344,7 +344,14 @@ def test_d0_640_batch2_bf16_train_step_layer_by_layer():
       assert float(mine.abs().max()) == 0.0, n
       assert float(g.abs().max()) <= 2e-2 * gmax, (n, float(g.abs().max()), gmax)
       continue
-    werr[n] = float((mine - g).abs().max()) / max(float(g.abs().max()), 1e-4 * gmax)
+    e = float((mine - g).abs().max()) / max(float(g.abs().max()), 1e-4 * gmax)
+    if n.rsplit('/', 1)[-1].startswith('WSM'):
+      # a fusion scalar's gradient is ONE signed sum over a whole pyramid level of d(out) * input: the device sums the
+      # fp32 products before d(out) is rounded for storage, the emulating oracle after; with the cancellation in that
+      # sum the two differ by 2-3 % from run to run (r02e 2.1 %, r02g 3.3 %; SE atomics reorder the step)
+      assert e <= 8e-2, (n, e)
+      continue
+    werr[n] = e
   print('teacher-forced variable gradients: %d tensors, worst %s' % (len(werr), gu.TeacherForce.worst(werr, 5)))
   assert max(werr.values()) <= TOL['layer_wgrad'], gu.TeacherForce.worst(werr, 8)
 
