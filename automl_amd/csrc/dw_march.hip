@@ -106,14 +106,19 @@ __device__ __forceinline__ Lane lane_setup(const Args& a, int C) {
   return l;
 }
 
-template <int CPT>
+// OACT: the view's activation is one of relu / relu6 / hswish (utils.activation_fn; the lite models) -- a template
+// parameter of every kernel here, so that the swish / linear instantiations keep their register budget
+template <int CPT, bool OACT>
 __device__ __forceinline__ void view_act(const edet_tview_t& v, const float sc[CPT], const float sh[CPT],
                                          float x[CPT]) {
   if (v.scale) {
 #pragma unroll
     for (int e = 0; e < CPT; ++e) x[e] = fmaf(x[e], sc[e], sh[e]);
   }
-  if (v.act == EDET_ACT_SWISH) {
+  if (OACT) {
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) x[e] = act_other_(v.act, x[e]);
+  } else if (v.act == EDET_ACT_SWISH) {
 #pragma unroll
     for (int e = 0; e < CPT; ++e) x[e] = swishf_(x[e]);
   }
@@ -198,7 +203,7 @@ template <int S, int CPT> struct PfDepth {
   static constexpr int dgrad = CPT == 4 ? (S == 1 ? 3 : 1) : (S == 1 ? 6 : 3);
 };
 
-template <int K, int S, int CPT>
+template <int K, int S, int CPT, bool OACT>
 __global__ __launch_bounds__(THREADS) void k_fwd_lx(const Args a) {
   constexpr int PF = PfDepth<S, CPT>::fwd;
   constexpr int NSL = (K + S - 1) / S;   // output rows in flight
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(THREADS) void k_fwd_lx(const Args a) {
           for (int j = 0; j < S; ++j) {
             float x[CPT];
             raw_unpack<CPT>(fm[0][j], x);
-            view_act<CPT>(a.in, sc, sh, x);
+            view_act<CPT, OACT>(a.in, sc, sh, x);
             if (!mok[j]) {
 #pragma unroll
               for (int e = 0; e < CPT; ++e) x[e] = 0.f;   // 'SAME' padding is zero in the activated domain
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(THREADS) void k_fwd_lx(const Args a) {
           if (hown) {
             float x[CPT];
             raw_unpack<CPT>(fh[0], x);
-            view_act<CPT>(a.in, sc, sh, x);
+            view_act<CPT, OACT>(a.in, sc, sh, x);
             if (!hok) {
 #pragma unroll
               for (int e = 0; e < CPT; ++e) x[e] = 0.f;
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(THREADS) void k_fwd_lx(const Args a) {
 
 // weight gradient with the activated input row exchanged through LDS (see k_fwd_lx); dy is the thread's own
 // column, so its BatchNorm backward was already applied once per element.
-template <int K, int S, int CPT, bool GBN>
+template <int K, int S, int CPT, bool GBN, bool OACT>
 __global__ __launch_bounds__(THREADS) void k_wgrad_lx(const Args a) {
   constexpr int PF = PfDepth<S, CPT>::bwd;          // input rows in flight
   constexpr int PG = (PF + S - 1) / S + 1;     // dy rows in flight
@@ -471,7 +476,7 @@ __global__ __launch_bounds__(THREADS) void k_wgrad_lx(const Args a) {
           for (int j = 0; j < S; ++j) {
             float x[CPT];
             raw_unpack<CPT>(fm[0][j], x);
-            view_act<CPT>(a.in, sc, sh, x);
+            view_act<CPT, OACT>(a.in, sc, sh, x);
             if (!mok[j]) {
 #pragma unroll
               for (int e = 0; e < CPT; ++e) x[e] = 0.f;
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(THREADS) void k_wgrad_lx(const Args a) {
           if (hown) {
             float x[CPT];
             raw_unpack<CPT>(fh[0], x);
-            view_act<CPT>(a.in, sc, sh, x);
+            view_act<CPT, OACT>(a.in, sc, sh, x);
             if (!hok) {
 #pragma unroll
               for (int e = 0; e < CPT; ++e) x[e] = 0.f;
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(THREADS) void k_wgrad_lx(const Args a) {
 // data gradient with the BatchNorm-backward-transformed dy row exchanged through LDS: thread q loads and
 // transforms dy[oy][q] (plus the halo columns q0 - (D-1) .. q0 - 1 by the first D - 1 threads) and reads
 // dy[oy][q - d] (d < D) back after the barrier.  Window column wc <-> dy column q0 - (D-1) + wc.
-template <int K, int S, int CPT, bool GBN>
+template <int K, int S, int CPT, bool GBN, bool OACT>
 __global__ __launch_bounds__(THREADS, 3) void k_dgrad_lx(const Args a) {
   constexpr int PF = PfDepth<S, CPT>::dgrad;       // dy rows (and the saved-input rows they complete) in flight
   constexpr int D = (K + S - 1) / S;
@@ -549,7 +554,8 @@ __global__ __launch_bounds__(THREADS, 3) void k_dgrad_lx(const Args a) {
 #pragma unroll
     for (int e = 0; e < CPT; ++e) w[t][e] = l.active ? a.w[(size_t)t * C + l.c + e] : 0.f;
   const bool want_stats = a.epi.stat_partials != nullptr;
-  const bool swish = a.in.act == EDET_ACT_SWISH;
+  constexpr bool other = OACT;
+  const bool swish = !OACT && a.in.act == EDET_ACT_SWISH;
   if (l.active) {
     if (a.in.scale) { loadf<CPT>(a.in.scale + l.c, sc); loadf<CPT>(a.in.shift + l.c, sh); }
     if (GBN) { loadf<CPT>(a.gy.a + l.c, ga); loadf<CPT>(a.gy.b + l.c, gb); loadf<CPT>(a.gy.cc + l.c, gc); }
@@ -589,7 +595,7 @@ __global__ __launch_bounds__(THREADS, 3) void k_dgrad_lx(const Args a) {
         for (int u = 0; u < S; ++u) fx[i][v][u] = raw_zero<CPT>();
     }
     if (!GBN) fy[0] = fhy[0] = raw_zero<CPT>();
-    const bool need_x = swish || want_stats;
+    const bool need_x = swish || other || want_stats;
     // saved conv input of the S x S pixels that dy step oy completes (needed for act' / BN backward sums)
     auto load_x = [&](int oy, Raw<CPT> (&xr)[S][S]) {
 #pragma unroll
@@ -698,6 +704,9 @@ __global__ __launch_bounds__(THREADS, 3) void k_dgrad_lx(const Args a) {
                 if (swish) {
 #pragma unroll
                   for (int e = 0; e < CPT; ++e) g[e] *= swish_gradf_(fmaf(x[e], sc[e], sh[e]));
+                } else if (other) {
+#pragma unroll
+                  for (int e = 0; e < CPT; ++e) g[e] *= act_other_grad_(a.in.act, fmaf(x[e], sc[e], sh[e]));
                 }
                 if (a.epi.beta) {
                   float old[CPT];
@@ -753,10 +762,10 @@ __global__ __launch_bounds__(THREADS, 3) void k_dgrad_lx(const Args a) {
 // A tile owns the input rows [r0, r1) x its columns: dy rows r0-p .. r1-1+p are marched (the 2p extra rows
 // are re-read by the neighbouring tile), x rows outside [r0, r1) enter the window as zeros so that every
 // (x pixel, dy pixel) pair is counted by exactly one tile.
-template <int K, int CPT, bool GBN>
+template <int K, int CPT, bool GBN, bool OACT, int PF = 3>
 __global__ __launch_bounds__(THREADS, CPT * K >= 10 ? 2 : 3) void k_bwd_fused(const Args a) {
   constexpr int PD = (K - 1) / 2;             // 'SAME' padding of an odd kernel at stride 1
-  constexpr int PF = 3;                       // rows of global loads in flight
+  // PF: rows of global loads in flight
   extern __shared__ float red[];
   const int C = a.in.c, H = a.in.h, W = a.in.w;
   const Lane l = lane_setup<CPT>(a, C);
@@ -783,7 +792,8 @@ __global__ __launch_bounds__(THREADS, CPT * K >= 10 ? 2 : 3) void k_bwd_fused(co
       wacc[t][e] = 0.f;
     }
   const bool want_stats = a.epi.stat_partials != nullptr;
-  const bool swish = a.in.act == EDET_ACT_SWISH;
+  constexpr bool other = OACT;
+  const bool swish = !OACT && a.in.act == EDET_ACT_SWISH;
   if (l.active) {
     if (a.in.scale) { loadf<CPT>(a.in.scale + l.c, sc); loadf<CPT>(a.in.shift + l.c, sh); }
     if (GBN) { loadf<CPT>(a.gy.a + l.c, ga); loadf<CPT>(a.gy.b + l.c, gb); loadf<CPT>(a.gy.cc + l.c, gc); }
@@ -866,6 +876,12 @@ __global__ __launch_bounds__(THREADS, CPT * K >= 10 ? 2 : 3) void k_bwd_fused(co
               const float sg = sigmoidf_(z[e]);
               xt[sl][e] = xin ? z[e] * sg : 0.f;
               dsw[sl][e] = sg * (1.f + z[e] * (1.f - sg));
+            }
+          } else if (other) {
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) {
+              xt[sl][e] = xin ? act_other_(a.in.act, z[e]) : 0.f;
+              dsw[sl][e] = act_other_grad_(a.in.act, z[e]);
             }
           } else {
 #pragma unroll
@@ -975,6 +991,11 @@ inline void plan(Args& a, int C, int n, int space_w, int space_h, int max_p) {
   a.ngroups = (nvec + a.nch - 1) / a.nch;
   a.TX = THREADS / a.nch;
   a.TY = 32;
+  {  // LAB (r02i): balanced tiles of at most EDET_DW_TY rows
+    const char* e = getenv("EDET_DW_TY");
+    const int cap = e ? atoi(e) : 0;
+    if (cap > 0) { const int nt = (space_h + cap - 1) / cap; a.TY = (space_h + nt - 1) / nt; }
+  }
   if (a.TY > space_h) a.TY = space_h;
   a.tiles_x = (space_w + a.TX - 1) / a.TX;
   a.tiles_y = (space_h + a.TY - 1) / a.TY;
@@ -991,11 +1012,11 @@ inline void plan(Args& a, int C, int n, int space_w, int space_h, int max_p) {
 // return 1 = handled, 0 = not applicable (caller falls back), < 0 = error
 int dwm_try_fwd(const edet_tview_t* in, const float* weight, int k, int s, void* out, int ldo,
                 float* stat_partials, int* nparts_out, hipStream_t st) {
-  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace dwm;
   if (in->gate || in->c % 8 != 0) return 0;
   Args a;
   memset(&a, 0, sizeof(a));
+  const bool oact = in->act > EDET_ACT_SWISH;      // relu / relu6 / hswish: the OACT instantiations
   a.in = *in; a.w = weight; a.out = reinterpret_cast<bf16_t*>(out); a.ldo = ldo; a.stat_partials = stat_partials;
   a.oh = same_out(in->h, s); a.ow = same_out(in->w, s);
   a.pad_t = same_pad_before(in->h, k, s); a.pad_l = same_pad_before(in->w, k, s);
@@ -1004,7 +1025,8 @@ int dwm_try_fwd(const edet_tview_t* in, const float* weight, int k, int s, void*
     plan<CPT_>(a, in->c, in->n, a.ow, a.oh, EDET_MAX_PARTS);                              \
     const size_t lds0 = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                  \
     const size_t ring = (size_t)2 * (a.TX * S_ + K_ - S_) * a.nch * CPT_ * sizeof(float); \
-    edet_launch(k_fwd_lx<K_, S_, CPT_>, dim3(a.P * a.ngroups), dim3(THREADS), lds0 + ring, st, a); \
+    if (oact) edet_launch(k_fwd_lx<K_, S_, CPT_, true>, dim3(a.P * a.ngroups), dim3(THREADS), lds0 + ring, st, a); \
+    else edet_launch(k_fwd_lx<K_, S_, CPT_, false>, dim3(a.P * a.ngroups), dim3(THREADS), lds0 + ring, st, a); \
   } while (0)
   if (k == 3 && s == 1) DWM_FWD(3, 1, 4);
   else if (k == 3 && s == 2) DWM_FWD(3, 2, 4);
@@ -1019,11 +1041,11 @@ int dwm_try_fwd(const edet_tview_t* in, const float* weight, int k, int s, void*
 
 int dwm_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, float* dweight, void* workspace,
                   size_t workspace_bytes, hipStream_t st) {
-  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace dwm;
   if (in->gate || in->c % 8 != 0 || !workspace) return 0;
   Args a;
   memset(&a, 0, sizeof(a));
+  const bool oact = in->act > EDET_ACT_SWISH;      // relu / relu6 / hswish: the OACT instantiations
   a.in = *in; a.gy = *dy; a.ws = reinterpret_cast<float*>(workspace);
   a.oh = same_out(in->h, s); a.ow = same_out(in->w, s);
   a.pad_t = same_pad_before(in->h, k, s); a.pad_l = same_pad_before(in->w, k, s);
@@ -1038,8 +1060,8 @@ int dwm_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, 
     const size_t lds = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                   \
     const size_t ring = (size_t)2 * (a.TX * S_ + K_ - S_) * a.nch * CPT_ * sizeof(float); \
     const dim3 grid(a.P * a.ngroups), block(THREADS);                                     \
-    if (gbn) edet_launch(k_wgrad_lx<K_, S_, CPT_, true>, grid, block, lds + ring, st, a);          \
-    else edet_launch(k_wgrad_lx<K_, S_, CPT_, false>, grid, block, lds + ring, st, a);             \
+    if (gbn) { if (oact) edet_launch(k_wgrad_lx<K_, S_, CPT_, true, true>, grid, block, lds + ring, st, a); else edet_launch(k_wgrad_lx<K_, S_, CPT_, true, false>, grid, block, lds + ring, st, a); }          \
+    else { if (oact) edet_launch(k_wgrad_lx<K_, S_, CPT_, false, true>, grid, block, lds + ring, st, a); else edet_launch(k_wgrad_lx<K_, S_, CPT_, false, false>, grid, block, lds + ring, st, a); }             \
   } while (0)
   if (k == 3 && s == 1) DWM_WG(3, 1, 4);
   else if (k == 3 && s == 2) DWM_WG(3, 2, 4);
@@ -1054,11 +1076,11 @@ int dwm_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, 
 
 int dwm_try_dgrad(const edet_gview_t* dy, const float* weight, int k, int s, const edet_tview_t* in,
                   const edet_bwd_epi_t* epi, int* nparts_out, hipStream_t st) {
-  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace dwm;
   if (in->gate || epi->dgate || in->c % 8 != 0) return 0;
   Args a;
   memset(&a, 0, sizeof(a));
+  const bool oact = in->act > EDET_ACT_SWISH;      // relu / relu6 / hswish: the OACT instantiations
   a.in = *in; a.gy = *dy; a.w = weight; a.epi = *epi;
   a.oh = same_out(in->h, s); a.ow = same_out(in->w, s);
   a.pad_t = same_pad_before(in->h, k, s); a.pad_l = same_pad_before(in->w, k, s);
@@ -1070,8 +1092,8 @@ int dwm_try_dgrad(const edet_gview_t* dy, const float* weight, int k, int s, con
     const size_t lds = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                   \
     const size_t ring = (size_t)2 * (a.TX + (K_ + S_ - 1) / S_ - 1) * a.nch * CPT_ * sizeof(float); \
     const dim3 grid(a.P * a.ngroups), block(THREADS);                                     \
-    if (gbn) edet_launch(k_dgrad_lx<K_, S_, CPT_, true>, grid, block, lds + ring, st, a);          \
-    else edet_launch(k_dgrad_lx<K_, S_, CPT_, false>, grid, block, lds + ring, st, a);             \
+    if (gbn) { if (oact) edet_launch(k_dgrad_lx<K_, S_, CPT_, true, true>, grid, block, lds + ring, st, a); else edet_launch(k_dgrad_lx<K_, S_, CPT_, true, false>, grid, block, lds + ring, st, a); }          \
+    else { if (oact) edet_launch(k_dgrad_lx<K_, S_, CPT_, false, true>, grid, block, lds + ring, st, a); else edet_launch(k_dgrad_lx<K_, S_, CPT_, false, false>, grid, block, lds + ring, st, a); }             \
   } while (0)
   if (k == 3 && s == 1) DWM_DG(3, 1, 4);
   else if (k == 3 && s == 2) DWM_DG(3, 2, 4);
@@ -1088,7 +1110,6 @@ int dwm_try_dgrad(const edet_gview_t* dy, const float* weight, int k, int s, con
 int dwm_try_bwd_fused(const edet_gview_t* dy, const float* weight, int k, int s, const edet_tview_t* in,
                       const edet_bwd_epi_t* epi, int* nparts_out, float* dweight, void* workspace,
                       size_t workspace_bytes, hipStream_t st) {
-  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace dwm;
   // k = 3: 4 channels per thread (8-byte loads, 2 waves/SIMD) wins on the large maps, 2 channels per thread
   // (3-4 waves/SIMD) on the small ones (measured: 320x320x32 1.08 vs 1.55 ms, 40x40x64 1.25 vs 1.05 ms)
@@ -1096,6 +1117,7 @@ int dwm_try_bwd_fused(const edet_gview_t* dy, const float* weight, int k, int s,
   if (s != 1 || (k != 3 && k != 5) || in->gate || epi->dgate || in->c % 8 != 0 || !workspace) return 0;
   Args a;
   memset(&a, 0, sizeof(a));
+  const bool oact = in->act > EDET_ACT_SWISH;      // relu / relu6 / hswish: the OACT instantiations
   a.in = *in; a.gy = *dy; a.w = weight; a.epi = *epi; a.ws = reinterpret_cast<float*>(workspace);
   a.oh = in->h; a.ow = in->w;
   a.pad_t = a.pad_l = (k - 1) / 2;
@@ -1110,9 +1132,33 @@ int dwm_try_bwd_fused(const edet_gview_t* dy, const float* weight, int k, int s,
     const size_t lds = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                   \
     const size_t ring = (size_t)2 * (a.TX + K_ - 1) * a.nch * CPT_ * sizeof(float);       \
     const dim3 grid(a.P * a.ngroups), block(THREADS);                                     \
-    if (gbn) edet_launch(k_bwd_fused<K_, CPT_, true>, grid, block, lds + ring, st, a);             \
-    else edet_launch(k_bwd_fused<K_, CPT_, false>, grid, block, lds + ring, st, a);                \
+    if (gbn) { if (oact) edet_launch(k_bwd_fused<K_, CPT_, true, true>, grid, block, lds + ring, st, a); else edet_launch(k_bwd_fused<K_, CPT_, true, false>, grid, block, lds + ring, st, a); }             \
+    else { if (oact) edet_launch(k_bwd_fused<K_, CPT_, false, true>, grid, block, lds + ring, st, a); else edet_launch(k_bwd_fused<K_, CPT_, false, false>, grid, block, lds + ring, st, a); }                \
   } while (0)
+  {  // LAB (r02i): EDET_DWB_PF=6 -> deeper load FIFO in the fused backward (swish / linear instantiations)
+    const char* e = getenv("EDET_DWB_PF");
+    const int pf = e ? atoi(e) : 0;
+    if (pf > 3 && !oact) {
+      const dim3 block(THREADS);
+#define DWM_FUSED_PF(K_, CPT_, PF_)                                                          \
+      do {                                                                                    \
+        plan<CPT_>(a, in->c, in->n, in->w, in->h, max_p);                                     \
+        const size_t lds = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                   \
+        const size_t ring = (size_t)2 * (a.TX + K_ - 1) * a.nch * CPT_ * sizeof(float);       \
+        const dim3 grid(a.P * a.ngroups);                                                     \
+        if (gbn) edet_launch(k_bwd_fused<K_, CPT_, true, false, PF_>, grid, block, lds + ring, st, a);   \
+        else edet_launch(k_bwd_fused<K_, CPT_, false, false, PF_>, grid, block, lds + ring, st, a);      \
+      } while (0)
+      if (k == 3 && k3c4) DWM_FUSED_PF(3, 4, 4);
+      else if (k == 3) DWM_FUSED_PF(3, 2, 6);
+      else DWM_FUSED_PF(5, 2, 6);
+#undef DWM_FUSED_PF
+      if (nparts_out) *nparts_out = a.P;
+      EDET_LAUNCH_CHECK("edet_dw_bwd(fused, pf)");
+      if (edet_reduce_partials(a.ws, a.P, kkc, dweight, st) != 0) return -2;
+      return 1;
+    }
+  }
   if (k == 3 && k3c4) DWM_FUSED(3, 4);
   else if (k == 3) DWM_FUSED(3, 2);
   else DWM_FUSED(5, 2);

@@ -108,6 +108,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
   const bool want_stats = a.stat_partials != nullptr;
   const bool want_gate = BWD && a.epi.dgate != nullptr;
   const bool swish = a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr;
+  const bool other = a.tv.act > EDET_ACT_SWISH;     // relu / relu6 / hswish (utils.activation_fn): kernel-uniform
+  const int act = a.tv.act;
   const bool gated = !BWD && a.tv.gate != nullptr;
 
   // staging geometry: thread -> chunk column lc (8 reduction elements), rows lr + 32*i
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
         uint4 v = ra[i];
         if (kok) {
           if (!BWD) {
-            if (affine || swish || gated) {
+            if (affine || swish || other || gated) {
               float x[8];
               unpack8(ra[i], x);
               if (affine) {
@@ -226,6 +228,9 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
               if (swish) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] = swishf_(x[e]);
+              } else if (other) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = act_other_(act, x[e]);
               }
               if (gated) {
                 float gt[8];
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
       __syncthreads();
       const bf16_t* X = reinterpret_cast<const bf16_t*>(a.tv.data);
       bf16_t* GO = reinterpret_cast<bf16_t*>(a.epi.gout);
-      const bool need_x = swish || want_gate || want_stats;
+      const bool need_x = swish || other || want_gate || want_stats;
       float sc[8], sh[8], s1[8], s2[8], gp[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; s1[e] = s2[e] = gp[e] = 0.f; }
@@ -386,12 +391,15 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const float z = fmaf(x[e], sc[e], sh[e]);
-              gp[e] = fmaf(d[e], swish ? swishf_(z) : z, gp[e]);
+              gp[e] = fmaf(d[e], swish ? swishf_(z) : (other ? act_other_(act, z) : z), gp[e]);
               g[e] = d[e];
             }
           } else if (swish) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) g[e] = d[e] * swish_gradf_(fmaf(x[e], sc[e], sh[e]));
+          } else if (other) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = d[e] * act_other_grad_(act, fmaf(x[e], sc[e], sh[e]));
           } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) g[e] = d[e];
@@ -524,6 +532,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_wgrad(const WgArgs a) {
   const bf16_t* SRCY = reinterpret_cast<const bf16_t*>(a.gv.y);
   const int ld = is_x ? a.tv.ld : a.gv.ld;
   const bool swish = a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr, gated = a.tv.gate != nullptr;
+  const bool other = a.tv.act > EDET_ACT_SWISH;     // relu / relu6 / hswish
+  const int act = a.tv.act;
   float c0[8], c1[8], c2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { c0[e] = 1.f; c1[e] = 0.f; c2[e] = 0.f; }
@@ -588,7 +598,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_wgrad(const WgArgs a) {
       p[r] = ra[r];
       if (c_ok && m < m_end) {
         if (is_x) {
-          if (affine || swish || gated) {
+          if (affine || swish || other || gated) {
             float x[8];
             unpack8(ra[r], x);
             if (affine) {
@@ -598,6 +608,9 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_wgrad(const WgArgs a) {
             if (swish) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) x[e] = swishf_(x[e]);
+            } else if (other) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[e] = act_other_(act, x[e]);
             }
             if (gated) {
               float gt[8];
@@ -700,6 +713,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_wgrad_bal(const WgArgs a) {
   const bf16_t* DZ = reinterpret_cast<const bf16_t*>(a.gv.dz);
   const bf16_t* DY = reinterpret_cast<const bf16_t*>(a.gv.y);
   const bool swish = a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr, gated = a.tv.gate != nullptr;
+  const bool other = a.tv.act > EDET_ACT_SWISH;     // relu / relu6 / hswish
+  const int act = a.tv.act;
   float xs[8], xt[8], ga[8], gb[8], gc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { xs[e] = 1.f; xt[e] = 0.f; ga[e] = 1.f; gb[e] = 0.f; gc[e] = 0.f; }
@@ -741,7 +756,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_wgrad_bal(const WgArgs a) {
       if (m < m_end) {
         if (x_ok) {
           px[r] = rx[r];
-          if (affine || swish || gated) {
+          if (affine || swish || other || gated) {
             float x[8];
             unpack8(rx[r], x);
             if (affine) {
@@ -751,6 +766,9 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_wgrad_bal(const WgArgs a) {
             if (swish) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) x[e] = swishf_(x[e]);
+            } else if (other) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[e] = act_other_(act, x[e]);
             }
             if (gated) {
               float gt[8];
@@ -817,7 +835,6 @@ inline bool big_lds_ok(const void* kern) {
 // return 1 = handled, 0 = shape outside the envelope (caller falls back), < 0 = error
 int pwb_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bias, void* out, int cout,
                 int ldo, float* stat_partials, int* nparts_out, hipStream_t st) {
-  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace pwb;
   const int K = in->c, N = cout;
   if (K % 8 != 0 || in->ld % 8 != 0 || ldw % 8 != 0 || ldo % 8 != 0 || ldo < (N + 7) / 8 * 8) return 0;
@@ -843,7 +860,6 @@ int pwb_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
 // (ky*k + kx)*cin + c contiguous.  return 1 = handled, 0 = shape outside the envelope, < 0 = error
 int pwb_try_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, int k, int s, const float* bias, void* out,
                      int cout, int ldo, float* stat_partials, int* nparts_out, hipStream_t st) {
-  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace pwb;
   const int cin = in->c, N = cout;
   if (cin % 8 != 0 || in->ld % 8 != 0 || ldw % 8 != 0 || ldo % 8 != 0 || ldo < (N + 7) / 8 * 8) return 0;
@@ -870,7 +886,6 @@ int pwb_try_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, int k, int
 
 int pwb_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tview_t* in,
                   const edet_bwd_epi_t* epi, int* nparts_out, hipStream_t st) {
-  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace pwb;
   const int R = dy->c, KO = in->c;
   if (KO % 8 != 0 || in->ld % 8 != 0 || dy->ld % 8 != 0 || ldw % 8 != 0 || R % 8 != 0) return 0;
@@ -896,7 +911,6 @@ int pwb_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tvi
 
 int pwb_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight, void* workspace,
                   size_t workspace_bytes, hipStream_t st) {
-  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace pwb;
   const int K = in->c, N = dy->c;
   if (!workspace || K % 8 != 0 || N % 8 != 0 || dy->ld % 8 != 0 || in->ld % 8 != 0) return 0;
@@ -933,7 +947,6 @@ int pwb_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight
 // data gradient: w_t [cin][ldw] with the reduction index (ky*k + kx)*cout + co contiguous; rows = input pixels
 int pwb_try_conv_dgrad(const edet_gview_t* dy, const void* w_t, int ldw, int k, int s, const edet_tview_t* in,
                        const edet_bwd_epi_t* epi, int* nparts_out, hipStream_t st) {
-  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace pwb;
   const int cout = dy->c, cin = in->c;
   if (cout % 8 != 0 || cin % 8 != 0 || in->ld % 8 != 0 || dy->ld % 8 != 0 || ldw % 8 != 0) return 0;
@@ -964,7 +977,6 @@ int pwb_try_conv_dgrad(const edet_gview_t* dy, const void* w_t, int ldw, int k, 
 // weight gradient: dweight fp32 HWIO [k][k][cin][cout] += gathered(in)^T dy
 int pwb_try_conv_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, float* dweight, void* workspace,
                        size_t workspace_bytes, hipStream_t st) {
-  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace pwb;
   const int cin = in->c, N = dy->c, K = k * k * cin;
   if (!workspace || cin % 8 != 0 || N % 8 != 0 || dy->ld % 8 != 0 || in->ld % 8 != 0) return 0;

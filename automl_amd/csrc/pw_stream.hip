@@ -99,16 +99,19 @@ __device__ __forceinline__ uint4 pack8(const float x[8]) {
 
 // activated value of 8 raw bf16 elements -> 8 bf16 packed
 __device__ __forceinline__ uint4 transform8(const uint4 raw, const float sc[8], const float sh[8],
-                                            const float gt[8], bool affine, bool swish, bool gate) {
+                                            const float gt[8], bool affine, int act, bool gate) {
   float x[8];
   unpack8(raw, x);
   if (affine) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], sc[e], sh[e]);
   }
-  if (swish) {
+  if (act == EDET_ACT_SWISH) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = swishf_(x[e]);
+  } else if (act > EDET_ACT_SWISH) {      // relu / relu6 / hswish (utils.activation_fn), kernel-uniform branch
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = act_other_(act, x[e]);
   }
   if (gate) {
 #pragma unroll
@@ -183,7 +186,8 @@ __global__ __launch_bounds__(THREADS, NS == 8 ? 3 : 2) void k_pw_fwd(const FwdAr
   const int lane_k = lane % (a.ck.nvec * a.ck.rp);
   const int colK = lane_k % a.ck.nvec, rsub = lane_k / a.ck.nvec;
   const bool activeK = true;
-  const bool affine = a.tv.scale != nullptr, swish = a.tv.act == EDET_ACT_SWISH, gated = a.tv.gate != nullptr;
+  const bool affine = a.tv.scale != nullptr, gated = a.tv.gate != nullptr;
+  const int act = a.tv.act;
   float sc[8], sh[8], gt[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; gt[e] = 1.f; }
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(THREADS, NS == 8 ? 3 : 2) void k_pw_fwd(const FwdAr
             const uint32_t rr = (uint32_t)min(row0 + r, a.M - 1);
             loadf8(a.tv.gate + (size_t)(rr / (uint32_t)a.hw) * a.K + colK * 8, gt);
           }
-          *reinterpret_cast<uint4*>(At + r * a.SA + colK * 16) = transform8(raw[i], sc, sh, gt, affine, swish, gated);
+          *reinterpret_cast<uint4*>(At + r * a.SA + colK * 16) = transform8(raw[i], sc, sh, gt, affine, act, gated);
         }
       }
       if (st + 1 < st1) issue(st + 1);               // next super-tile's loads fly during the MFMA phase
@@ -390,6 +394,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_pw_dgrad(const BwdArgs a) {
   const bool want_stats = a.epi.stat_partials != nullptr;
   const bool want_gate = a.epi.dgate != nullptr;
   const bool swish = a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr;
+  const bool other = a.tv.act > EDET_ACT_SWISH;     // relu / relu6 / hswish
+  const int act = a.tv.act;
 
   for (int i = tid; i < 2 * a.KOpad; i += THREADS) red[i] = 0.f;
   for (int i = lane; i < 3 * a.KOpad; i += 64) wst[i] = 0.f;
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_pw_dgrad(const BwdArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; s1[e] = s2[e] = 0.f; }
       if (col_ok && affine) { loadf8(a.tv.scale + ch0, sc); loadf8(a.tv.shift + ch0, sh); }
-      const bool need_x = swish || want_gate || want_stats;
+      const bool need_x = swish || other || want_gate || want_stats;
       for (int sub = 0; sub * TR < rows_in_st; ++sub) {
         const int trow0 = row0 + sub * TR;
         const int rows_valid = min(TR, rows_in_st - sub * TR);
@@ -534,7 +540,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_pw_dgrad(const BwdArgs a) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
                 const float z = fmaf(x[e], sc[e], sh[e]);
-                gsum[e] = d[e] * (swish ? swishf_(z) : z);
+                gsum[e] = d[e] * (swish ? swishf_(z) : (other ? act_other_(act, z) : z));
                 g[e] = d[e];
               }
               if (gate_direct) {
@@ -549,6 +555,9 @@ __global__ __launch_bounds__(THREADS, 2) void k_pw_dgrad(const BwdArgs a) {
             } else if (swish) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) g[e] = d[e] * swish_gradf_(fmaf(x[e], sc[e], sh[e]));
+            } else if (other) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) g[e] = d[e] * act_other_grad_(act, fmaf(x[e], sc[e], sh[e]));
             } else {
 #pragma unroll
               for (int e = 0; e < 8; ++e) g[e] = d[e];
@@ -703,6 +712,9 @@ __device__ __forceinline__ void wg_stage(const WgArgs& a, const OperandRegs<IS_G
           if (a.tv.act == EDET_ACT_SWISH) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = swishf_(x[e]);
+          } else if (a.tv.act > EDET_ACT_SWISH) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = act_other_(a.tv.act, x[e]);
           }
           if (a.tv.gate) {
             float gt[8];
@@ -888,6 +900,8 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
   const bool want_stats = a.epi.stat_partials != nullptr;
   const bool want_gate = a.epi.dgate != nullptr;
   const bool swish = a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr, gated = a.tv.gate != nullptr;
+  const bool other = a.tv.act > EDET_ACT_SWISH;     // relu / relu6 / hswish
+  const int act = a.tv.act;
 
   // Nothing inside the tile loop may wait on a global load other than the prefetched tile (vmcnt is in order: a
   // wait for a later small load would drain the whole prefetch): per-channel vectors live in LDS.
@@ -1071,6 +1085,13 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
                 av[e] = z * sg;
                 g[e] = want_gate ? d[e] : d[e] * (sg * (1.0f + z * (1.0f - sg)));
               }
+            } else if (other) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float z = fmaf(x[e], sc[e], sh[e]);
+                av[e] = act_other_(act, z);
+                g[e] = want_gate ? d[e] : d[e] * act_other_grad_(act, z);
+              }
             } else {
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
@@ -1226,7 +1247,6 @@ inline bool allow_big_lds(KernelT kern, size_t lds) {
 // (the caller then falls back to the tiled kernel in pw_gemm.hip), negative on error.
 int pws_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bias, void* out, int cout,
                 int ldo, float* stat_partials, int* nparts_out, hipStream_t st) {
-  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace pws;
   const int K = in->c, N = cout;
   if (K > 256 || K % 8 != 0) return 0;
@@ -1282,7 +1302,6 @@ int pws_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
 
 int pws_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tview_t* in,
                   const edet_bwd_epi_t* epi, int* nparts_out, hipStream_t st) {
-  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace pws;
   const int R = dy->c, KO = in->c;
   if (R > 128 || KO > 512 || KO % 8 != 0 || dy->ld % 8 != 0) return 0;
@@ -1332,7 +1351,6 @@ int pws_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tvi
 
 int pws_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight, void* workspace,
                   size_t workspace_bytes, hipStream_t st) {
-  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace pws;
   const int K = in->c, N = dy->c;
   if (!workspace || K % 8 != 0 || dy->ld % 8 != 0 || in->ld % 8 != 0) return 0;
@@ -1376,7 +1394,6 @@ int pws_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight
 int pws_try_bwd_fused(const edet_gview_t* dy, const void* w, int ldw, const edet_tview_t* in,
                       const edet_bwd_epi_t* epi, int* nparts_out, float* dweight, void* workspace,
                       size_t workspace_bytes, hipStream_t st) {
-  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the generic kernels handle them
   using namespace pws;
   const int R = dy->c, KO = in->c;
   if (!workspace || KO % 8 != 0 || dy->ld % 8 != 0 || in->ld % 8 != 0 || R > 160 || KO > 160) return 0;

@@ -139,8 +139,8 @@ class V2Engine(engine_lib.Engine):
   primitives come from engine.Engine)."""
 
   def __init__(self, spec, batch_size, image_size, dtype='bf16', device='cuda:0', seed=0, params=None, arena=None):
-    if params is None and arena is None:
-      params = init_params(spec, seed)
+    if arena is None and (params is None or any(p.name not in params for p in spec.params)):
+      params = {**init_params(spec, seed), **(params or {})}      # a partial set keeps the other initial values
     super().__init__(spec.mconfig, batch_size, image_size, dtype=dtype, device=device, seed=seed,
                      params=params, spec=spec, arena=arena)
 

@@ -1,12 +1,13 @@
 """-m gpu: every HIP kernel, called through the C ABI, against the CPU oracle's ops (+ autograd)."""
 import ctypes
+import sys
 
 import numpy as np
 import pytest
 import torch
 
 from automl_amd import _lib
-from automl_amd._lib import ACT_NONE, ACT_SWISH, BwdEpi, call, ptr
+from automl_amd._lib import ACT_HSWISH, ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SWISH, BwdEpi, call, ptr
 from oracle import efficientdet_oracle as orc
 from tests import gpu_util as gu
 
@@ -23,13 +24,38 @@ def nchw_to_nhwc(t):
   return t.permute(0, 2, 3, 1).contiguous()
 
 
+# The activation the 'swish' modes of the tests below put on a view.  test_tuned_kernels_with_the_other_activations
+# re-runs the same bodies with relu / relu6 / hswish (utils.activation_fn, utils.py:36-53).
+VIEW_ACT = ACT_SWISH
+ACT_NAMES = {ACT_SWISH: 'swish', ACT_RELU: 'relu', ACT_RELU6: 'relu6', ACT_HSWISH: 'hswish'}
+ACT_KINKS = {ACT_RELU: (0.0,), ACT_RELU6: (0.0, 6.0), ACT_HSWISH: (-3.0, 3.0)}
+
+
+def act_oracle(z, act):
+  return z if act == ACT_NONE else orc.activation_fn(z, ACT_NAMES[act])
+
+
+def off_kinks(x, scale, shift, act):
+  """Moves the elements whose pre-activation lies within 0.02 of a kink of a piecewise activation by 0.25 (exact in
+  bf16 for these magnitudes): the device evaluates z with one fused multiply-add, the oracle with two roundings,
+  and a derivative that jumps at the kink would turn that last-bit difference into a whole-element one."""
+  for _ in range(3):
+    z = x * scale + shift if scale is not None else x
+    bad = torch.zeros_like(x, dtype=torch.bool)
+    for k in ACT_KINKS.get(act, ()):
+      bad |= (z - k).abs() < 0.02
+    if not bool(bad.any()):
+      break
+    x = torch.where(bad, x + 0.25, x)
+  return x
+
+
 def apply_view(x, scale, shift, act, gate):
   """oracle version of the activated view; x [n,h,w,c]."""
   z = x
   if scale is not None:
     z = z * scale + shift
-  if act == ACT_SWISH:
-    z = orc.swish(z)
+  z = act_oracle(z, act)
   if gate is not None:
     z = z * gate[:, None, None, :]
   return z
@@ -77,7 +103,8 @@ def test_pw_fwd(dt, shape, mode, pw_impl):
   if mode != 'plain':
     scale = torch.from_numpy((1 + 0.3 * rng.standard_normal(cin)).astype(np.float32))
     shift = torch.from_numpy((0.3 * rng.standard_normal(cin)).astype(np.float32))
-    act = ACT_SWISH
+    act = VIEW_ACT
+    x = off_kinks(x, scale, shift, act)
   if mode == 'bn_swish_gate':
     gate = torch.from_numpy(rng.uniform(0.2, 1.0, (n, cin)).astype(np.float32))
   a = apply_view(x, scale, shift, act, gate)
@@ -146,15 +173,16 @@ def test_pw_bwd_data(dt, shape, mode, gbn, pw_impl, one_call=False, ws_mib=16):
     mean = torch.from_numpy((0.2 * rng.standard_normal(cin)).astype(np.float32))
     rstd = torch.from_numpy(rng.uniform(0.5, 2.0, cin).astype(np.float32))
   if mode in ('bn_swish_stats', 'gate'):
-    act = ACT_SWISH
+    act = VIEW_ACT
+    x = off_kinks(x, scale, shift, act)
   z = x * scale + shift if scale is not None else x
   if mode == 'gate':
     gate = torch.from_numpy(rng.uniform(0.2, 1.0, (n, cin)).astype(np.float32))
     want_g = d
-    want_dgate = (d * orc.swish(z)).sum((1, 2))
+    want_dgate = (d * act_oracle(z, act)).sum((1, 2))
   else:
     zz = z.clone().requires_grad_(True)
-    (orc.swish(zz) if act == ACT_SWISH else zz).backward(d)
+    act_oracle(zz, act).backward(d)
     want_g = zz.grad
   if mode == 'plain_beta':
     old = gu.rnd(rng, (n, h, w, cin), tdt)
@@ -244,7 +272,8 @@ def test_pw_bwd_weight(dt, shape, mode, use_ws, pw_impl, ws_mib=16):
     scale = torch.from_numpy((1 + 0.3 * rng.standard_normal(cin)).astype(np.float32))
     shift = torch.from_numpy((0.3 * rng.standard_normal(cin)).astype(np.float32))
     gate = torch.from_numpy(rng.uniform(0.2, 1.0, (n, cin)).astype(np.float32))
-    act = ACT_SWISH
+    act = VIEW_ACT
+    x = off_kinks(x, scale, shift, act)
   a = apply_view(x, scale, shift, act, gate)
   if name == 'bf16':
     a, dyq = a.to(torch.bfloat16).float(), dy.to(torch.bfloat16).float()
@@ -291,7 +320,8 @@ def test_dw_fwd(dt, shape, ks, mode):
   if mode != 'plain':
     scale = torch.from_numpy((1 + 0.3 * rng.standard_normal(c)).astype(np.float32))
     shift = torch.from_numpy((0.3 * rng.standard_normal(c)).astype(np.float32))
-    act = ACT_SWISH
+    act = VIEW_ACT
+    x = off_kinks(x, scale, shift, act)
   want = dw_oracle(apply_view(x, scale, shift, act, None), wk, k, s)
   xd = gu.to_dev(x, tdt)
   oh, ow = want.shape[1], want.shape[2]
@@ -341,12 +371,13 @@ def test_dw_bwd(dt, shape, ks, mode, entry, ws_mib=16):
     shift = torch.from_numpy((0.3 * rng.standard_normal(c)).astype(np.float32))
     mean = torch.from_numpy((0.2 * rng.standard_normal(c)).astype(np.float32))
     rstd = torch.from_numpy(rng.uniform(0.5, 2.0, c).astype(np.float32))
-    act = ACT_SWISH
+    act = VIEW_ACT
+    x = off_kinks(x, scale, shift, act)
   else:
     old = gu.rnd(rng, (n, h, w, c), tdt)
   zz = (x * scale + shift if scale is not None else x).clone().requires_grad_(True)
   wq = wk.clone().requires_grad_(True)
-  a = orc.swish(zz) if act == ACT_SWISH else zz
+  a = act_oracle(zz, act)
   dw_oracle(a, wq, k, s).backward(dy)
   want_g = zz.grad + (old if old is not None else 0)
   want_dw = wq.grad
@@ -746,3 +777,47 @@ def test_optimizer():
   call('edet_opt_scale', ptr(gd2), ptr(od), ptr(fac), len(sizes), gu.stream())
   torch.cuda.synchronize()
   gu.check(gd2, g2, 'f32', 'scaled grads', rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------ relu / relu6 / hswish
+GENERIC_KERNELS = ('k_gemm<', 'k_wgrad<', 'k_dw_fwd<', 'k_dw_bwd_data<', 'k_dw_bwd_weight<')
+
+
+@pytest.mark.parametrize('act', [ACT_RELU, ACT_RELU6, ACT_HSWISH], ids=lambda a: ACT_NAMES[a])
+def test_tuned_kernels_with_the_other_activations(act, monkeypatch):
+  """utils.activation_fn's relu / relu6 / hswish (the efficientdet-lite family) in the TUNED bf16 kernels: the view
+  activation is a run-time code in the streaming / tiled pointwise kernels and a template parameter (OACT) of the
+  row-marching depthwise kernels.  The bodies of the swish tests above run with the other activation on the view, at
+  shapes that reach every tuned family, and the library's launch log must show that none of them fell back to the
+  generic kernels of pw_gemm.hip / dwconv.hip."""
+  monkeypatch.setattr(sys.modules[__name__], 'VIEW_ACT', act)
+  bf16 = gu.DTYPES[1]
+  _lib.launch_log_start()
+  try:
+    for impl in ('auto', 'big'):
+      monkeypatch.setenv('EDET_PW_IMPL', 'big') if impl == 'big' else monkeypatch.delenv('EDET_PW_IMPL', raising=False)
+      for shape in [(2, 9, 7, 24, 40), (1, 16, 16, 16, 96), (3, 13, 11, 144, 24), (2, 23, 17, 112, 672), (2, 12, 12, 480, 80)]:
+        test_pw_fwd(bf16, shape, 'bn_swish', impl)
+        test_pw_fwd(bf16, shape, 'bn_swish_gate', impl)
+        test_pw_bwd_weight(bf16, shape, 'bn_swish_gate', True, impl)
+      for shape in [(2, 9, 7, 24, 40), (3, 13, 11, 144, 24), (2, 23, 17, 112, 672), (3, 7, 9, 672, 112)]:
+        test_pw_bwd_data(bf16, shape, 'bn_swish_stats', True, impl)
+        test_pw_bwd_data(bf16, shape, 'gate', True, impl)
+    monkeypatch.delenv('EDET_PW_IMPL', raising=False)
+    for shape in [(2, 64, 64, 16, 96), (2, 48, 40, 24, 144)]:          # the fused data + weight gradient kernel
+      test_pw_bwd_data(bf16, shape, 'bn_swish_stats', True, 'auto', one_call=True)
+    for shape in [(2, 11, 9, 48), (1, 33, 17, 96), (2, 5, 5, 672)]:
+      for ks in [(3, 1), (3, 2), (5, 1), (5, 2)]:
+        test_dw_fwd(bf16, shape, ks, 'bn_swish')
+        test_dw_bwd(bf16, shape, ks, 'bn_swish_stats', 'separate')
+        if ks[1] == 1:
+          test_dw_bwd(bf16, shape, ks, 'bn_swish_stats', 'one_call')
+  finally:
+    log = _lib.launch_log_stop()
+  generic = {k: v for k, v in log.items() if any(g in k for g in GENERIC_KERNELS)}
+  assert not generic, 'fell back to the generic kernels: %s' % generic
+  for family in ('pws::k_pw_fwd', 'pws::k_pw_dgrad', 'pws::k_pw_wgrad', 'pws::k_pw_bwd_fused', 'pwb::k_big_gemm',
+                 'pwb::k_big_wgrad', 'dwm::k_fwd_lx', 'dwm::k_dgrad_lx', 'dwm::k_wgrad_lx', 'dwm::k_bwd_fused'):
+    assert any(family in k for k in log), (family, sorted(log))
+  assert all(', true>' in k for k in log if k.startswith('void dwm::') or ' dwm::' in k), \
+      [k for k in log if 'dwm::' in k]
