@@ -121,7 +121,22 @@ __global__ __launch_bounds__(THREADS) void k_bn_bwd_reduce(const T* __restrict__
     if (ok) {
       loadf8(mean + c0, mu);
       loadf8(rstd + c0, rs);
-      for (int64_t r = (int64_t)blockIdx.x * m.rpp + rr; r < rows; r += (int64_t)gridDim.x * m.rpp) {
+      // three rows (six 16-byte loads) in flight per thread, see k_se_pool; sums in row order
+      const int64_t st = (int64_t)gridDim.x * m.rpp;
+      int64_t r = (int64_t)blockIdx.x * m.rpp + rr;
+      for (; r + 2 * st < rows; r += 3 * st) {
+        float g[3][8], x[3][8];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          load8<T>(dz + (r + u * st) * ld + c0, g[u]);
+          load8<T>(y + (r + u * st) * ld + c0, x[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s1[e] += g[u][e]; s2[e] += g[u][e] * (x[u][e] - mu[e]) * rs[e]; }
+      }
+      for (; r < rows; r += st) {
         float g[8], x[8];
         load8<T>(dz + r * ld + c0, g);
         load8<T>(y + r * ld + c0, x);
@@ -223,7 +238,22 @@ __global__ __launch_bounds__(THREADS) void k_se_pool(const edet_tview_t in, floa
       for (int e = 0; e < 8; ++e) s[e] = 0.f;
       ViewCoef vc;
       view_load_coef(in, c0, vc);
-      for (int r = part * m.rpp + rr; r < hw; r += wg_per_img * m.rpp) {
+      // four rows of loads in flight per thread (16 waves/CU x 16 B per lane is ~4 MB in flight over the chip, a
+      // third of what 2 us of HBM latency at 5 TB/s needs); the sums keep their row order
+      const int st = wg_per_img * m.rpp;
+      int r = part * m.rpp + rr;
+      for (; r + 3 * st < hw; r += 4 * st) {
+        float x[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load8<T>(base + (size_t)(r + u * st) * in.ld + c0, x[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          view_apply(v, vc, c0, n, x[u]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s[e] += x[u][e];
+        }
+      }
+      for (; r < hw; r += st) {
         float x[8];
         load8<T>(base + (size_t)r * in.ld + c0, x);
         view_apply(v, vc, c0, n, x);
@@ -430,11 +460,7 @@ __global__ __launch_bounds__(THREADS) void k_se_gate_bwd(const edet_tview_t in, 
     loadf8(in.gate + (size_t)n * in.c + c0, gt);
     loadf8(dpool + (size_t)n * in.c + c0, dp);
     const size_t base = (size_t)n * hw * in.ld;
-    for (int r = part * m.rpp + rr; r < hw; r += wg_per_img * m.rpp) {
-      const size_t off = base + (size_t)r * in.ld + c0;
-      float d[8], x[8];
-      load8<T>(g + off, d);
-      load8<T>(reinterpret_cast<const T*>(in.data) + off, x);
+    auto chain = [&](float (&d)[8], const float (&x)[8]) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float z = fmaf(x[e], sc[e], sh[e]);
@@ -444,6 +470,31 @@ __global__ __launch_bounds__(THREADS) void k_se_gate_bwd(const edet_tview_t in, 
         s1[e] += d[e];
         s2[e] += d[e] * (x[e] - mu[e]) * rs[e];
       }
+    };
+    // two rows (four 16-byte loads) in flight per thread, see k_se_pool (three rows would cost the fourth wave per
+    // SIMD that the 1024-workgroup grid needs to be resident at once); sums in row order
+    const int st = wg_per_img * m.rpp;
+    int r = part * m.rpp + rr;
+    for (; r + st < hw; r += 2 * st) {
+      float d[2][8], x[2][8];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const size_t off = base + (size_t)(r + u * st) * in.ld + c0;
+        load8<T>(g + off, d[u]);
+        load8<T>(reinterpret_cast<const T*>(in.data) + off, x[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        chain(d[u], x[u]);
+        store8<T>(g + base + (size_t)(r + u * st) * in.ld + c0, d[u]);
+      }
+    }
+    for (; r < hw; r += st) {
+      const size_t off = base + (size_t)r * in.ld + c0;
+      float d[8], x[8];
+      load8<T>(g + off, d);
+      load8<T>(reinterpret_cast<const T*>(in.data) + off, x);
+      chain(d, x);
       store8<T>(g + off, d);
     }
 #pragma unroll

@@ -197,6 +197,9 @@ __host__ __device__ inline int red_floats(int nch, int cpt) { return THREADS * c
 // PF = rows of global loads in flight per thread ahead of the row being consumed (register FIFO).  With two
 // rows the march was latency-bound: a row step (~0.3 us of work) had to wait for a load issued only two
 // steps earlier (HBM latency under load ~2 us).
+// r02j lab: deeper forward FIFOs (8-9 rows at stride 1, 6 at stride 2) are slower (4.79 -> 5.24 ms over the 15 layer
+// shapes: they cost the fourth wave per SIMD), and so are stride-2 gradient kernels with 3-6 rows in flight at two
+// waves per SIMD (11.05 -> 11.29 ms).
 template <int S, int CPT> struct PfDepth {
   static constexpr int fwd = CPT == 8 ? 3 : (S == 1 ? 6 : 4);
   static constexpr int bwd = CPT == 4 ? (S == 1 ? 4 : 2) : (S == 1 ? 6 : 3);   // register budget of the 3-wave kernels
@@ -762,10 +765,13 @@ __global__ __launch_bounds__(THREADS, 3) void k_dgrad_lx(const Args a) {
 // A tile owns the input rows [r0, r1) x its columns: dy rows r0-p .. r1-1+p are marched (the 2p extra rows
 // are re-read by the neighbouring tile), x rows outside [r0, r1) enter the window as zeros so that every
 // (x pixel, dy pixel) pair is counted by exactly one tile.
-template <int K, int CPT, bool GBN, bool OACT, int PF = 3>
+template <int K, int CPT, bool GBN, bool OACT>
 __global__ __launch_bounds__(THREADS, CPT * K >= 10 ? 2 : 3) void k_bwd_fused(const Args a) {
+  // rows of global loads in flight: 3 rows left the march latency-bound (a row step is ~0.2 us of work, HBM latency
+  // under load ~2 us); r02i lab: 6 rows (4 with four channels per thread: register budget) 12.08 -> 11.44 ms over
+  // the 15 depthwise layer shapes of D0 640x640 batch 128; 8 rows: 11.07 -> 10.92 ms (r02j), not worth the registers
+  constexpr int PF = CPT == 4 ? 4 : 6;
   constexpr int PD = (K - 1) / 2;             // 'SAME' padding of an odd kernel at stride 1
-  // PF: rows of global loads in flight
   extern __shared__ float red[];
   const int C = a.in.c, H = a.in.h, W = a.in.w;
   const Lane l = lane_setup<CPT>(a, C);
@@ -990,11 +996,14 @@ inline void plan(Args& a, int C, int n, int space_w, int space_h, int max_p) {
   a.nch = pick_nch(nvec, 128 / (CPT * 2));      // <= 128 contiguous bytes per pixel and workgroup
   a.ngroups = (nvec + a.nch - 1) / a.nch;
   a.TX = THREADS / a.nch;
-  a.TY = 32;
-  {  // LAB (r02i): balanced tiles of at most EDET_DW_TY rows
-    const char* e = getenv("EDET_DW_TY");
-    const int cap = e ? atoi(e) : 0;
-    if (cap > 0) { const int nt = (space_h + cap - 1) / cap; a.TY = (space_h + nt - 1) / nt; }
+  {
+    // Balanced row tiles: at most 80 rows on the 160 / 320-row maps, 40 below (fixed 32-row tiles left a short last
+    // tile that still pays the K - 1 halo rows and the pipeline fill; taller tiles than this leave the 80-row maps
+    // with too few tiles to fill the chip).  r02i / r02j lab, 15 depthwise layer shapes of D0 640x640 batch 128:
+    // backward 12.08 -> 11.49 (40) -> 10.81 ms (80), forward 5.08 -> 4.71 -> 4.59 ms.
+    const int cap = space_h >= 160 ? 80 : 40;
+    const int nt = (space_h + cap - 1) / cap;
+    a.TY = (space_h + nt - 1) / nt;
   }
   if (a.TY > space_h) a.TY = space_h;
   a.tiles_x = (space_w + a.TX - 1) / a.TX;
@@ -1135,30 +1144,6 @@ int dwm_try_bwd_fused(const edet_gview_t* dy, const float* weight, int k, int s,
     if (gbn) { if (oact) edet_launch(k_bwd_fused<K_, CPT_, true, true>, grid, block, lds + ring, st, a); else edet_launch(k_bwd_fused<K_, CPT_, true, false>, grid, block, lds + ring, st, a); }             \
     else { if (oact) edet_launch(k_bwd_fused<K_, CPT_, false, true>, grid, block, lds + ring, st, a); else edet_launch(k_bwd_fused<K_, CPT_, false, false>, grid, block, lds + ring, st, a); }                \
   } while (0)
-  {  // LAB (r02i): EDET_DWB_PF=6 -> deeper load FIFO in the fused backward (swish / linear instantiations)
-    const char* e = getenv("EDET_DWB_PF");
-    const int pf = e ? atoi(e) : 0;
-    if (pf > 3 && !oact) {
-      const dim3 block(THREADS);
-#define DWM_FUSED_PF(K_, CPT_, PF_)                                                          \
-      do {                                                                                    \
-        plan<CPT_>(a, in->c, in->n, in->w, in->h, max_p);                                     \
-        const size_t lds = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                   \
-        const size_t ring = (size_t)2 * (a.TX + K_ - 1) * a.nch * CPT_ * sizeof(float);       \
-        const dim3 grid(a.P * a.ngroups);                                                     \
-        if (gbn) edet_launch(k_bwd_fused<K_, CPT_, true, false, PF_>, grid, block, lds + ring, st, a);   \
-        else edet_launch(k_bwd_fused<K_, CPT_, false, false, PF_>, grid, block, lds + ring, st, a);      \
-      } while (0)
-      if (k == 3 && k3c4) DWM_FUSED_PF(3, 4, 4);
-      else if (k == 3) DWM_FUSED_PF(3, 2, 6);
-      else DWM_FUSED_PF(5, 2, 6);
-#undef DWM_FUSED_PF
-      if (nparts_out) *nparts_out = a.P;
-      EDET_LAUNCH_CHECK("edet_dw_bwd(fused, pf)");
-      if (edet_reduce_partials(a.ws, a.P, kkc, dweight, st) != 0) return -2;
-      return 1;
-    }
-  }
   if (k == 3 && k3c4) DWM_FUSED(3, 4);
   else if (k == 3) DWM_FUSED(3, 2);
   else DWM_FUSED(5, 2);

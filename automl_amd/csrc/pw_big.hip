@@ -92,7 +92,9 @@ __device__ __forceinline__ void mma_stage(const unsigned char* As, const unsigne
   }
 }
 
-template <bool BWD, bool GBN, bool CONV = false>
+// OACT: the view's activation is relu / relu6 / hswish (utils.activation_fn; a.tv.act carries the code) -- a template
+// parameter, so that the swish / linear instantiations keep their code and registers
+template <bool BWD, bool GBN, bool CONV = false, bool OACT = false>
 __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
   // CONV && BWD: data gradient of the dense convolution -- rows = INPUT pixels, the streamed operand dy is
   // gathered at (iy + pad - ky) / s when that is an integer inside the dy image, reduction index (ky*k+kx)*cout+co
@@ -107,9 +109,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
   const int j0 = jt * BJ;
   const bool want_stats = a.stat_partials != nullptr;
   const bool want_gate = BWD && a.epi.dgate != nullptr;
-  const bool swish = a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr;
-  const bool other = a.tv.act > EDET_ACT_SWISH;     // relu / relu6 / hswish (utils.activation_fn): kernel-uniform
-  const int act = a.tv.act;
+  const bool swish = !OACT && a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr;
+  constexpr bool other = OACT;
   const bool gated = !BWD && a.tv.gate != nullptr;
 
   // staging geometry: thread -> chunk column lc (8 reduction elements), rows lr + 32*i
@@ -225,12 +226,12 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], c0[e], c1[e]);
               }
-              if (swish) {
+              if (other) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = act_other_(a.tv.act, x[e]);
+              } else if (swish) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] = swishf_(x[e]);
-              } else if (other) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = act_other_(act, x[e]);
               }
               if (gated) {
                 float gt[8];
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const float z = fmaf(x[e], sc[e], sh[e]);
-              gp[e] = fmaf(d[e], swish ? swishf_(z) : (other ? act_other_(act, z) : z), gp[e]);
+              gp[e] = fmaf(d[e], other ? act_other_(a.tv.act, z) : (swish ? swishf_(z) : z), gp[e]);
               g[e] = d[e];
             }
           } else if (swish) {
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
             for (int e = 0; e < 8; ++e) g[e] = d[e] * swish_gradf_(fmaf(x[e], sc[e], sh[e]));
           } else if (other) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) g[e] = d[e] * act_other_grad_(act, fmaf(x[e], sc[e], sh[e]));
+            for (int e = 0; e < 8; ++e) g[e] = d[e] * act_other_grad_(a.tv.act, fmaf(x[e], sc[e], sh[e]));
           } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) g[e] = d[e];
@@ -532,8 +533,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_wgrad(const WgArgs a) {
   const bf16_t* SRCY = reinterpret_cast<const bf16_t*>(a.gv.y);
   const int ld = is_x ? a.tv.ld : a.gv.ld;
   const bool swish = a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr, gated = a.tv.gate != nullptr;
-  const bool other = a.tv.act > EDET_ACT_SWISH;     // relu / relu6 / hswish
-  const int act = a.tv.act;
+  constexpr bool other = false;     // (the dense-convolution instantiations: swish / linear views only)
   float c0[8], c1[8], c2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { c0[e] = 1.f; c1[e] = 0.f; c2[e] = 0.f; }
@@ -605,12 +605,12 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_wgrad(const WgArgs a) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], c0[e], c1[e]);
             }
-            if (swish) {
+            if (other) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[e] = act_other_(a.tv.act, x[e]);
+            } else if (swish) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) x[e] = swishf_(x[e]);
-            } else if (other) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) x[e] = act_other_(act, x[e]);
             }
             if (gated) {
               float gt[8];
@@ -689,7 +689,7 @@ __device__ __forceinline__ void store_transposed4(unsigned char* tile, int cb, i
   }
 }
 
-template <bool GBN>
+template <bool GBN, bool OACT = false>
 __global__ __launch_bounds__(THREADS, 2) void k_big_wgrad_bal(const WgArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -712,9 +712,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_wgrad_bal(const WgArgs a) {
   const bf16_t* XS = reinterpret_cast<const bf16_t*>(a.tv.data);
   const bf16_t* DZ = reinterpret_cast<const bf16_t*>(a.gv.dz);
   const bf16_t* DY = reinterpret_cast<const bf16_t*>(a.gv.y);
-  const bool swish = a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr, gated = a.tv.gate != nullptr;
-  const bool other = a.tv.act > EDET_ACT_SWISH;     // relu / relu6 / hswish
-  const int act = a.tv.act;
+  const bool swish = !OACT && a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr, gated = a.tv.gate != nullptr;
+  constexpr bool other = OACT;
   float xs[8], xt[8], ga[8], gb[8], gc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { xs[e] = 1.f; xt[e] = 0.f; ga[e] = 1.f; gb[e] = 0.f; gc[e] = 0.f; }
@@ -763,12 +762,12 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_wgrad_bal(const WgArgs a) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], xs[e], xt[e]);
             }
-            if (swish) {
+            if (other) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[e] = act_other_(a.tv.act, x[e]);
+            } else if (swish) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) x[e] = swishf_(x[e]);
-            } else if (other) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) x[e] = act_other_(act, x[e]);
             }
             if (gated) {
               float gt[8];
@@ -848,10 +847,12 @@ int pwb_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
   a.tpw = (a.ntm + EDET_MAX_PARTS - 1) / EDET_MAX_PARTS;
   a.ngrp = (a.ntm + a.tpw - 1) / a.tpw;
   if (nparts_out) *nparts_out = a.ngrp;
-  static const bool ok = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<false, false>));
+  static const bool ok = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<false, false>)) &&
+                         big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<false, false, false, true>));
   if (!ok) return 0;
   const int grid = (a.ngrp + 7) / 8 * 8 * a.ntj;
-  edet_launch(k_big_gemm<false, false>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
+  if (in->act > EDET_ACT_SWISH) edet_launch(k_big_gemm<false, false, false, true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
+  else edet_launch(k_big_gemm<false, false>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
   EDET_LAUNCH_CHECK("edet_pw_fwd(big)");
   return 1;
 }
@@ -860,6 +861,7 @@ int pwb_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
 // (ky*k + kx)*cin + c contiguous.  return 1 = handled, 0 = shape outside the envelope, < 0 = error
 int pwb_try_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, int k, int s, const float* bias, void* out,
                      int cout, int ldo, float* stat_partials, int* nparts_out, hipStream_t st) {
+  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the direct dense-convolution kernels (conv.hip)
   using namespace pwb;
   const int cin = in->c, N = cout;
   if (cin % 8 != 0 || in->ld % 8 != 0 || ldw % 8 != 0 || ldo % 8 != 0 || ldo < (N + 7) / 8 * 8) return 0;
@@ -899,11 +901,16 @@ int pwb_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tvi
   a.tpw = (a.ntm + EDET_MAX_PARTS - 1) / EDET_MAX_PARTS;
   a.ngrp = (a.ntm + a.tpw - 1) / a.tpw;
   if (nparts_out) *nparts_out = a.ngrp;
-  static const bool ok1 = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<true, false>));
-  static const bool ok2 = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<true, true>));
+  static const bool ok1 = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<true, false>)) &&
+                          big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<true, false, false, true>));
+  static const bool ok2 = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<true, true>)) &&
+                          big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<true, true, false, true>));
   if (!ok1 || !ok2) return 0;
   const int grid = (a.ngrp + 7) / 8 * 8 * a.ntj;
-  if (dy->a) edet_launch(k_big_gemm<true, true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
+  if (in->act > EDET_ACT_SWISH) {
+    if (dy->a) edet_launch(k_big_gemm<true, true, false, true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
+    else edet_launch(k_big_gemm<true, false, false, true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
+  } else if (dy->a) edet_launch(k_big_gemm<true, true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
   else edet_launch(k_big_gemm<true, false>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
   EDET_LAUNCH_CHECK("edet_pw_bwd_data(big)");
   return 1;
@@ -932,11 +939,16 @@ int pwb_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight
   a.S = (a.M + a.rows_per_split - 1) / a.rows_per_split;
   // the balanced-staging kernel (r02a, 17 mid-size layers of D0 at batch 128: 6.03 ms against 6.53 ms for the
   // two-waves-per-operand staging of k_big_wgrad, which remains for the dense-convolution variant)
-  static const bool ok1 = big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad_bal<false>));
-  static const bool ok2 = big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad_bal<true>));
+  static const bool ok1 = big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad_bal<false>)) &&
+                          big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad_bal<false, true>));
+  static const bool ok2 = big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad_bal<true>)) &&
+                          big_lds_ok(reinterpret_cast<const void*>(&k_big_wgrad_bal<true, true>));
   if (!ok1 || !ok2) return 0;
   const int grid = (a.S + 7) / 8 * 8 * ntile;
-  if (dy->a) edet_launch(k_big_wgrad_bal<true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
+  if (in->act > EDET_ACT_SWISH) {
+    if (dy->a) edet_launch(k_big_wgrad_bal<true, true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
+    else edet_launch(k_big_wgrad_bal<false, true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
+  } else if (dy->a) edet_launch(k_big_wgrad_bal<true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
   else edet_launch(k_big_wgrad_bal<false>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
   EDET_LAUNCH_CHECK("edet_pw_bwd_weight(big)");
   if (edet_reduce_partials(a.ws, a.S, kn, dweight, st) != 0) return -2;
@@ -947,6 +959,7 @@ int pwb_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight
 // data gradient: w_t [cin][ldw] with the reduction index (ky*k + kx)*cout + co contiguous; rows = input pixels
 int pwb_try_conv_dgrad(const edet_gview_t* dy, const void* w_t, int ldw, int k, int s, const edet_tview_t* in,
                        const edet_bwd_epi_t* epi, int* nparts_out, hipStream_t st) {
+  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the direct dense-convolution kernels (conv.hip)
   using namespace pwb;
   const int cout = dy->c, cin = in->c;
   if (cout % 8 != 0 || cin % 8 != 0 || in->ld % 8 != 0 || dy->ld % 8 != 0 || ldw % 8 != 0) return 0;
@@ -977,6 +990,7 @@ int pwb_try_conv_dgrad(const edet_gview_t* dy, const void* w_t, int ldw, int k, 
 // weight gradient: dweight fp32 HWIO [k][k][cin][cout] += gathered(in)^T dy
 int pwb_try_conv_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, float* dweight, void* workspace,
                        size_t workspace_bytes, hipStream_t st) {
+  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the direct dense-convolution kernels (conv.hip)
   using namespace pwb;
   const int cin = in->c, N = dy->c, K = k * k * cin;
   if (!workspace || cin % 8 != 0 || N % 8 != 0 || dy->ld % 8 != 0 || in->ld % 8 != 0) return 0;

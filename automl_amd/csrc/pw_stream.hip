@@ -98,20 +98,23 @@ __device__ __forceinline__ uint4 pack8(const float x[8]) {
 }
 
 // activated value of 8 raw bf16 elements -> 8 bf16 packed
+// OACT: the view's activation is relu / relu6 / hswish (utils.activation_fn, utils.py:36-53; `act` carries the code) --
+// a template parameter of the kernels, so that the swish / linear instantiations keep their code and registers
+template <bool OACT>
 __device__ __forceinline__ uint4 transform8(const uint4 raw, const float sc[8], const float sh[8],
-                                            const float gt[8], bool affine, int act, bool gate) {
+                                            const float gt[8], bool affine, bool swish, bool gate, int act) {
   float x[8];
   unpack8(raw, x);
   if (affine) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], sc[e], sh[e]);
   }
-  if (act == EDET_ACT_SWISH) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = swishf_(x[e]);
-  } else if (act > EDET_ACT_SWISH) {      // relu / relu6 / hswish (utils.activation_fn), kernel-uniform branch
+  if (OACT) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = act_other_(act, x[e]);
+  } else if (swish) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = swishf_(x[e]);
   }
   if (gate) {
 #pragma unroll
@@ -158,7 +161,7 @@ __device__ __forceinline__ void column_stats(const unsigned char* Ct, int SC, in
 }
 
 // ------------------------------------------------------------------------------------ forward
-template <int NS>
+template <int NS, bool OACT>
 __global__ __launch_bounds__(THREADS, NS == 8 ? 3 : 2) void k_pw_fwd(const FwdArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -186,8 +189,7 @@ __global__ __launch_bounds__(THREADS, NS == 8 ? 3 : 2) void k_pw_fwd(const FwdAr
   const int lane_k = lane % (a.ck.nvec * a.ck.rp);
   const int colK = lane_k % a.ck.nvec, rsub = lane_k / a.ck.nvec;
   const bool activeK = true;
-  const bool affine = a.tv.scale != nullptr, gated = a.tv.gate != nullptr;
-  const int act = a.tv.act;
+  const bool affine = a.tv.scale != nullptr, swish = a.tv.act == EDET_ACT_SWISH, gated = a.tv.gate != nullptr;
   float sc[8], sh[8], gt[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; gt[e] = 1.f; }
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(THREADS, NS == 8 ? 3 : 2) void k_pw_fwd(const FwdAr
             const uint32_t rr = (uint32_t)min(row0 + r, a.M - 1);
             loadf8(a.tv.gate + (size_t)(rr / (uint32_t)a.hw) * a.K + colK * 8, gt);
           }
-          *reinterpret_cast<uint4*>(At + r * a.SA + colK * 16) = transform8(raw[i], sc, sh, gt, affine, act, gated);
+          *reinterpret_cast<uint4*>(At + r * a.SA + colK * 16) = transform8<OACT>(raw[i], sc, sh, gt, affine, swish, gated, a.tv.act);
         }
       }
       if (st + 1 < st1) issue(st + 1);               // next super-tile's loads fly during the MFMA phase
@@ -376,7 +378,7 @@ struct BwdArgs {
 
 constexpr int ECC = 64;   // epilogue chunk: channels per C tile
 
-template <int NS, bool GBN>
+template <int NS, bool GBN, bool OACT>
 __global__ __launch_bounds__(THREADS, 2) void k_pw_dgrad(const BwdArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -393,9 +395,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_pw_dgrad(const BwdArgs a) {
   float* wgt = wst + 2 * a.KOpad;                                       // [KOpad] dgate sums of the current image
   const bool want_stats = a.epi.stat_partials != nullptr;
   const bool want_gate = a.epi.dgate != nullptr;
-  const bool swish = a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr;
-  const bool other = a.tv.act > EDET_ACT_SWISH;     // relu / relu6 / hswish
-  const int act = a.tv.act;
+  const bool swish = !OACT && a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr;
+  constexpr bool other = OACT;
 
   for (int i = tid; i < 2 * a.KOpad; i += THREADS) red[i] = 0.f;
   for (int i = lane; i < 3 * a.KOpad; i += 64) wst[i] = 0.f;
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_pw_dgrad(const BwdArgs a) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
                 const float z = fmaf(x[e], sc[e], sh[e]);
-                gsum[e] = d[e] * (swish ? swishf_(z) : (other ? act_other_(act, z) : z));
+                gsum[e] = d[e] * (other ? act_other_(a.tv.act, z) : (swish ? swishf_(z) : z));
                 g[e] = d[e];
               }
               if (gate_direct) {
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_pw_dgrad(const BwdArgs a) {
               for (int e = 0; e < 8; ++e) g[e] = d[e] * swish_gradf_(fmaf(x[e], sc[e], sh[e]));
             } else if (other) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) g[e] = d[e] * act_other_grad_(act, fmaf(x[e], sc[e], sh[e]));
+              for (int e = 0; e < 8; ++e) g[e] = d[e] * act_other_grad_(a.tv.act, fmaf(x[e], sc[e], sh[e]));
             } else {
 #pragma unroll
               for (int e = 0; e < 8; ++e) g[e] = d[e];
@@ -674,7 +675,7 @@ __device__ __forceinline__ void wg_issue(const WgArgs& a, OperandRegs<IS_G, GBN>
 }
 
 // transforms the loaded passes and writes them (bf16) into the operand's LDS tile [32][stride]
-template <bool IS_G, bool GBN>
+template <bool IS_G, bool GBN, bool OACT>
 __device__ __forceinline__ void wg_stage(const WgArgs& a, const OperandRegs<IS_G, GBN>& o, int npass, int rpp,
                                          int rowl, int coll, int ch, int cmax, bool col_ok, int m0, int m_end,
                                          unsigned char* tile, int stride) {
@@ -709,12 +710,12 @@ __device__ __forceinline__ void wg_stage(const WgArgs& a, const OperandRegs<IS_G
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], c0[e], c1[e]);
           }
-          if (a.tv.act == EDET_ACT_SWISH) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = swishf_(x[e]);
-          } else if (a.tv.act > EDET_ACT_SWISH) {
+          if (OACT) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = act_other_(a.tv.act, x[e]);
+          } else if (a.tv.act == EDET_ACT_SWISH) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = swishf_(x[e]);
           }
           if (a.tv.gate) {
             float gt[8];
@@ -749,7 +750,7 @@ __device__ __forceinline__ bf16x8 column_frag(const unsigned char* tile, int str
 constexpr int WG_SU = 64 * 2 + 16;   // U tile stride (64 channels)
 constexpr int WG_SV = 64 * 2 + 16;   // V tile stride (up to 64 channels)
 
-template <bool UG, bool GBN>   // UG: U is the gradient operand (N >= K)
+template <bool UG, bool GBN, bool OACT>   // UG: U is the gradient operand (N >= K)
 __global__ __launch_bounds__(THREADS, 2) void k_pw_wgrad(const WgArgs a) {
   __shared__ __align__(16) unsigned char smem[WAVES * TR * (WG_SU + WG_SV)];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -799,8 +800,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_pw_wgrad(const WgArgs a) {
   }
   const int j = lane & 31, h = lane >> 5;
   for (int m0 = m_begin; m0 < m_end; m0 += TR) {
-    wg_stage<UG, GBN>(a, ou, 4, 8, urow, ucol, uch, a.CU, u_ok, m0, m_end, Ut, WG_SU);
-    wg_stage<!UG, GBN>(a, ov, npassV, rppV, vrow, vcol, vch, a.CV, v_ok, m0, m_end, Vt, WG_SV);
+    wg_stage<UG, GBN, OACT>(a, ou, 4, 8, urow, ucol, uch, a.CU, u_ok, m0, m_end, Ut, WG_SU);
+    wg_stage<!UG, GBN, OACT>(a, ov, npassV, rppV, vrow, vcol, vch, a.CV, v_ok, m0, m_end, Vt, WG_SV);
     if (m0 + TR < m_end) {
       wg_issue<UG, GBN>(a, ou, 4, 8, urow, uch, u_ok, m0 + TR, m_end);
       wg_issue<!UG, GBN>(a, ov, npassV, rppV, vrow, vch, v_ok, m0 + TR, m_end);
@@ -900,8 +901,6 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
   const bool want_stats = a.epi.stat_partials != nullptr;
   const bool want_gate = a.epi.dgate != nullptr;
   const bool swish = a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr, gated = a.tv.gate != nullptr;
-  const bool other = a.tv.act > EDET_ACT_SWISH;     // relu / relu6 / hswish
-  const int act = a.tv.act;
 
   // Nothing inside the tile loop may wait on a global load other than the prefetched tile (vmcnt is in order: a
   // wait for a later small load would drain the whole prefetch): per-channel vectors live in LDS.
@@ -1084,13 +1083,6 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
                 const float sg = sigmoidf_(z);
                 av[e] = z * sg;
                 g[e] = want_gate ? d[e] : d[e] * (sg * (1.0f + z * (1.0f - sg)));
-              }
-            } else if (other) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const float z = fmaf(x[e], sc[e], sh[e]);
-                av[e] = act_other_(act, z);
-                g[e] = want_gate ? d[e] : d[e] * act_other_grad_(act, z);
               }
             } else {
 #pragma unroll
@@ -1289,13 +1281,15 @@ int pws_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
   a.spw = (nst + grid * WAVES - 1) / (grid * WAVES);
   grid = (nst + a.spw * WAVES - 1) / (a.spw * WAVES);
   if (nparts_out) *nparts_out = grid;
-  if (NS == 8) {
-    if (!allow_big_lds(&k_pw_fwd<8>, lds)) return 0;
-    edet_launch(k_pw_fwd<8>, dim3(grid), dim3(THREADS), lds, st, a);
-  } else {
-    if (!allow_big_lds(&k_pw_fwd<16>, lds)) return 0;
-    edet_launch(k_pw_fwd<16>, dim3(grid), dim3(THREADS), lds, st, a);
-  }
+#define PWS_FWD(NS_, OACT_)                                                      \
+  do {                                                                          \
+    if (!allow_big_lds(&k_pw_fwd<NS_, OACT_>, lds)) return 0;                   \
+    edet_launch(k_pw_fwd<NS_, OACT_>, dim3(grid), dim3(THREADS), lds, st, a);   \
+  } while (0)
+  const bool oact = in->act > EDET_ACT_SWISH;      // relu / relu6 / hswish: the OACT instantiations
+  if (NS == 8) { if (oact) PWS_FWD(8, true); else PWS_FWD(8, false); }
+  else { if (oact) PWS_FWD(16, true); else PWS_FWD(16, false); }
+#undef PWS_FWD
   EDET_LAUNCH_CHECK("edet_pw_fwd(stream)");
   return 1;
 }
@@ -1338,12 +1332,13 @@ int pws_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tvi
   a.spw = (nst + grid * WAVES - 1) / (grid * WAVES);
   grid = (nst + a.spw * WAVES - 1) / (a.spw * WAVES);
   if (nparts_out) *nparts_out = grid;
-#define PWS_DGRAD(NS_, GBN_)                                                    \
-  do {                                                                          \
-    if (!allow_big_lds(&k_pw_dgrad<NS_, GBN_>, lds)) return 0;                  \
-    edet_launch(k_pw_dgrad<NS_, GBN_>, dim3(grid), dim3(THREADS), lds, st, a);           \
+#define PWS_DGRAD(NS_, GBN_, OACT_)                                                    \
+  do {                                                                                 \
+    if (!allow_big_lds(&k_pw_dgrad<NS_, GBN_, OACT_>, lds)) return 0;                  \
+    edet_launch(k_pw_dgrad<NS_, GBN_, OACT_>, dim3(grid), dim3(THREADS), lds, st, a);  \
   } while (0)
-  if (gbn) PWS_DGRAD(8, true); else PWS_DGRAD(8, false);
+  if (in->act > EDET_ACT_SWISH) { if (gbn) PWS_DGRAD(8, true, true); else PWS_DGRAD(8, false, true); }
+  else { if (gbn) PWS_DGRAD(8, true, false); else PWS_DGRAD(8, false, false); }
 #undef PWS_DGRAD
   EDET_LAUNCH_CHECK("edet_pw_bwd_data(stream)");
   return 1;
@@ -1380,7 +1375,11 @@ int pws_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight
   int grid;
   if (a.nus >= 3) grid = ((a.nus + 3) / 4) * a.S;
   else grid = (a.S + WAVES / a.nus - 1) / (WAVES / a.nus);
-#define PWS_WG(UG_, GBN_) edet_launch(k_pw_wgrad<UG_, GBN_>, dim3(grid), dim3(THREADS), 0, st, a)
+#define PWS_WG(UG_, GBN_)                                                                          \
+  do {                                                                                             \
+    if (in->act > EDET_ACT_SWISH) edet_launch(k_pw_wgrad<UG_, GBN_, true>, dim3(grid), dim3(THREADS), 0, st, a); \
+    else edet_launch(k_pw_wgrad<UG_, GBN_, false>, dim3(grid), dim3(THREADS), 0, st, a);           \
+  } while (0)
   if (ug) { if (gbn) PWS_WG(true, true); else PWS_WG(true, false); }
   else { if (gbn) PWS_WG(false, true); else PWS_WG(false, false); }
 #undef PWS_WG
@@ -1394,6 +1393,7 @@ int pws_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight
 int pws_try_bwd_fused(const edet_gview_t* dy, const void* w, int ldw, const edet_tview_t* in,
                       const edet_bwd_epi_t* epi, int* nparts_out, float* dweight, void* workspace,
                       size_t workspace_bytes, hipStream_t st) {
+  if (in->act > EDET_ACT_SWISH) return 0;     // relu / relu6 / hswish: the two streaming kernels (OACT instantiations)
   using namespace pws;
   const int R = dy->c, KO = in->c;
   if (!workspace || KO % 8 != 0 || dy->ld % 8 != 0 || in->ld % 8 != 0 || R > 160 || KO > 160) return 0;

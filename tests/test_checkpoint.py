@@ -420,8 +420,12 @@ def test_train_save_restore_round_trip_on_device(tmp_path):
   cls_e, _ = infer(torch.from_numpy(images), training=False)
   want = efficientdet_net.EfficientDetNet(config=config, dtype='f32', params=ema)
   cls_w, _ = want(torch.from_numpy(images), training=False)
-  assert all(torch.equal(a, b) for a, b in zip(cls_e, cls_w))
+  # (two executions of the same network agree to fp32 rounding, not bit for bit: the SE pooled sums are atomics)
+  def rel(a, b):
+    return float((a.float() - b.float()).abs().max()) / float(b.float().abs().max())
+  assert max(rel(a, b) for a, b in zip(cls_e, cls_w)) <= 1e-5, [rel(a, b) for a, b in zip(cls_e, cls_w)]
+  assert all(np.array_equal(infer.get_weights()[n], ema[n]) for n in ema)
   plain = efficientdet_net.EfficientDetNet(config=config, dtype='f32')
   util_keras.restore_ckpt(plain, prefix, ema_decay=0, skip_mismatch=False)
-  cls_p, _ = plain(torch.from_numpy(images), training=False)
-  assert not all(torch.equal(a, b) for a, b in zip(cls_p, cls_w))
+  plain(torch.from_numpy(images), training=False)
+  assert all(np.array_equal(plain.get_weights()[n], w[n]) for n in w)

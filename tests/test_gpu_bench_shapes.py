@@ -43,7 +43,7 @@ from tests.test_gpu_network import _seg_index, make_labels, perturbed_params, re
 pytestmark = pytest.mark.gpu
 
 BF16 = gu.DTYPES[1]
-TOL = {'f32': 1e-3, 'bf16_vs_f32': 3e-2, 'bf16_vs_emu': 1e-2, 'layer': 1.2e-2, 'layer_grad': 3e-2, 'layer_wgrad': 2.5e-2}
+TOL = {'f32': 1e-3, 'bf16_vs_f32': 3e-2, 'bf16_vs_emu': 1e-2, 'layer': 1.2e-2, 'layer_grad': 3e-2, 'layer_wgrad': 2e-2}
 ENGINE_WS_MIB = 64          # automl_amd/engine.py: the weight-gradient workspace the benchmark step hands over
 COVERED = {}                # kernel symbol -> launches, accumulated over the oracle-checked tests of this module
 
@@ -332,7 +332,7 @@ def test_d0_640_batch2_bf16_train_step_layer_by_layer():
   assert len(hook.fwd_err) >= 220 and len(hook.bwd_err) >= 200, (len(hook.fwd_err), len(hook.bwd_err), hook.missing[:8])
   assert max(hook.fwd_err.values()) <= TOL['layer'], hook.worst(hook.fwd_err, 6)
   assert max(hook.bwd_err.values()) <= TOL['layer_grad'], hook.worst(hook.bwd_err, 6)
-  werr = {}
+  werr, wsm_mine, wsm_ref = {}, [], []
   gmax = max(float(P[n].grad.abs().max()) for n in names)
   for n in names:
     g = P[n].grad
@@ -344,14 +344,19 @@ def test_d0_640_batch2_bf16_train_step_layer_by_layer():
       assert float(mine.abs().max()) == 0.0, n
       assert float(g.abs().max()) <= 2e-2 * gmax, (n, float(g.abs().max()), gmax)
       continue
-    e = float((mine - g).abs().max()) / max(float(g.abs().max()), 1e-4 * gmax)
     if n.rsplit('/', 1)[-1].startswith('WSM'):
-      # a fusion scalar's gradient is ONE signed sum over a whole pyramid level of d(out) * input: the device sums the
-      # fp32 products before d(out) is rounded for storage, the emulating oracle after; with the cancellation in that
-      # sum the two differ by 2-3 % from run to run (r02e 2.1 %, r02g 3.3 %; SE atomics reorder the step)
-      assert e <= 8e-2, (n, e)
+      # A fusion scalar's gradient is ONE number: a difference of whole-level sums of d(out) * input that cancel to a
+      # small remainder (fast attention with equal weights: dw_i = (2 dwn_i - dwn_j - dwn_k) / 9), so its relative
+      # error is set by that cancellation and moves from 2 % to 11 % between runs (r02e/g/h: SE atomics reorder the
+      # step).  The 57 scalars are checked TOGETHER below, as one vector.
+      wsm_mine.append(float(mine.reshape(-1)[0]))
+      wsm_ref.append(float(g.reshape(-1)[0]))
       continue
-    werr[n] = e
+    werr[n] = float((mine - g).abs().max()) / max(float(g.abs().max()), 1e-4 * gmax)
+  wsm_mine, wsm_ref = np.asarray(wsm_mine), np.asarray(wsm_ref)
+  wsm_err = float(np.linalg.norm(wsm_mine - wsm_ref) / np.linalg.norm(wsm_ref))
+  print('fusion scalars: %d, relative L2 error of their gradient vector %.4f' % (len(wsm_ref), wsm_err))
+  assert len(wsm_ref) >= 50 and wsm_err <= 3e-2, wsm_err
   print('teacher-forced variable gradients: %d tensors, worst %s' % (len(werr), gu.TeacherForce.worst(werr, 5)))
   assert max(werr.values()) <= TOL['layer_wgrad'], gu.TeacherForce.worst(werr, 8)
 
