@@ -220,6 +220,7 @@ class Engine(object):
     self.image_size = utils.parse_image_size(image_size if image_size is not None else config.image_size)
     self._bufs = {}
     self._zero_list = []
+    self._zfree, self._zcur = 0, None
     self.tape = []
     self.training = False
     self._nparts = ctypes.c_int(0)
@@ -265,13 +266,28 @@ class Engine(object):
     assert tuple(t.shape) == tuple(shape), (key, tuple(t.shape), tuple(shape))
     return t
 
+  ZCHUNK = 4 * 1024 * 1024      # floats per zero-arena chunk (16 MiB)
+
   def zbuf(self, key, shape):
-    """fp32 buffer that is zeroed at the start of every step (atomic accumulation targets)."""
+    """fp32 buffer that is zeroed at the start of every step (atomic accumulation targets: SE pooled sums and gate
+    gradients, fusion-weight gradients, loss sums).  Carved out of a few large chunks so that the ~60 buffers of a
+    step cost one fill launch per chunk instead of one each."""
     t = self._bufs.get(key)
     if t is None:
-      t = torch.zeros(shape, dtype=torch.float32, device=self.device)
+      n = int(np.prod(shape))
+      padded = (n + 63) // 64 * 64                   # every buffer starts 256-byte aligned
+      if padded > self.ZCHUNK:
+        chunk = torch.zeros(padded, dtype=torch.float32, device=self.device)
+        self._zero_list.append(chunk)
+        t = chunk[:n].view(shape)
+      else:
+        if self._zcur is None or self._zfree + padded > self.ZCHUNK:
+          self._zero_list.append(torch.zeros(self.ZCHUNK, dtype=torch.float32, device=self.device))
+          self._zfree = 0
+          self._zcur = self._zero_list[-1]
+        t = self._zcur[self._zfree:self._zfree + n].view(shape)
+        self._zfree += padded
       self._bufs[key] = t
-      self._zero_list.append(t)
     return t
 
   def _build_params(self, params, seed, arena):
