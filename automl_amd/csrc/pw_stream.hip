@@ -1407,7 +1407,7 @@ int pws_try_bwd_fused(const edet_gview_t* dy, const void* w, int ldw, const edet
   // 16 x 16).  r02d, D0 640x640 batch 128, both gradients: 320x320x16->96 2.44 -> 1.95 ms, 160x160x24->144 1.45 ->
   // 0.73 ms.  With one wave per SIMD the kernel is epilogue-bound on the K-heavy project layers (160x160x144->24:
   // 1.79 ms against 1.83 ms for the two kernels; 160x160x96->24 and the 64->64 BiFPN / head layers are slower
-  // fused), so those keep the two-kernel path.
+  // fused; r02l: 320x320x32->16 with the SE-gated view 2.64 ms fused against 1.79 ms), so those keep the two-kernel path.
   if (R < 2 * KO || a.TK > 2 || a.TN > 9) return 0;
   a.cr = make_colmap(R);
   a.cx = make_colmap(KO);

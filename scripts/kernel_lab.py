@@ -102,13 +102,19 @@ def build_case(entry, shape):
       return (lambda: (keep, call('edet_pw_bwd_data', ctypes.byref(gv), ptr(wk), gu.pad8(cout), ctypes.byref(tv),
                                   ctypes.byref(epi), ctypes.byref(npart), edt, gu.stream()))), nbytes
     if entry == 'pw_bwd':
-      tv = gu.tview(x, cin, vec(cin), vec(cin, -0.3, 0.3), None, _lib.ACT_SWISH)
       wk = rand(cin, gu.pad8(cout)) * (1.0 / np.sqrt(cout))
       gout = torch.empty(n, h, w, gu.pad8(cin), dtype=tdt, device=dev)
       mean, rstd = vec(cin, -0.2, 0.2), vec(cin)
-      epi = BwdEpi(ptr(gout), 0, ptr(mean), ptr(rstd), ptr(parts), None)
       dwt = torch.zeros(cin, cout, dtype=torch.float32, device=dev)
-      keep = (wk, gout, mean, rstd, dwt)
+      if cin > cout:      # project layer: SE-gated view, the epilogue leaves D and the gate-gradient sums (engine._pw_bwd)
+        dgate = torch.zeros(n, cin, dtype=torch.float32, device=dev)
+        tv = gu.tview(x, cin, vec(cin), vec(cin, -0.3, 0.3), gate, _lib.ACT_SWISH)
+        epi = BwdEpi(ptr(gout), 0, None, None, None, ptr(dgate))
+        keep = (wk, gout, dgate, dwt)
+      else:
+        tv = gu.tview(x, cin, vec(cin), vec(cin, -0.3, 0.3), None, _lib.ACT_SWISH)
+        epi = BwdEpi(ptr(gout), 0, ptr(mean), ptr(rstd), ptr(parts), None)
+        keep = (wk, gout, mean, rstd, dwt)
       return (lambda: (keep, call('edet_pw_bwd', ctypes.byref(gv), ptr(wk), gu.pad8(cout), ctypes.byref(tv),
                                   ctypes.byref(epi), ctypes.byref(npart), ptr(dwt), ptr(wsp), wsp.numel() * 4, edt,
                                   gu.stream()))), 2 * nbytes
