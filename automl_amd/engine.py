@@ -62,8 +62,8 @@ class BN(object):
     self.beta = eng.param(name + '/beta')
     self.mm = eng.param(name + '/moving_mean')
     self.mv = eng.param(name + '/moving_variance')
-    self.dgamma = eng.grad(name + '/gamma')
-    self.dbeta = eng.grad(name + '/beta')
+    self.dgamma = eng.arena.grad(name + '/gamma')     # per-layer variables: always the main gradient arena
+    self.dbeta = eng.arena.grad(name + '/beta')
     v = eng.buf('bn:' + name, (7, c), torch.float32)
     self.scale, self.shift, self.mean, self.rstd, self.a, self.b, self.cc = (v[i] for i in range(7))
     self.count = 0
@@ -199,6 +199,16 @@ class ParamArena(object):
     self.step_count = int(state['iterations'])
 
 
+class Branch(object):
+  """What an independent chain of launches needs of its own: a HIP stream, the BatchNorm partial-sum rows and the
+  weight-gradient workspace its kernels scribble on, and -- for a chain that shares variables with another one (the
+  class / box towers use the same kernels on every pyramid level, efficientdet_keras.py:336-480) -- a private
+  gradient arena that is added to the main one after the join (deterministic, no atomics)."""
+
+  def __init__(self, stream, partials, workspace, grads=None):
+    self.stream, self.partials, self.workspace, self.grads = stream, partials, workspace, grads
+
+
 class Engine(object):
   """Builds buffers for (config, batch, image size, dtype) and runs forward / backward / update."""
 
@@ -227,8 +237,18 @@ class Engine(object):
     self._cast_version = -1
     self._build_params(params, seed, arena)
     cmax = max([p.shape[0] for p in self.spec.params if len(p.shape) == 1] + [64])
-    self.partials = torch.empty(_lib.MAX_PARTS * 2 * cmax, dtype=torch.float32, device=self.device)
-    self.workspace = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=self.device)  # 64 MiB scratch
+    self._cmax = cmax
+    self._main = self._branch = Branch(None, torch.empty(_lib.MAX_PARTS * 2 * cmax, dtype=torch.float32, device=self.device),
+                                       torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=self.device))  # 64 MiB scratch
+    self._side = None
+    # The class / box towers of the SMALL pyramid levels (20x20 and below: ~300 latency-bound launches per step that
+    # each use a fraction of the chip) run as one chain on a second HIP stream, forked and joined with events (a
+    # parallel branch of the captured hipGraph), under the chain of the 80x80 / 40x40 levels: r02m/n 69.04 -> 67.7 /
+    # 68.3 ms per step.  What was measured and NOT kept: one stream per level (five chains, the big kernels of levels
+    # 3 and 4 compete: 71.7 -> 75.1 ms, r02g); every weight-gradient kernel deferred to the side stream (nothing on
+    # the data-gradient chain waits for them: 68.3 -> 69.7 ms, r02n).
+    self.small_level_stream = True
+    self._side_pending = False
     self.bns = {}
     self._cast_plan = None
     self.loss_sums = self.zbuf('loss_sums', (4,))
@@ -257,6 +277,57 @@ class Engine(object):
   @property
   def stream(self):
     return torch.cuda.current_stream(self.device).cuda_stream
+
+  @property
+  def partials(self):
+    return self._branch.partials
+
+  @property
+  def workspace(self):
+    return self._branch.workspace
+
+  # ------------------------------------------------------------------ a second chain on its own stream
+  def _side_branch(self):
+    if self._side is None:
+      names = [n for n in self.seg_names if n.startswith('class_net/') or n.startswith('box_net/')]
+      lo = min(self.offsets[n][0] for n in names)
+      hi = max(self.offsets[n][0] + self.offsets[n][1] for n in names)
+      self._side_range = (lo, hi)       # the slice of the arena that holds the tower variables
+      self._side_grads = torch.zeros(self.n_train_elems, dtype=torch.float32, device=self.device)
+      self._side = Branch(torch.cuda.Stream(device=self.device),
+                          torch.empty(_lib.MAX_PARTS * 2 * self._cmax, dtype=torch.float32, device=self.device),
+                          torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=self.device),   # 64 MiB, as the main one
+                          self._side_grads)
+    return self._side
+
+  def _fork_join(self, main_job, side_job):
+    """main_job() on the current stream, side_job() on the side stream between an event recorded now and an event
+    the current stream waits for afterwards (legal inside a stream capture: the side stream joins it)."""
+    side = self._side_branch()
+    main = torch.cuda.current_stream(self.device)
+    fork = torch.cuda.Event()
+    fork.record(main)
+    side.stream.wait_event(fork)
+    try:
+      self._branch = side
+      with torch.cuda.stream(side.stream):
+        b = side_job()
+        done = torch.cuda.Event()
+        done.record(side.stream)
+      self._branch = self._main
+      a = main_job()
+    finally:
+      self._branch = self._main
+    main.wait_event(done)
+    return a, b
+
+  def _join_side(self):
+    """Adds (and clears) the side chain's gradient arena; called once at the end of the backward pass, after the join."""
+    if self._side_pending:
+      lo, hi = self._side_range
+      self.grads_flat[lo:hi].add_(self._side_grads[lo:hi])
+      self._side_grads[lo:hi].zero_()
+      self._side_pending = False
 
   def buf(self, key, shape, dtype):
     t = self._bufs.get(key)
@@ -314,6 +385,11 @@ class Engine(object):
     return self.arena.param(name)
 
   def grad(self, name):
+    """Gradient slice of a variable in the arena the current chain accumulates into (Branch.grads)."""
+    if self._branch.grads is not None:
+      off, n, _, tr = self.offsets[name]
+      assert tr, name
+      return self._branch.grads[off:off + n]
     return self.arena.grad(name)
 
   def set_params(self, values):
@@ -809,8 +885,12 @@ class Engine(object):
     self.fpn_feats = feats
     # ---- heads
     na = spec.num_anchors
-    cls = self._head(feats, 'class_net', 'class', c.num_classes * na)
-    box = self._head(feats, 'box_net', 'box', 4 * na)
+    nbig = sum(1 for f in feats if f.raw.h * f.raw.w > 400)
+    if self.small_level_stream and self.sync_bn is None and 0 < nbig < len(feats):
+      cls, box = self._heads_two_chains(feats, nbig, c.num_classes * na, 4 * na)
+    else:
+      cls = self._head(feats, 'class_net', 'class', c.num_classes * na)
+      box = self._head(feats, 'box_net', 'box', 4 * na)
     self.cls_views, self.box_views = cls, box
     if self.batched_casts and self._cast_items and not torch.cuda.is_current_stream_capturing() and \
         (self._cast_table is None or self._cast_table[0] != list(self._cast_items)):
@@ -883,24 +963,66 @@ class Engine(object):
     assert len(out) == num_in
     return out
 
-  def _head(self, feats, net, prefix, out_ch):
+  def _head_level(self, feat, level, net, prefix, out_ch):
+    """One tower (class or box net) on one pyramid level (efficientdet_keras.py:336-480, 483-641)."""
     c = self.config
     wf = c.fpn_num_filters
-    outs = []
-    for li, feat in enumerate(feats):
-      level = c.min_level + li
-      x = feat
-      for i in range(c.box_class_repeats):
-        s = '%s/%s-%d' % (net, prefix, i)
-        key = '%s:l%d' % (s, level)
-        d = self.dw(key + ':dw', x, s + '/depthwise_kernel', 3, 1)
-        x = self.pw(key + ':pw', d, s + '/pointwise_kernel', wf, bias=s + '/bias',
-                    bn='%s/%s-%d-bn-%d' % (net, prefix, i, level), act=self.act)
-      s = '%s/%s-predict' % (net, prefix)
+    x = feat
+    for i in range(c.box_class_repeats):
+      s = '%s/%s-%d' % (net, prefix, i)
       key = '%s:l%d' % (s, level)
       d = self.dw(key + ':dw', x, s + '/depthwise_kernel', 3, 1)
-      outs.append(self.pw(key + ':pw', d, s + '/pointwise_kernel', out_ch, bias=s + '/bias'))
-    return outs
+      x = self.pw(key + ':pw', d, s + '/pointwise_kernel', wf, bias=s + '/bias',
+                  bn='%s/%s-%d-bn-%d' % (net, prefix, i, level), act=self.act)
+    s = '%s/%s-predict' % (net, prefix)
+    key = '%s:l%d' % (s, level)
+    d = self.dw(key + ':dw', x, s + '/depthwise_kernel', 3, 1)
+    return self.pw(key + ':pw', d, s + '/pointwise_kernel', out_ch, bias=s + '/bias')
+
+  def _head(self, feats, net, prefix, out_ch):
+    return [self._head_level(feat, self.config.min_level + li, net, prefix, out_ch) for li, feat in enumerate(feats)]
+
+  def _heads_two_chains(self, feats, nbig, cls_ch, box_ch):
+    """Both towers as two chains: the big levels (the first nbig) on the current stream, the small ones on the side
+    stream (Engine.small_level_stream); the backward pass replays each chain's tape the same way, the side chain's
+    gradients of the shared tower kernels going to its own arena, which _join_side adds after the join."""
+    c = self.config
+    for net, prefix, out_ch in (('class_net', 'class', cls_ch), ('box_net', 'box', box_ch)):
+      # compute copies of the shared tower kernels are made BEFORE the fork (the chain that would otherwise make them
+      # first runs concurrently with the one that uses them)
+      for i in range(c.box_class_repeats):
+        self._pw_copies('%s/%s-%d/pointwise_kernel' % (net, prefix, i), c.fpn_num_filters, c.fpn_num_filters)
+      self._pw_copies('%s/%s-predict/pointwise_kernel' % (net, prefix), c.fpn_num_filters, out_ch)
+    main_tape = self.tape
+    tapes = {}
+
+    def chain(which, lis):
+      def job():
+        self.tape = []
+        out = []
+        for li in lis:
+          level = c.min_level + li
+          out.append((self._head_level(feats[li], level, 'class_net', 'class', cls_ch),
+                      self._head_level(feats[li], level, 'box_net', 'box', box_ch)))
+        tapes[which] = self.tape
+        return out
+      return job
+    try:
+      big, small = self._fork_join(chain('main', range(nbig)), chain('side', range(nbig, len(feats))))
+    finally:
+      self.tape = main_tape
+    outs = big + small
+    if self.training:
+      def bwd():
+        def replay(which):
+          def job():
+            for fn in reversed(tapes[which]):
+              fn()
+          return job
+        self._fork_join(replay('main'), replay('side'))
+        self._side_pending = True
+      self.tape.append(bwd)
+    return [o[0] for o in outs], [o[1] for o in outs]
 
   # ------------------------------------------------------------------ outputs
   def outputs(self):
@@ -949,6 +1071,7 @@ class Engine(object):
     for fn in reversed(self.tape):
       fn()
     self.tape = []
+    self._join_side()
 
   def set_hyper(self, lr, ema_decay=None):
     """Per-step scalars -> device (hyper[0] = learning rate, hyper[1] = EMA decay).  Stream-ordered H2D
