@@ -72,3 +72,23 @@ def test_losses_against_closed_forms():
   e = torch.tensor([0.05, -0.1, 0.3, -2.0])
   np.testing.assert_allclose(orc.huber(e, 0.1).numpy(), [0.00125, 0.005, 0.1 * 0.3 - 0.005, 0.1 * 2 - 0.005],
                              rtol=1e-6)
+
+
+def test_same_padding_rule_is_stated_twice_and_agrees():
+  """The TF 'SAME' geometry exists once in the product (automl_amd.utils.same_padding, used by the host code that sizes
+  every stencil launch) and once, in another algebraic form, in the oracle (tf_same_pads).  Documented cases of the TF
+  convolution guide plus an exhaustive sweep over the sizes / windows / strides the networks use."""
+  from automl_amd import utils
+  from oracle import efficientdet_oracle as orc
+  # (size, window, stride) -> (before, after): the odd pixel goes after; no padding for 1x1; k < s never pads negative
+  known = {(5, 3, 2): (1, 1), (4, 3, 2): (0, 1), (640, 3, 2): (0, 1), (7, 5, 2): (2, 2), (8, 5, 2): (1, 2),
+           (13, 1, 1): (0, 0), (13, 3, 1): (1, 1), (13, 5, 1): (2, 2), (6, 1, 2): (0, 0), (5, 2, 2): (0, 1),
+           (10, 3, 2): (0, 1), (9, 3, 2): (1, 1)}
+  for (size, k, s), want in known.items():
+    assert orc.tf_same_pads(size, k, s) == want, (size, k, s)
+  for size in range(1, 130):
+    for k in (1, 2, 3, 5, 7):
+      for s in (1, 2, 3):
+        out, before, after = utils.same_padding(size, k, s)
+        assert (before, after) == orc.tf_same_pads(size, k, s), (size, k, s)
+        assert out == -(-size // s) and (out - 1) * s + k <= size + before + after
