@@ -885,6 +885,8 @@ class Engine(object):
     self.fpn_feats = feats
     # ---- heads
     na = spec.num_anchors
+    # side chain = the levels of at most 20x20 pixels (r02q: also moving the 40x40 level there 68.3 -> 68.5 ms, only the
+    # 10x10 and 5x5 levels 69.0 ms)
     nbig = sum(1 for f in feats if f.raw.h * f.raw.w > 400)
     if self.small_level_stream and self.sync_bn is None and 0 < nbig < len(feats):
       cls, box = self._heads_two_chains(feats, nbig, c.num_classes * na, 4 * na)

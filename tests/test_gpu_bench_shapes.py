@@ -43,7 +43,7 @@ from tests.test_gpu_network import _seg_index, make_labels, perturbed_params, re
 pytestmark = pytest.mark.gpu
 
 BF16 = gu.DTYPES[1]
-TOL = {'f32': 1e-3, 'bf16_vs_f32': 3e-2, 'bf16_vs_emu': 1e-2, 'layer': 1.2e-2, 'layer_grad': 3e-2, 'layer_wgrad': 3e-2}
+TOL = {'f32': 1e-3, 'bf16_vs_f32': 3e-2, 'bf16_vs_emu': 1e-2, 'layer': 1.2e-2, 'layer_grad': 3e-2, 'layer_wgrad': 4e-2}
 ENGINE_WS_MIB = 64          # automl_amd/engine.py: the weight-gradient workspace the benchmark step hands over
 COVERED = {}                # kernel symbol -> launches, accumulated over the oracle-checked tests of this module
 
