@@ -127,12 +127,14 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
 
   float tot1 = 0.f, tot2 = 0.f;     // thread j < BJ: running column sums of this workgroup (stat partials)
 
-  for (int mt = grp * a.tpw; mt < min(a.ntm, (grp + 1) * a.tpw); ++mt) {
-    const int m0 = mt * BM;
-    int64_t arow[4];
-    int aimg[4];
-    int ciy[CONV ? 4 : 1], cix[CONV ? 4 : 1];          // CONV: top-left input pixel of the row's window
-    unsigned cvalid = 0;                               // CONV: taps of the chunk in flight that hit the image
+  int64_t arow[4];
+  int aimg[4];
+  int ciy[CONV ? 4 : 1], cix[CONV ? 4 : 1];          // CONV: top-left input pixel of the row's window
+  unsigned cvalid = 0;                               // CONV: taps of the chunk in flight that hit the image
+  uint4 ra[4], ry[GBN ? 4 : 1], rb[4];
+  // staging rows of row tile mt_
+  auto setup = [&](int mt_) {
+    const int m0 = mt_ * BM;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = min(m0 + lr + 32 * i, a.M - 1);     // rows past M re-read row M-1 (never stored)
@@ -148,15 +150,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
         aimg[i] = gated ? m / a.hw : 0;
       }
     }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-      for (int y = 0; y < 2; ++y)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[x][y][e] = 0.f;
-
-    uint4 ra[4], ry[GBN ? 4 : 1], rb[4];
+  };
+  {
     auto issue = [&](int kt) {
       const int k = kt * BK + lc * 8;
       const bool kok = k < a.R;
@@ -258,16 +253,53 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
       }
     };
 
+  // Row tiles of this workgroup.  The first reduction stage of tile mt+1 is requested at the START of tile mt's epilogue
+  // (the accumulators are in LDS by then, their registers are free), so that it is in flight under the epilogue instead
+  // of being waited for at the top of the next tile.
+  const int mt_end = min(a.ntm, (grp + 1) * a.tpw);
+  bool prefetched = false;
+  for (int mt = grp * a.tpw; mt < mt_end; ++mt) {
+    const int m0 = mt * BM;
+    if (!prefetched) setup(mt);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[x][y][e] = 0.f;
+
+    // BWD: the saved conv input of this tile's epilogue (act', SE gate sums, BatchNorm-backward sums).  Requested
+    // during the LAST reduction step -- the staging registers of the streamed operand are free by then -- so that it
+    // is in flight under the last MFMAs, the C-tile round trip through LDS and its barrier instead of after them.
+    uint4 xr[BWD ? BM / 16 : 1];
+    const bool need_x = BWD && (swish || other || want_gate || want_stats);
+
     __syncthreads();                     // the previous row tile's epilogue is done with the LDS
-    issue(0);
+    if (!prefetched) issue(0);
     commit(0, smem);
     if (nk > 1) issue(1);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; kt + 1 < nk; ++kt) {
       unsigned char* cur = smem + (kt & 1) * STAGE_BYTES;
       unsigned char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
-      if (kt + 1 < nk) commit(kt + 1, nxt);
+      commit(kt + 1, nxt);
       if (kt + 2 < nk) issue(kt + 2);
+      mma_stage(cur, cur + TILE_BYTES, wm, wj, lane, BK / 16, acc);
+      __syncthreads();
+    }
+    {  // last reduction step, peeled: nothing is staged any more
+      if (BWD) {
+        const bf16_t* Xp = reinterpret_cast<const bf16_t*>(a.tv.data);
+#pragma unroll
+        for (int i = 0; i < BM / 16; ++i) {
+          const int m = m0 + er + 16 * i;
+          xr[i] = make_uint4(0, 0, 0, 0);
+          if (need_x && ecol_ok && m < a.M) xr[i] = *reinterpret_cast<const uint4*>(Xp + (size_t)m * a.tv.ld + ej);
+        }
+      }
+      const int kt = nk - 1;
+      unsigned char* cur = smem + (kt & 1) * STAGE_BYTES;
       const int krem = a.R - kt * BK;
       mma_stage(cur, cur + TILE_BYTES, wm, wj, lane, krem >= BK ? BK / 16 : (krem + 15) / 16, acc);
       __syncthreads();
@@ -298,6 +330,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
         }
       }
       __syncthreads();
+      if (!CONV && mt + 1 < mt_end) { setup(mt + 1); issue(0); prefetched = true; } else prefetched = false;   // next tile's first stage
       float s1[8], s2[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
@@ -344,9 +377,9 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
                             acc[nj][mi][4 * g + 3]);
           }
       __syncthreads();
+      if (!CONV && mt + 1 < mt_end) { setup(mt + 1); issue(0); prefetched = true; } else prefetched = false;   // next tile's first stage
       const bf16_t* X = reinterpret_cast<const bf16_t*>(a.tv.data);
       bf16_t* GO = reinterpret_cast<bf16_t*>(a.epi.gout);
-      const bool need_x = swish || other || want_gate || want_stats;
       float sc[8], sh[8], s1[8], s2[8], gp[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; s1[e] = s2[e] = gp[e] = 0.f; }
@@ -364,15 +397,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) gp[e] = 0.f;
       };
-      // the 16 threads of one row group walk the rows er, er+16, ...: the saved input of the next row is
-      // requested before the current one is finished
-      uint4 xr[BM / 16];
-#pragma unroll
-      for (int i = 0; i < BM / 16; ++i) {
-        const int m = m0 + er + 16 * i;
-        xr[i] = make_uint4(0, 0, 0, 0);
-        if (need_x && ecol_ok && m < a.M) xr[i] = *reinterpret_cast<const uint4*>(X + (size_t)m * a.tv.ld + ej);
-      }
+      // the 16 threads of one row group walk the rows er, er+16, ... (xr: requested in the last reduction step)
 #pragma unroll
       for (int i = 0; i < BM / 16; ++i) {
         const int row = er + 16 * i;
@@ -455,6 +480,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
       }
     }
   }
+  }   // (scope of the staging lambdas)
   if (want_stats && tid < BJ && j0 + tid < a.J) {
     float* dst = a.stat_partials + (size_t)grp * 2 * a.J;
     dst[j0 + tid] = tot1;
