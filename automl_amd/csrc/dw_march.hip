@@ -993,7 +993,10 @@ inline int pick_nch(int nvec, int maxch) {
 template <int CPT>
 inline void plan(Args& a, int C, int n, int space_w, int space_h, int max_p) {
   const int nvec = (C + CPT - 1) / CPT;
-  a.nch = pick_nch(nvec, 128 / (CPT * 2));      // <= 128 contiguous bytes per pixel and workgroup
+  // <= 128 contiguous bytes per pixel and workgroup.  (r02t lab: 64- or 32-byte channel groups for the two-channel
+  // kernels -- wider column tiles, half the column halo -- are slower: backward 11.04 -> 11.40 / 12.01 ms, forward
+  // 4.77 -> 4.87 / 5.01 ms over the 15 layer shapes.)
+  a.nch = pick_nch(nvec, 128 / (CPT * 2));
   a.ngroups = (nvec + a.nch - 1) / a.nch;
   a.TX = THREADS / a.nch;
   {
