@@ -44,3 +44,35 @@ def test_bf16_training_forward_is_ill_conditioned_and_fp32_is_not():
   assert moved['f32', True] <= 2e-2 and moved['f32', False] <= 2e-3
   assert moved['bf16', False] <= 2e-2            # inference: rounding flips stay local
   assert moved['bf16', True] >= 5 * moved['f32', True]      # training: flips breed flips
+
+
+def test_fp32_per_tensor_gradients_are_conditioned_to_about_1e_2():
+  """The yardstick for the fp32 end-to-end gradient checks on the device (tests/test_gpu_bench_shapes.py,
+  tests/test_gpu_network.py): the oracle's OWN train step of d0 at 640x640, two images, run twice -- the second time
+  with the input scaled by 1 + 1e-7, less than one fp32 ulp for most pixels.  The direction of the whole gradient does
+  not move (cosine 1 - 2e-7), but individual tensors do: dozens by more than 1e-3 of their max, a fusion scalar by
+  ~1e-2.  A device implementation whose fp32 sums add in another order (atomics) cannot agree with the oracle more
+  closely than the oracle agrees with itself."""
+  from tests.test_gpu_network import make_labels, perturbed_params
+  torch.set_num_threads(min(16, torch.get_num_threads()))
+  config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  vals = perturbed_params(config, 5)
+  rng = np.random.default_rng(13)
+  images = torch.from_numpy(rng.standard_normal((2, 640, 640, 3)).astype(np.float32))
+  labels = {k: torch.from_numpy(v) for k, v in make_labels(config, 2, 640, 19).items()}
+
+  def grads(x):
+    o = orc.Oracle(config=config, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
+    with torch.no_grad():
+      o.forward(x[:1, :64, :64], False)
+    _, g = orc.train_step(o, x, labels, {}, 0.02, 0.9)
+    return {k: v.detach().double() for k, v in g.items()}
+  g0, g1 = grads(images), grads(images * (1 + 1e-7))
+  gmax = max(float(g.abs().max()) for g in g0.values())
+  errs = sorted((float((g1[k] - g0[k]).abs().max()) / max(float(g0[k].abs().max()), 1e-3 * gmax) for k in g0),
+                reverse=True)
+  num = sum(float((g0[k] * g1[k]).sum()) for k in g0)
+  den = np.sqrt(sum(float((g0[k]**2).sum()) for k in g0) * sum(float((g1[k]**2).sum()) for k in g0))
+  print('cosine %.9f, worst per-tensor moves %s, tensors moved by > 1e-3: %d' % (num / den, errs[:4], sum(e > 1e-3 for e in errs)))
+  assert num / den >= 0.999999
+  assert errs[0] >= 2e-3 and sum(e > 1e-3 for e in errs) >= 5, errs[:8]
