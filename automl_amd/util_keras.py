@@ -82,22 +82,24 @@ def _assign(model, values, ema_values):
 def load_from_hub_checkpoint(model, ckpt_path_or_file):
   """Loads EfficientDetNet weights from an EfficientDetNetTrainHub checkpoint (util_keras.py:83-105)."""
 
-  def _get_cpt_var_name(var_name):
-    for name_prefix, hub_name_prefix in HUB_CPT_NAME.items():
-      if var_name.startswith(name_prefix):
-        cpt_var_name = var_name[len(name_prefix):]  # remove the name_prefix
-        cpt_var_name = cpt_var_name.replace('/', '.S')
-        cpt_var_name = hub_name_prefix + '/' + cpt_var_name
-        if name_prefix:
-          cpt_var_name = cpt_var_name.replace(':0', '')
-        break
-    return cpt_var_name + '/.ATTRIBUTES/VARIABLE_VALUE'
+  def hub_key(variable_name):
+    """Checkpoint key of a model variable (name WITH its ':0' suffix, as the reference passes var.name): the first
+    matching prefix of HUB_CPT_NAME is cut off, '/' becomes '.S' and the hub attribute name goes in front; only the
+    catch-all 'base_model' entry (empty prefix) keeps the ':0'."""
+    for prefix, hub_attr in HUB_CPT_NAME.items():
+      if not variable_name.startswith(prefix):
+        continue
+      tail = variable_name[len(prefix):].replace('/', '.S')
+      if prefix:
+        tail = tail.replace(':0', '')
+      return '%s/%s/.ATTRIBUTES/VARIABLE_VALUE' % (hub_attr, tail)
+    raise KeyError(variable_name)
 
   reader = tf_checkpoint.load_checkpoint(ckpt_path_or_file)
   values = {}
   for name, shape, _ in model_variables(model):
     # the reference passes var.name, which ends in ':0'; the base_model branch keeps that suffix in the key
-    key = _get_cpt_var_name(name + ':0')
+    key = hub_key(name + ':0')
     v = reader.get_tensor(key)
     values[name] = np.asarray(v, np.float32).reshape(shape)
   _assign(model, values, None)
