@@ -92,3 +92,26 @@ def test_same_padding_rule_is_stated_twice_and_agrees():
         out, before, after = utils.same_padding(size, k, s)
         assert (before, after) == orc.tf_same_pads(size, k, s), (size, k, s)
         assert out == -(-size // s) and (out - 1) * s + k <= size + before + after
+
+
+@pytest.mark.parametrize('h,w', [(8, 8), (7, 9), (5, 4)])
+@pytest.mark.parametrize('k,s', [(3, 1), (3, 2), (5, 1), (5, 2)])
+def test_conv_against_scipy_as_a_third_witness(h, w, k, s):
+  """A third, library-independent statement of the 'SAME' convolution: scipy.signal.correlate2d over an explicitly
+  zero-padded image, sub-sampled at the stride -- padding written here from the TF rule (extra pixel after), so the
+  torch oracle, the direct loops and this agree only if all three place the window the same way."""
+  from scipy import signal
+  rng = np.random.default_rng(1000 + h * 100 + w * 10 + k + s)
+  x = rng.standard_normal((1, h, w, 3)).astype(np.float64)
+  wk = rng.standard_normal((k, k, 3, 2)).astype(np.float64)
+  oh, ow = -(-h // s), -(-w // s)
+  ph, pw_ = max((oh - 1) * s + k - h, 0), max((ow - 1) * s + k - w, 0)
+  xp = np.pad(x[0], ((ph // 2, ph - ph // 2), (pw_ // 2, pw_ - pw_ // 2), (0, 0)))
+  want = np.zeros((oh, ow, 2))
+  for co in range(2):
+    for ci in range(3):
+      full = signal.correlate2d(xp[:, :, ci], wk[:, :, ci, co], mode='valid')
+      want[:, :, co] += full[::s, ::s][:oh, :ow]
+  got = nhwc(orc.conv2d_same(nchw(x.astype(np.float32)), torch.from_numpy(wk.astype(np.float32)), s))[0]
+  np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+  np.testing.assert_allclose(dl.conv2d_same(x.astype(np.float32), wk.astype(np.float32), s)[0], want, rtol=1e-4, atol=1e-5)
