@@ -57,7 +57,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_label_force(const LabelArgs a) {
   __shared__ float rs[LB_THREADS / 64];
   __shared__ int rp[LB_THREADS / 64];
   const int m = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (m >= a.gt_count[b]) return;
+  if (m >= min(max(a.gt_count[b], 0), min(a.max_gt, MAX_GT))) return;    // a count beyond the padded rows is clamped
   const float4 g = *reinterpret_cast<const float4*>(a.gt_boxes + ((size_t)b * a.max_gt + m) * 4);
   float best = -1.f;
   int pos = 0x7fffffff;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_label_assign(const LabelArgs a) 
   __shared__ int glab[MAX_GT];
   __shared__ int wcount[LB_THREADS / 64];
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int M = a.gt_count[b];
+  const int M = min(max(a.gt_count[b], 0), min(a.max_gt, MAX_GT));    // device value: never trust it past the padded rows / LDS arrays
   for (int m = tid; m < M; m += LB_THREADS) {
     gbox[m] = *reinterpret_cast<const float4*>(a.gt_boxes + ((size_t)b * a.max_gt + m) * 4);
     glab[m] = a.gt_labels[(size_t)b * a.max_gt + m];

@@ -113,6 +113,14 @@ class Config(object):
   def __deepcopy__(self, memo):
     return type(self)(self.as_dict())
 
+  def __copy__(self):
+    return type(self)(self.as_dict())
+
+  def __reduce__(self):
+    # pickle / copy protocol: the default slot-state path would setattr('_fields') through the redirecting
+    # __setattr__ before the mapping exists (torch.multiprocessing spawn arguments, DataLoader workers)
+    return (type(self), (self.as_dict(),))
+
   def __repr__(self):
     return 'Config(%r)' % (self.as_dict(),)
 

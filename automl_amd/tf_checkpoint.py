@@ -417,25 +417,51 @@ def _encode_header(num_shards):
   return bytes(out)
 
 
+def _string_length_crc(lengths):
+  """Running CRC-32C over the element lengths as tensor_bundle.cc computes it (WriteStringTensor / ReadStringTensor):
+  every length enters as a FIXED-WIDTH little-endian integer -- 4 bytes when it fits a uint32, 8 bytes otherwise --
+  not as the varint bytes that are stored."""
+  crc = 0
+  for ln in lengths:
+    crc = crc32c(struct.pack('<I' if ln <= 0xffffffff else '<Q', ln), crc)
+  return crc
+
+
 def _encode_string_tensor(strings):
+  """-> (bytes as stored in the data shard, unmasked CRC-32C of the BundleEntry).  Layout: [varint64 length] * n,
+  4-byte masked checksum of the lengths, the string bytes.  The entry's CRC continues the length CRC over the 4 stored
+  checksum bytes and then over every string (tensor_bundle.cc WriteStringTensor) -- it is NOT the CRC of the raw bytes
+  on disk, because the lengths enter it in fixed width."""
   lengths = bytearray()
   for s in strings:
     _put_varint(lengths, len(s))
-  return bytes(lengths) + struct.pack('<I', mask_crc(crc32c(bytes(lengths)))) + b''.join(strings)
+  crc = _string_length_crc([len(s) for s in strings])
+  cks = struct.pack('<I', mask_crc(crc))
+  crc = crc32c(cks, crc)
+  for s in strings:
+    crc = crc32c(s, crc)
+  return bytes(lengths) + cks + b''.join(strings), crc
 
 
-def _decode_string_tensor(raw, count):
+def _decode_string_tensor(raw, count, verify=True, entry_crc=None):
+  """entry_crc: the BundleEntry's stored (masked) crc32c, checked when verify is set (ReadStringTensor)."""
   pos, lens = 0, []
   for _ in range(count):
     v, pos = _get_varint(raw, pos)
     lens.append(v)
-  if unmask_crc(struct.unpack_from('<I', raw, pos)[0]) != crc32c(raw[:pos]):
+  crc = _string_length_crc(lens)
+  stored = raw[pos:pos + 4]
+  if verify and unmask_crc(struct.unpack_from('<I', raw, pos)[0]) != crc:
     raise ValueError('string tensor: length checksum mismatch')
+  crc = crc32c(bytes(stored), crc)
   pos += 4
   out = []
   for ln in lens:
     out.append(bytes(raw[pos:pos + ln]))
+    crc = crc32c(out[-1], crc)
     pos += ln
+  if verify and entry_crc is not None and unmask_crc(entry_crc) != crc:
+    raise ValueError('string tensor: checksum mismatch')
   return out
 
 
@@ -489,7 +515,7 @@ class CheckpointReader(object):
       raise ValueError('%s: data shard is truncated' % name)
     count = int(np.prod(e.shape)) if e.shape else 1
     if e.dtype == DT_STRING:
-      strings = _decode_string_tensor(bytes(raw), count)
+      strings = _decode_string_tensor(bytes(raw), count, self.verify, e.crc32c)
       if not e.shape:
         return strings[0]
       return np.array(strings, dtype=object).reshape(e.shape)
@@ -501,6 +527,41 @@ class CheckpointReader(object):
       raise NotImplementedError('%s: dtype enum %d is not supported' % (name, e.dtype))
     dt = np.dtype(_NP_OF_DT[e.dtype]).newbyteorder('<')
     return np.frombuffer(raw, dtype=dt, count=count).reshape(e.shape).copy()
+
+
+def _text_proto_unescape(text):
+  """A quoted string of a text-format protobuf (the `checkpoint` state file is a CheckpointState in text format) ->
+  str: C escapes act on BYTES (protobuf's text_format writes non-ASCII UTF-8 bytes as 3-digit octal escapes), the
+  result is decoded as UTF-8; literal non-ASCII characters pass through."""
+  out = bytearray()
+  i, n = 0, len(text)
+  simple = {'n': 10, 't': 9, 'r': 13, 'a': 7, 'b': 8, 'f': 12, 'v': 11, '\\': 92, '"': 34, "'": 39, '?': 63}
+  while i < n:
+    ch = text[i]
+    if ch != '\\' or i + 1 >= n:
+      out += ch.encode('utf-8')
+      i += 1
+      continue
+    e = text[i + 1]
+    if e in simple:
+      out.append(simple[e])
+      i += 2
+    elif e in '01234567':
+      j = i + 1
+      while j < n and j < i + 4 and text[j] in '01234567':
+        j += 1
+      out.append(int(text[i + 1:j], 8) & 0xff)
+      i = j
+    elif e in 'xX':
+      j = i + 2
+      while j < n and j < i + 4 and text[j] in '0123456789abcdefABCDEF':
+        j += 1
+      out.append(int(text[i + 2:j] or '0', 16))
+      i = j
+    else:
+      out += e.encode('utf-8')
+      i += 2
+  return out.decode('utf-8')
 
 
 def load_checkpoint(ckpt_dir_or_file):
@@ -537,7 +598,7 @@ def latest_checkpoint(checkpoint_dir, latest_filename=None):
     m = re.search(r'^\s*model_checkpoint_path:\s*"((?:[^"\\]|\\.)*)"', f.read(), re.M)
   if not m:
     return None
-  path = m.group(1).encode().decode('unicode_escape')
+  path = _text_proto_unescape(m.group(1))
   if not os.path.isabs(path):
     path = os.path.join(checkpoint_dir, path)
   return path if os.path.exists(path + '.index') else None
@@ -564,8 +625,8 @@ def write_checkpoint(prefix, tensors):
         raise ValueError('the empty tensor name is reserved for the bundle header')
       v = tensors[name]
       if isinstance(v, (bytes, str)):
-        raw = _encode_string_tensor([v.encode('utf-8') if isinstance(v, str) else v])
-        entry = BundleEntry(DT_STRING, (), 0, offset, len(raw), mask_crc(crc32c(raw)))
+        raw, crc = _encode_string_tensor([v.encode('utf-8') if isinstance(v, str) else v])
+        entry = BundleEntry(DT_STRING, (), 0, offset, len(raw), mask_crc(crc))
       else:
         a = np.asarray(v, order='C')          # (ascontiguousarray would turn a scalar into shape [1])
         if a.dtype.byteorder == '>':

@@ -139,6 +139,12 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
     self._lr_fn = None
     self.iterations = 0
 
+  def set_optimizer_state(self, state):
+    """Optimizer slots + iteration count; the count also drives the learning-rate schedule and the dynamic EMA decay
+    of the next train_step (optimizer.iterations in the reference, train_lib.py:37-173,193-197)."""
+    super().set_optimizer_state(state)
+    self.iterations = int(state['iterations'])
+
   @staticmethod
   def _check_training_options(c):
     """The train step here is the reference's default one (train_lib.py:606-684 with the d0..d7x settings); options
@@ -234,6 +240,9 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
     else:
       if g['graphs'] is None:
         torch.cuda.synchronize()
+        # the capture pass runs optimizer_apply's host bookkeeping once WITHOUT executing anything: keep the counters
+        # where they were, the replay below accounts for the step
+        counters = (eng.arena.version, eng.arena.step_count)
         ga = torch.cuda.CUDAGraph()
         # thread_local: other threads of the process (the RCCL watchdog) may touch the HIP runtime meanwhile
         with torch.cuda.graph(ga, capture_error_mode='thread_local'):
@@ -244,6 +253,7 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
           with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode='thread_local'):
             body_b()
         g['graphs'] = (ga, gb)
+        eng.arena.version, eng.arena.step_count = counters
       ga, gb = g['graphs']
       eng.refresh_drop_masks()      # stochastic-depth draws live in static buffers the graph reads
       ga.replay()

@@ -119,6 +119,13 @@ def restore_ckpt(model, ckpt_path_or_file, ema_decay=0.9998, skip_mismatch=True,
 
   Raises:
     KeyError / ValueError: a variable is missing / has another shape and skip_mismatch is False.
+
+  Limitation (object-based checkpoints): the reference builds ``tf.train.Checkpoint(**{key: getattr(model, key)})`` and
+  TensorFlow matches variables by walking the object graph's attribute paths; here a saved variable is matched through
+  the ``full_name`` its SerializedTensor carries (= the Keras variable name, which is what this code base addresses
+  variables by), restricted to the top-level attributes present.  A checkpoint whose variables were saved with an
+  empty / different ``full_name`` (e.g. a model built under another name scope) does not match and falls through to
+  the hub loader, exactly as a trivial match does in the reference.
   """
   if ckpt_path_or_file == '_':
     logging.info('Running test: do not load any ckpt.')

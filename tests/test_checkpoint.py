@@ -138,9 +138,9 @@ def test_hand_assembled_two_shard_bundle(tmp_path, compress):
     e = tfc.BundleEntry(dt, t[name].shape, sh, len(data[sh]), len(raw), tfc.mask_crc(tfc.crc32c(raw)))
     data[sh] += raw
     entries.append((name.encode(), e.encode()))
-  sraw = tfc._encode_string_tensor([b'hello', b'', b'bundle'])
+  sraw, scrc = tfc._encode_string_tensor([b'hello', b'', b'bundle'])
   entries.append((b'd/strings', tfc.BundleEntry(tfc.DT_STRING, (3,), 0, len(data[0]), len(sraw),
-                                                tfc.mask_crc(tfc.crc32c(sraw))).encode()))
+                                                tfc.mask_crc(scrc)).encode()))
   data[0] += sraw
   header = bytearray()
   tfc._emit(header, 1, 0, 2)                                         # num_shards = 2
@@ -170,6 +170,67 @@ def test_hand_assembled_two_shard_bundle(tmp_path, compress):
     f.write(bytes([b[0] ^ 0x40]))
   with pytest.raises(ValueError, match='checksum'):
     tfc.CheckpointReader(prefix).get_tensor('a/kernel/ExponentialMovingAverage')
+
+
+def _crc32c_bitwise(data, crc=0):
+  """Bit-at-a-time CRC-32C (reflected polynomial 0x82f63b78), written here independently of tf_checkpoint's tables."""
+  c = crc ^ 0xffffffff
+  for b in bytes(data):
+    c ^= b
+    for _ in range(8):
+      c = (c >> 1) ^ (0x82f63b78 if c & 1 else 0)
+  return c ^ 0xffffffff
+
+
+def test_string_tensor_checksums_follow_tensor_bundle_cc(tmp_path):
+  """DT_STRING layout of tensorflow/core/util/tensor_bundle/tensor_bundle.cc (WriteStringTensor / ReadStringTensor),
+  assembled here byte by byte from that definition with an independent CRC: varint64 lengths, then Mask(crc) of the
+  lengths taken as FIXED-WIDTH little-endian uint32 (not of the varint bytes), then the strings; the BundleEntry's
+  crc32c continues the length CRC over the 4 stored checksum bytes and over every string, then is masked.  A 300-byte
+  string makes the varint (2 bytes) and the fixed-width form (4 bytes) differ, which is what the first version of the
+  encoder got wrong.  No TF-written file exists here: this pins the code against the format definition."""
+  strings = [b'x' * 300, b'', b'object graph']
+  varints = b'\xac\x02' + b'\x00' + b'\x0c'
+  crc = 0
+  for s_ in strings:
+    crc = _crc32c_bitwise(len(s_).to_bytes(4, 'little'), crc)
+  masked = (((crc >> 15) | (crc << 17)) + 0xa282ead8) & 0xffffffff
+  want_raw = varints + masked.to_bytes(4, 'little') + b''.join(strings)
+  entry_crc = _crc32c_bitwise(masked.to_bytes(4, 'little'), crc)
+  for s_ in strings:
+    entry_crc = _crc32c_bitwise(s_, entry_crc)
+  raw, got_crc = tfc._encode_string_tensor(strings)
+  assert raw == want_raw and got_crc == entry_crc
+  assert _crc32c_bitwise(varints) != crc            # the varint-byte checksum is a different number
+  assert tfc._decode_string_tensor(raw, 3, True, tfc.mask_crc(entry_crc)) == strings
+  with pytest.raises(ValueError):
+    tfc._decode_string_tensor(raw, 3, True, tfc.mask_crc(entry_crc ^ 1))
+  bad = bytearray(raw)
+  bad[4] ^= 0xff                                      # a checksum byte
+  with pytest.raises(ValueError):
+    tfc._decode_string_tensor(bytes(bad), 3, True, None)
+  # through the bundle writer / reader: a scalar string tensor (what _CHECKPOINTABLE_OBJECT_GRAPH is)
+  prefix = str(tmp_path / 'ckpt-1')
+  tfc.write_checkpoint(prefix, {'graph': b'g' * 70000, 'w': np.arange(3, dtype=np.float32)})
+  r = tfc.CheckpointReader(prefix)
+  assert r.get_tensor('graph') == b'g' * 70000
+  e = r.entries['graph']
+  c2 = _crc32c_bitwise((70000).to_bytes(4, 'little'))
+  m2 = (((c2 >> 15) | (c2 << 17)) + 0xa282ead8) & 0xffffffff
+  assert tfc.unmask_crc(e.crc32c) == _crc32c_bitwise(b'g' * 70000, _crc32c_bitwise(m2.to_bytes(4, 'little'), c2))
+
+
+def test_checkpoint_state_path_unescape(tmp_path):
+  """The `checkpoint` state file is a text-format CheckpointState: C escapes on bytes, UTF-8 underneath."""
+  d = tmp_path / 'mod\u00e8le'
+  d.mkdir()
+  prefix = str(d / 'ckpt-3')
+  tfc.write_checkpoint(prefix, {'w': np.zeros(2, np.float32)})
+  for line in ('model_checkpoint_path: "ckpt-3"', 'model_checkpoint_path: "%s"' % prefix,
+               'model_checkpoint_path: "%s"' % ''.join(chr(b) if b < 128 else '\\%03o' % b for b in prefix.encode())):
+    (d / 'checkpoint').write_text(line + '\n', encoding='utf-8')
+    assert tfc.latest_checkpoint(str(d)) == prefix, line
+  assert tfc._text_proto_unescape(r'a\"b\\c\x41\101') == 'a"b\\cAA'
 
 
 def test_write_read_round_trip_many_blocks(tmp_path):

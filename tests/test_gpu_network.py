@@ -364,6 +364,13 @@ def test_graph_replay_matches_eager_steps(use_dist):
                                            global_batch_size=64, use_graph=use_graph, use_dist=use_dist)
       losses = [net.train_step(b) for b in batches]
       torch.cuda.synchronize()
+      # host counters: 4 optimizer iterations whichever way the step ran (the capture pass does not count),
+      # and a restored optimizer state also restores the count that drives the LR schedule / dynamic EMA decay
+      state = net.get_optimizer_state()
+      assert state['iterations'] == 4 and net.iterations == 4, (use_graph, state['iterations'], net.iterations)
+      state['iterations'] = 7
+      net.set_optimizer_state(state)
+      assert net.iterations == 7 and net.engine.arena.step_count == 7
       results.append((losses, net.get_weights(), net.engine.ema.cpu().numpy().copy()))
     (l0, w0, e0), (l1, w1, e1) = results
     for a, b in zip(l0, l1):

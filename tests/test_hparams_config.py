@@ -107,3 +107,17 @@ def test_unbuilt_options_raise_instead_of_being_ignored():
   with pytest.raises(ValueError, match='not built'):
     efficientdet_net.EfficientDetNet(config=config)
   train_lib.EfficientDetNetTrain(config=hparams_config.get_efficientdet_config('efficientdet-d0'))   # defaults pass
+
+
+def test_config_pickle_and_copy_round_trip():
+  """Config travels through pickle / copy (torch.multiprocessing spawn arguments, DataLoader workers): the slot-based
+  table needs an explicit reduce."""
+  import copy
+  import pickle
+  c = hparams_config.get_efficientdet_config('efficientdet-d1')
+  c.override('image_size=640,nms_configs.sigma=0.7')
+  for clone in (pickle.loads(pickle.dumps(c)), copy.copy(c), copy.deepcopy(c)):
+    assert isinstance(clone, hparams_config.Config) and clone.as_dict() == c.as_dict()
+    assert isinstance(clone.nms_configs, hparams_config.Config)
+    clone.nms_configs.sigma = 0.1
+    assert c.nms_configs.sigma == 0.7
