@@ -79,7 +79,9 @@ SIGNATURES = {
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     'edet_bn_res': [PT, c_void_p, c_void_p, c_int, c_int, c_void_p],
     'edet_add': [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
-    'edet_se_pool': [PT, c_void_p, c_int, c_void_p],
+    'edet_se_pool': [PT, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],
+    'edet_se_squeeze_excite': [PT, c_void_p, ctypes.c_size_t, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     'edet_se_fc': [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                    c_void_p, c_void_p, c_int, c_void_p],
     'edet_se_fc_bwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,

@@ -216,20 +216,27 @@ __global__ void k_add(T* __restrict__ dst, const T* __restrict__ src, int64_t ro
 }
 
 // ------------------------------------------------------------------ squeeze-and-excitation
-// pooled_sum[n][c] += sum over this workgroup's pixels of view(in)
+// Global average pooling WITHOUT atomics and with a summation order that does not depend on the batch: an image's
+// rows are cut into chunks of `cr` rows (a function of the map and channel count only, se_chunk_rows), one workgroup
+// per (image, chunk); thread (rr, cv) adds the rows rr, rr + rpp, ... of its chunk in row order, the rpp row-slices of
+// a workgroup are added in slice order through LDS, and the chunk sums of an image are added in chunk order by the
+// consumer (k_se_pool_finish or k_se_fc).  The same image therefore gives bit-identical pooled sums whatever batch it
+// sits in and from run to run (the first version used fp32 atomics on both levels).
+// parts[(n * nchunks + chunk) * c + i] = sum over the chunk's pixels of view(in)
 template <typename T>
-__global__ __launch_bounds__(THREADS) void k_se_pool(const edet_tview_t in, float* pooled, int wg_per_img,
-                                                    RowMap m) {
+__global__ __launch_bounds__(THREADS) void k_se_pool(const edet_tview_t in, float* __restrict__ parts, int nchunks,
+                                                    int cr, RowMap m) {
   const int tid = threadIdx.x;
-  const int n = blockIdx.x / wg_per_img, part = blockIdx.x % wg_per_img;
+  const int n = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
   const int cv = tid % m.tpr, rr = tid / m.tpr;
   const int hw = in.h * in.w;
-  extern __shared__ float red[];  // [c]
-  for (int i = tid; i < in.c; i += THREADS) red[i] = 0.f;
-  __syncthreads();
+  const int r0 = chunk * cr, r1 = min(hw, r0 + cr);
+  extern __shared__ float red[];  // [rpp][cblk], cblk = min(c, tpr * 8)
+  const int cblk = min(in.c, m.tpr * 8);
   edet_tview_t v = in;
   v.gate = nullptr;
   const T* base = reinterpret_cast<const T*>(in.data) + (size_t)n * hw * in.ld;
+  float* out = parts + ((size_t)n * nchunks + chunk) * in.c;
   for (int cb = 0; cb < in.c; cb += m.tpr * 8) {     // channel blocks of <= 2048 channels
     const int c0 = cb + cv * 8;
     if (c0 < in.c) {
@@ -240,9 +247,9 @@ __global__ __launch_bounds__(THREADS) void k_se_pool(const edet_tview_t in, floa
       view_load_coef(in, c0, vc);
       // four rows of loads in flight per thread (16 waves/CU x 16 B per lane is ~4 MB in flight over the chip, a
       // third of what 2 us of HBM latency at 5 TB/s needs); the sums keep their row order
-      const int st = wg_per_img * m.rpp;
-      int r = part * m.rpp + rr;
-      for (; r + 3 * st < hw; r += 4 * st) {
+      const int st = m.rpp;
+      int r = r0 + rr;
+      for (; r + 3 * st < r1; r += 4 * st) {
         float x[4][8];
 #pragma unroll
         for (int u = 0; u < 4; ++u) load8<T>(base + (size_t)(r + u * st) * in.ld + c0, x[u]);
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(THREADS) void k_se_pool(const edet_tview_t in, floa
           for (int e = 0; e < 8; ++e) s[e] += x[u][e];
         }
       }
-      for (; r < hw; r += st) {
+      for (; r < r1; r += st) {
         float x[8];
         load8<T>(base + (size_t)r * in.ld + c0, x);
         view_apply(v, vc, c0, n, x);
@@ -261,27 +268,58 @@ __global__ __launch_bounds__(THREADS) void k_se_pool(const edet_tview_t in, floa
         for (int e = 0; e < 8; ++e) s[e] += x[e];
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) atomicAdd(&red[c0 + e], s[e]);
+      for (int e = 0; e < 8; ++e) red[rr * cblk + cv * 8 + e] = s[e];
     }
+    __syncthreads();
+    for (int i = tid; i < cblk && cb + i < in.c; i += THREADS) {
+      float t = red[i];
+      for (int q = 1; q < m.rpp; ++q) t += red[q * cblk + i];      // row slices in slice order
+      out[cb + i] = t;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  for (int i = tid; i < in.c; i += THREADS) atomicAdd(&pooled[(size_t)n * in.c + i], red[i]);
 }
 
-// one workgroup (SE_FC_THREADS lanes) per image
+// pooled[n][i] = chunk sums of image n added in chunk order
+__global__ __launch_bounds__(THREADS) void k_se_pool_finish(const float* __restrict__ parts, int nchunks, int c,
+                                                           float* __restrict__ pooled, int total) {
+  const int idx = blockIdx.x * THREADS + threadIdx.x;
+  if (idx >= total) return;
+  const int n = idx / c, i = idx - n * c;
+  const float* p = parts + (size_t)n * nchunks * c + i;
+  float t = p[0];
+  for (int k = 1; k < nchunks; ++k) t += p[(size_t)k * c];
+  pooled[idx] = t;
+}
+
+// one workgroup (SE_FC_THREADS lanes) per image.  pooled_parts != nullptr: the pooled sums are still k_se_pool's chunk
+// rows [n][nchunks][c]; they are added here in chunk order and written to pooled (the backward pass reads them).
 constexpr int SE_FC_THREADS = 1024;
-__global__ __launch_bounds__(SE_FC_THREADS) void k_se_fc(const float* __restrict__ pooled, int c, int se, float inv_hw,
-                                                        const float* w1, const float* b1, const float* w2,
-                                                        const float* b2, float* hidden_pre, float* gate, int act) {
-  extern __shared__ float sm[];  // p[c], h[se]
+__global__ __launch_bounds__(SE_FC_THREADS) void k_se_fc(float* __restrict__ pooled,
+                                                        const float* __restrict__ pooled_parts, int nchunks, int c,
+                                                        int se, float inv_hw, const float* w1, const float* b1,
+                                                        const float* w2, const float* b2, float* hidden_pre,
+                                                        float* gate, int act) {
+  extern __shared__ float sm[];  // p[c], h[se], hp[nthr]
   float* p = sm;
   float* h = sm + c;
+  float* hp = sm + c + se;
   const int n = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-  for (int i = tid; i < c; i += nthr) p[i] = pooled[(size_t)n * c + i] * inv_hw;
-  for (int j = tid; j < se; j += nthr) h[j] = 0.f;
+  for (int i = tid; i < c; i += nthr) {
+    float t;
+    if (pooled_parts) {
+      const float* q = pooled_parts + (size_t)n * nchunks * c + i;
+      t = q[0];
+      for (int k = 1; k < nchunks; ++k) t += q[(size_t)k * c];
+      pooled[(size_t)n * c + i] = t;
+    } else {
+      t = pooled[(size_t)n * c + i];
+    }
+    p[i] = t * inv_hw;
+  }
   __syncthreads();
   // thread (j, part): hidden unit j over the channels i = part, part + nparts, ... (w1 loads coalesced along
-  // j; four independent partial sums keep four loads in flight)
+  // j; four independent partial sums keep four loads in flight); the parts of a unit are added in part order
   if (se <= nthr) {
     const int nparts = nthr / se, j = tid % se, part = tid / se;
     if (part < nparts) {
@@ -294,7 +332,13 @@ __global__ __launch_bounds__(SE_FC_THREADS) void k_se_fc(const float* __restrict
         a3 = fmaf(p[i + 3 * nparts], w1[(size_t)(i + 3 * nparts) * se + j], a3);
       }
       for (; i < c; i += nparts) a0 = fmaf(p[i], w1[(size_t)i * se + j], a0);
-      atomicAdd(&h[j], (a0 + a1) + (a2 + a3));
+      hp[part * se + j] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    if (tid < se) {
+      float t = hp[tid];
+      for (int q = 1; q < nparts; ++q) t += hp[q * se + tid];
+      h[tid] = t;
     }
   } else {
     for (int j = tid; j < se; j += nthr) {
@@ -632,18 +676,48 @@ static int se_wg_per_img(int n, int hw, int rpp) {
   return w;
 }
 
-extern "C" int edet_se_pool(const edet_tview_t* in, float* pooled_sum, int dtype, void* stream) {
-  EDET_CHECK(in && in->data && pooled_sum, "edet_se_pool: null pointer");
+// Rows of one image per k_se_pool workgroup: ~64 K elements (128 KB of bf16), at least four passes of the row map; a
+// function of the map size and channel count ONLY, so an image is summed the same way in every batch.  If the chunk rows
+// of the whole batch do not fit the caller's scratch the chunks grow (then the order depends on the scratch size; the
+// engine's scratch -- EDET_MAX_PARTS * 2 * widest layer floats -- holds every EfficientDet / EfficientNetV2 layer up to
+// batch x chunks = 2048 at the widest layer).
+static int se_chunk_rows(int hw, int c, int rpp, int n, size_t scratch_floats, int* nchunks_out) {
+  int cr = cdiv(cdiv(65536, c), rpp) * rpp;
+  if (cr < 4 * rpp) cr = 4 * rpp;
+  while ((size_t)n * cdiv(hw, cr) * c > scratch_floats && cr < hw) cr *= 2;
+  *nchunks_out = cdiv(hw, cr);
+  return cr;
+}
+
+static int se_pool_launch(const edet_tview_t* in, float* parts, size_t scratch_floats, int dtype, void* stream,
+                          int* nchunks_out) {
   EDET_CHECK(in->c % 8 == 0 && in->ld % 8 == 0 && in->c <= 8192, "edet_se_pool: c/ld");
   const RowMap m = row_map(in->c);
-  const int wpi = se_wg_per_img(in->n, in->h * in->w, m.rpp);
-  const size_t lds = (size_t)in->c * sizeof(float);
-  if (dtype == EDET_BF16) edet_launch(k_se_pool<bf16_t>, dim3(in->n * wpi), dim3(THREADS), lds, to_stream(stream), *in, pooled_sum, wpi, m);
-  else if (dtype == EDET_F32) edet_launch(k_se_pool<float>, dim3(in->n * wpi), dim3(THREADS), lds, to_stream(stream), *in, pooled_sum, wpi, m);
+  int nchunks = 1;
+  const int cr = se_chunk_rows(in->h * in->w, in->c, m.rpp, in->n, scratch_floats, &nchunks);
+  EDET_CHECK((size_t)in->n * nchunks * in->c <= scratch_floats, "edet_se_pool: scratch of %zu floats < %d x %d", scratch_floats,
+             in->n, in->c);
+  const int cblk = in->c < m.tpr * 8 ? in->c : m.tpr * 8;
+  const size_t lds = (size_t)m.rpp * cblk * sizeof(float);
+  if (dtype == EDET_BF16) edet_launch(k_se_pool<bf16_t>, dim3(in->n * nchunks), dim3(THREADS), lds, to_stream(stream), *in, parts, nchunks, cr, m);
+  else if (dtype == EDET_F32) edet_launch(k_se_pool<float>, dim3(in->n * nchunks), dim3(THREADS), lds, to_stream(stream), *in, parts, nchunks, cr, m);
   else EDET_CHECK(false, "edet_se_pool: bad dtype %d", dtype);
+  *nchunks_out = nchunks;
+  return 0;
+}
+
+extern "C" int edet_se_pool(const edet_tview_t* in, float* pooled_sum, void* scratch, size_t scratch_bytes,
+                            int dtype, void* stream) {
+  EDET_CHECK(in && in->data && pooled_sum && scratch, "edet_se_pool: null pointer");
+  int nchunks = 1;
+  if (se_pool_launch(in, (float*)scratch, scratch_bytes / sizeof(float), dtype, stream, &nchunks)) return -1;
+  const int total = in->n * in->c;
+  edet_launch(k_se_pool_finish, dim3(cdiv(total, THREADS)), dim3(THREADS), 0, to_stream(stream), (const float*)scratch, nchunks, in->c, pooled_sum, total);
   EDET_LAUNCH_CHECK("edet_se_pool");
   return 0;
 }
+
+static size_t se_fc_lds(int c, int se, int threads) { return (size_t)(c + se + threads) * sizeof(float); }
 
 extern "C" int edet_se_fc(const float* pooled_sum, int n, int c, int se, float inv_hw,
                           const float* w1, const float* b1, const float* w2, const float* b2,
@@ -651,8 +725,24 @@ extern "C" int edet_se_fc(const float* pooled_sum, int n, int c, int se, float i
   EDET_CHECK(pooled_sum && w1 && b1 && w2 && b2 && hidden_pre && gate, "edet_se_fc: null pointer");
   EDET_CHECK(act >= EDET_ACT_NONE && act <= EDET_ACT_HSWISH, "edet_se_fc: activation %d", act);
   const int fc_threads = c >= 512 ? SE_FC_THREADS : THREADS;
-  edet_launch(k_se_fc, dim3(n), dim3(fc_threads), (size_t)(c + se) * sizeof(float), to_stream(stream), pooled_sum, c, se, inv_hw, w1, b1, w2, b2, hidden_pre, gate, act);
+  edet_launch(k_se_fc, dim3(n), dim3(fc_threads), se_fc_lds(c, se, fc_threads), to_stream(stream), const_cast<float*>(pooled_sum), (const float*)nullptr, 0, c, se, inv_hw, w1, b1, w2, b2, hidden_pre, gate, act);
   EDET_LAUNCH_CHECK("edet_se_fc");
+  return 0;
+}
+
+extern "C" int edet_se_squeeze_excite(const edet_tview_t* in, void* scratch, size_t scratch_bytes, int se,
+                                      float inv_hw, const float* w1, const float* b1, const float* w2, const float* b2,
+                                      float* pooled_sum, float* hidden_pre, float* gate, int act, int dtype,
+                                      void* stream) {
+  EDET_CHECK(in && in->data && scratch && pooled_sum && w1 && b1 && w2 && b2 && hidden_pre && gate,
+             "edet_se_squeeze_excite: null pointer");
+  EDET_CHECK(act >= EDET_ACT_NONE && act <= EDET_ACT_HSWISH, "edet_se_squeeze_excite: activation %d", act);
+  int nchunks = 1;
+  if (se_pool_launch(in, (float*)scratch, scratch_bytes / sizeof(float), dtype, stream, &nchunks)) return -1;
+  const int c = in->c;
+  const int fc_threads = c >= 512 ? SE_FC_THREADS : THREADS;
+  edet_launch(k_se_fc, dim3(in->n), dim3(fc_threads), se_fc_lds(c, se, fc_threads), to_stream(stream), pooled_sum, (const float*)scratch, nchunks, c, se, inv_hw, w1, b1, w2, b2, hidden_pre, gate, act);
+  EDET_LAUNCH_CHECK("edet_se_squeeze_excite");
   return 0;
 }
 

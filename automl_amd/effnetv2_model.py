@@ -189,11 +189,9 @@ class V2Engine(engine_lib.Engine):
                  bn=name + '/head/tpu_batch_normalization', act=ACT_SWISH)
     self.endpoints['head_1x1'] = hv
     r = hv.raw
-    pooled = self.zbuf('head:pool', (n, r.c))
-    if not training:
-      pooled.zero_()        # zbufs are cleared per training step only
-    call('edet_se_pool', ctypes.byref(hv.tview()), ptr(pooled), self.dtype, self.stream,
-         nbytes=r.rows * r.c * self.esize)
+    pooled = self.buf('head:pool', (n, r.c), torch.float32)
+    call('edet_se_pool', ctypes.byref(hv.tview()), ptr(pooled), ptr(self.partials), self.partials.numel() * 4,
+         self.dtype, self.stream, nbytes=r.rows * r.c * self.esize)
     self.pooled_sum, self.pooled_inv_hw = pooled, 1.0 / (r.h * r.w)
     self.head_view = hv
     self.logits = None

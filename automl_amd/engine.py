@@ -652,15 +652,16 @@ class Engine(object):
     r = v.raw
     n, c = r.n, r.c
     inv_hw = 1.0 / (r.h * r.w)
-    pooled = self.zbuf(key + ':pool', (n, c))
+    pooled = self.buf(key + ':pool', (n, c), torch.float32)
     hidden = self.buf(key + ':hid', (n, se_filters), torch.float32)
     gate = self.buf(key + ':gate', (n, c), torch.float32)
     w1, b1 = scope + '/se/conv2d/kernel', scope + '/se/conv2d/bias'
     w2, b2 = scope + '/se/conv2d_1/kernel', scope + '/se/conv2d_1/bias'
-    call('edet_se_pool', ctypes.byref(v.tview()), ptr(pooled), self.dtype, self.stream,
-         nbytes=r.rows * c * self.esize)
-    call('edet_se_fc', ptr(pooled), n, c, se_filters, inv_hw, ptr(self.param(w1)), ptr(self.param(b1)),
-         ptr(self.param(w2)), ptr(self.param(b2)), ptr(hidden), ptr(gate), v.act, self.stream)
+    # pooling (chunk sums in the BatchNorm partial-row scratch, free between two layers) + both 1x1 layers; no atomics,
+    # batch-independent summation order
+    call('edet_se_squeeze_excite', ctypes.byref(v.tview()), ptr(self.partials), self.partials.numel() * 4,
+         se_filters, inv_hw, ptr(self.param(w1)), ptr(self.param(b1)), ptr(self.param(w2)), ptr(self.param(b2)),
+         ptr(pooled), ptr(hidden), ptr(gate), v.act, self.dtype, self.stream, nbytes=r.rows * c * self.esize)
     vg = View(r, v.bn, v.act, gate)
     vg.dgate = self.zbuf(key + ':dgate', (n, c)) if self.training else None
     v.consumers += 1

@@ -247,11 +247,21 @@ int edet_add(void* dst, const void* src, int64_t rows, int c, int ld, int beta,
 
 /* ---- squeeze-and-excitation --------------------------------------------------
  * efficientnet_model.py:153-195: mean over H,W -> 1x1 (+bias) -> act (the model's relu_fn, an EDET_ACT_* code)
- * -> 1x1 (+bias) -> sigmoid.  pooled [n,c] must be zero before edet_se_pool (atomics).  */
-int edet_se_pool(const edet_tview_t* in, float* pooled_sum, int dtype, void* stream);
+ * -> 1x1 (+bias) -> sigmoid.
+ * edet_se_pool: pooled_sum [n,c] = sum over H,W of view(in) (the gate of `in` is ignored).  No atomics: an image's rows
+ * are summed in chunks whose size depends on (H*W, c) only, the chunk sums (written to `scratch`, caller-owned, at
+ * least n * ceil(H*W / chunk) * c floats: 8 MB covers every EfficientDet / EfficientNetV2 layer; the chunks grow if it
+ * is smaller) are added in chunk order -- the same image gives the same bits in every batch and on every run.
+ * edet_se_squeeze_excite: the pooling and both 1x1 layers in two launches (the FC kernel adds the chunk sums itself);
+ * also writes pooled_sum (edet_se_fc_bwd reads it).  inv_hw = 1 / (H*W).  */
+int edet_se_pool(const edet_tview_t* in, float* pooled_sum, void* scratch, size_t scratch_bytes,
+                 int dtype, void* stream);
 int edet_se_fc(const float* pooled_sum, int n, int c, int se, float inv_hw,
                const float* w1, const float* b1, const float* w2, const float* b2,
                float* hidden_pre, float* gate, int act, void* stream);
+int edet_se_squeeze_excite(const edet_tview_t* in, void* scratch, size_t scratch_bytes, int se, float inv_hw,
+                           const float* w1, const float* b1, const float* w2, const float* b2,
+                           float* pooled_sum, float* hidden_pre, float* gate, int act, int dtype, void* stream);
 /* dgate [n,c] -> dpool [n,c] (already divided by H*W), parameter gradients.
  * scratch: caller-owned fp32 workspace of n*(c + 2*se) elements.  */
 int edet_se_fc_bwd(const float* pooled_sum, const float* hidden_pre, const float* gate,

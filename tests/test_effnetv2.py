@@ -146,64 +146,115 @@ def _perturbed(spec, seed):
   return vals
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize('model_name,size', [('efficientnetv2-s', 128), ('efficientnetv2-b0', 128),
-                                             ('efficientnet-b0', 96)])
-@pytest.mark.parametrize('dtype,tol', [('f32', 1e-3), ('bf16', 2e-1)])
-@pytest.mark.parametrize('training', [False, True])
-def test_model_forward_matches_oracle(model_name, size, dtype, tol, training):
-  """Logits, pooled features and every reduction endpoint vs the oracle; fp32 storage within 1e-3 of the
-  tensor's max (north_star tolerance).  bf16 storage: relative L2 error within 2e-1 (measured 0.10-0.15
-  at reduction_5, <= 0.1 for the logits) -- every stored tensor is
-  rounded to 2^-8, and on random (untrained) weights the SE-gated residual stages amplify a perturbation by
-  ~1.2x per block (measured: 0.7 % after stage 1, 1.5 % after stage 3, 6 % after stage 4), so a max-norm
-  bound over 40-57 blocks would only measure the conditioning of the random network."""
-  over = 'num_classes=40,survival_prob=0,dropout_rate=0'
-  batch = 4
+V2_ENDPOINTS = ['head'] + ['reduction_%d' % i for i in range(1, 6)] + ['pooled_features']
+TOL_F32, TOL_BF16_VS_EMU, TOL_LAYER = 1e-3, 1e-2, 1.2e-2
+
+
+def _v2_problem(model_name, size, batch, training, over='num_classes=40,survival_prob=0,dropout_rate=0', bf16=False):
+  """-> (model_config override, variables, images): reference initialisers with every BatchNorm / bias perturbed; in
+  inference mode the moving statistics are the ones of the data (as after training): with arbitrary moving statistics a
+  40-block network is not normalised, activations grow by orders of magnitude and the comparison is ill conditioned.
+  bn_momentum=0 makes the oracle's updated moving statistics the batch ones."""
   spec = effnetv2_model.V2Spec(effnetv2_configs.model_config(model_name, over))
   vals = _perturbed(spec, 5)
   rng = np.random.default_rng(11)
-  images = rng.standard_normal((batch, size, size, 3)).astype(np.float32)
-  if dtype == 'bf16':
-    images = torch.from_numpy(images).to(torch.bfloat16).float().numpy()
+  images = torch.from_numpy(rng.standard_normal((batch, size, size, 3)).astype(np.float32))
+  if bf16:
+    images = images.to(torch.bfloat16).float()
   if not training:
-    # inference statistics that match the data (as after training): with arbitrary moving statistics a
-    # 40-block network is not normalised, activations grow by orders of magnitude and the comparison
-    # becomes ill-conditioned.  bn_momentum=0 makes the oracle's updated moving statistics the batch ones.
     warm = v2orc.V2Oracle(model_name, over + ',bn_momentum=0.0',
                           params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
     with torch.no_grad():
-      warm.forward(torch.from_numpy(images), True)
+      warm.forward(images, True)
     for k, v in warm.new_moving.items():
       vals[k] = v.numpy().copy()
-  else:
-    pass
-  oracle = v2orc.V2Oracle(model_name, over, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
-  with torch.no_grad():
-    want = oracle.forward(torch.from_numpy(images), training)
-  net = effnetv2_model.EffNetV2Model(model_name, over, dtype=dtype, params=vals)
-  outs = net(torch.from_numpy(images), training=training, with_endpoints=True)
+  return over, vals, images
+
+
+def _v2_oracle(model_name, over, vals, storage='f32'):
+  return v2orc.V2Oracle(model_name, over, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()},
+                        storage=storage)
+
+
+def _v2_device(net, images, training):
+  """-> {endpoint: fp32 CPU tensor} of one device forward."""
+  outs = net(images, training=training, with_endpoints=True)
   torch.cuda.synchronize()
-  outs = [o.float().cpu() for o in outs]
   assert len(outs) == 6
-  names = ['head'] + ['reduction_%d' % i for i in range(1, 6)]
-  errs = {}
-  for nm, got in list(zip(names, outs)) + [('pooled_features', net.endpoints['pooled_features'])]:
-    ref = want[nm]
-    d = got.float().cpu() - ref
-    if dtype == 'f32':
-      errs[nm] = float(d.abs().max()) / max(float(ref.abs().max()), 1e-20)       # max-norm, north_star 1e-3
-    else:
-      errs[nm] = float(d.norm()) / max(float(ref.norm()), 1e-20)                 # relative L2 (see docstring)
-  assert all(e <= tol for e in errs.values()), '%s %s: relative errors vs the oracle %s (tol %.1e)' % (
-      model_name, dtype, {k: '%.2e' % v for k, v in errs.items()}, tol)
+  got = dict(zip(V2_ENDPOINTS[:6], [o.float().cpu() for o in outs]))
+  got['pooled_features'] = net.endpoints['pooled_features'].float().cpu()
+  return got
+
+
+def _v2_errs(got, want):
+  """max |difference| / max |oracle value| per endpoint (the north_star's relative measure)."""
+  return {nm: float((got[nm] - want[nm]).abs().max()) / max(float(want[nm].abs().max()), 1e-20) for nm in V2_ENDPOINTS}
+
+
+V2_MODELS = [('efficientnetv2-s', 128), ('efficientnetv2-b0', 128), ('efficientnet-b0', 96)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('model_name,size', V2_MODELS)
+@pytest.mark.parametrize('training', [False, True])
+def test_model_forward_matches_oracle_fp32(model_name, size, training):
+  """fp32 storage: logits, pooled features and every reduction endpoint within 1e-3 of the tensor's max (north_star
+  tolerance), both BatchNorm modes."""
+  over, vals, images = _v2_problem(model_name, size, 4, training)
+  with torch.no_grad():
+    want = _v2_oracle(model_name, over, vals).forward(images, training)
+  net = effnetv2_model.EffNetV2Model(model_name, over, dtype='f32', params=vals)
+  errs = _v2_errs(_v2_device(net, images, training), want)
+  assert max(errs.values()) <= TOL_F32, '%s f32: relative errors vs the oracle %s' % (
+      model_name, {k: '%.2e' % v for k, v in errs.items()})
   # a second call must give the same answer (accumulation buffers are re-zeroed)
-  again = net(torch.from_numpy(images), training=training)
-  torch.cuda.synchronize()
-  # (atomic fp32 pooling sums may round differently from run to run; in bf16 storage a flipped rounding
-  # propagates, so the bound is the storage tolerance, not bit equality)
-  first = outs[0].float().cpu()
-  assert float((again.float().cpu() - first).abs().max()) <= tol * float(first.abs().max()) + 1e-6
+  again = _v2_device(net, images, training)
+  assert max(_v2_errs(again, want).values()) <= TOL_F32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('model_name,size', V2_MODELS)
+def test_model_inference_forward_bf16_matches_emulating_oracle(model_name, size):
+  """bf16 storage (the path BASELINE configs[1] times), inference BatchNorm: every endpoint within TOL_BF16_VS_EMU of
+  the oracle that rounds exactly where V2Engine stores (a few bf16 ulps: what is left are one-ulp flips from fp32
+  summation order).  The distance to the fp32 oracle -- the accumulated storage rounding of 40-57 blocks -- is printed,
+  not asserted: it measures the conditioning of a random-weight network (0.7 % after stage 1, 6 % after stage 4), not
+  the kernels."""
+  over, vals, images = _v2_problem(model_name, size, 4, False, bf16=True)
+  net = effnetv2_model.EffNetV2Model(model_name, over, dtype='bf16', params=vals)
+  got = _v2_device(net, images, False)
+  with torch.no_grad():
+    emu = _v2_oracle(model_name, over, vals, 'bf16').forward(images, False)
+    f32 = _v2_oracle(model_name, over, vals).forward(images, False)
+  errs = _v2_errs(got, emu)
+  print('%s@%d inference bf16: vs emulating oracle %s\n   vs fp32 oracle %s' % (
+      model_name, size, {k: '%.2e' % v for k, v in errs.items()}, {k: '%.2e' % v for k, v in _v2_errs(got, f32).items()}))
+  assert max(errs.values()) <= TOL_BF16_VS_EMU, errs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('model_name,size', V2_MODELS)
+def test_model_training_forward_bf16_layer_by_layer(model_name, size):
+  """bf16 storage, training-mode BatchNorm, teacher forced (oracle/teacher_force.py): every stored tensor -- stem, the
+  materialised stem output, every dense / expand / depthwise / project convolution output and block output, the head
+  convolution -- against the emulating oracle's value computed from the DEVICE's stored inputs of that layer, and the
+  pooled features / logits from the device's stored head convolution: TOL_LAYER of the tensor's max, i.e. nothing
+  beyond single rounding flips (one bf16 ulp of the largest element is 0.78 %)."""
+  over, vals, images = _v2_problem(model_name, size, 4, True, bf16=True)
+  net = effnetv2_model.EffNetV2Model(model_name, over, dtype='bf16', params=vals)
+  got = _v2_device(net, images, True)
+  o = _v2_oracle(model_name, over, vals, 'bf16')
+  hook = o.hook = gu.TeacherForce(net.engine)
+  with torch.no_grad():
+    want = o.forward(images, True)
+  nblocks = len(net.spec.blocks)
+  print('%s@%d training bf16 teacher-forced: %d tensors, worst %s; missing %s' % (
+      model_name, size, len(hook.fwd_err), hook.worst(hook.fwd_err), hook.missing[:4]))
+  assert len(hook.fwd_err) >= 2 * nblocks + 3 and not hook.missing, (len(hook.fwd_err), hook.missing[:8])
+  assert max(hook.fwd_err.values()) <= TOL_LAYER, hook.worst(hook.fwd_err, 6)
+  tail = {nm: float((got[nm] - want[nm]).abs().max()) / max(float(want[nm].abs().max()), 1e-20)
+          for nm in ('pooled_features', 'head')}
+  assert max(tail.values()) <= TOL_LAYER, tail
 
 
 @pytest.mark.gpu

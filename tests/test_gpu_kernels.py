@@ -524,7 +524,7 @@ def test_batchnorm_train_fwd_bwd(dt, shape):
 # ------------------------------------------------------------------------------------ SE
 @pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
 @pytest.mark.parametrize('shape', [(2, 9, 7, 32, 8), (3, 20, 20, 144, 6), (2, 5, 5, 1152, 48), (3, 5, 5, 2304, 96),
-                                   (2, 6, 6, 3840, 160)])
+                                   (2, 6, 6, 3840, 160), (2, 48, 43, 64, 16)])     # the last: three row chunks per image
 def test_squeeze_excite(dt, shape):
   name, edt, tdt = dt
   n, h, w, c, se = shape
@@ -554,12 +554,34 @@ def test_squeeze_excite(dt, shape):
   gd = torch.zeros(n, c, dtype=torch.float32, device=gu.DEV)
   tv = gu.tview(xd, c, sc, sh, None, ACT_SWISH)
   w1d, b1d, w2d, b2d = (gu.fdev(t) for t in (w1, b1, w2, b2))
-  call('edet_se_pool', ctypes.byref(tv), ptr(pd), edt, gu.stream())
+  scr = torch.full((2 * 1024 * 1024,), float('nan'), dtype=torch.float32, device=gu.DEV)     # chunk sums (8 MB)
+  pd.fill_(float('nan'))       # nothing has to be zeroed beforehand: the pooling has no atomics
+  call('edet_se_pool', ctypes.byref(tv), ptr(pd), ptr(scr), scr.numel() * 4, edt, gu.stream())
   call('edet_se_fc', ptr(pd), n, c, se, 1.0 / (h * w), ptr(w1d), ptr(b1d), ptr(w2d), ptr(b2d), ptr(hd), ptr(gd),
        ACT_SWISH, gu.stream())
   torch.cuda.synchronize()
   gu.check(pd / (h * w), pooled.detach(), 'f32', 'se pooled', rtol=1e-3, atol=1e-4)
   gu.check(gd, gate.detach(), 'f32', 'se gate', rtol=1e-3, atol=1e-4)
+  # the one-call form the engine uses (pooling + both 1x1 layers) gives the same bits; so does the same image inside a
+  # larger batch, and a scratch too small for the standard chunks still gives the right sums (larger chunks)
+  pd2, hd2, gd2 = torch.full_like(pd, float('nan')), torch.full_like(hd, float('nan')), torch.full_like(gd, float('nan'))
+  call('edet_se_squeeze_excite', ctypes.byref(tv), ptr(scr), scr.numel() * 4, se, 1.0 / (h * w), ptr(w1d), ptr(b1d),
+       ptr(w2d), ptr(b2d), ptr(pd2), ptr(hd2), ptr(gd2), ACT_SWISH, edt, gu.stream())
+  torch.cuda.synchronize()
+  assert torch.equal(pd2, pd) and torch.equal(hd2, hd) and torch.equal(gd2, gd), 'edet_se_squeeze_excite != pool + fc'
+  reps = 5
+  xrep = xd.repeat(reps, 1, 1, 1).contiguous()
+  pd3, hd3, gd3 = (torch.full((reps * n, k), float('nan'), dtype=torch.float32, device=gu.DEV) for k in (c, se, c))
+  tvr = gu.tview(xrep, c, sc, sh, None, ACT_SWISH)
+  call('edet_se_squeeze_excite', ctypes.byref(tvr), ptr(scr), scr.numel() * 4, se, 1.0 / (h * w), ptr(w1d), ptr(b1d),
+       ptr(w2d), ptr(b2d), ptr(pd3), ptr(hd3), ptr(gd3), ACT_SWISH, edt, gu.stream())
+  small = torch.full((n * c + 7,), float('nan'), dtype=torch.float32, device=gu.DEV)
+  pd4 = torch.full_like(pd, float('nan'))
+  call('edet_se_pool', ctypes.byref(tv), ptr(pd4), ptr(small), small.numel() * 4, edt, gu.stream())
+  torch.cuda.synchronize()
+  for k in range(reps):
+    assert torch.equal(pd3[k * n:(k + 1) * n], pd) and torch.equal(gd3[k * n:(k + 1) * n], gd), 'batch-dependent SE sums'
+  gu.check(pd4 / (h * w), pooled.detach(), 'f32', 'se pooled, minimal scratch', rtol=1e-3, atol=1e-4)
   # backward: D = dout (what the project dgrad would store), dgate = sum D * act(z)
   D = gu.to_dev(dout, tdt)
   dgate = gu.fdev((dout * a.detach()).sum((1, 2)))
