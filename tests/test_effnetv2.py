@@ -147,16 +147,41 @@ def _perturbed(spec, seed):
 
 
 V2_ENDPOINTS = ['head'] + ['reduction_%d' % i for i in range(1, 6)] + ['pooled_features']
-TOL_F32, TOL_BF16_VS_EMU, TOL_LAYER = 1e-3, 1e-2, 1.2e-2
+TOL_F32, TOL_LAYER = 1e-3, 1.2e-2
+# End to end in bf16 storage the comparison is bounded by the CONDITIONING of the network, not by the kernels: the
+# emulating oracle's own endpoints move by these amounts when 0.05 % of the input pixels move by one bf16 ulp
+# (test_v2_bf16_end_to_end_conditioning below, CPU) -- every rounding flip is a 0.4 % perturbation of one element and 40
+# residual blocks amplify it.  The device differs from the oracle by exactly such flips (fp32 summation order), so the
+# end-to-end bound per endpoint is about twice the oracle's measured self-sensitivity; the parity statement proper is
+# the layer-by-layer one (TOL_LAYER, every stored tensor from the device's own stored inputs).
+TOL_E2E_BF16 = {'reduction_1': 1.5e-2, 'reduction_2': 2e-2, 'reduction_3': 2.5e-2, 'reduction_4': 5e-2,
+                'reduction_5': 8e-2, 'pooled_features': 8e-2, 'head': 8e-2}
+RESIDUAL_GAMMA = 0.3      # last BatchNorm scale of every residual block in the end-to-end bf16 problems
 
 
-def _v2_problem(model_name, size, batch, training, over='num_classes=40,survival_prob=0,dropout_rate=0', bf16=False):
+def _damp_residual_branches(spec, vals, factor):
+  """gamma of the LAST BatchNorm of every block that adds its input back, times `factor`: residual branches that
+  contribute a fraction of the identity path, as in a trained network (and as zero-gamma initialisation starts them).
+  With gamma ~ 1 on all 30-40 residual blocks of random weights the forward map amplifies a one-ulp flip to 17 % at
+  reduction_5 in the ORACLE ITSELF; with 0.3 to 3.6 % (measured, see the conditioning test)."""
+  for b in spec.blocks:
+    if b.has_residual:
+      scope = '%s/blocks_%d/' % (spec.name, b.index)
+      gammas = [p.name for p in spec.params if p.name.startswith(scope) and p.name.endswith('/gamma')]
+      vals[gammas[-1]] = vals[gammas[-1]] * np.float32(factor)
+  return vals
+
+
+def _v2_problem(model_name, size, batch, training, over='num_classes=40,survival_prob=0,dropout_rate=0', bf16=False,
+                residual_gamma=1.0):
   """-> (model_config override, variables, images): reference initialisers with every BatchNorm / bias perturbed; in
   inference mode the moving statistics are the ones of the data (as after training): with arbitrary moving statistics a
   40-block network is not normalised, activations grow by orders of magnitude and the comparison is ill conditioned.
   bn_momentum=0 makes the oracle's updated moving statistics the batch ones."""
   spec = effnetv2_model.V2Spec(effnetv2_configs.model_config(model_name, over))
   vals = _perturbed(spec, 5)
+  if residual_gamma != 1.0:
+    _damp_residual_branches(spec, vals, residual_gamma)
   rng = np.random.default_rng(11)
   images = torch.from_numpy(rng.standard_normal((batch, size, size, 3)).astype(np.float32))
   if bf16:
@@ -191,6 +216,55 @@ def _v2_errs(got, want):
   return {nm: float((got[nm] - want[nm]).abs().max()) / max(float(want[nm].abs().max()), 1e-20) for nm in V2_ENDPOINTS}
 
 
+def _fmt(errs):
+  return {k: '%.2e' % v for k, v in errs.items()}
+
+
+def test_v2_bf16_end_to_end_conditioning():
+  """CPU, oracle only: why TOL_E2E_BF16 is what it is.  efficientnetv2-s, inference BatchNorm, the same forward twice --
+  the second time with 0.05 % of the input pixels moved by one bf16 ulp.  fp32 storage: every endpoint moves by ~1e-3.
+  bf16 storage (the oracle that rounds where V2Engine stores), residual BatchNorm scales ~1: reduction_5 / logits move by
+  more than 5 % -- no bf16-storage implementation can agree with the oracle end to end more closely than the oracle
+  agrees with itself; with the residual branches damped to RESIDUAL_GAMMA (the end-to-end test problems) every endpoint
+  stays within half of TOL_E2E_BF16."""
+  torch.set_num_threads(min(16, torch.get_num_threads()))
+  name, size, batch = 'efficientnetv2-s', 128, 4
+  moved = {}
+  for gamma in (1.0, RESIDUAL_GAMMA):
+    over, vals, images = _v2_problem(name, size, batch, False, bf16=True, residual_gamma=gamma)
+    rng = np.random.default_rng(0)
+    mask = torch.from_numpy(rng.random(images.shape) < 5e-4)
+    bumped = torch.where(mask, (images * (1 + 2.0**-8)).to(torch.bfloat16).float(), images)
+    assert 0 < int((bumped != images).sum()) < 200
+    for storage in ('f32', 'bf16'):
+      with torch.no_grad():
+        a = _v2_oracle(name, over, vals, storage).forward(images, False)
+        b = _v2_oracle(name, over, vals, storage).forward(bumped, False)
+      moved[gamma, storage] = _v2_errs(b, a)
+      print('residual gamma %.1f, %s storage: endpoints moved by %s' % (gamma, storage, _fmt(moved[gamma, storage])))
+  assert max(moved[1.0, 'f32'].values()) <= 5e-3
+  assert moved[1.0, 'bf16']['reduction_5'] >= 5e-2 and moved[1.0, 'bf16']['head'] >= 5e-2
+  for nm, tol in TOL_E2E_BF16.items():
+    assert moved[RESIDUAL_GAMMA, 'bf16'][nm] <= 0.5 * tol, (nm, moved[RESIDUAL_GAMMA, 'bf16'][nm], tol)
+
+
+def test_v2_emulating_oracle_is_the_fp32_oracle_plus_storage_rounding():
+  """CPU: storage='bf16' changes nothing but roundings -- early endpoints stay within a few bf16 ulps of the fp32 oracle,
+  both oracles agree exactly on which variables exist, and autograd runs through the rounding points."""
+  name = 'efficientnetv2-b0'
+  over, vals, images = _v2_problem(name, 64, 2, True, bf16=True)
+  with torch.no_grad():
+    a = _v2_oracle(name, over, vals).forward(images, True)
+    b = _v2_oracle(name, over, vals, 'bf16').forward(images, True)
+  e = _v2_errs(b, a)
+  assert e['reduction_1'] <= 2e-2 and e['reduction_2'] <= 4e-2, e
+  params = {k: torch.from_numpy(v.copy()).requires_grad_(not k.endswith(('moving_mean', 'moving_variance')))
+            for k, v in vals.items()}
+  o = v2orc.V2Oracle(name, over, params=params, storage='bf16')
+  o.forward(images, True)['head'].sum().backward()
+  assert all(p.grad is not None for k, p in params.items() if p.requires_grad and not k.endswith('/bias'))
+
+
 V2_MODELS = [('efficientnetv2-s', 128), ('efficientnetv2-b0', 128), ('efficientnet-b0', 96)]
 
 
@@ -205,56 +279,65 @@ def test_model_forward_matches_oracle_fp32(model_name, size, training):
     want = _v2_oracle(model_name, over, vals).forward(images, training)
   net = effnetv2_model.EffNetV2Model(model_name, over, dtype='f32', params=vals)
   errs = _v2_errs(_v2_device(net, images, training), want)
-  assert max(errs.values()) <= TOL_F32, '%s f32: relative errors vs the oracle %s' % (
-      model_name, {k: '%.2e' % v for k, v in errs.items()})
-  # a second call must give the same answer (accumulation buffers are re-zeroed)
-  again = _v2_device(net, images, training)
+  assert max(errs.values()) <= TOL_F32, '%s f32: relative errors vs the oracle %s' % (model_name, _fmt(errs))
+  # a second call gives the same bits in inference mode (no atomics on that path) and the same answer in training mode
+  again = _v2_device(net, images, training)         # (_v2_device copies to the host)
   assert max(_v2_errs(again, want).values()) <= TOL_F32
+  if not training:
+    third = _v2_device(net, images, training)
+    assert all(torch.equal(third[k], again[k]) for k in V2_ENDPOINTS), 'inference forward is not run-to-run deterministic'
+
+
+def _teacher_forced_forward(model_name, size, batch, training, residual_gamma=1.0):
+  over, vals, images = _v2_problem(model_name, size, batch, training, bf16=True, residual_gamma=residual_gamma)
+  net = effnetv2_model.EffNetV2Model(model_name, over, dtype='bf16', params=vals)
+  got = _v2_device(net, images, training)
+  o = _v2_oracle(model_name, over, vals, 'bf16')
+  hook = o.hook = gu.TeacherForce(net.engine)
+  with torch.no_grad():
+    want = o.forward(images, training)
+  tail = {nm: float((got[nm] - want[nm]).abs().max()) / max(float(want[nm].abs().max()), 1e-20)
+          for nm in ('pooled_features', 'head')}
+  return net, got, hook, tail, (over, vals, images)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('model_name,size', V2_MODELS)
-def test_model_inference_forward_bf16_matches_emulating_oracle(model_name, size):
-  """bf16 storage (the path BASELINE configs[1] times), inference BatchNorm: every endpoint within TOL_BF16_VS_EMU of
-  the oracle that rounds exactly where V2Engine stores (a few bf16 ulps: what is left are one-ulp flips from fp32
-  summation order).  The distance to the fp32 oracle -- the accumulated storage rounding of 40-57 blocks -- is printed,
-  not asserted: it measures the conditioning of a random-weight network (0.7 % after stage 1, 6 % after stage 4), not
-  the kernels."""
-  over, vals, images = _v2_problem(model_name, size, 4, False, bf16=True)
+@pytest.mark.parametrize('training', [False, True])
+def test_model_forward_bf16_layer_by_layer(model_name, size, training):
+  """bf16 storage (the path BASELINE configs[1] times), both BatchNorm modes, teacher forced (oracle/teacher_force.py):
+  every stored tensor -- stem, the materialised stem output, every dense / expand / depthwise / project convolution
+  output and block output, the head convolution -- against the emulating oracle's value computed from the DEVICE's
+  stored inputs of that layer, and the pooled features / logits from the device's stored head convolution: TOL_LAYER of
+  the tensor's max, i.e. nothing beyond single rounding flips (one bf16 ulp of the largest element is 0.78 %).  Random
+  weights with BatchNorm scales ~1: the hardest case end to end, irrelevant layer by layer."""
+  net, got, hook, tail, _ = _teacher_forced_forward(model_name, size, 4, training)
+  nblocks = len(net.spec.blocks)
+  print('%s@%d training=%s bf16 teacher-forced: %d tensors, worst %s; tail %s' % (
+      model_name, size, training, len(hook.fwd_err), hook.worst(hook.fwd_err), _fmt(tail)))
+  assert len(hook.fwd_err) >= 2 * nblocks + 2 and not hook.missing, (len(hook.fwd_err), hook.missing[:8])
+  assert max(hook.fwd_err.values()) <= TOL_LAYER, hook.worst(hook.fwd_err, 6)
+  assert max(tail.values()) <= TOL_LAYER, tail
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('model_name,size', V2_MODELS)
+def test_model_inference_forward_bf16_end_to_end(model_name, size):
+  """bf16 storage, inference BatchNorm, END TO END against the oracle that rounds exactly where V2Engine stores, on the
+  conditioned problem (residual BatchNorm scales RESIDUAL_GAMMA): every endpoint within TOL_E2E_BF16 -- about twice the
+  oracle's own sensitivity to one-ulp flips, see the constants.  The distance to the fp32 oracle (accumulated storage
+  rounding) is printed."""
+  over, vals, images = _v2_problem(model_name, size, 4, False, bf16=True, residual_gamma=RESIDUAL_GAMMA)
   net = effnetv2_model.EffNetV2Model(model_name, over, dtype='bf16', params=vals)
   got = _v2_device(net, images, False)
   with torch.no_grad():
     emu = _v2_oracle(model_name, over, vals, 'bf16').forward(images, False)
     f32 = _v2_oracle(model_name, over, vals).forward(images, False)
   errs = _v2_errs(got, emu)
-  print('%s@%d inference bf16: vs emulating oracle %s\n   vs fp32 oracle %s' % (
-      model_name, size, {k: '%.2e' % v for k, v in errs.items()}, {k: '%.2e' % v for k, v in _v2_errs(got, f32).items()}))
-  assert max(errs.values()) <= TOL_BF16_VS_EMU, errs
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('model_name,size', V2_MODELS)
-def test_model_training_forward_bf16_layer_by_layer(model_name, size):
-  """bf16 storage, training-mode BatchNorm, teacher forced (oracle/teacher_force.py): every stored tensor -- stem, the
-  materialised stem output, every dense / expand / depthwise / project convolution output and block output, the head
-  convolution -- against the emulating oracle's value computed from the DEVICE's stored inputs of that layer, and the
-  pooled features / logits from the device's stored head convolution: TOL_LAYER of the tensor's max, i.e. nothing
-  beyond single rounding flips (one bf16 ulp of the largest element is 0.78 %)."""
-  over, vals, images = _v2_problem(model_name, size, 4, True, bf16=True)
-  net = effnetv2_model.EffNetV2Model(model_name, over, dtype='bf16', params=vals)
-  got = _v2_device(net, images, True)
-  o = _v2_oracle(model_name, over, vals, 'bf16')
-  hook = o.hook = gu.TeacherForce(net.engine)
-  with torch.no_grad():
-    want = o.forward(images, True)
-  nblocks = len(net.spec.blocks)
-  print('%s@%d training bf16 teacher-forced: %d tensors, worst %s; missing %s' % (
-      model_name, size, len(hook.fwd_err), hook.worst(hook.fwd_err), hook.missing[:4]))
-  assert len(hook.fwd_err) >= 2 * nblocks + 3 and not hook.missing, (len(hook.fwd_err), hook.missing[:8])
-  assert max(hook.fwd_err.values()) <= TOL_LAYER, hook.worst(hook.fwd_err, 6)
-  tail = {nm: float((got[nm] - want[nm]).abs().max()) / max(float(want[nm].abs().max()), 1e-20)
-          for nm in ('pooled_features', 'head')}
-  assert max(tail.values()) <= TOL_LAYER, tail
+  print('%s@%d inference bf16 end to end: vs emulating oracle %s\n   vs fp32 oracle %s' % (
+      model_name, size, _fmt(errs), _fmt(_v2_errs(got, f32))))
+  bad = {k: v for k, v in errs.items() if v > TOL_E2E_BF16[k]}
+  assert not bad, (bad, errs)
 
 
 @pytest.mark.gpu
