@@ -186,9 +186,10 @@ def parity_block(config, size):
   oracle's value computed from the device's own stored inputs (end to end that mode is ill conditioned in bf16:
   tests/test_oracle_conditioning.py)."""
   from oracle import efficientdet_oracle as orc
-  from oracle import teacher_force
-  spec = netspec.NetSpec(config)
-  vals = netspec.init_params(spec, 0)
+  from oracle import problems, teacher_force
+  # perturbed variables (the tests' problem): with the plain initialisers every class logit is the -log(99) bias and
+  # the class column of this block would be vacuous
+  vals = problems.perturbed_params(config, 0)
   rng = np.random.default_rng(5)
   images = torch.from_numpy(rng.standard_normal((2, size, size, 3)).astype(np.float32)).to(torch.bfloat16).float()
   net = train_lib.EfficientDetNetTrain(config=config, dtype='bf16', params=vals)
@@ -264,6 +265,30 @@ def other_configs():
   out['efficientdet-d7x 1536x1536 batch 8 bf16 train step, stochastic depth on (BASELINE configs[4], per-GPU leg)'] = {
       'images_per_sec': 8 / dt, 'ms_per_step': dt * 1e3, 'steps': 5,
       'hbm_frac': 38630.0e6 * 8 / dt / 1e9 / HBM_PEAK_GBS}      # 38,630 MB / image fwd+bwd
+  net._graph, net.engine = None, None
+  net._engines.clear()
+  eng._bufs.clear()
+  del net, eng, images, labels
+  torch.cuda.empty_cache()
+  # the headline workload in the storage precision that meets the north_star's 1e-3 logit tolerance end to end (fp32
+  # activations / gradients, the validation kernels: 16x16x4 fp32 MFMA pointwise, generic depthwise) -- what the
+  # tolerance costs next to the bf16 line
+  config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  config.override('image_size=640')
+  net = train_lib.EfficientDetNetTrain(config=config, dtype='f32', seed=0, global_batch_size=128, steps_per_epoch=1000)
+  eng = net._ensure_engine(128, 640, 640)
+  images, labels = synth_batch(config, 128, 640, 3, 'cuda:0', eng.tdtype)
+  for _ in range(2):
+    net.train_step((images, labels), sync_loss=False)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(3):
+    net.train_step((images, labels), sync_loss=False)
+  torch.cuda.synchronize()
+  dt = (time.perf_counter() - t0) / 3
+  out['efficientdet-d0 640x640 batch 128 fp32-storage train step (the precision that meets 1e-3 end to end; eager)'] = {
+      'images_per_sec': 128 / dt, 'ms_per_step': dt * 1e3, 'steps': 3,
+      'hbm_frac': 2 * ALG_MB_PER_IMG * 1e6 * 128 / dt / 1e9 / HBM_PEAK_GBS}     # fp32: twice the bf16 bytes
   return out
 
 

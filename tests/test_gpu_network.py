@@ -17,25 +17,7 @@ from oracle import efficientdet_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def perturbed_params(config, seed):
-  """Reference initialisers, then every BN / bias / fusion weight perturbed so no path is trivial."""
-  spec = netspec.NetSpec(config)
-  vals = netspec.init_params(spec, seed)
-  rng = np.random.default_rng(seed + 1)
-  for p in spec.params:
-    v = vals[p.name]
-    if p.name.endswith('/gamma'):
-      v += 0.2 * rng.standard_normal(v.shape).astype(np.float32)
-    elif p.name.endswith('/beta') or p.name.endswith('/moving_mean'):
-      v += 0.2 * rng.standard_normal(v.shape).astype(np.float32)
-    elif p.name.endswith('/moving_variance'):
-      v *= rng.uniform(0.5, 1.5, v.shape).astype(np.float32)
-    elif p.name.endswith('/bias'):
-      v += 0.1 * rng.standard_normal(v.shape).astype(np.float32)
-    elif '/WSM' in p.name:
-      v += 0.3 * rng.standard_normal(v.shape).astype(np.float32)
-    vals[p.name] = v
-  return vals
+from oracle.problems import perturbed_params  # noqa: E402,F401  (shared with bench.py's parity block)
 
 
 def make_labels(config, batch, image_size, seed):
@@ -508,3 +490,31 @@ def test_device_train_step_equals_the_executed_reference_train_step():
   bad = check_trainstep_gradients(g, grads, 1e-2)
   print('worst', bad[:5])
   assert not bad, (len(bad), bad[:8])
+
+
+def test_bench_spawns_two_ranks_and_reports_them(tmp_path):
+  """`python bench.py --gpus 2` started WITHOUT torch.distributed.run (the way the driver's scaling run may start it)
+  goes through bench.spawn_ranks -> torch.distributed.run on 127.0.0.1 -> two ranks of the data-parallel step.
+  Rehearsed on this 1-GPU box with both ranks on cuda:0 and gloo between them (EDET_BENCH_SAME_DEVICE /
+  EDET_BENCH_BACKEND; RCCL refuses two ranks on one device): rc 0, one parsable JSON line, n_gpus = ranks_seen = 2 (the
+  count comes from an all-reduce through the same process group as the gradients), whole-job value = 2 x batch.  So
+  the first real SCALE run cannot die in the launcher."""
+  import json
+  import os
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, EDET_BENCH_SAME_DEVICE='1', EDET_BENCH_BACKEND='gloo')
+  for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+    env.pop(k, None)
+  for graph in ('1', '0'):
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--batch', '8', '--steps', '3',
+                        '--warmup', '1', '--image_size', '256', '--graph', graph, '--no_cpu_baseline',
+                        '--no_other_configs'], env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, (graph, r.stdout[-2000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['config']['ranks_seen'] == 2 and line['config']['global_batch'] == 16, line['config']
+    assert line['steps'] == 3 and line['value'] > 0 and abs(line['value'] - 16 * 3 / (line['ms_per_step'] * 3e-3)) < 1e-6 * line['value']
+    assert line['scaling'] == 'weak' and line['config']['parallelism'] == 'dp2' and np.isfinite(line['config']['loss'])
