@@ -119,6 +119,8 @@ SIGNATURES = {
                            ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
     'edet_preprocess_infer': [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_int, c_void_p],
+    'edet_preprocess_train': [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     'edet_nms_gather': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
 }

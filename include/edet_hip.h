@@ -421,6 +421,26 @@ int edet_preprocess_infer(const void* raw_images, int raw_is_float, int batch, i
                           int out_height, int out_width, const float* mean_rgb, const float* stddev_rgb, void* out,
                           float* image_scale_to_original, int dtype, void* stream);
 
+
+/* ---- training image + box preprocessing --------------------------------
+ * dataloader.py DetectionInputProcessor as InputReader.process_example drives it in training (:321-336): normalize_image
+ * :58-64, random_horizontal_flip :150-153 (object_detection/preprocessor.py:113-199), set_training_random_scale_factors
+ * :66-111, resize_and_crop_image :126-139, resize_and_crop_boxes :165-189 (clip_boxes :155-163, zero-area filter).
+ * The random draws and the float32 scale arithmetic of set_training_random_scale_factors stay with the caller, who
+ * hands over five integers per image (DEVICE array): flip decision, size of the resized image, crop offset.
+ * raw_images as for edet_preprocess_infer.  boxes_in [batch][max_boxes][4] normalised (ymin, xmin, ymax, xmax),
+ * classes_in [batch][max_boxes] float, counts_in [batch] valid rows; outputs: the kept boxes in pixels of the output
+ * image and their classes IN ORDER, rows past counts_out[b] filled with -1 (dataloader.pad_to_fixed_size).  max_boxes
+ * = 0 skips the box part (all box pointers may be NULL).  */
+typedef struct edet_prep_image {
+  int flip, scaled_h, scaled_w, offset_y, offset_x;
+} edet_prep_image_t;
+int edet_preprocess_train(const void* raw_images, int raw_is_float, int batch, int height, int width,
+                          int out_height, int out_width, const float* mean_rgb, const float* stddev_rgb,
+                          const edet_prep_image_t* per_image_dev, void* out, const float* boxes_in,
+                          const float* classes_in, const int* counts_in, int max_boxes, float* boxes_out,
+                          float* classes_out, int* counts_out, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

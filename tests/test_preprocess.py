@@ -1,6 +1,6 @@
 """Image / box preprocessing: the numpy oracle against the reference's own InputProcessor /
-DetectionInputProcessor executed on the stand-in (tests/golden/make_golden_preprocess.py).  The device kernels of this
-row are not built yet; this file pins the oracle they will be checked against."""
+DetectionInputProcessor executed on the stand-in (tests/golden/make_golden_preprocess.py), and the device kernels
+(edet_preprocess_infer, edet_preprocess_train behind automl_amd.preprocess) against those fixtures and the oracle."""
 import os
 
 import numpy as np
@@ -121,3 +121,107 @@ def test_model_call_with_infer_preprocessing_equals_preprocessed_call():
   assert np.abs(boxes.cpu().numpy() - want).max() <= 2e-3 * 420
   with pytest.raises(ValueError):
     model(torch.from_numpy(raw), pre_mode='train')
+
+
+def _train_oracle(raw, boxes, classes, osize, tsize, draws, jitter):
+  """One image through the oracle's training path with the given draws (flip, scale, u_y, u_x)."""
+  image = porc.normalize_image(raw, MEAN, STD)
+  flip_u, scale_u, uy, ux = (np.float32(v) for v in draws)
+  if flip_u > 0.5:
+    image, boxes = porc.flip_left_right(image, boxes)
+  factor = np.float32(jitter[0]) + scale_u * (np.float32(jitter[1]) - np.float32(jitter[0]))
+  scale, sh, sw, oy, ox = porc.training_random_scale_factors(raw.shape[0], raw.shape[1], osize, tsize, factor, uy, ux)
+  out = porc.resize_and_crop_image(image, sh, sw, oy, ox, osize)
+  b, c = porc.resize_and_crop_boxes(boxes, classes, sh, sw, oy, ox, osize)
+  return out, b, c, (scale, sh, sw, oy, ox)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['train_up_noflip', 'train_down_flip', 'train_crop_flip', 'infer_wide'])
+def test_device_equals_the_executed_reference_detection_input_processor(name):
+  """preprocess.DetectionInputProcessor (edet_preprocess_train) driven like InputReader.process_example
+  (dataloader.py:321-336) with the fixtures' draws, against the outputs of the reference's own DetectionInputProcessor:
+  scale / scaled size / crop offset exactly, image to 1e-4, kept boxes (scaled, shifted, clipped, zero-area filtered,
+  in order) to 1e-5, classes exactly, padding rows -1."""
+  import torch
+  from automl_amd import preprocess
+  g = np.load(GOLDEN)
+  osize, tsize, training = CASES[name]
+  raw, boxes, classes = g[name + '/raw'], g[name + '/boxes_in'], g[name + '/classes_in']
+  pad = 3                                           # padded rows behind the valid ones must be ignored
+  bpad = np.concatenate([boxes, np.full((pad, 4), 0.5, np.float32)])[None]
+  cpad = np.concatenate([classes.reshape(-1), np.full((pad,), 77, np.float32)])[None]
+  p = preprocess.DetectionInputProcessor(torch.from_numpy(raw)[None], osize, bpad, cpad, counts=[len(boxes)])
+  p.normalize_image(MEAN, STD)
+  if training:
+    d = g[name + '/draws']
+    p.random_horizontal_flip(draws=[d[0]])
+    p.set_training_random_scale_factors(0.1, 2.0, tsize, draws=[d[1:4]])
+  else:
+    p.set_scale_factors_to_output_size()
+  image = p.resize_and_crop_image()
+  bo, co, cnt = p.resize_and_crop_boxes()
+  torch.cuda.synchronize()
+  assert p.scaled_size[0].tolist() + [int(p.offset_y[0]), int(p.offset_x[0])] == g[name + '/scaled'].tolist()
+  assert np.float32(p.image_scale[0]) == g[name + '/image_scale']
+  assert abs(float(p.image_scale_to_original[0]) - 1.0 / float(g[name + '/image_scale'])) <= 1e-6
+  want = g[name + '/image']
+  assert tuple(image.shape) == (1,) + want.shape and np.abs(image[0].cpu().numpy() - want).max() <= 1e-4
+  k = int(cnt[0])
+  assert k == len(g[name + '/boxes'])
+  assert np.abs(bo[0, :k].cpu().numpy() - g[name + '/boxes']).max() <= 1e-5
+  assert np.array_equal(co[0, :k].cpu().numpy(), g[name + '/classes'].reshape(-1))
+  assert bool((bo[0, k:] == -1).all()) and bool((co[0, k:] == -1).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_device_training_preprocessing_matches_oracle_batch(dtype):
+  """A batch of 8 frames, every image with its own flip / scale / crop draws (jitter 0.1 .. 2.0 as the reference's
+  default hparams), uint8 and float inputs, against the oracle image by image; the processor's own random generator
+  gives the same result as handing its draws in."""
+  import torch
+  from automl_amd import preprocess
+  tdt = torch.float32 if dtype == 'f32' else torch.bfloat16
+  rng = np.random.default_rng(6)
+  for (h, w, osize, tsize, as_float) in ((180, 240, (160, 160), None, False), (90, 70, (96, 128), (128, 128), True)):
+    batch, nbox = 8, 12
+    raw = rng.integers(0, 256, (batch, h, w, 3)).astype(np.uint8)
+    ctr, hw = rng.uniform(0.1, 0.9, (batch, nbox, 2)), rng.uniform(0.02, 0.6, (batch, nbox, 2))
+    boxes = np.clip(np.concatenate([ctr - hw / 2, ctr + hw / 2], 2), 0, 1).astype(np.float32)
+    boxes[:, 0] = [0.3, 0.1, 0.3, 0.5]                                   # zero height: filtered everywhere
+    classes = rng.integers(1, 91, (batch, nbox)).astype(np.float32)
+    counts = rng.integers(3, nbox + 1, batch).astype(np.int32)
+    draws = rng.random((batch, 4)).astype(np.float32)
+    t = torch.from_numpy(raw.astype(np.float32)) if as_float else torch.from_numpy(raw)
+    p = preprocess.DetectionInputProcessor(t, osize, boxes, classes, counts, dtype=tdt)
+    p.normalize_image(MEAN, STD)
+    p.random_horizontal_flip(draws=draws[:, :1])
+    p.set_training_random_scale_factors(0.1, 2.0, tsize, draws=draws[:, 1:])
+    image, (bo, co, cnt) = p.resize_and_crop_image(), p.resize_and_crop_boxes()
+    torch.cuda.synchronize()
+    tol = 1e-4 if dtype == 'f32' else 2e-2
+    flips = 0
+    for i in range(batch):
+      want, wb, wc, (scale, sh, sw, oy, ox) = _train_oracle(raw[i], boxes[i, :counts[i]], classes[i, :counts[i]], osize,
+                                                           tsize, draws[i], (0.1, 2.0))
+      flips += int(draws[i, 0] > 0.5)
+      assert p.scaled_size[i].tolist() == [sh, sw] and [int(p.offset_y[i]), int(p.offset_x[i])] == [oy, ox]
+      assert np.abs(image[i].float().cpu().numpy() - want).max() <= tol, (i, h, w)
+      k = int(cnt[i])
+      assert k == len(wb) and (k == 0 or np.abs(bo[i, :k].cpu().numpy() - wb).max() <= 1e-4)
+      assert np.array_equal(co[i, :k].cpu().numpy(), wc)
+      assert bool((bo[i, k:] == -1).all())
+    assert 0 < flips < batch
+    # the built-in generator: same seed -> the same draws -> the same tensors
+    q = preprocess.DetectionInputProcessor(t, osize, boxes, classes, counts, rng=np.random.default_rng(99), dtype=tdt)
+    q.normalize_image(MEAN, STD)
+    q.random_horizontal_flip()
+    q.set_training_random_scale_factors(0.1, 2.0, tsize)
+    r = np.random.default_rng(99)
+    d1, d3 = r.random((batch, 1)).astype(np.float32), r.random((batch, 3)).astype(np.float32)
+    q2 = preprocess.DetectionInputProcessor(t, osize, boxes, classes, counts, dtype=tdt)
+    q2.normalize_image(MEAN, STD)
+    q2.random_horizontal_flip(draws=d1)
+    q2.set_training_random_scale_factors(0.1, 2.0, tsize, draws=d3)
+    assert torch.equal(q.resize_and_crop_image(), q2.resize_and_crop_image())
