@@ -10,9 +10,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libedet_hip.so')
 
 EDET_F32, EDET_BF16 = 0, 1
-ACT_NONE, ACT_SWISH, ACT_RELU, ACT_RELU6, ACT_HSWISH = 0, 1, 2, 3, 4
+ACT_NONE, ACT_SWISH, ACT_RELU, ACT_RELU6, ACT_HSWISH, ACT_MISH, ACT_SRELU = 0, 1, 2, 3, 4, 5, 6
 ACT_CODES = {'swish': ACT_SWISH, 'silu': ACT_SWISH, 'swish_native': ACT_SWISH, 'relu': ACT_RELU, 'relu6': ACT_RELU6,
-             'hswish': ACT_HSWISH}
+             'hswish': ACT_HSWISH, 'mish': ACT_MISH, 'srelu': ACT_SRELU}
 RS_IDENTITY, RS_UP2, RS_POOL = 0, 1, 2
 MAX_PARTS = 1024
 OPT_SPLIT = 16   # EDET_OPT_SPLIT: partial squared norms per tensor segment

@@ -723,7 +723,7 @@ extern "C" int edet_se_fc(const float* pooled_sum, int n, int c, int se, float i
                           const float* w1, const float* b1, const float* w2, const float* b2,
                           float* hidden_pre, float* gate, int act, void* stream) {
   EDET_CHECK(pooled_sum && w1 && b1 && w2 && b2 && hidden_pre && gate, "edet_se_fc: null pointer");
-  EDET_CHECK(act >= EDET_ACT_NONE && act <= EDET_ACT_HSWISH, "edet_se_fc: activation %d", act);
+  EDET_CHECK(act >= EDET_ACT_NONE && act <= EDET_ACT_LAST, "edet_se_fc: activation %d", act);
   const int fc_threads = c >= 512 ? SE_FC_THREADS : THREADS;
   edet_launch(k_se_fc, dim3(n), dim3(fc_threads), se_fc_lds(c, se, fc_threads), to_stream(stream), const_cast<float*>(pooled_sum), (const float*)nullptr, 0, c, se, inv_hw, w1, b1, w2, b2, hidden_pre, gate, act);
   EDET_LAUNCH_CHECK("edet_se_fc");
@@ -736,7 +736,7 @@ extern "C" int edet_se_squeeze_excite(const edet_tview_t* in, void* scratch, siz
                                       void* stream) {
   EDET_CHECK(in && in->data && scratch && pooled_sum && w1 && b1 && w2 && b2 && hidden_pre && gate,
              "edet_se_squeeze_excite: null pointer");
-  EDET_CHECK(act >= EDET_ACT_NONE && act <= EDET_ACT_HSWISH, "edet_se_squeeze_excite: activation %d", act);
+  EDET_CHECK(act >= EDET_ACT_NONE && act <= EDET_ACT_LAST, "edet_se_squeeze_excite: activation %d", act);
   int nchunks = 1;
   if (se_pool_launch(in, (float*)scratch, scratch_bytes / sizeof(float), dtype, stream, &nchunks)) return -1;
   const int c = in->c;
@@ -751,7 +751,7 @@ extern "C" int edet_se_fc_bwd(const float* pooled_sum, const float* hidden_pre, 
                               const float* w1, const float* w2,
                               float* dw1, float* db1, float* dw2, float* db2,
                               float* dpool, float* scratch, int act, void* stream) {
-  EDET_CHECK(act >= EDET_ACT_NONE && act <= EDET_ACT_HSWISH, "edet_se_fc_bwd: activation %d", act);
+  EDET_CHECK(act >= EDET_ACT_NONE && act <= EDET_ACT_LAST, "edet_se_fc_bwd: activation %d", act);
   EDET_CHECK(pooled_sum && hidden_pre && gate && dgate && w1 && w2 && dw1 && db1 && dw2 && db2 && dpool && scratch,
              "edet_se_fc_bwd: null pointer");
   edet_launch(k_se_fc_bwd_img, dim3(n), dim3(c >= 512 ? SE_FC_THREADS : THREADS), (size_t)(c + se) * sizeof(float), to_stream(stream), hidden_pre, gate, dgate, n, c, se, inv_hw, w1, w2, dpool, scratch, act);

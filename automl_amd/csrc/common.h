@@ -136,17 +136,33 @@ __device__ __forceinline__ float swish_gradf_(float x) {
   return s * (1.0f + x * (1.0f - s));
 }
 
-// The other activation types of utils.activation_fn (act > EDET_ACT_SWISH): relu, relu6, hswish.  Derivatives as
-// TensorFlow's gradient kernels define them at the kinks (ReluGrad: x > 0; Relu6Grad: 0 < x < 6).
+// The other activation types of utils.activation_fn (act > EDET_ACT_SWISH): relu, relu6, hswish, mish, srelu.
+// Derivatives as TensorFlow's gradient kernels define them at the kinks (ReluGrad: x > 0; Relu6Grad: 0 < x < 6).
+// mish: tanh(softplus(z)) = w / (w + 2) with w = e^z (e^z + 2) (exact identity; z > 20: 1 to fp32 precision).
+// srelu (utils.srelu_fn, utils.py:25-31): beta = (20^2)^2 -- the reference makes its `srelu_beta` variable afresh, at 20.0,
+// in every call, so it is a constant of the graph, not a trained value.
+constexpr float SRELU_BETA = 160000.f;
 __device__ __forceinline__ float act_other_(int act, float z) {
   if (act == EDET_ACT_RELU) return fmaxf(z, 0.f);
   if (act == EDET_ACT_RELU6) return fminf(fmaxf(z, 0.f), 6.f);
-  return z * fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f;
+  if (act == EDET_ACT_HSWISH) return z * fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f;
+  if (act == EDET_ACT_MISH) {
+    if (z > 20.f) return z;
+    const float n = __expf(z), w = n * (n + 2.f);
+    return z * w / (w + 2.f);
+  }
+  return z > 0.f ? z - __logf(fmaf(SRELU_BETA, z, 1.f)) * (1.f / SRELU_BETA) : 0.f;
 }
 __device__ __forceinline__ float act_other_grad_(int act, float z) {
   if (act == EDET_ACT_RELU) return z > 0.f ? 1.f : 0.f;
   if (act == EDET_ACT_RELU6) return (z > 0.f && z < 6.f) ? 1.f : 0.f;
-  return z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) / 6.f);
+  if (act == EDET_ACT_HSWISH) return z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) / 6.f);
+  if (act == EDET_ACT_MISH) {
+    if (z > 20.f) return 1.f;
+    const float n = __expf(z), w = n * (n + 2.f), t = w / (w + 2.f);
+    return fmaf(z * (1.f - t * t), n / (1.f + n), t);          // t + z (1 - t^2) sigmoid(z)
+  }
+  return z > 0.f ? 1.f - 1.f / fmaf(SRELU_BETA, z, 1.f) : 0.f;
 }
 // any activation code (kernel-uniform): value and derivative
 __device__ __forceinline__ float act_apply_(int act, float z) {

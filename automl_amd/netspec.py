@@ -33,10 +33,10 @@ class NetSpec(object):
     c = config
     if not c.backbone_name.startswith('efficientnet-b'):
       raise ValueError('backbone %r is out of scope (efficientnet-b0..b7 are built)' % c.backbone_name)
-    # utils.activation_fn (utils.py:36-53): codes of include/edet_hip.h; mish / srelu are not built
-    codes = {'swish': 1, 'silu': 1, 'swish_native': 1, 'relu': 2, 'relu6': 3, 'hswish': 4}
+    # utils.activation_fn (utils.py:36-53): codes of include/edet_hip.h (every type the reference knows)
+    codes = {'swish': 1, 'silu': 1, 'swish_native': 1, 'relu': 2, 'relu6': 3, 'hswish': 4, 'mish': 5, 'srelu': 6}
     if c.act_type not in codes:
-      raise ValueError('act_type %r is not built (swish, relu, relu6, hswish are)' % c.act_type)
+      raise ValueError('Unsupported act_type {}'.format(c.act_type))
     self.act_code = codes[c.act_type]
     if not c.separable_conv or c.conv_bn_act_pattern or c.conv_after_downsample or \
         not c.apply_bn_for_resampling:

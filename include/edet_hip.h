@@ -40,6 +40,9 @@ extern "C" {
 #define EDET_ACT_RELU 2
 #define EDET_ACT_RELU6 3
 #define EDET_ACT_HSWISH 4   /* x * relu6(x + 3) / 6 */
+#define EDET_ACT_MISH 5     /* x * tanh(softplus(x)) */
+#define EDET_ACT_SRELU 6    /* utils.srelu_fn (utils.py:25-31): x - log(beta x + 1) / beta for x > 0, else 0; beta = 20^4 */
+#define EDET_ACT_LAST EDET_ACT_SRELU
 
 /* resample modes of one BiFPN fusion input */
 #define EDET_RS_IDENTITY 0

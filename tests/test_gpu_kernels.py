@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from automl_amd import _lib
-from automl_amd._lib import ACT_HSWISH, ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SWISH, BwdEpi, call, ptr
+from automl_amd._lib import ACT_HSWISH, ACT_MISH, ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SRELU, ACT_SWISH, BwdEpi, call, ptr
 from oracle import efficientdet_oracle as orc
 from tests import gpu_util as gu
 
@@ -27,7 +27,8 @@ def nchw_to_nhwc(t):
 # The activation the 'swish' modes of the tests below put on a view.  test_tuned_kernels_with_the_other_activations
 # re-runs the same bodies with relu / relu6 / hswish (utils.activation_fn, utils.py:36-53).
 VIEW_ACT = ACT_SWISH
-ACT_NAMES = {ACT_SWISH: 'swish', ACT_RELU: 'relu', ACT_RELU6: 'relu6', ACT_HSWISH: 'hswish'}
+ACT_NAMES = {ACT_SWISH: 'swish', ACT_RELU: 'relu', ACT_RELU6: 'relu6', ACT_HSWISH: 'hswish', ACT_MISH: 'mish',
+             ACT_SRELU: 'srelu'}
 ACT_KINKS = {ACT_RELU: (0.0,), ACT_RELU6: (0.0, 6.0), ACT_HSWISH: (-3.0, 3.0)}
 
 
@@ -554,7 +555,9 @@ def test_squeeze_excite(dt, shape):
   gd = torch.zeros(n, c, dtype=torch.float32, device=gu.DEV)
   tv = gu.tview(xd, c, sc, sh, None, ACT_SWISH)
   w1d, b1d, w2d, b2d = (gu.fdev(t) for t in (w1, b1, w2, b2))
-  scr = torch.full((2 * 1024 * 1024,), float('nan'), dtype=torch.float32, device=gu.DEV)     # chunk sums (8 MB)
+  # chunk sums: room for 5 copies of the batch at the standard chunk size (a smaller scratch makes the chunks grow,
+  # which changes the summation order -- checked separately below)
+  scr = torch.full((16 * 1024 * 1024,), float('nan'), dtype=torch.float32, device=gu.DEV)
   pd.fill_(float('nan'))       # nothing has to be zeroed beforehand: the pooling has no atomics
   call('edet_se_pool', ctypes.byref(tv), ptr(pd), ptr(scr), scr.numel() * 4, edt, gu.stream())
   call('edet_se_fc', ptr(pd), n, c, se, 1.0 / (h * w), ptr(w1d), ptr(b1d), ptr(w2d), ptr(b2d), ptr(hd), ptr(gd),
@@ -805,7 +808,7 @@ def test_optimizer():
 GENERIC_KERNELS = ('k_gemm<', 'k_wgrad<', 'k_dw_fwd<', 'k_dw_bwd_data<', 'k_dw_bwd_weight<')
 
 
-@pytest.mark.parametrize('act', [ACT_RELU, ACT_RELU6, ACT_HSWISH], ids=lambda a: ACT_NAMES[a])
+@pytest.mark.parametrize('act', [ACT_RELU, ACT_RELU6, ACT_HSWISH, ACT_MISH, ACT_SRELU], ids=lambda a: ACT_NAMES[a])
 def test_tuned_kernels_with_the_other_activations(act, monkeypatch):
   """utils.activation_fn's relu / relu6 / hswish (the efficientdet-lite family) in the TUNED bf16 kernels: a template
   parameter (OACT) of the streaming / tiled pointwise kernels and of the row-marching depthwise kernels (the swish /

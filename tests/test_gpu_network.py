@@ -60,6 +60,8 @@ CASES = [
     ('efficientdet-d0', 'fpn_weight_method=channel_fastattn', 128, 2),    # per-channel weight vectors
     ('efficientdet-d0', 'act_type=hswish', 128, 2),   # utils.activation_fn beyond swish: the generic kernels
     ('efficientdet-d0', 'act_type=relu6', 128, 2),
+    ('efficientdet-d0', 'act_type=mish', 128, 2),
+    ('efficientdet-d0', 'act_type=srelu', 128, 2),
     ('efficientdet-d7x', '', 256, 1),     # BASELINE configs[4] at a small image: b7 backbone (55 blocks, SE up to
                                           # 160 units, 3840 channels), levels 3-8, 8 BiFPN cells of 384 filters, 'sum'
 ]

@@ -20,6 +20,8 @@ under the discipline tests/test_gpu_bench_shapes.py applies to the headline conf
 The D7x oracle runs cost ~1 minute of host time each (815 GFLOP forward in fp32 on the CPU), which is why this module
 keeps them to three.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -36,6 +38,7 @@ pytestmark = pytest.mark.gpu
 
 BF16 = gu.DTYPES[1]
 TOL_LAYER, TOL_D7X_E2E = 1.2e-2, 1.5e-2      # the tolerances of tests/test_gpu_network.py (TOL_LAYER, TOL_BF16_VS_EMU)
+TOL_LAYER_GRAD = 3e-2                        # tests/test_gpu_bench_shapes.py TOL['layer_grad'] / ['layer_wgrad']
 COVERED = {}
 
 
@@ -341,12 +344,13 @@ class _D7xStep(object):
   copies (per-image draws would make the copies different problems); the generator is seeded identically for every
   batch size, so the 1-image and the 8-image step drop the same blocks."""
 
-  def __init__(self, batch):
+  def __init__(self, batch, keep_engine=False):
     config, vals, images = _d7x_problem()
-    labels1 = make_labels(config, 1, D7X_SIZE, 37)
-    labels = {k: np.tile(v, (batch,) + (1,) * (v.ndim - 1)) for k, v in labels1.items()}
-    labels['normalizer'] = batch * (float(labels1['mean_num_positives'].sum()) + 1.0)
-    net = train_lib.EfficientDetNetTrain(config=config, dtype='bf16', params=vals)
+    self.config, self.vals, self.images = config, vals, images
+    self.labels1 = make_labels(config, 1, D7X_SIZE, 37)
+    labels = {k: np.tile(v, (batch,) + (1,) * (v.ndim - 1)) for k, v in self.labels1.items()}
+    labels['normalizer'] = batch * (float(self.labels1['mean_num_positives'].sum()) + 1.0)
+    net = self.net = train_lib.EfficientDetNetTrain(config=config, dtype='bf16', params=vals)
     eng = self.eng = net._ensure_engine(batch, D7X_SIZE, D7X_SIZE)
 
     def one_draw_per_block():
@@ -362,29 +366,52 @@ class _D7xStep(object):
     self.kernels = _lib.launch_log_stop()
     _lib.launch_log_start()
     self.losses = eng.loss_values()
-    self.grads = {name: (eng.grad(name).cpu() * eng.seg_factor.cpu()[_seg_index(eng, name)]).double().reshape(-1)
-                  for name in eng.seg_names}
-    net._engines.clear()
-    self.eng = None
-    del net, eng
-    torch.cuda.empty_cache()
+    # the gradient of the logits (image 0; per-image loss terms are 1 / batch of the 1-image problem's) and the raw
+    # (unclipped) gradient of every variable
+    self.dlogits = [(v.raw.grad[0].float().cpu() * batch) for v in eng.cls_views + eng.box_views]
+    self.grads = {name: eng.grad(name).detach().cpu().double().reshape(-1) for name in eng.seg_names}
+    if not keep_engine:
+      self.release()
+
+  def release(self):
+    if self.net is not None:
+      self.net._engines.clear()
+      self.net = self.eng = None
+      torch.cuda.empty_cache()
+
+
+def _cos(a, b):
+  return float((a * b).sum()) / max(float(np.sqrt((a * a).sum() * (b * b).sum())), 1e-300)
 
 
 def test_d7x_1536_batch8_train_step_tracks_the_1_image_step_and_is_covered():
   """BASELINE configs[4] per GPU at the timed size (8 images, ~90 GB of activations): 8 copies of one image with the
-  loss normalizer scaled by 8 define the same optimisation step as the single image.  Training-mode BatchNorm in bf16
-  makes the comparison statistical (tests/test_oracle_conditioning.py): losses to 2e-3, direction of the whole clipped
-  gradient (cosine >= 0.9; a wrong offset, a skipped tile or a mis-sized grid at this size would destroy it).  Every
-  kernel symbol of the batch-8 step must be launched by an oracle-checked test of this module (entry points above, the
-  1-image forwards) or be one of the 1-image step's, whose forward is checked layer by layer above."""
+  loss normalizer scaled by 8 define the same optimisation step as the single image.  What CAN be compared: the forward
+  (all six loss values to 2e-3; measured 3e-5), the gradient of the logits (a pointwise function of the forward outputs:
+  1e-2 of its max) and the variable gradients ONE layer behind the loss (the predict layers of both towers: cosine >=
+  0.99).  Deeper into the backward pass the bf16 train step of this network is chaotic in the ORACLE ITSELF: the cosine
+  between the oracle's own clipped gradient of efficientdet-d7x and the one it computes after 0.05 % of the input pixels
+  moved by one bf16 ulp is 0.04 with bf16 storage (0.96 with fp32 storage; tests/test_oracle_conditioning.py) -- 8
+  BiFPN cells and 55 blocks of batch-statistics BatchNorm on random weights -- so no implementation can reproduce a
+  direction there; the per-depth cosines are printed.  The backward kernels at this size are pinned layer by layer
+  (next test) and through the bit-identical tiles above.  Every kernel symbol of the batch-8 step must be launched by
+  an oracle-checked test of this module."""
   one, big = _D7xStep(1), _D7xStep(D7X_BATCH)
-  for k in ('cls_loss', 'box_loss', 'det_loss', 'reg_l2_loss', 'loss', 'gradient_norm'):
+  for k in ('cls_loss', 'box_loss', 'det_loss', 'reg_l2_loss', 'loss'):
     assert abs(big.losses[k] - one.losses[k]) <= 2e-3 * abs(one.losses[k]) + 1e-6, (k, big.losses[k], one.losses[k])
-  num = sum(float((big.grads[n] * one.grads[n]).sum()) for n in one.grads)
-  den = np.sqrt(sum(float((big.grads[n]**2).sum()) for n in one.grads) * sum(float((one.grads[n]**2).sum()) for n in one.grads))
-  print('d7x 1536 batch 8 vs 1: losses %s vs %s, gradient cosine %.6f' % (
-      {k: round(v, 5) for k, v in big.losses.items()}, {k: round(v, 5) for k, v in one.losses.items()}, num / den))
-  assert num / den >= 0.9, num / den
+  worst = max(rel_err(b, o) for b, o in zip(big.dlogits, one.dlogits))
+  assert worst <= 1e-2, 'gradient of the logits, batch 8 vs 1: %g' % worst
+  groups = {'predict': [], 'tower': [], 'fpn': [], 'backbone': []}
+  for n in one.grads:
+    if one.grads[n].numel() < 2:
+      continue
+    g = 'predict' if '-predict/' in n else ('tower' if n.startswith(('class_net/', 'box_net/')) else
+                                            ('fpn' if n.startswith(('fpn_cells/', 'resample_p')) else 'backbone'))
+    groups[g].append(_cos(big.grads[n] * D7X_BATCH, one.grads[n]))
+  profile = {g: (round(float(np.median(v)), 4), round(float(np.min(v)), 4)) for g, v in groups.items()}
+  print('d7x 1536 batch 8 vs 1: losses %s vs %s; dlogits %.2e; per-variable gradient cosine (median, min) by depth: %s' % (
+      {k: round(v, 4) for k, v in big.losses.items()}, {k: round(v, 4) for k, v in one.losses.items()}, worst, profile))
+  assert profile['predict'][1] >= 0.99, profile
   for k, v in one.kernels.items():
     COVERED[k] = COVERED.get(k, 0) + v
   if 'inf' in _D7X:
@@ -392,3 +419,59 @@ def test_d7x_1536_batch8_train_step_tracks_the_1_image_step_and_is_covered():
       COVERED[k] = COVERED.get(k, 0) + v
   _assert_covered(big.kernels, 'the efficientdet-d7x 1536x1536 batch-8 train step')
   _D7X.clear()
+
+
+@pytest.mark.skipif(os.environ.get('EDET_SKIP_SLOW') == '1', reason='EDET_SKIP_SLOW=1: ~4 minutes of host autograd')
+def test_d7x_1536_batch1_bf16_train_step_layer_by_layer():
+  """The bf16 train step of efficientdet-d7x at 1536x1536 (one image, stochastic depth on, the device's draws handed to
+  the oracle) against the storage-emulating oracle with teacher forcing, forward AND backward: every stored activation,
+  every stored gradient buffer and every variable's gradient against the oracle's value computed from the DEVICE's
+  stored inputs of that layer (tests/test_gpu_bench_shapes.py does the same for the headline configuration).  This is
+  what pins the backward kernels at the D7x shapes -- 768x768 maps, 3840-channel stages, 384-filter BiFPN, 5-layer
+  towers -- where end-to-end gradient comparisons are meaningless (previous test).  ~2.4 TFLOP of fp32 autograd on the
+  host: the slowest test of the suite."""
+  step = _D7xStep(1, keep_engine=True)
+  config, vals, images = step.config, step.vals, step.images
+  labels = {k: torch.from_numpy(v) for k, v in step.labels1.items()}
+  o = _d7x_oracle(config, vals)
+  with torch.no_grad():
+    o.forward(images[:1, :64, :64], False)         # registers the trainable list
+  o.drop_scale = drop_scales(step.eng)
+  hook = o.hook = gu.TeacherForce(step.eng)
+  P = o.params()
+  names = o.trainable_names()
+  for n in names:
+    P[n].requires_grad_(True)
+  cls, box = o.forward(images, True)
+  det, _, _ = orc.detection_loss(config, cls, box, labels)
+  l2 = config.weight_decay * sum((P[n]**2).sum() / 2 for n in names if orc.is_l2_regularised(n))
+  (det + l2).backward()
+  print('d7x 1536 teacher-forced train step: %d activations, worst %s; %d gradient buffers, worst %s' % (
+      len(hook.fwd_err), hook.worst(hook.fwd_err), len(hook.bwd_err), hook.worst(hook.bwd_err)))
+  assert len(hook.fwd_err) >= 550 and len(hook.bwd_err) >= 500, (len(hook.fwd_err), len(hook.bwd_err), hook.missing[:8])
+  assert max(hook.fwd_err.values()) <= TOL_LAYER, hook.worst(hook.fwd_err, 6)
+  assert max(hook.bwd_err.values()) <= TOL_LAYER_GRAD, hook.worst(hook.bwd_err, 6)
+  werr, bn_mine, bn_ref = {}, [], []
+  gmax = max(float(P[n].grad.abs().max()) for n in names if P[n].grad is not None)
+  for n in names:
+    g = P[n].grad
+    if g is None or n.rsplit('/', 1)[-1].startswith('WSM'):
+      continue
+    mine = step.eng.grad(n).cpu().reshape(g.shape)
+    if n.endswith('/bias') and 'predict' not in n and '/se/' not in n:
+      assert float(mine.abs().max()) == 0.0, n        # a bias in front of a BatchNorm: analytically zero
+      continue
+    e = float((mine - g).abs().max()) / max(float(g.abs().max()), 1e-4 * gmax)
+    if n.endswith('/gamma') or n.endswith('/beta'):
+      # whole-tensor sums that cancel by orders of magnitude: checked together as one vector (as for d0)
+      bn_mine.append(mine.reshape(-1).double().numpy())
+      bn_ref.append(g.reshape(-1).double().numpy())
+      continue
+    werr[n] = e
+  bn_mine, bn_ref = np.concatenate(bn_mine), np.concatenate(bn_ref)
+  bn_err = float(np.linalg.norm(bn_mine - bn_ref) / np.linalg.norm(bn_ref))
+  print('d7x 1536 teacher-forced: %d kernel gradients, worst %s; BatchNorm gamma / beta vector error %.4f' % (
+      len(werr), gu.TeacherForce.worst(werr, 5), bn_err))
+  assert max(werr.values()) <= TOL_LAYER_GRAD, gu.TeacherForce.worst(werr, 8)
+  assert bn_err <= 3e-2, bn_err
+  step.release()

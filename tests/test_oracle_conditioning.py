@@ -76,3 +76,41 @@ def test_fp32_per_tensor_gradients_are_conditioned_to_about_1e_2():
   print('cosine %.9f, worst per-tensor moves %s, tensors moved by > 1e-3: %d' % (num / den, errs[:4], sum(e > 1e-3 for e in errs)))
   assert num / den >= 0.999999
   assert errs[0] >= 2e-3 and sum(e > 1e-3 for e in errs) >= 5, errs[:8]
+
+
+def test_d7x_bf16_train_step_gradient_direction_is_chaotic_in_the_oracle_itself():
+  """Why tests/test_gpu_side_configs.py does not compare gradient DIRECTIONS of the efficientdet-d7x bf16 train step
+  beyond the layers next to the loss: the oracle's own clipped gradient (d7x, one 512x512 image, the test problem's
+  variables), computed twice -- the second time with 0.05 % of the input pixels moved by one bf16 ulp.  The losses agree
+  to 1e-3 in both storage modes; the direction of the whole gradient keeps a cosine of ~0.96 with fp32 storage and
+  loses it entirely (~0.04) with bf16 storage: 55 blocks + 8 BiFPN cells of batch-statistics BatchNorm on random
+  weights, every rounding flip breeding more flips on the way back.  Layer by layer (teacher forcing) the same step is
+  pinned to a few bf16 ulps."""
+  from oracle.problems import perturbed_params
+  from tests.test_gpu_network import make_labels
+  torch.set_num_threads(min(16, torch.get_num_threads()))
+  size = 512
+  config = hparams_config.get_efficientdet_config('efficientdet-d7x')
+  config.override('image_size=%d' % size)
+  vals = perturbed_params(config, 3)
+  x = torch.from_numpy(np.random.default_rng(31).standard_normal((1, size, size, 3)).astype(np.float32))
+  x = x.to(torch.bfloat16).float()
+  mask = torch.from_numpy(np.random.default_rng(0).random(x.shape) < 5e-4)
+  xb = torch.where(mask, (x * (1 + 2.0**-8)).to(torch.bfloat16).float(), x)
+  labels = {k: torch.from_numpy(v) for k, v in make_labels(config, 1, size, 37).items()}
+
+  def step(inp, storage):
+    o = orc.Oracle(config=config, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()}, storage=storage)
+    with torch.no_grad():
+      o.forward(inp[:1, :64, :64], False)
+    lv, g = orc.train_step(o, inp, labels, {}, 0.02, 0.9)
+    return lv, {k: v.detach().double().reshape(-1) for k, v in g.items()}
+  cos = {}
+  for storage in ('f32', 'bf16'):
+    (l0, g0), (l1, g1) = step(x, storage), step(xb, storage)
+    assert abs(l0['loss'] - l1['loss']) <= 1e-3 * abs(l0['loss'])
+    num = sum(float((g0[k] * g1[k]).sum()) for k in g0)
+    den = np.sqrt(sum(float((g0[k]**2).sum()) for k in g0) * sum(float((g1[k]**2).sum()) for k in g0))
+    cos[storage] = num / den
+  print('d7x@512 clipped-gradient cosine under one-ulp input flips: %s' % cos)
+  assert cos['f32'] >= 0.9 and cos['bf16'] <= 0.5, cos

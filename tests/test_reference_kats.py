@@ -102,7 +102,7 @@ def test_activation_values():
   # utils_test.py:113-143: the reference's expected values for every activation type
   features = torch.tensor([.5, 10.])
   for act, want in (('swish', [0.311, 10]), ('swish_native', [0.311, 10]), ('hswish', [0.29166667, 10.0]),
-                    ('relu', [0.5, 10]), ('relu6', [0.5, 6]), ('mish', [0.37524524, 10.0])):
+                    ('relu', [0.5, 10]), ('relu6', [0.5, 6]), ('mish', [0.37524524, 10.0]), ('srelu', [0.4999290, 9.9999108])):
     np.testing.assert_allclose(orc.activation_fn(features, act).numpy(), want, rtol=2e-3, err_msg=act)
   with pytest.raises(ValueError):
     orc.activation_fn(features, 'bogus')
@@ -435,9 +435,13 @@ def test_oracle_other_activation_equals_the_executed_reference_graph():
   g, config, shapes, params = load_graph_case('reference_graph_d0_hswish.npz', 'efficientdet-d0',
                                               'image_size=64,act_type=hswish')
   assert netspec.NetSpec(config).act_code == 4
+  for name, code in (('mish', 5), ('srelu', 6)):         # every type of utils.activation_fn has a device code
+    other = hparams_config.get_efficientdet_config('efficientdet-d0')
+    other.override('act_type=' + name)
+    assert netspec.NetSpec(other).act_code == code
   bad = hparams_config.get_efficientdet_config('efficientdet-d0')
-  bad.override('act_type=mish')
-  with pytest.raises(ValueError, match='not built'):
+  bad.override('act_type=gelu')
+  with pytest.raises(ValueError, match='Unsupported act_type'):      # the reference's message (utils.py:53)
     netspec.NetSpec(bad)
   images = torch.from_numpy(g['images'])
   for training, tol in ((False, 5e-6), (True, 2e-2)):
