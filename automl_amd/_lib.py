@@ -33,7 +33,10 @@ class GView(ctypes.Structure):
 
 class BwdEpi(ctypes.Structure):
   _fields_ = [('gout', c_void_p), ('beta', c_int), ('mean', c_void_p), ('rstd', c_void_p),
-              ('stat_partials', c_void_p), ('dgate', c_void_p)]
+              ('stat_partials', c_void_p), ('dgate', c_void_p), ('flags', c_int)]
+
+
+EPI_Y_IS_CONV_OF_INPUT = 1      # EDET_EPI_Y_IS_CONV_OF_INPUT
 
 
 class NmsCfg(ctypes.Structure):

@@ -553,7 +553,7 @@ __global__ __launch_bounds__(THREADS) void k_se_gate_bwd(const edet_tview_t in, 
 // sl, sl+64, ... with two independent loads in flight, the 64 slices are combined through LDS.
 constexpr int RED_SL = 64;      // row slices per element: 16 elements x 64 slices = 1024 lanes
 __global__ __launch_bounds__(16 * RED_SL) void k_reduce_partials(const float* __restrict__ ws, int P, int64_t n,
-                                                                float* __restrict__ dst) {
+                                                                float* __restrict__ dst, int accumulate) {
   __shared__ float red[RED_SL][17];
   const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int64_t i = (int64_t)blockIdx.x * 16 + e;
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(16 * RED_SL) void k_reduce_partials(const float* __
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < RED_SL; ++k) t += red[k][e];
-    dst[i] += t;
+    dst[i] = accumulate ? dst[i] + t : t;
   }
 }
 
@@ -586,7 +586,13 @@ inline int ew_grid(int64_t total) {
 }  // namespace
 
 int edet_reduce_partials(const float* ws, int P, int64_t n, float* dst, hipStream_t st) {
-  edet_launch(k_reduce_partials, dim3((unsigned)((n + 15) / 16)), dim3(16 * RED_SL), 0, st, ws, P, n, dst);
+  edet_launch(k_reduce_partials, dim3((unsigned)((n + 15) / 16)), dim3(16 * RED_SL), 0, st, ws, P, n, dst, 1);
+  EDET_LAUNCH_CHECK("edet_reduce_partials");
+  return 0;
+}
+// dst[i] = sum of the partial rows (no accumulation)
+int edet_reduce_partials_set(const float* ws, int P, int64_t n, float* dst, hipStream_t st) {
+  edet_launch(k_reduce_partials, dim3((unsigned)((n + 15) / 16)), dim3(16 * RED_SL), 0, st, ws, P, n, dst, 0);
   EDET_LAUNCH_CHECK("edet_reduce_partials");
   return 0;
 }

@@ -239,6 +239,7 @@ __host__ __device__ inline int same_pad_before(int in, int k, int s) {
 
 // dst[i] += sum_p ws[p*n + i]  (p < P): 16 elements x 16 partial-row slices per workgroup (bn_se.hip)
 int edet_reduce_partials(const float* ws, int P, int64_t n, float* dst, hipStream_t st);
+int edet_reduce_partials_set(const float* ws, int P, int64_t n, float* dst, hipStream_t st);
 
 static inline hipStream_t to_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

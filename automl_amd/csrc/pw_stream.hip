@@ -136,6 +136,17 @@ __device__ __forceinline__ f32x16 mma_tile(const unsigned char* wrow, const unsi
   return acc;
 }
 
+// the same, continuing an accumulator (a second operand pair contracted into the same D' tile)
+__device__ __forceinline__ f32x16 mma_tile_more(const unsigned char* wrow, const unsigned char* arow, int ksteps,
+                                                f32x16 acc) {
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + ks * 32);
+    const bf16x8 bf = *reinterpret_cast<const bf16x8*>(arow + ks * 32);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, bf, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
 // column sums of a [rows][.] bf16 LDS tile: lane = column `c`
 __device__ __forceinline__ void column_stats(const unsigned char* Ct, int SC, int c, int rows_valid, float& s,
                                              float& s2) {
@@ -860,6 +871,17 @@ __global__ __launch_bounds__(THREADS, 2) void k_pw_wgrad(const WgArgs a) {
 // One wave per SIMD (the accumulators and a whole tile of loads in flight take ~400 registers): latency is hidden
 // by the 14-21 KB every wave keeps in flight, not by occupancy.  At the end the four waves of a workgroup add their
 // dW blocks in LDS (fixed order) and write one partial per workgroup; edet_reduce_partials sums them.
+//
+// NOY (r03): the BatchNorm backward WITHOUT the saved convolution output.  dy = a*dz + b*y + c and y = x~ W (x~ the
+// operand the forward fed the matrix cores), so
+//     dx~ = dy W^T   = dz (W diag(a))^T + x~ (W diag(b) W^T) + c W^T          = dz Wa^T + x~ G + v
+//     dW  = x~^T dy  = (x~^T dz) diag(a) + (x~^T x~) W diag(b) + (sum_p x~) c^T = P diag(a) + S W diag(b) + s c^T
+// with G = W diag(b) W^T a KO x KO matrix and S = x~^T x~ the Gram matrix of the input (KO <= 32 here): the 6x wider
+// y is never read (the kernel's traffic drops from 2N + 2K to N + 2K channels per row: -43 % for 16 -> 96), dz goes
+// from HBM to the LDS operand tile without being unpacked, and the only extra matrix work is one k-step against G
+// and one or four 16 x 16 tiles of S.  Wa, G and v are made in the prologue from the weights already in LDS; the
+// partial written per workgroup is [P | S | s] and k_noy_apply finishes dW.  Used when the convolution input is a
+// plain stored tensor (every MBConv expansion reads a block output), so x~ = x and there is no chain epilogue work.
 struct FusedArgs {
   edet_gview_t gv;    // dy: R = gv.c channels (the convolution's output channels)
   edet_tview_t tv;    // conv input view: raw x, scale, shift, gate, act; KO = tv.c channels
@@ -873,12 +895,14 @@ struct FusedArgs {
   int KOpad;          // KO rounded up to 32
   int TK, TN;         // 16-wide tiles of dW along k and n
   int tpw, ksteps;    // tiles per wave; ceil(R / 16)
+  int SG, kxsteps;    // NOY: LDS row stride of G in bytes, ceil(KOpad / 16)
 };
 
 // FT_S x FT_L = 16 x 16 tiles of dW kept per wave (min(TK, TN) <= FT_S, max(TK, TN) <= FT_L): 2 x 9 covers the expand
 // layers the host routes here (16..32 input channels, up to 144 output channels)
-template <int NSR, int NSX, bool GBN, int FT_S, int FT_L>
+template <int NSR, int NSX, bool GBN, int FT_S, int FT_L, bool NOY = false>
 __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) {
+  static_assert(!NOY || GBN, "NOY is a form of the BatchNorm backward on load");
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int j = lane & 31, h = lane >> 5;
@@ -890,7 +914,9 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
   const int d_alloc = NSR * a.cr.rp, x_alloc = NSX * a.cx.rp;           // >= 32 rows each (NSR / NSX load passes)
   const size_t wave_bytes = (size_t)d_alloc * a.SA + (size_t)(has_beta ? 2 : 1) * x_alloc * a.SX +
                             (size_t)TR * a.SC + (size_t)4 * a.KOpad * 4;
-  unsigned char* wbase = reinterpret_cast<unsigned char*>(coefH + a.KOpad) + (size_t)wave * wave_bytes;
+  float* vL = coefH + a.KOpad;                                          // NOY: [KOpad] v = c W^T
+  unsigned char* Gl = reinterpret_cast<unsigned char*>(vL + (NOY ? a.KOpad : 0));      // NOY: [KOpad][SG] bf16 G
+  unsigned char* wbase = Gl + (NOY ? (size_t)a.KOpad * a.SG : 0) + (size_t)wave * wave_bytes;
   unsigned char* Dt = wbase;                                            // [d_alloc][SA] bf16 dy
   unsigned char* Xt = Dt + (size_t)d_alloc * a.SA;                      // [x_alloc][SX] bf16 x, then act(x)
   unsigned char* Ot = Xt + (size_t)x_alloc * a.SX;                      // [x_alloc][SX] bf16 old gout (beta only)
@@ -923,6 +949,39 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
     }
   }
   __syncthreads();
+  if (NOY) {
+    // G[k][k'] = sum_n W[k][n] b[n] W[k'][n] (bf16 MFMA operand, zero beyond KO), v[k] = sum_n c[n] W[k][n] -- from the
+    // bf16 weights the forward used; then the LDS weights become Wa[k][n] = a[n] W[k][n]
+    for (int q = tid; q < a.KOpad * a.KOpad; q += THREADS) {
+      const int k = q / a.KOpad, k2 = q - k * a.KOpad;
+      float g = 0.f;
+      if (k < a.KO && k2 < a.KO) {
+        const bf16_t* w1 = reinterpret_cast<const bf16_t*>(Wl + (size_t)k * a.SW);
+        const bf16_t* w2 = reinterpret_cast<const bf16_t*>(Wl + (size_t)k2 * a.SW);
+        for (int n = 0; n < a.R; ++n) g = fmaf(bf2f(w1[n]) * a.gv.b[n], bf2f(w2[n]), g);
+      }
+      reinterpret_cast<bf16_t*>(Gl + (size_t)k * a.SG)[k2] = f2bf(g);
+    }
+    for (int q = tid; q < a.KOpad * (a.SG / 2 - a.KOpad); q += THREADS) {      // zero tail of every G row
+      const int k = q / (a.SG / 2 - a.KOpad), t = q - k * (a.SG / 2 - a.KOpad);
+      reinterpret_cast<bf16_t*>(Gl + (size_t)k * a.SG)[a.KOpad + t] = 0;
+    }
+    for (int k = tid; k < a.KOpad; k += THREADS) {
+      float t = 0.f;
+      if (k < a.KO) {
+        const bf16_t* w1 = reinterpret_cast<const bf16_t*>(Wl + (size_t)k * a.SW);
+        for (int n = 0; n < a.R; ++n) t = fmaf(a.gv.cc[n], bf2f(w1[n]), t);
+      }
+      vL[k] = t;
+    }
+    __syncthreads();
+    for (int q = tid; q < a.KO * a.R; q += THREADS) {
+      const int k = q / a.R, n = q - k * a.R;
+      bf16_t* wp = reinterpret_cast<bf16_t*>(Wl + (size_t)k * a.SW) + n;
+      *wp = f2bf(bf2f(*wp) * a.gv.a[n]);
+    }
+    __syncthreads();
+  }
 
   // load mappings (lanes beyond nvec*rp duplicate the work of lane % (nvec*rp): no divergence)
   const int lane_r = lane % (a.cr.nvec * a.cr.rp);
@@ -941,7 +1000,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
 
   // native vector types: a HIP uint4 struct copied whole from a register array to LDS is not promoted to registers
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  uint4 rz[NSR], ry[GBN ? NSR : 1];
+  uint4 rz[NSR], ry[(GBN && !NOY) ? NSR : 1];
   u32x4 rx[NSX], ro[NSX];
   auto issue = [&](int t) {
     const int row0 = t * TR;
@@ -949,7 +1008,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
     for (int i = 0; i < NSR; ++i) {   // rows past M re-read row M-1 (finite values; zeroed when they are staged)
       const size_t off = ((size_t)min(row0 + i * a.cr.rp + rsubR, a.M - 1) * a.gv.ld + colR * 8) * 2;
       rz[i] = *reinterpret_cast<const uint4*>(DZ + off);
-      if (GBN) ry[i] = *reinterpret_cast<const uint4*>(Y + off);
+      if (GBN && !NOY) ry[i] = *reinterpret_cast<const uint4*>(Y + off);
     }
 #pragma unroll
     for (int i = 0; i < NSX; ++i) {
@@ -977,9 +1036,17 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
       for (int e = 0; e < 4; ++e) acc[s][l][e] = 0.f;
 
   float ga[8], gb[8], gc[8];
-  if (GBN) {
+  if (GBN && !NOY) {
     loadf8(a.gv.a + colR * 8, ga); loadf8(a.gv.b + colR * 8, gb); loadf8(a.gv.cc + colR * 8, gc);
   }
+  // NOY: the Gram matrix S = x^T x of this wave's rows, 16 x 16 tiles (s, s2) of the k side
+  f32x4 accS[NOY ? FT_S : 1][NOY ? FT_S : 1];
+#pragma unroll
+  for (int s = 0; s < (NOY ? FT_S : 1); ++s)
+#pragma unroll
+    for (int s2 = 0; s2 < (NOY ? FT_S : 1); ++s2)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) accS[s][s2][e] = 0.f;
   const int ecol = lane & 7, erow = lane >> 3;     // epilogue mapping: 64-channel chunk, 8 lanes per row
   const int fi = lane & 15, fq = lane >> 4;        // 16x16x32 fragment coordinates
   int gate_img = -1;                               // image whose dgate sums are in wgt
@@ -992,6 +1059,10 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
 #pragma unroll
     for (int i = 0; i < NSR; ++i) {
       const int r = i * a.cr.rp + rsubR;
+      if (NOY) {           // dz is the matrix-core operand as it is (R % 8 == 0 on this path: whole chunks)
+        *reinterpret_cast<uint4*>(Dt + r * a.SA + colR * 16) = r < rows_valid ? rz[i] : make_uint4(0, 0, 0, 0);
+        continue;
+      }
       float x[8];
       unpack8(rz[i], x);
       if (GBN) {
@@ -1057,13 +1128,21 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
         if (gated && one_img) loadf8(gateL + ch0, gt);
       }
       for (int nt = 0; nt < ccols / 32; ++nt) {
-        const f32x16 d = mma_tile(Wl + (size_t)(c0 + nt * 32 + j) * a.SW + h * 16, arow, a.ksteps);
+        f32x16 d = mma_tile(Wl + (size_t)(c0 + nt * 32 + j) * a.SW + h * 16, arow, a.ksteps);
+        if (NOY)           // + x G: the rows of Xt (raw x = the forward's operand on this path) against G
+          d = mma_tile_more(Gl + (size_t)(c0 + nt * 32 + j) * a.SG + h * 16, Xt + (size_t)j * a.SX + h * 16, a.kxsteps, d);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           *reinterpret_cast<float4*>(Ct + j * a.SC + (nt * 32 + 8 * g + 4 * h) * 4) =
               make_float4(d[4 * g + 0], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]);
       }
       __builtin_amdgcn_wave_barrier();
+      float vv[8];
+      if (NOY) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vv[e] = 0.f;
+        if (col_ok) loadf8(vL + ch0, vv);
+      }
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int r = p * 8 + erow;
@@ -1075,6 +1154,10 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
             float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
             float x[8], g[8], av[8];
             unpack8(*xslot, x);
+            if (NOY) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { d[e] += vv[e]; s1[e] += x[e]; }       // s1: sum_p x (the s of dW)
+            }
             // z (pre-activation), its activation av and the chained gradient g
             if (swish) {
 #pragma unroll
@@ -1133,7 +1216,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
       // chunk sums -> wave LDS accumulators (8 lanes share a column: LDS atomics); raw sums (g, g*x): the
       // BatchNorm-backward form sum g*(x-mean)*rstd is taken from the totals at the end of the kernel
       if (col_ok) {
-        if (want_stats) {
+        if (want_stats || NOY) {          // (NOY: no chain epilogue on that path; wst[0] collects sum_p x)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             if (ch0 + e < a.KO) {
@@ -1160,6 +1243,15 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
 #pragma unroll
       for (int s = 0; s < FT_S; ++s)
         if (s < TS) sf[s] = column_frag(St, sS, fq * 8, s * 16 + fi);
+      if (NOY) {           // S = x^T x (ksmall on this path: sf are the fragments of x)
+#pragma unroll
+        for (int s = 0; s < FT_S; ++s)
+#pragma unroll
+          for (int s2 = 0; s2 < FT_S; ++s2)
+            if (s < TS && s2 < TS)
+              accS[NOY ? s : 0][NOY ? s2 : 0] =
+                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf[s], sf[s2], accS[NOY ? s : 0][NOY ? s2 : 0], 0, 0, 0);
+      }
 #pragma unroll
       for (int l = 0; l < FT_L; ++l) {
         if (l < TL) {
@@ -1178,6 +1270,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
     __builtin_amdgcn_wave_barrier();
   }
   __builtin_amdgcn_wave_barrier();
+  const float xsum = (NOY && lane < a.KO) ? wst[lane] : 0.f;      // NOY: this wave's sum_p x[p][lane] (KO <= 32)
   if (want_gate && gate_img >= 0) {
     for (int c = lane; c < a.KO; c += 64) {
       const float v = wgt[c];
@@ -1222,8 +1315,52 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
     }
     __syncthreads();
   }
-  float* dstw = a.ws + (size_t)blockIdx.x * a.KO * a.R;
+  const size_t part = (size_t)a.KO * a.R + (NOY ? (size_t)a.KO * a.KO + a.KO : 0);
+  float* dstw = a.ws + (size_t)blockIdx.x * part;
   for (int i = tid; i < a.KO * a.R; i += THREADS) dstw[i] = scratch[i];
+  if (NOY) {
+    // [S | s] behind P: the waves' Gram tiles and column sums in wave order (deterministic)
+    __syncthreads();
+    float* sS = scratch;                                  // [KO][KO]
+    float* ss = scratch + (size_t)a.KO * a.KO;            // [KO]
+    for (int w = 0; w < WAVES; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int s = 0; s < FT_S; ++s)
+#pragma unroll
+          for (int s2 = 0; s2 < FT_S; ++s2) {
+            if (s < TS && s2 < TS) {
+              const int k2 = s2 * 16 + fi;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int k = s * 16 + fq * 4 + e;
+                if (k < a.KO && k2 < a.KO) {
+                  float* p = sS + (size_t)k * a.KO + k2;
+                  *p = (w == 0 ? 0.f : *p) + accS[NOY ? s : 0][NOY ? s2 : 0][e];
+                }
+              }
+            }
+          }
+        if (lane < a.KO) ss[lane] = (w == 0 ? 0.f : ss[lane]) + xsum;
+      }
+      __syncthreads();
+    }
+    for (int i = tid; i < a.KO * a.KO + a.KO; i += THREADS) dstw[(size_t)a.KO * a.R + i] = scratch[i];
+  }
+}
+
+// NOY: dW[k][n] += a[n] P[k][n] + b[n] sum_k' S[k][k'] W[k'][n] + c[n] s[k] from the summed partial [P | S | s]
+__global__ __launch_bounds__(256) void k_noy_apply(const float* __restrict__ psum, const bf16_t* __restrict__ W, int ldw,
+                                                  int KO, int R, const float* __restrict__ ga,
+                                                  const float* __restrict__ gb, const float* __restrict__ gc,
+                                                  float* __restrict__ dweight) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= KO * R) return;
+  const int k = i / R, n = i - k * R;
+  const float* S = psum + (size_t)KO * R + (size_t)k * KO;
+  float t = 0.f;
+  for (int k2 = 0; k2 < KO; ++k2) t = fmaf(S[k2], bf2f(W[(size_t)k2 * ldw + n]), t);
+  dweight[i] += ga[n] * psum[i] + gb[n] * t + gc[n] * psum[(size_t)KO * R + (size_t)KO * KO + k];
 }
 
 template <typename KernelT>
@@ -1426,14 +1563,25 @@ int pws_try_bwd_fused(const edet_gview_t* dy, const void* w, int ldw, const edet
   a.KOpad = (KO + 31) / 32 * 32;
   if (a.SX < a.KOpad * 2) a.SX = frag_stride(a.KOpad, false);     // the epilogue addresses whole 32-channel tiles
   a.SC = ECC * 4 + 16;
-  const size_t lds = (size_t)a.KOpad * a.SW + (size_t)4 * a.KOpad * 4 +
+  const bool gbn = dy->a != nullptr;
+  // NOY: BatchNorm backward without the saved convolution output (see the kernel's header): dy carries a BatchNorm
+  // backward, the input is a plain stored tensor (x~ = x; no chain epilogue), whole 16-byte chunks of dz.
+  // EDET_PW_NOY=0 keeps the form that reads y (lab switch, read per call).
+  const char* noy_env = getenv("EDET_PW_NOY");
+  const bool noy = gbn && (epi->flags & EDET_EPI_Y_IS_CONV_OF_INPUT) && dy->b && dy->cc && !in->scale && !in->gate &&
+                   in->act == EDET_ACT_NONE &&
+                   !epi->stat_partials && !epi->dgate && R % 8 == 0 && !(noy_env && noy_env[0] == '0');
+  a.SG = frag_stride(a.KOpad, false);
+  a.kxsteps = (KO + 15) / 16;
+  const size_t part = (size_t)KO * R + (noy ? (size_t)KO * KO + KO : 0);      // floats per workgroup partial
+  const size_t lds = (size_t)a.KOpad * a.SW + (size_t)4 * a.KOpad * 4 + (noy ? (size_t)a.KOpad * 4 + (size_t)a.KOpad * a.SG : 0) +
                      (size_t)WAVES * ((size_t)nsr * a.cr.rp * a.SA + (size_t)(epi->beta ? 2 : 1) * nsx * a.cx.rp * a.SX +
                                       (size_t)TR * a.SC + (size_t)4 * a.KOpad * 4);
   if (lds > 150 * 1024 || lds < (size_t)KO * R * 4) return 0;
   const int ntile = (a.M + TR - 1) / TR;
   // one workgroup per CU and wave (1 wave per SIMD); at least 4 tiles per wave, partials bounded by the workspace
   int grid = 1024;
-  const int64_t max_by_ws = (int64_t)(workspace_bytes / sizeof(float)) / ((int64_t)KO * R);
+  const int64_t max_by_ws = (int64_t)(workspace_bytes / sizeof(float)) / (int64_t)part - (noy ? 1 : 0);
   if (grid > max_by_ws) grid = (int)max_by_ws;
   if (grid > EDET_MAX_PARTS) grid = EDET_MAX_PARTS;
   const int max_by_tiles = (ntile + WAVES * 4 - 1) / (WAVES * 4);
@@ -1442,19 +1590,30 @@ int pws_try_bwd_fused(const edet_gview_t* dy, const void* w, int ldw, const edet
   a.tpw = (ntile + grid * WAVES - 1) / (grid * WAVES);
   grid = (ntile + a.tpw * WAVES - 1) / (a.tpw * WAVES);
   if (nparts_out) *nparts_out = grid;
-  const bool gbn = dy->a != nullptr;
-#define PWS_FUSED(NSR_, NSX_, GBN_, FS_, FL_)                                                       \
-  do {                                                                                              \
-    if (!allow_big_lds(&k_pw_bwd_fused<NSR_, NSX_, GBN_, FS_, FL_>, lds)) return 0;                 \
-    edet_launch(k_pw_bwd_fused<NSR_, NSX_, GBN_, FS_, FL_>, dim3(grid), dim3(THREADS), lds, st, a); \
+#define PWS_FUSED(NSR_, NSX_, GBN_, FS_, FL_, NOY_)                                                       \
+  do {                                                                                                    \
+    if (!allow_big_lds(&k_pw_bwd_fused<NSR_, NSX_, GBN_, FS_, FL_, NOY_>, lds)) return 0;                 \
+    edet_launch(k_pw_bwd_fused<NSR_, NSX_, GBN_, FS_, FL_, NOY_>, dim3(grid), dim3(THREADS), lds, st, a); \
   } while (0)
-#define PWS_FUSED_G(NSR_, NSX_, FS_, FL_) \
-  do { if (gbn) PWS_FUSED(NSR_, NSX_, true, FS_, FL_); else PWS_FUSED(NSR_, NSX_, false, FS_, FL_); } while (0)
+#define PWS_FUSED_G(NSR_, NSX_, FS_, FL_)                        \
+  do {                                                           \
+    if (noy) PWS_FUSED(NSR_, NSX_, true, FS_, FL_, true);        \
+    else if (gbn) PWS_FUSED(NSR_, NSX_, true, FS_, FL_, false);  \
+    else PWS_FUSED(NSR_, NSX_, false, FS_, FL_, false);          \
+  } while (0)
   if (nsr == 8) PWS_FUSED_G(8, 1, 2, 9);
   else PWS_FUSED_G(12, 2, 2, 9);
 #undef PWS_FUSED_G
 #undef PWS_FUSED
   EDET_LAUNCH_CHECK("edet_pw_bwd(fused)");
+  if (noy) {
+    // partials [grid][P | S | s] -> their sum behind them in the workspace -> dW
+    float* psum = a.ws + (size_t)grid * part;
+    if (edet_reduce_partials_set(a.ws, grid, (int64_t)part, psum, st) != 0) return -2;
+    edet_launch(k_noy_apply, dim3((KO * R + 255) / 256), dim3(256), 0, st, psum, a.W, ldw, KO, R, dy->a, dy->b, dy->cc, dweight);
+    EDET_LAUNCH_CHECK("edet_pw_bwd(noy apply)");
+    return 1;
+  }
   if (edet_reduce_partials(a.ws, grid, (int64_t)KO * R, dweight, st) != 0) return -2;
   return 1;
 }

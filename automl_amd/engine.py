@@ -528,10 +528,10 @@ class Engine(object):
     vout = View(out, bnl, act)
     vin.consumers += 1
     if self.training:
-      self.tape.append(lambda: self._pw_bwd(vin, vout, wname, w, ldn))
+      self.tape.append(lambda: self._pw_bwd(vin, vout, wname, w, ldn, bias is None))
     return vout
 
-  def _pw_bwd(self, vin, vout, wname, w, ldn):
+  def _pw_bwd(self, vin, vout, wname, w, ldn, no_bias=False):
     g = self._gview(vout)
     nb = vin.raw.rows * (vin.raw.c + vout.raw.c) * self.esize
     tag = '%dx%dx%d->%d' % (vin.raw.h, vin.raw.w, vin.raw.c, vout.raw.c)
@@ -539,6 +539,8 @@ class Engine(object):
       # both gradients in one call: one pass over (dz, y, x) where the layer fits the fused kernel
       dgate = vin.dgate if vin.gate is not None else None
       epi, fused = self._epi(vin, dgate)
+      if no_bias:
+        epi.flags = _lib.EPI_Y_IS_CONV_OF_INPUT      # y = view(x) W exactly: the library need not read it
       call('edet_pw_bwd', ctypes.byref(g), ptr(w), ldn, ctypes.byref(vin.tview()), ctypes.byref(epi),
            ctypes.byref(self._nparts), ptr(self.grad(wname)), ptr(self.workspace), self.workspace.numel() * 4,
            self.dtype, self.stream, nbytes=2 * nb, tag=tag)

@@ -72,8 +72,8 @@ typedef struct edet_tview {
 /*
  * Gradient view: dy(n,h,w,c) = a[c]*dz + b[c]*y + cc[c]  (a == NULL -> dy = dz).
  * This is the BatchNorm backward applied on load: dz is the gradient w.r.t. the
- * BN output, y the saved conv output, and (a,b,cc) come from
- * edet_bn_bwd_finalize.
+ * BN output, y the saved output of THE convolution whose gradients are being taken
+ * (see EDET_EPI_Y_IS_CONV_OF_INPUT), and (a,b,cc) come from edet_bn_bwd_finalize.
  */
 typedef struct edet_gview {
   const void* dz;
@@ -102,7 +102,14 @@ typedef struct edet_bwd_epi {
   const float* rstd;
   float* stat_partials;
   float* dgate;
+  int flags;      /* EDET_EPI_* bits */
 } edet_bwd_epi_t;
+/* The convolution whose output gradient `dy` is has NO bias, so dy->y (its saved output) equals view(in) * W as
+ * edet_pw_fwd stored it.  With this bit set the pointwise backward entry points may apply the b*y term of the
+ * BatchNorm backward through the convolution INPUT (dx = dz (W diag a)^T + x~ (W diag(b) W^T) + c W^T, dW = (x~^T dz)
+ * diag a + (x~^T x~) W diag b + (sum x~) c^T) and never read y: for an MBConv expansion that is 43 % less HBM traffic.
+ * Without it they read y.  */
+#define EDET_EPI_Y_IS_CONV_OF_INPUT 1
 
 const char* edet_last_error(void);
 int edet_version(void);

@@ -45,7 +45,7 @@ def test_library_exports_every_symbol():
 def test_struct_layouts_match_header():
   assert ctypes.sizeof(_lib.TView) == 4 * 8 + 6 * 4
   assert ctypes.sizeof(_lib.GView) == 5 * 8 + 5 * 4 + 4      # padded to 8
-  assert ctypes.sizeof(_lib.BwdEpi) == 6 * 8                  # int beta padded
+  assert ctypes.sizeof(_lib.BwdEpi) == 7 * 8                  # int beta and int flags padded
 
 
 def test_missing_library_fails_loudly(monkeypatch):

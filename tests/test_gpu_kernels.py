@@ -153,18 +153,22 @@ def make_grad_view(rng, n, h, w, c, tdt, with_bn):
                                    (2, 9, 8, 384, 384)])
 @pytest.mark.parametrize('mode', ['plain', 'plain_beta', 'bn', 'bn_swish_stats', 'gate'])
 @pytest.mark.parametrize('gbn', [False, True])
-def test_pw_bwd_data(dt, shape, mode, gbn, pw_impl, one_call=False, ws_mib=16):
+def test_pw_bwd_data(dt, shape, mode, gbn, pw_impl, one_call=False, ws_mib=16, conv_y=None):
   """one_call: through edet_pw_bwd (both gradients in one call; bf16: the fused kernel where the layer fits it), which
-  must give the data gradient of edet_pw_bwd_data AND the weight gradient of edet_pw_bwd_weight."""
+  must give the data gradient of edet_pw_bwd_data AND the weight gradient of edet_pw_bwd_weight.
+  conv_y (default: on for one_call with a BatchNorm backward on dy): the saved tensor y behind dy IS the output of this
+  convolution, y = view(x) W rounded to the storage type, as in the network, and the call says so
+  (EDET_EPI_Y_IS_CONV_OF_INPUT): the library may then apply the b*y term through x and never read y.  Off: y is an
+  arbitrary tensor and the flag is not set (the library must read it)."""
   name, edt, tdt = dt
   skip_f32_big(name, pw_impl)
   n, h, w, cin, cout = shape
+  if conv_y is None:
+    conv_y = one_call and gbn
   rng = np.random.default_rng(gu.seed_of((shape, mode, gbn)))
   dz, y, ga, gb, gcc, dy = make_grad_view(rng, n, h, w, cout, tdt, gbn)
   wk = gu.rnd(rng, (cin, cout), tdt, 1.0 / np.sqrt(cout))
   x = gu.rnd(rng, (n, h, w, cin), tdt)
-  dyk = dy.to(torch.bfloat16).float() if name == 'bf16' else dy
-  d = (dyk.reshape(-1, cout) @ wk.t()).reshape(n, h, w, cin)   # gradient w.r.t. the view value
   scale = shift = gate = mean = rstd = None
   act = ACT_NONE
   old = None
@@ -176,9 +180,19 @@ def test_pw_bwd_data(dt, shape, mode, gbn, pw_impl, one_call=False, ws_mib=16):
   if mode in ('bn_swish_stats', 'gate'):
     act = VIEW_ACT
     x = off_kinks(x, scale, shift, act)
-  z = x * scale + shift if scale is not None else x
   if mode == 'gate':
     gate = torch.from_numpy(rng.uniform(0.2, 1.0, (n, cin)).astype(np.float32))
+  if conv_y and gbn:
+    # the forward this backward belongs to: bf16 operand, fp32 accumulate, stored in the storage type
+    fwd_in = apply_view(x, scale, shift, act, gate)
+    if name == 'bf16':
+      fwd_in = fwd_in.to(torch.bfloat16).float()
+    y = (fwd_in.reshape(-1, cin) @ wk).reshape(n, h, w, cout).to(tdt).float()
+    dy = ga * dz + gb * y + gcc
+  dyk = dy.to(torch.bfloat16).float() if name == 'bf16' else dy
+  d = (dyk.reshape(-1, cout) @ wk.t()).reshape(n, h, w, cin)   # gradient w.r.t. the view value
+  z = x * scale + shift if scale is not None else x
+  if mode == 'gate':
     want_g = d
     want_dgate = (d * act_oracle(z, act)).sum((1, 2))
   else:
@@ -207,7 +221,8 @@ def test_pw_bwd_data(dt, shape, mode, gbn, pw_impl, one_call=False, ws_mib=16):
   stats = mode == 'bn_swish_stats'
   md, rd = gu.fdev(mean), gu.fdev(rstd)
   epi = BwdEpi(ptr(gout), 1 if old is not None else 0, ptr(md) if stats else None, ptr(rd) if stats else None,
-               ptr(parts) if stats else None, ptr(dgate) if mode == 'gate' else None)
+               ptr(parts) if stats else None, ptr(dgate) if mode == 'gate' else None,
+               _lib.EPI_Y_IS_CONV_OF_INPUT if (conv_y and gbn) else 0)
   npart = NP(0)
   if one_call:
     av = apply_view(x, scale, shift, act, gate)
@@ -248,8 +263,12 @@ PW_BWD_SHAPES = [(4, 33, 31, 16, 96), (2, 17, 19, 24, 144), (3, 11, 13, 8, 16), 
 def test_pw_bwd(dt, shape, mode, gbn):
   """edet_pw_bwd: both gradients in one call.  The first five shapes are inside the fused kernel's envelope (cout >=
   2 cin: both load-pass instantiations, ragged maps, tiles that straddle images, cout % 8 != 0), the others outside
-  (the entry point then runs the two separate kernels)."""
+  (the entry point then runs the two separate kernels).  With a BatchNorm backward on dy both contracts are run: y is
+  this convolution's own output and the call says so (the plain-input cases inside the envelope then never read y),
+  and y is an arbitrary tensor without the flag."""
   test_pw_bwd_data(dt, shape, mode, gbn, 'auto', one_call=True)
+  if gbn:
+    test_pw_bwd_data(dt, shape, mode, gbn, 'auto', one_call=True, conv_y=False)
 
 
 @pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
