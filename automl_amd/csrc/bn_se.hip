@@ -366,6 +366,88 @@ __global__ __launch_bounds__(SE_FC_THREADS) void k_se_fc(float* __restrict__ poo
   }
 }
 
+// ---- the two 1x1 layers for WIDE squeeze-and-excitation blocks (c * se >= SE_SPLIT_MIN: the b5..b7 backbones) ----------
+// k_se_fc streams both weight matrices through ONE compute unit per image (3840 x 160: 4.9 MB; 144 us per call at
+// efficientdet-d7x batch 8, 7.5 ms per step).  Here the channel axis is cut into slices of SE_SLICE channels -- a
+// function of c only, so the summation order does not depend on the batch: (slice, image) workgroups produce partial
+// hidden sums (k_se_fc1_split), (slice, image) workgroups add them in slice order, apply bias + activation and compute
+// the gates of their slice (k_se_fc2_split).
+constexpr int SE_SLICE = 128;
+constexpr int SE_SPLIT_MIN = 1 << 17;
+__global__ __launch_bounds__(THREADS) void k_se_fc1_split(float* __restrict__ pooled,
+                                                         const float* __restrict__ pooled_parts, int nchunks, int c,
+                                                         int se, float inv_hw, const float* __restrict__ w1,
+                                                         float* __restrict__ hpart, int nslice) {
+  __shared__ float p[SE_SLICE];
+  __shared__ float hp[THREADS];
+  const int sl = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int c0 = sl * SE_SLICE, cn = min(SE_SLICE, c - c0);
+  for (int i = tid; i < cn; i += THREADS) {
+    float t;
+    if (pooled_parts) {
+      const float* q = pooled_parts + (size_t)n * nchunks * c + c0 + i;
+      t = q[0];
+      for (int k = 1; k < nchunks; ++k) t += q[(size_t)k * c];
+      pooled[(size_t)n * c + c0 + i] = t;
+    } else {
+      t = pooled[(size_t)n * c + c0 + i];
+    }
+    p[i] = t * inv_hw;
+  }
+  __syncthreads();
+  // thread (j, part): hidden unit j over the slice's channels part, part + nparts, ...; parts added in part order
+  float* dst = hpart + ((size_t)n * nslice + sl) * se;
+  for (int j0 = 0; j0 < se; j0 += THREADS) {           // se <= THREADS in practice: one round
+    const int seb = min(THREADS, se - j0);
+    const int nparts = THREADS / seb, j = tid % seb, part = tid / seb;
+    float a0 = 0.f, a1 = 0.f;
+    if (part < nparts) {
+      int i = part;
+      for (; i + nparts < cn; i += 2 * nparts) {
+        a0 = fmaf(p[i], w1[(size_t)(c0 + i) * se + j0 + j], a0);
+        a1 = fmaf(p[i + nparts], w1[(size_t)(c0 + i + nparts) * se + j0 + j], a1);
+      }
+      if (i < cn) a0 = fmaf(p[i], w1[(size_t)(c0 + i) * se + j0 + j], a0);
+      hp[part * seb + j] = a0 + a1;
+    }
+    __syncthreads();
+    if (tid < seb) {
+      float t = hp[tid];
+      for (int q = 1; q < nparts; ++q) t += hp[q * seb + tid];
+      dst[j0 + tid] = t;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(THREADS) void k_se_fc2_split(const float* __restrict__ hpart, int nslice, int c, int se,
+                                                         const float* __restrict__ b1, const float* __restrict__ w2,
+                                                         const float* __restrict__ b2, float* __restrict__ hidden_pre,
+                                                         float* __restrict__ gate, int act) {
+  extern __shared__ float h[];       // [se]
+  const int sl = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  for (int j = tid; j < se; j += THREADS) {
+    const float* q = hpart + (size_t)n * nslice * se + j;
+    float t = q[0];
+    for (int k = 1; k < nslice; ++k) t += q[(size_t)k * se];       // slices in slice order
+    const float acc = t + b1[j];
+    if (sl == 0) hidden_pre[(size_t)n * se + j] = acc;
+    h[j] = act_apply_(act, acc);
+  }
+  __syncthreads();
+  const int c0 = sl * SE_SLICE;
+  for (int i = c0 + tid; i < min(c, c0 + SE_SLICE); i += THREADS) {
+    float a0 = b2[i], a1 = 0.f;
+    int j = 0;
+    for (; j + 1 < se; j += 2) {
+      a0 = fmaf(h[j], w2[(size_t)j * c + i], a0);
+      a1 = fmaf(h[j + 1], w2[(size_t)(j + 1) * c + i], a1);
+    }
+    if (j < se) a0 = fmaf(h[j], w2[(size_t)j * c + i], a0);
+    gate[(size_t)n * c + i] = sigmoidf_(a0 + a1);
+  }
+}
+
 // per image: dgate -> dpre2, dh, dpre1, dpool.
 // scratch: dpre2 [n][c], dpre1 [n][se], hact = swish(hidden_pre) [n][se]
 __global__ __launch_bounds__(SE_FC_THREADS) void k_se_fc_bwd_img(const float* __restrict__ hidden_pre,
@@ -746,6 +828,16 @@ extern "C" int edet_se_squeeze_excite(const edet_tview_t* in, void* scratch, siz
   int nchunks = 1;
   if (se_pool_launch(in, (float*)scratch, scratch_bytes / sizeof(float), dtype, stream, &nchunks)) return -1;
   const int c = in->c;
+  // wide blocks: the sliced pair of kernels, if the partial hidden sums fit behind the pooling's chunk sums
+  const int nslice = cdiv(c, SE_SLICE);
+  const size_t used = ((size_t)in->n * nchunks * c + 63) / 64 * 64;
+  if ((int64_t)c * se >= SE_SPLIT_MIN && used + (size_t)in->n * nslice * se <= scratch_bytes / sizeof(float)) {
+    float* hpart = (float*)scratch + used;
+    edet_launch(k_se_fc1_split, dim3(nslice, in->n), dim3(THREADS), 0, to_stream(stream), pooled_sum, (const float*)scratch, nchunks, c, se, inv_hw, w1, hpart, nslice);
+    edet_launch(k_se_fc2_split, dim3(nslice, in->n), dim3(THREADS), (size_t)se * sizeof(float), to_stream(stream), (const float*)hpart, nslice, c, se, b1, w2, b2, hidden_pre, gate, act);
+    EDET_LAUNCH_CHECK("edet_se_squeeze_excite");
+    return 0;
+  }
   const int fc_threads = c >= 512 ? SE_FC_THREADS : THREADS;
   edet_launch(k_se_fc, dim3(in->n), dim3(fc_threads), se_fc_lds(c, se, fc_threads), to_stream(stream), pooled_sum, (const float*)scratch, nchunks, c, se, inv_hw, w1, b1, w2, b2, hidden_pre, gate, act);
   EDET_LAUNCH_CHECK("edet_se_squeeze_excite");

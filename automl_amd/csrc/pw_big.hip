@@ -23,6 +23,8 @@
 // Reference call sites replaced: tf.keras.layers.Conv2D 1x1 in efficientdet/backbone/efficientnet_model.py
 // :304-312 (expand), :345-353 (project), efficientdet/tf2/efficientdet_keras.py:286-290 (resample) and their
 // gradients (TF Conv2DBackpropInput / Conv2DBackpropFilter under tf.GradientTape, train_lib.py:623-669).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace pwb {
@@ -50,6 +52,18 @@ __device__ __forceinline__ uint4 pack8(const float x[8]) {
   o.x = pack2bf(x[0], x[1]); o.y = pack2bf(x[2], x[3]);
   o.z = pack2bf(x[4], x[5]); o.w = pack2bf(x[6], x[7]);
   return o;
+}
+
+// the first `nvalid` (1..7) bf16 elements of a 16-byte chunk, the others zeroed (a reduction length that is not a multiple
+// of 8: the chunk that straddles it carries padding columns, which may hold anything)
+__device__ __forceinline__ uint4 keep_first(uint4 v, int nvalid) {
+  uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (2 * i >= nvalid) w[i] = 0u;
+    else if (2 * i + 1 >= nvalid) w[i] &= 0xffffu;
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 struct GemmArgs {
@@ -248,8 +262,13 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
             if (CONV && !((cvalid >> i) & 1u)) v = make_uint4(0, 0, 0, 0);   // taps outside dy contribute nothing
           }
         }
+        uint4 bv = rb[i];
+        if (BWD && !GBN && !CONV && kok && a.R - k < 8) {     // ragged reduction length (the 810-column predict layers)
+          v = keep_first(v, a.R - k);
+          bv = keep_first(bv, a.R - k);
+        }
         *reinterpret_cast<uint4*>(As + (lr + 32 * i) * LDT + lc * 16) = v;
-        *reinterpret_cast<uint4*>(Bs + (lr + 32 * i) * LDT + lc * 16) = rb[i];
+        *reinterpret_cast<uint4*>(Bs + (lr + 32 * i) * LDT + lc * 16) = bv;
       }
     };
 
@@ -916,7 +935,11 @@ int pwb_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tvi
                   const edet_bwd_epi_t* epi, int* nparts_out, hipStream_t st) {
   using namespace pwb;
   const int R = dy->c, KO = in->c;
-  if (KO % 8 != 0 || in->ld % 8 != 0 || dy->ld % 8 != 0 || ldw % 8 != 0 || R % 8 != 0) return 0;
+  if (KO % 8 != 0 || in->ld % 8 != 0 || dy->ld % 8 != 0 || ldw % 8 != 0) return 0;
+  // a reduction length that is not a multiple of 8 (the 810 / 36 columns of the predict layers) only without a
+  // BatchNorm backward on dy (per-channel vectors are read in chunks of 8) and for the wide inputs the streaming
+  // kernels cannot take (efficientdet-d3 and up: 160 .. 384 filters); the straddling chunk is masked
+  if (R % 8 != 0 && (dy->a || KO < 160 || dy->ld < (R + 7) / 8 * 8 || ldw < (R + 7) / 8 * 8)) return 0;
   GemmArgs a;
   memset(&a, 0, sizeof(a));
   a.tv = *in; a.gv = *dy;
@@ -946,7 +969,11 @@ int pwb_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight
                   size_t workspace_bytes, hipStream_t st) {
   using namespace pwb;
   const int K = in->c, N = dy->c;
-  if (!workspace || K % 8 != 0 || N % 8 != 0 || dy->ld % 8 != 0 || in->ld % 8 != 0) return 0;
+  if (!workspace || K % 8 != 0 || dy->ld % 8 != 0 || in->ld % 8 != 0) return 0;
+  // N % 8 != 0 (predict layers): every output column depends on its own dy column only and the stores are guarded per
+  // element, so the padding columns of the straddling chunk never reach dW; as for the data gradient, only without a
+  // BatchNorm backward on dy and for the wide inputs
+  if (N % 8 != 0 && (dy->a || K < 160 || dy->ld < (N + 7) / 8 * 8)) return 0;
   WgArgs a;
   memset(&a, 0, sizeof(a));
   a.tv = *in; a.gv = *dy; a.ws = reinterpret_cast<float*>(workspace);
@@ -954,8 +981,11 @@ int pwb_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight
   a.ntk = (K + 127) / 128; a.ntn = (N + 127) / 128;
   const int ntile = a.ntk * a.ntn;
   const int64_t kn = (int64_t)K * N;
-  // ~2048 workgroups, at least 4 steps of 64 rows each, bounded by the workspace
-  int S = (2048 + ntile - 1) / ntile;
+  // ~2048 workgroups, at least 4 steps of 64 rows each, bounded by the workspace (EDET_WGRAD_WGS: lab switch for the
+  // workgroup target -- every split writes a K x N fp32 partial that edet_reduce_partials reads back)
+  const char* wgs_env = getenv("EDET_WGRAD_WGS");
+  const int wg_target = wgs_env ? atoi(wgs_env) : 2048;
+  int S = (wg_target + ntile - 1) / ntile;
   const int max_by_rows = (a.M + 4 * BK - 1) / (4 * BK);
   if (S > max_by_rows) S = max_by_rows;
   const int64_t max_by_ws = (int64_t)(workspace_bytes / sizeof(float)) / kn;

@@ -111,6 +111,12 @@ def build_case(entry, shape):
         tv = gu.tview(x, cin, vec(cin), vec(cin, -0.3, 0.3), gate, _lib.ACT_SWISH)
         epi = BwdEpi(ptr(gout), 0, None, None, None, ptr(dgate))
         keep = (wk, gout, dgate, dwt)
+      elif cout >= 2 * cin and cout != 810:
+        # MBConv expansion: the input is a stored block output (plain view, nothing to chain into) and dy's saved
+        # tensor is this convolution's own output -- the contract bit that lets the library leave y unread
+        tv = gu.tview(x, cin)
+        epi = BwdEpi(ptr(gout), 0, None, None, None, None, _lib.EPI_Y_IS_CONV_OF_INPUT)
+        keep = (wk, gout, dwt)
       else:
         tv = gu.tview(x, cin, vec(cin), vec(cin, -0.3, 0.3), None, _lib.ACT_SWISH)
         epi = BwdEpi(ptr(gout), 0, ptr(mean), ptr(rstd), ptr(parts), None)

@@ -368,7 +368,7 @@ class _D7xStep(object):
     self.losses = eng.loss_values()
     # the gradient of the logits (image 0; per-image loss terms are 1 / batch of the 1-image problem's) and the raw
     # (unclipped) gradient of every variable
-    self.dlogits = [(v.raw.grad[0].float().cpu() * batch) for v in eng.cls_views + eng.box_views]
+    self.dlogits = [(v.raw.grad[0, ..., :v.raw.c].float().cpu() * batch) for v in eng.cls_views + eng.box_views]
     self.grads = {name: eng.grad(name).detach().cpu().double().reshape(-1) for name in eng.seg_names}
     if not keep_engine:
       self.release()
