@@ -492,6 +492,69 @@ __global__ __launch_bounds__(SE_FC_THREADS) void k_se_fc_bwd_img(const float* __
   }
 }
 
+// the same per-image work for WIDE blocks (c * se >= SE_SPLIT_MIN), sliced over the channel axis like k_se_fc1_split /
+// k_se_fc2_split: (slice, image) workgroups make dpre2 and the slice's share of dh, then add the shares in slice order,
+// finish dpre1 / the activated hidden units and compute dpool of their slice.  hpart: [n][nslice][se] behind the
+// caller's scratch rows.
+__global__ __launch_bounds__(THREADS) void k_se_fc_bwd_img1(const float* __restrict__ gate,
+                                                           const float* __restrict__ dgate, int nimg, int c, int se,
+                                                           const float* __restrict__ w2, float* __restrict__ scratch,
+                                                           float* __restrict__ hpart, int nslice) {
+  __shared__ float d2[SE_SLICE];
+  const int sl = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int c0 = sl * SE_SLICE, cn = min(SE_SLICE, c - c0);
+  float* dpre2_g = scratch + (size_t)n * c;
+  for (int i = tid; i < SE_SLICE; i += THREADS) {
+    float v = 0.f;
+    if (i < cn) {
+      const float g = gate[(size_t)n * c + c0 + i];
+      v = dgate[(size_t)n * c + c0 + i] * g * (1.f - g);
+      dpre2_g[c0 + i] = v;
+    }
+    d2[i] = v;
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  float* dst = hpart + ((size_t)n * nslice + sl) * se;
+  for (int j = wave; j < se; j += THREADS / 64) {
+    float acc = 0.f;
+    for (int i = lane; i < cn; i += 64) acc = fmaf(d2[i], w2[(size_t)j * c + c0 + i], acc);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) dst[j] = acc;
+  }
+}
+
+__global__ __launch_bounds__(THREADS) void k_se_fc_bwd_img2(const float* __restrict__ hidden_pre,
+                                                           const float* __restrict__ hpart, int nslice, int nimg,
+                                                           int c, int se, float inv_hw, const float* __restrict__ w1,
+                                                           float* __restrict__ dpool, float* __restrict__ scratch,
+                                                           int act) {
+  extern __shared__ float d1[];      // [se]
+  const int sl = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  float* dpre1_g = scratch + (size_t)nimg * c + (size_t)n * se;
+  float* hact_g = scratch + (size_t)nimg * (c + se) + (size_t)n * se;
+  for (int j = tid; j < se; j += THREADS) {
+    const float* q = hpart + (size_t)n * nslice * se + j;
+    float t = q[0];
+    for (int k = 1; k < nslice; ++k) t += q[(size_t)k * se];
+    const float hp = hidden_pre[(size_t)n * se + j];
+    const float v = t * act_grad_(act, hp);
+    d1[j] = v;
+    if (sl == 0) {
+      dpre1_g[j] = v;
+      hact_g[j] = act_apply_(act, hp);
+    }
+  }
+  __syncthreads();
+  const int c0 = sl * SE_SLICE;
+  for (int i = c0 + tid; i < min(c, c0 + SE_SLICE); i += THREADS) {
+    float acc = 0.f;
+    for (int j = 0; j < se; ++j) acc = fmaf(d1[j], w1[(size_t)i * se + j], acc);
+    dpool[(size_t)n * c + i] = acc * inv_hw;
+  }
+}
+
 // parameter gradients.  Workgroup = 64 channels i x 4 hidden-unit groups, for one slice of the images
 // (blockIdx.y) and one block of SE_JB hidden units (blockIdx.z); thread (i, jg) owns the (i, j) pairs with
 // j % 4 == jg and sums over its images (loads coalesced along i); the image slices are combined with fp32
@@ -772,6 +835,10 @@ static int se_wg_per_img(int n, int hw, int rpp) {
 static int se_chunk_rows(int hw, int c, int rpp, int n, size_t scratch_floats, int* nchunks_out) {
   int cr = cdiv(cdiv(65536, c), rpp) * rpp;
   if (cr < 4 * rpp) cr = 4 * rpp;
+  // at most 64 chunks per image: the consumer adds an image's chunk sums one after the other (r03c: the 768x768 and
+  // 384x384 maps of efficientdet-d7x had 400-650 chunks and the FC kernel spent 100 us adding them)
+  const int cap = cdiv(cdiv(hw, 64), rpp) * rpp;
+  if (cr < cap) cr = cap;
   while ((size_t)n * cdiv(hw, cr) * c > scratch_floats && cr < hw) cr *= 2;
   *nchunks_out = cdiv(hw, cr);
   return cr;
@@ -852,7 +919,14 @@ extern "C" int edet_se_fc_bwd(const float* pooled_sum, const float* hidden_pre, 
   EDET_CHECK(act >= EDET_ACT_NONE && act <= EDET_ACT_LAST, "edet_se_fc_bwd: activation %d", act);
   EDET_CHECK(pooled_sum && hidden_pre && gate && dgate && w1 && w2 && dw1 && db1 && dw2 && db2 && dpool && scratch,
              "edet_se_fc_bwd: null pointer");
-  edet_launch(k_se_fc_bwd_img, dim3(n), dim3(c >= 512 ? SE_FC_THREADS : THREADS), (size_t)(c + se) * sizeof(float), to_stream(stream), hidden_pre, gate, dgate, n, c, se, inv_hw, w1, w2, dpool, scratch, act);
+  if ((int64_t)c * se >= SE_SPLIT_MIN) {      // wide blocks: sliced over the channel axis (the scratch holds [n][slices][se] more)
+    const int nslice = cdiv(c, SE_SLICE);
+    float* hpart = scratch + (size_t)n * (c + 2 * se);
+    edet_launch(k_se_fc_bwd_img1, dim3(nslice, n), dim3(THREADS), 0, to_stream(stream), gate, dgate, n, c, se, w2, scratch, hpart, nslice);
+    edet_launch(k_se_fc_bwd_img2, dim3(nslice, n), dim3(THREADS), (size_t)se * sizeof(float), to_stream(stream), hidden_pre, (const float*)hpart, nslice, n, c, se, inv_hw, w1, dpool, scratch, act);
+  } else {
+    edet_launch(k_se_fc_bwd_img, dim3(n), dim3(c >= 512 ? SE_FC_THREADS : THREADS), (size_t)(c + se) * sizeof(float), to_stream(stream), hidden_pre, gate, dgate, n, c, se, inv_hw, w1, w2, dpool, scratch, act);
+  }
   const int nsplit = n >= 2 * SE_SPLIT ? SE_SPLIT : 1;
   const int per_split = cdiv(n, nsplit);
   edet_launch(k_se_fc_bwd_par, dim3(cdiv(c, 64), cdiv(n, per_split), cdiv(se, SE_JB)), dim3(THREADS), (size_t)2 * SE_NB * SE_JB * sizeof(float), to_stream(stream), 

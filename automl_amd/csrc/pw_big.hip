@@ -981,10 +981,14 @@ int pwb_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight
   a.ntk = (K + 127) / 128; a.ntn = (N + 127) / 128;
   const int ntile = a.ntk * a.ntn;
   const int64_t kn = (int64_t)K * N;
-  // ~2048 workgroups, at least 4 steps of 64 rows each, bounded by the workspace (EDET_WGRAD_WGS: lab switch for the
-  // workgroup target -- every split writes a K x N fp32 partial that edet_reduce_partials reads back)
+  // Workgroup target, at least 4 steps of 64 rows each, bounded by the workspace.  Every split writes a K x N fp32
+  // partial that edet_reduce_partials reads back, so more splits are not free: r03c lab (scripts/kernel_lab.py
+  // --entry pw_bwd_weight --layers mid --ab EDET_WGRAD_WGS=2048,1024,512,256, D0 640x640 batch 128): the 16 mid-size
+  // layers take 2.96 ms at 2048 workgroups (round 2), 2.59 ms with 512 for K*N < 64 K and 1024 above -- at 2048 the
+  // partials of 1152 x 320 (76 splits, 112 MB written and read back) outweigh the 183 MB the kernel streams.
+  // EDET_WGRAD_WGS overrides (lab switch, read per call).
   const char* wgs_env = getenv("EDET_WGRAD_WGS");
-  const int wg_target = wgs_env ? atoi(wgs_env) : 2048;
+  const int wg_target = wgs_env ? atoi(wgs_env) : (kn >= 65536 ? 1024 : 512);
   int S = (wg_target + ntile - 1) / ntile;
   const int max_by_rows = (a.M + 4 * BK - 1) / (4 * BK);
   if (S > max_by_rows) S = max_by_rows;

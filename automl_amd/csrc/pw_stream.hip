@@ -1039,6 +1039,11 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
   if (GBN && !NOY) {
     loadf8(a.gv.a + colR * 8, ga); loadf8(a.gv.b + colR * 8, gb); loadf8(a.gv.cc + colR * 8, gc);
   }
+  // NOY: this lane's running column sums of x over all its tiles (KO <= 32: one epilogue chunk, the lane's 8 channels
+  // never change), added into wst once at the end
+  float xacc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) xacc[e] = 0.f;
   // NOY: the Gram matrix S = x^T x of this wave's rows, 16 x 16 tiles (s, s2) of the k side
   f32x4 accS[NOY ? FT_S : 1][NOY ? FT_S : 1];
 #pragma unroll
@@ -1156,7 +1161,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
             unpack8(*xslot, x);
             if (NOY) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) { d[e] += vv[e]; s1[e] += x[e]; }       // s1: sum_p x (the s of dW)
+              for (int e = 0; e < 8; ++e) { d[e] += vv[e]; xacc[e] += x[e]; }     // xacc: sum_p x (the s of dW)
             }
             // z (pre-activation), its activation av and the chained gradient g
             if (swish) {
@@ -1216,7 +1221,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
       // chunk sums -> wave LDS accumulators (8 lanes share a column: LDS atomics); raw sums (g, g*x): the
       // BatchNorm-backward form sum g*(x-mean)*rstd is taken from the totals at the end of the kernel
       if (col_ok) {
-        if (want_stats || NOY) {          // (NOY: no chain epilogue on that path; wst[0] collects sum_p x)
+        if (want_stats) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             if (ch0 + e < a.KO) {
@@ -1270,6 +1275,15 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
     __builtin_amdgcn_wave_barrier();
   }
   __builtin_amdgcn_wave_barrier();
+  if (NOY) {     // the lanes' column sums -> wst[0 .. KO) (8 row-lanes per column: LDS atomics, once per kernel)
+    const int ch0 = ecol * 8;
+    if (ch0 < a.KO) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (ch0 + e < a.KO) atomicAdd(&wst[ch0 + e], xacc[e]);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
   const float xsum = (NOY && lane < a.KO) ? wst[lane] : 0.f;      // NOY: this wave's sum_p x[p][lane] (KO <= 32)
   if (want_gate && gate_img >= 0) {
     for (int c = lane; c < a.KO; c += 64) {
@@ -1566,11 +1580,14 @@ int pws_try_bwd_fused(const edet_gview_t* dy, const void* w, int ldw, const edet
   const bool gbn = dy->a != nullptr;
   // NOY: BatchNorm backward without the saved convolution output (see the kernel's header): dy carries a BatchNorm
   // backward, the input is a plain stored tensor (x~ = x; no chain epilogue), whole 16-byte chunks of dz.
-  // EDET_PW_NOY=0 keeps the form that reads y (lab switch, read per call).
+  // OFF by default, EDET_PW_NOY=1 turns it on (lab switch, read per call): measured r03c, D0 640x640 batch 128 --
+  // 320x320x16->96 1.86 ms reading y, 2.31 ms without; 160x160x24->144 0.70 / 0.87 ms: the kernel runs one wave per
+  // SIMD with one tile of loads in flight and is bound by that latency, not by the 43 % of traffic NOY removes (and
+  // the registers y frees are not enough for a second tile in flight at 12 load passes).
   const char* noy_env = getenv("EDET_PW_NOY");
   const bool noy = gbn && (epi->flags & EDET_EPI_Y_IS_CONV_OF_INPUT) && dy->b && dy->cc && !in->scale && !in->gate &&
                    in->act == EDET_ACT_NONE &&
-                   !epi->stat_partials && !epi->dgate && R % 8 == 0 && !(noy_env && noy_env[0] == '0');
+                   !epi->stat_partials && !epi->dgate && R % 8 == 0 && KO <= 32 && noy_env && noy_env[0] == '1';
   a.SG = frag_stride(a.KOpad, false);
   a.kxsteps = (KO + 15) / 16;
   const size_t part = (size_t)KO * R + (noy ? (size_t)KO * KO + KO : 0);      // floats per workgroup partial
