@@ -1012,7 +1012,8 @@ inline void plan(Args& a, int C, int n, int space_w, int space_h, int max_p) {
   a.tiles_x = (space_w + a.TX - 1) / a.TX;
   a.tiles_y = (space_h + a.TY - 1) / a.TY;
   a.ntiles = n * a.tiles_x * a.tiles_y;
-  int P = 4096 / a.ngroups;
+  const char* p_env = getenv("EDET_DWM_P");          // lab switch: persistent workgroups x channel groups
+  int P = ((p_env && p_env[0]) ? atoi(p_env) : 4096) / a.ngroups;
   if (P < 64) P = 64;
   if (P > max_p) P = max_p;
   if (P > a.ntiles) P = a.ntiles;

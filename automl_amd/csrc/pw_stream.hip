@@ -21,6 +21,8 @@
 // Reference call sites replaced: tf.keras.layers.Conv2D 1x1 in efficientdet/backbone/efficientnet_model.py
 // :304-312 (expand), :345-353 (project); efficientdet/tf2/efficientdet_keras.py:286-290 (resample 1x1)
 // and the pointwise half of SeparableConv2D (:195-207, :459-464, :546-556).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace pws {
@@ -1377,6 +1379,12 @@ __global__ __launch_bounds__(256) void k_noy_apply(const float* __restrict__ psu
   dweight[i] += ga[n] * psum[i] + gb[n] * t + gc[n] * psum[(size_t)KO * R + (size_t)KO * KO + k];
 }
 
+// lab switches (read per call): integer environment variable or the default
+inline int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && e[0]) ? atoi(e) : dflt;
+}
+
 template <typename KernelT>
 inline bool allow_big_lds(KernelT kern, size_t lds) {
   if (lds <= 64 * 1024) return true;
@@ -1426,7 +1434,8 @@ int pws_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
   a.nwc = (a.Npad + a.NWC - 1) / a.NWC;
   if (a.nwc > 2) return 0;   // the big operand would be re-read too often: leave it to the tiled kernel
   const int nst = (a.M + TR * a.G - 1) / (TR * a.G);
-  int grid = (nst + WAVES * 2 - 1) / (WAVES * 2);      // >= 2 super-tiles per wave
+  const int spw_min = env_int("EDET_PWS_SPW", 2);          // >= 2 super-tiles per wave
+  int grid = (nst + WAVES * spw_min - 1) / (WAVES * spw_min);
   if (grid > EDET_MAX_PARTS) grid = EDET_MAX_PARTS;
   if (grid < 1) grid = 1;
   a.spw = (nst + grid * WAVES - 1) / (grid * WAVES);
@@ -1477,7 +1486,8 @@ int pws_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tvi
   }
   if (lds > 150 * 1024) return 0;
   const int nst = (a.M + TR * a.G - 1) / (TR * a.G);
-  int grid = (nst + WAVES * 2 - 1) / (WAVES * 2);
+  const int spw_min = env_int("EDET_PWS_SPW", 2);
+  int grid = (nst + WAVES * spw_min - 1) / (WAVES * spw_min);
   if (grid > EDET_MAX_PARTS) grid = EDET_MAX_PARTS;
   if (grid < 1) grid = 1;
   a.spw = (nst + grid * WAVES - 1) / (grid * WAVES);
@@ -1515,7 +1525,7 @@ int pws_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight
   while (a.cpwV < nvecV) a.cpwV <<= 1;
   // row splits: ~2048 waves in total, at least 8 steps of 32 rows each, bounded by the workspace
   const int64_t kn = (int64_t)K * N;
-  int S = 2048 / a.nus;
+  int S = env_int("EDET_PWS_WG_TARGET", 2048) / a.nus;
   const int max_by_rows = (a.M + 8 * TR - 1) / (8 * TR);
   if (S > max_by_rows) S = max_by_rows;
   const int64_t max_by_ws = (int64_t)(workspace_bytes / sizeof(float)) / kn;
@@ -1597,7 +1607,7 @@ int pws_try_bwd_fused(const edet_gview_t* dy, const void* w, int ldw, const edet
   if (lds > 150 * 1024 || lds < (size_t)KO * R * 4) return 0;
   const int ntile = (a.M + TR - 1) / TR;
   // one workgroup per CU and wave (1 wave per SIMD); at least 4 tiles per wave, partials bounded by the workspace
-  int grid = 1024;
+  int grid = env_int("EDET_PWS_FUSED_GRID", 1024);
   const int64_t max_by_ws = (int64_t)(workspace_bytes / sizeof(float)) / (int64_t)part - (noy ? 1 : 0);
   if (grid > max_by_ws) grid = (int)max_by_ws;
   if (grid > EDET_MAX_PARTS) grid = EDET_MAX_PARTS;
