@@ -366,55 +366,73 @@ __global__ __launch_bounds__(SE_FC_THREADS) void k_se_fc(float* __restrict__ poo
   }
 }
 
-// ---- the two 1x1 layers for WIDE squeeze-and-excitation blocks (c * se >= SE_SPLIT_MIN: the b5..b7 backbones) ----------
-// k_se_fc streams both weight matrices through ONE compute unit per image (3840 x 160: 4.9 MB; 144 us per call at
-// efficientdet-d7x batch 8, 7.5 ms per step).  Here the channel axis is cut into slices of SE_SLICE channels -- a
-// function of c only, so the summation order does not depend on the batch: (slice, image) workgroups produce partial
-// hidden sums (k_se_fc1_split), (slice, image) workgroups add them in slice order, apply bias + activation and compute
-// the gates of their slice (k_se_fc2_split).
+// ---- the two 1x1 layers for WIDE squeeze-and-excitation blocks (c * se >= SE_SPLIT_MIN) ------------------------------
+// k_se_fc streams both weight matrices through ONE compute unit per image: 3840 x 160 is 4.9 MB (144 us per call at
+// efficientdet-d7x batch 8, 7.5 ms per step), and at batch 256 (efficientnetv2-s, 1536 x 64) every image's workgroup
+// re-reads the same 0.8 MB from L2 (17 us per call, L2-bound).  Here the channel axis is cut into slices of SE_SLICE
+// channels -- a function of c only, so the summation order of an image does not depend on the batch -- and a workgroup
+// handles SE_IB images at once, so a weight element is loaded once per SE_IB images: (slice, image block) workgroups
+// produce partial hidden sums (k_se_fc1_split), (slice, image block) workgroups add them in slice order, apply bias +
+// activation and compute the gates of their slice (k_se_fc2_split).  Each image's sums are formed exactly as with
+// SE_IB = 1 (its own accumulators, same order).
 constexpr int SE_SLICE = 128;
-constexpr int SE_SPLIT_MIN = 1 << 17;
+constexpr int SE_IB = 4;
+constexpr int SE_SPLIT_MIN = 1 << 15;       // forward (image-blocked: also pays at large batch)
+constexpr int SE_SPLIT_MIN_BWD = 1 << 17;   // backward (per image: pays where one CU per image is the bottleneck)
 __global__ __launch_bounds__(THREADS) void k_se_fc1_split(float* __restrict__ pooled,
                                                          const float* __restrict__ pooled_parts, int nchunks, int c,
                                                          int se, float inv_hw, const float* __restrict__ w1,
-                                                         float* __restrict__ hpart, int nslice) {
-  __shared__ float p[SE_SLICE];
-  __shared__ float hp[THREADS];
-  const int sl = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+                                                         float* __restrict__ hpart, int nslice, int nimg) {
+  __shared__ float p[SE_IB][SE_SLICE];
+  __shared__ float hp[SE_IB][THREADS];
+  const int sl = blockIdx.x, n0 = blockIdx.y * SE_IB, tid = threadIdx.x;
   const int c0 = sl * SE_SLICE, cn = min(SE_SLICE, c - c0);
-  for (int i = tid; i < cn; i += THREADS) {
-    float t;
-    if (pooled_parts) {
-      const float* q = pooled_parts + (size_t)n * nchunks * c + c0 + i;
-      t = q[0];
-      for (int k = 1; k < nchunks; ++k) t += q[(size_t)k * c];
-      pooled[(size_t)n * c + c0 + i] = t;
-    } else {
-      t = pooled[(size_t)n * c + c0 + i];
+  for (int q = tid; q < SE_IB * SE_SLICE; q += THREADS) {
+    const int b = q / SE_SLICE, i = q - b * SE_SLICE, n = n0 + b;
+    float t = 0.f;
+    if (i < cn && n < nimg) {
+      if (pooled_parts) {
+        const float* src = pooled_parts + (size_t)n * nchunks * c + c0 + i;
+        t = src[0];
+        for (int k = 1; k < nchunks; ++k) t += src[(size_t)k * c];
+        pooled[(size_t)n * c + c0 + i] = t;
+      } else {
+        t = pooled[(size_t)n * c + c0 + i];
+      }
     }
-    p[i] = t * inv_hw;
+    p[b][i] = t * inv_hw;
   }
   __syncthreads();
   // thread (j, part): hidden unit j over the slice's channels part, part + nparts, ...; parts added in part order
-  float* dst = hpart + ((size_t)n * nslice + sl) * se;
   for (int j0 = 0; j0 < se; j0 += THREADS) {           // se <= THREADS in practice: one round
     const int seb = min(THREADS, se - j0);
     const int nparts = THREADS / seb, j = tid % seb, part = tid / seb;
-    float a0 = 0.f, a1 = 0.f;
     if (part < nparts) {
+      float a0[SE_IB], a1[SE_IB];
+#pragma unroll
+      for (int b = 0; b < SE_IB; ++b) a0[b] = a1[b] = 0.f;
       int i = part;
       for (; i + nparts < cn; i += 2 * nparts) {
-        a0 = fmaf(p[i], w1[(size_t)(c0 + i) * se + j0 + j], a0);
-        a1 = fmaf(p[i + nparts], w1[(size_t)(c0 + i + nparts) * se + j0 + j], a1);
+        const float u = w1[(size_t)(c0 + i) * se + j0 + j], v = w1[(size_t)(c0 + i + nparts) * se + j0 + j];
+#pragma unroll
+        for (int b = 0; b < SE_IB; ++b) { a0[b] = fmaf(p[b][i], u, a0[b]); a1[b] = fmaf(p[b][i + nparts], v, a1[b]); }
       }
-      if (i < cn) a0 = fmaf(p[i], w1[(size_t)(c0 + i) * se + j0 + j], a0);
-      hp[part * seb + j] = a0 + a1;
+      if (i < cn) {
+        const float u = w1[(size_t)(c0 + i) * se + j0 + j];
+#pragma unroll
+        for (int b = 0; b < SE_IB; ++b) a0[b] = fmaf(p[b][i], u, a0[b]);
+      }
+#pragma unroll
+      for (int b = 0; b < SE_IB; ++b) hp[b][part * seb + j] = a0[b] + a1[b];
     }
     __syncthreads();
-    if (tid < seb) {
-      float t = hp[tid];
-      for (int q = 1; q < nparts; ++q) t += hp[q * seb + tid];
-      dst[j0 + tid] = t;
+    for (int q = tid; q < SE_IB * seb; q += THREADS) {
+      const int b = q / seb, jj = q - b * seb;
+      if (n0 + b < nimg) {
+        float t = hp[b][jj];
+        for (int r = 1; r < nparts; ++r) t += hp[b][r * seb + jj];
+        hpart[((size_t)(n0 + b) * nslice + sl) * se + j0 + jj] = t;
+      }
     }
     __syncthreads();
   }
@@ -423,28 +441,42 @@ __global__ __launch_bounds__(THREADS) void k_se_fc1_split(float* __restrict__ po
 __global__ __launch_bounds__(THREADS) void k_se_fc2_split(const float* __restrict__ hpart, int nslice, int c, int se,
                                                          const float* __restrict__ b1, const float* __restrict__ w2,
                                                          const float* __restrict__ b2, float* __restrict__ hidden_pre,
-                                                         float* __restrict__ gate, int act) {
-  extern __shared__ float h[];       // [se]
-  const int sl = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
-  for (int j = tid; j < se; j += THREADS) {
-    const float* q = hpart + (size_t)n * nslice * se + j;
-    float t = q[0];
-    for (int k = 1; k < nslice; ++k) t += q[(size_t)k * se];       // slices in slice order
-    const float acc = t + b1[j];
-    if (sl == 0) hidden_pre[(size_t)n * se + j] = acc;
-    h[j] = act_apply_(act, acc);
+                                                         float* __restrict__ gate, int act, int nimg) {
+  extern __shared__ float h[];       // [SE_IB][se]
+  const int sl = blockIdx.x, n0 = blockIdx.y * SE_IB, tid = threadIdx.x;
+  for (int q = tid; q < SE_IB * se; q += THREADS) {
+    const int b = q / se, j = q - b * se, n = n0 + b;
+    float v = 0.f;
+    if (n < nimg) {
+      const float* src = hpart + (size_t)n * nslice * se + j;
+      float t = src[0];
+      for (int k = 1; k < nslice; ++k) t += src[(size_t)k * se];       // slices in slice order
+      const float acc = t + b1[j];
+      if (sl == 0) hidden_pre[(size_t)n * se + j] = acc;
+      v = act_apply_(act, acc);
+    }
+    h[q] = v;
   }
   __syncthreads();
   const int c0 = sl * SE_SLICE;
   for (int i = c0 + tid; i < min(c, c0 + SE_SLICE); i += THREADS) {
-    float a0 = b2[i], a1 = 0.f;
+    float a0[SE_IB], a1[SE_IB];
+#pragma unroll
+    for (int b = 0; b < SE_IB; ++b) { a0[b] = b2[i]; a1[b] = 0.f; }
     int j = 0;
     for (; j + 1 < se; j += 2) {
-      a0 = fmaf(h[j], w2[(size_t)j * c + i], a0);
-      a1 = fmaf(h[j + 1], w2[(size_t)(j + 1) * c + i], a1);
+      const float u = w2[(size_t)j * c + i], v = w2[(size_t)(j + 1) * c + i];
+#pragma unroll
+      for (int b = 0; b < SE_IB; ++b) { a0[b] = fmaf(h[b * se + j], u, a0[b]); a1[b] = fmaf(h[b * se + j + 1], v, a1[b]); }
     }
-    if (j < se) a0 = fmaf(h[j], w2[(size_t)j * c + i], a0);
-    gate[(size_t)n * c + i] = sigmoidf_(a0 + a1);
+    if (j < se) {
+      const float u = w2[(size_t)j * c + i];
+#pragma unroll
+      for (int b = 0; b < SE_IB; ++b) a0[b] = fmaf(h[b * se + j], u, a0[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < SE_IB; ++b)
+      if (n0 + b < nimg) gate[(size_t)(n0 + b) * c + i] = sigmoidf_(a0[b] + a1[b]);
   }
 }
 
@@ -492,7 +524,7 @@ __global__ __launch_bounds__(SE_FC_THREADS) void k_se_fc_bwd_img(const float* __
   }
 }
 
-// the same per-image work for WIDE blocks (c * se >= SE_SPLIT_MIN), sliced over the channel axis like k_se_fc1_split /
+// the same per-image work for WIDE blocks (c * se >= SE_SPLIT_MIN_BWD), sliced over the channel axis like k_se_fc1_split /
 // k_se_fc2_split: (slice, image) workgroups make dpre2 and the slice's share of dh, then add the shares in slice order,
 // finish dpre1 / the activated hidden units and compute dpool of their slice.  hpart: [n][nslice][se] behind the
 // caller's scratch rows.
@@ -900,8 +932,9 @@ extern "C" int edet_se_squeeze_excite(const edet_tview_t* in, void* scratch, siz
   const size_t used = ((size_t)in->n * nchunks * c + 63) / 64 * 64;
   if ((int64_t)c * se >= SE_SPLIT_MIN && used + (size_t)in->n * nslice * se <= scratch_bytes / sizeof(float)) {
     float* hpart = (float*)scratch + used;
-    edet_launch(k_se_fc1_split, dim3(nslice, in->n), dim3(THREADS), 0, to_stream(stream), pooled_sum, (const float*)scratch, nchunks, c, se, inv_hw, w1, hpart, nslice);
-    edet_launch(k_se_fc2_split, dim3(nslice, in->n), dim3(THREADS), (size_t)se * sizeof(float), to_stream(stream), (const float*)hpart, nslice, c, se, b1, w2, b2, hidden_pre, gate, act);
+    const int nblk = cdiv(in->n, SE_IB);
+    edet_launch(k_se_fc1_split, dim3(nslice, nblk), dim3(THREADS), 0, to_stream(stream), pooled_sum, (const float*)scratch, nchunks, c, se, inv_hw, w1, hpart, nslice, in->n);
+    edet_launch(k_se_fc2_split, dim3(nslice, nblk), dim3(THREADS), (size_t)SE_IB * se * sizeof(float), to_stream(stream), (const float*)hpart, nslice, c, se, b1, w2, b2, hidden_pre, gate, act, in->n);
     EDET_LAUNCH_CHECK("edet_se_squeeze_excite");
     return 0;
   }
@@ -919,7 +952,7 @@ extern "C" int edet_se_fc_bwd(const float* pooled_sum, const float* hidden_pre, 
   EDET_CHECK(act >= EDET_ACT_NONE && act <= EDET_ACT_LAST, "edet_se_fc_bwd: activation %d", act);
   EDET_CHECK(pooled_sum && hidden_pre && gate && dgate && w1 && w2 && dw1 && db1 && dw2 && db2 && dpool && scratch,
              "edet_se_fc_bwd: null pointer");
-  if ((int64_t)c * se >= SE_SPLIT_MIN) {      // wide blocks: sliced over the channel axis (the scratch holds [n][slices][se] more)
+  if ((int64_t)c * se >= SE_SPLIT_MIN_BWD) {      // wide blocks: sliced over the channel axis (the scratch holds [n][slices][se] more)
     const int nslice = cdiv(c, SE_SLICE);
     float* hpart = scratch + (size_t)n * (c + 2 * se);
     edet_launch(k_se_fc_bwd_img1, dim3(nslice, n), dim3(THREADS), 0, to_stream(stream), gate, dgate, n, c, se, w2, scratch, hpart, nslice);

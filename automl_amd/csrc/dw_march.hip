@@ -991,7 +991,7 @@ inline int pick_nch(int nvec, int maxch) {
 
 // space_w / space_h: extent of the marched tile space (output pixels; for dgrad the q / oy step space)
 template <int CPT>
-inline void plan(Args& a, int C, int n, int space_w, int space_h, int max_p) {
+inline void plan(Args& a, int C, int n, int space_w, int space_h, int max_p, int k) {
   const int nvec = (C + CPT - 1) / CPT;
   // <= 128 contiguous bytes per pixel and workgroup.  (r02t lab: 64- or 32-byte channel groups for the two-channel
   // kernels -- wider column tiles, half the column halo -- are slower: backward 11.04 -> 11.40 / 12.01 ms, forward
@@ -1012,8 +1012,13 @@ inline void plan(Args& a, int C, int n, int space_w, int space_h, int max_p) {
   a.tiles_x = (space_w + a.TX - 1) / a.TX;
   a.tiles_y = (space_h + a.TY - 1) / a.TY;
   a.ntiles = n * a.tiles_x * a.tiles_y;
-  const char* p_env = getenv("EDET_DWM_P");          // lab switch: persistent workgroups x channel groups
-  int P = ((p_env && p_env[0]) ? atoi(p_env) : 4096) / a.ngroups;
+  // Persistent workgroups x channel groups.  r03d lab (scripts/kernel_lab.py --ab EDET_DWM_P=4096,2048,8192, the 15
+  // depthwise layer shapes of D0 640x640 batch 128): the 3x3 layers on the 160 / 320-row maps want many short-lived
+  // workgroups (8192: 320x320x32 fused backward 1.00 -> 0.86 ms, forward 0.61 -> 0.52 ms), every other layer fewer,
+  // longer-lived ones (2048: 40x40x480 k5 backward 0.65 -> 0.54, 20x20x1152 k5 0.46 -> 0.38 ms); over the 15 shapes
+  // backward 11.21 -> 10.52 ms, forward 4.84 -> 4.67 ms against round 2's 4096 everywhere.  EDET_DWM_P overrides.
+  const char* p_env = getenv("EDET_DWM_P");
+  int P = ((p_env && p_env[0]) ? atoi(p_env) : ((k == 3 && a.in.h >= 160) ? 8192 : 2048)) / a.ngroups;
   if (P < 64) P = 64;
   if (P > max_p) P = max_p;
   if (P > a.ntiles) P = a.ntiles;
@@ -1035,7 +1040,7 @@ int dwm_try_fwd(const edet_tview_t* in, const float* weight, int k, int s, void*
   a.pad_t = same_pad_before(in->h, k, s); a.pad_l = same_pad_before(in->w, k, s);
 #define DWM_FWD(K_, S_, CPT_)                                                             \
   do {                                                                                    \
-    plan<CPT_>(a, in->c, in->n, a.ow, a.oh, EDET_MAX_PARTS);                              \
+    plan<CPT_>(a, in->c, in->n, a.ow, a.oh, EDET_MAX_PARTS, K_);                          \
     const size_t lds0 = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                  \
     const size_t ring = (size_t)2 * (a.TX * S_ + K_ - S_) * a.nch * CPT_ * sizeof(float); \
     if (oact) edet_launch(k_fwd_lx<K_, S_, CPT_, true>, dim3(a.P * a.ngroups), dim3(THREADS), lds0 + ring, st, a); \
@@ -1069,7 +1074,7 @@ int dwm_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, 
   const bool gbn = dy->a != nullptr;
 #define DWM_WG(K_, S_, CPT_)                                                              \
   do {                                                                                    \
-    plan<CPT_>(a, in->c, in->n, a.ow, a.oh, max_p);                                       \
+    plan<CPT_>(a, in->c, in->n, a.ow, a.oh, max_p, K_);                                   \
     const size_t lds = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                   \
     const size_t ring = (size_t)2 * (a.TX * S_ + K_ - S_) * a.nch * CPT_ * sizeof(float); \
     const dim3 grid(a.P * a.ngroups), block(THREADS);                                     \
@@ -1101,7 +1106,7 @@ int dwm_try_dgrad(const edet_gview_t* dy, const float* weight, int k, int s, con
   const bool gbn = dy->a != nullptr;
 #define DWM_DG(K_, S_, CPT_)                                                              \
   do {                                                                                    \
-    plan<CPT_>(a, in->c, in->n, QW, QH, EDET_MAX_PARTS);                                  \
+    plan<CPT_>(a, in->c, in->n, QW, QH, EDET_MAX_PARTS, K_);                              \
     const size_t lds = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                   \
     const size_t ring = (size_t)2 * (a.TX + (K_ + S_ - 1) / S_ - 1) * a.nch * CPT_ * sizeof(float); \
     const dim3 grid(a.P * a.ngroups), block(THREADS);                                     \
@@ -1141,7 +1146,7 @@ int dwm_try_bwd_fused(const edet_gview_t* dy, const float* weight, int k, int s,
   const bool gbn = dy->a != nullptr;
 #define DWM_FUSED(K_, CPT_)                                                               \
   do {                                                                                    \
-    plan<CPT_>(a, in->c, in->n, in->w, in->h, max_p);                                     \
+    plan<CPT_>(a, in->c, in->n, in->w, in->h, max_p, K_);                                 \
     const size_t lds = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                   \
     const size_t ring = (size_t)2 * (a.TX + K_ - 1) * a.nch * CPT_ * sizeof(float);       \
     const dim3 grid(a.P * a.ngroups), block(THREADS);                                     \

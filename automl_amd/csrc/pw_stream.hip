@@ -1434,7 +1434,8 @@ int pws_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
   a.nwc = (a.Npad + a.NWC - 1) / a.NWC;
   if (a.nwc > 2) return 0;   // the big operand would be re-read too often: leave it to the tiled kernel
   const int nst = (a.M + TR * a.G - 1) / (TR * a.G);
-  const int spw_min = env_int("EDET_PWS_SPW", 2);          // >= 2 super-tiles per wave
+  // >= 4 super-tiles per wave (r03d lab, 24 pointwise layer shapes: 2 / 4 / 8 / 16 -> forward 4.85 / 4.79 / 4.82 / 4.87 ms)
+  const int spw_min = env_int("EDET_PWS_SPW", 4);
   int grid = (nst + WAVES * spw_min - 1) / (WAVES * spw_min);
   if (grid > EDET_MAX_PARTS) grid = EDET_MAX_PARTS;
   if (grid < 1) grid = 1;
@@ -1486,7 +1487,7 @@ int pws_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tvi
   }
   if (lds > 150 * 1024) return 0;
   const int nst = (a.M + TR * a.G - 1) / (TR * a.G);
-  const int spw_min = env_int("EDET_PWS_SPW", 2);
+  const int spw_min = env_int("EDET_PWS_SPW", 4);      // r03d lab: 2 / 4 / 8 -> backward 16.62 / 16.49 / 16.45 ms over 24 shapes
   int grid = (nst + WAVES * spw_min - 1) / (WAVES * spw_min);
   if (grid > EDET_MAX_PARTS) grid = EDET_MAX_PARTS;
   if (grid < 1) grid = 1;
@@ -1590,14 +1591,14 @@ int pws_try_bwd_fused(const edet_gview_t* dy, const void* w, int ldw, const edet
   const bool gbn = dy->a != nullptr;
   // NOY: BatchNorm backward without the saved convolution output (see the kernel's header): dy carries a BatchNorm
   // backward, the input is a plain stored tensor (x~ = x; no chain epilogue), whole 16-byte chunks of dz.
-  // OFF by default, EDET_PW_NOY=1 turns it on (lab switch, read per call): measured r03c, D0 640x640 batch 128 --
-  // 320x320x16->96 1.86 ms reading y, 2.31 ms without; 160x160x24->144 0.70 / 0.87 ms: the kernel runs one wave per
-  // SIMD with one tile of loads in flight and is bound by that latency, not by the 43 % of traffic NOY removes (and
-  // the registers y frees are not enough for a second tile in flight at 12 load passes).
+  // EDET_PW_NOY=0 keeps the form that reads y (lab switch, read per call).  r03c, first version (column sums of x through
+  // 16 LDS atomics per tile): SLOWER than reading y, 320x320x16->96 1.86 -> 2.31 ms -- the kernel runs one wave per SIMD
+  // with one tile of loads in flight and is bound by that latency, not by bytes.  r03d, sums kept in registers across the
+  // tiles: 1.90 -> 1.75 ms, 160x160x24->144 0.76 -> 0.68 ms (-8 / -10 %), with 43 % less traffic.
   const char* noy_env = getenv("EDET_PW_NOY");
   const bool noy = gbn && (epi->flags & EDET_EPI_Y_IS_CONV_OF_INPUT) && dy->b && dy->cc && !in->scale && !in->gate &&
                    in->act == EDET_ACT_NONE &&
-                   !epi->stat_partials && !epi->dgate && R % 8 == 0 && KO <= 32 && noy_env && noy_env[0] == '1';
+                   !epi->stat_partials && !epi->dgate && R % 8 == 0 && KO <= 32 && !(noy_env && noy_env[0] == '0');
   a.SG = frag_stride(a.KOpad, false);
   a.kxsteps = (KO + 15) / 16;
   const size_t part = (size_t)KO * R + (noy ? (size_t)KO * KO + KO : 0);      // floats per workgroup partial
@@ -1607,7 +1608,9 @@ int pws_try_bwd_fused(const edet_gview_t* dy, const void* w, int ldw, const edet
   if (lds > 150 * 1024 || lds < (size_t)KO * R * 4) return 0;
   const int ntile = (a.M + TR - 1) / TR;
   // one workgroup per CU and wave (1 wave per SIMD); at least 4 tiles per wave, partials bounded by the workspace
-  int grid = env_int("EDET_PWS_FUSED_GRID", 1024);
+  // one workgroup per compute unit, a single round (r03d lab: grids of 1024 / 512 / 256 -> 320x320x16->96 1.90 / 1.83 /
+  // 1.81 ms, 160x160x24->144 0.69 / 0.64 / 0.61 ms: every workgroup pays the prologue and the dW partial once)
+  int grid = env_int("EDET_PWS_FUSED_GRID", 256);
   const int64_t max_by_ws = (int64_t)(workspace_bytes / sizeof(float)) / (int64_t)part - (noy ? 1 : 0);
   if (grid > max_by_ws) grid = (int)max_by_ws;
   if (grid > EDET_MAX_PARTS) grid = EDET_MAX_PARTS;
