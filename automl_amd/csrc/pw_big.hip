@@ -876,6 +876,14 @@ inline bool big_lds_ok(const void* kern) {
 
 }  // namespace pwb
 
+// consecutive row tiles per workgroup: as few as the partial-row limit allows; EDET_BIG_TPW = a minimum (lab switch)
+static int big_tpw(int ntm) {
+  int t = (ntm + EDET_MAX_PARTS - 1) / EDET_MAX_PARTS;
+  const char* e = getenv("EDET_BIG_TPW");
+  if (e && e[0] && atoi(e) > t) t = atoi(e);
+  return t;
+}
+
 // return 1 = handled, 0 = shape outside the envelope (caller falls back), < 0 = error
 int pwb_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bias, void* out, int cout,
                 int ldo, float* stat_partials, int* nparts_out, hipStream_t st) {
@@ -889,7 +897,7 @@ int pwb_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
   a.M = in->n * in->h * in->w; a.R = K; a.J = N; a.hw = in->h * in->w;
   a.bias = bias; a.out = reinterpret_cast<bf16_t*>(out); a.ldo = ldo; a.stat_partials = stat_partials;
   a.ntm = (a.M + BM - 1) / BM; a.ntj = (N + BJ - 1) / BJ;
-  a.tpw = (a.ntm + EDET_MAX_PARTS - 1) / EDET_MAX_PARTS;
+  a.tpw = big_tpw(a.ntm);
   a.ngrp = (a.ntm + a.tpw - 1) / a.tpw;
   if (nparts_out) *nparts_out = a.ngrp;
   static const bool ok = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<false, false>)) &&
@@ -920,7 +928,7 @@ int pwb_try_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, int k, int
   a.pad_t = same_pad_before(in->h, k, s); a.pad_l = same_pad_before(in->w, k, s);
   a.bias = bias; a.out = reinterpret_cast<bf16_t*>(out); a.ldo = ldo; a.stat_partials = stat_partials;
   a.ntm = (a.M + BM - 1) / BM; a.ntj = (N + BJ - 1) / BJ;
-  a.tpw = (a.ntm + EDET_MAX_PARTS - 1) / EDET_MAX_PARTS;
+  a.tpw = big_tpw(a.ntm);
   a.ngrp = (a.ntm + a.tpw - 1) / a.tpw;
   if (nparts_out) *nparts_out = a.ngrp;
   static const bool ok = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<false, false, true>));
@@ -947,7 +955,7 @@ int pwb_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tvi
   a.M = in->n * in->h * in->w; a.R = R; a.J = KO; a.hw = in->h * in->w;
   a.epi = *epi; a.stat_partials = epi->stat_partials;
   a.ntm = (a.M + BM - 1) / BM; a.ntj = (KO + BJ - 1) / BJ;
-  a.tpw = (a.ntm + EDET_MAX_PARTS - 1) / EDET_MAX_PARTS;
+  a.tpw = big_tpw(a.ntm);
   a.ngrp = (a.ntm + a.tpw - 1) / a.tpw;
   if (nparts_out) *nparts_out = a.ngrp;
   static const bool ok1 = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<true, false>)) &&
@@ -1034,7 +1042,7 @@ int pwb_try_conv_dgrad(const edet_gview_t* dy, const void* w_t, int ldw, int k, 
   a.pad_t = same_pad_before(in->h, k, s); a.pad_l = same_pad_before(in->w, k, s);
   a.epi = *epi; a.stat_partials = epi->stat_partials;
   a.ntm = (a.M + BM - 1) / BM; a.ntj = (cin + BJ - 1) / BJ;
-  a.tpw = (a.ntm + EDET_MAX_PARTS - 1) / EDET_MAX_PARTS;
+  a.tpw = big_tpw(a.ntm);
   a.ngrp = (a.ntm + a.tpw - 1) / a.tpw;
   if (nparts_out) *nparts_out = a.ngrp;
   static const bool ok1 = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<true, false, true>));
