@@ -664,9 +664,15 @@ static int pw_impl_env() {
 // totals in ms at threshold 2048 / 4096 / 8192 / 24576: forward 8.54 / 7.98 / 7.87 / 8.05, data gradient
 // 12.15 / 12.85 / 12.88 / 13.4, weight gradient 14.21 / 14.26 / 14.51 / 14.4).
 enum { PW_OP_FWD = 0, PW_OP_DGRAD = 1, PW_OP_WGRAD = 2 };
+// r03e (lab, per layer, EDET_PW_IMPL=big against stream with the round-3 workgroup targets): the weight gradient of
+// the 96 -> 24 and 144 -> 24 project layers on the 160-row maps is 7 / 22 % faster tiled (0.42 / 0.80 ms against
+// 0.45 / 1.02 ms) -> threshold 4096 -> 2048; the forward 64 -> 64 layers of the 20x20 and smaller levels take 9 us
+// tiled against 19 us streamed -> tiled from 4096 when the map has at most 64 K rows.
 static bool pw_prefers_big(int op, int64_t rows, int cin, int cout) {
-  static const int64_t minkn[3] = {8192, 2048, 4096};
-  return (int64_t)cin * cout >= minkn[op] && rows >= 1024;
+  static const int64_t minkn[3] = {8192, 2048, 2048};
+  const int64_t kn = (int64_t)cin * cout;
+  if (op == PW_OP_FWD && kn >= 4096 && rows <= 65536 && rows >= 1024) return true;
+  return kn >= minkn[op] && rows >= 1024;
 }
 
 // streaming bf16 kernels (pw_stream.hip); return 1 = handled, 0 = shape outside their envelope
