@@ -39,7 +39,9 @@ __global__ __launch_bounds__(THREADS) void k_focal(const T* __restrict__ logits,
   float loss_acc = 0.f, db[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) db[e] = 0.f;
-  if (ok) {
+  if (ok && nc < 8) {
+    // fewer than 8 classes: an 8-element chunk can span more than two anchors -- the simple form, one row at a time,
+    // the anchor's target fetched when the class index wraps
     for (int64_t p = (int64_t)blockIdx.x * m.rpp + rr; p < positions; p += (int64_t)gridDim.x * m.rpp) {
       float x[8], g[8];
       load8<T>(logits + p * ld + j0, x);
@@ -51,17 +53,13 @@ __global__ __launch_bounds__(THREADS) void k_focal(const T* __restrict__ logits,
         if (j0 + e < nch && t != -2) {
           const bool pos = (t == k);
           const float u = pos ? -x[e] : x[e];
-          // hardware transcendentals (1 ulp: v_exp_f32, v_rcp_f32, v_log_f32, v_sqrt_f32); the IEEE-rounded
-          // library forms (__frcp_rn, __fsqrt_rn, __logf) expanded to ~35 extra VALU instructions per logit and
-          // made this kernel 100 % VALU-bound.  1 + ex is in [1, 2]: no denormal handling is needed.
           const float ex = __builtin_amdgcn_exp2f(-1.44269504f * fabsf(u));
           const float inv = __builtin_amdgcn_rcpf(1.f + ex);
-          const float sg = u >= 0.f ? inv : ex * inv;          // sigmoid(u) = 1 - p_t
-          const float sp = fmaxf(u, 0.f) + 0.69314718f * __builtin_amdgcn_logf(1.f + ex);   // softplus(u) = cross entropy
+          const float sg = u >= 0.f ? inv : ex * inv;
+          const float sp = fmaxf(u, 0.f) + 0.69314718f * __builtin_amdgcn_logf(1.f + ex);
           const float af = pos ? alpha : 1.f - alpha;
           const float mod = G15 ? sg * __builtin_amdgcn_sqrtf(sg) : __powf(sg, gamma);
           loss_acc = fmaf(af * mod, sp * inv_norm, loss_acc);
-          // d/du [sg^gamma * softplus(u)] = sg^gamma * (gamma*(1-sg)*sp + sg)
           const float dldu = af * mod * fmaf(gamma * (1.f - sg), sp, sg) * inv_norm;
           g[e] = pos ? -dldu : dldu;
         }
@@ -73,6 +71,62 @@ __global__ __launch_bounds__(THREADS) void k_focal(const T* __restrict__ logits,
         }
       }
       store8<T>(dlogits + p * ld + j0, g);
+    }
+  } else if (ok) {
+    // One row per step, the next row's logits and targets requested before this row is worked on (r03: the first
+    // version loaded, computed and stored one row at a time and fetched the second anchor's target in the middle of the
+    // element loop -- a dependent global load under a branch; 85 % "VALU busy" was mostly that wait).  An 8-element
+    // chunk spans at most two anchors (num_classes >= 8): both targets are loaded up front, the element loop is
+    // branch-free.
+    const int64_t step = (int64_t)gridDim.x * m.rpp;
+    int64_t p = (int64_t)blockIdx.x * m.rpp + rr;
+    const bool has_a1 = a0 + 1 < na;
+    float x[8], xn[8];
+    int t0 = -2, t1 = -2, t0n = -2, t1n = -2;
+    if (p < positions) {
+      load8<T>(logits + p * ld + j0, x);
+      t0 = a0 < na ? tgt[p * na + a0] : -2;
+      t1 = has_a1 ? tgt[p * na + a0 + 1] : -2;
+    }
+    while (p < positions) {
+      const int64_t pn = p + step;
+      if (pn < positions) {
+        load8<T>(logits + pn * ld + j0, xn);
+        t0n = a0 < na ? tgt[pn * na + a0] : -2;
+        t1n = has_a1 ? tgt[pn * na + a0 + 1] : -2;
+      }
+      float g[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int idx = k0 + e;
+        const bool cross = idx >= nc;
+        const int k = cross ? idx - nc : idx;
+        const int t = cross ? t1 : t0;
+        const bool pos = (t == k);
+        const bool valid = (j0 + e < nch) && t != -2;
+        const float xe = valid ? x[e] : 0.f;                 // padding columns / ignored anchors may hold anything
+        const float u = pos ? -xe : xe;
+        // hardware transcendentals (1 ulp: v_exp_f32, v_rcp_f32, v_log_f32, v_sqrt_f32); the IEEE-rounded
+        // library forms (__frcp_rn, __fsqrt_rn, __logf) expanded to ~35 extra VALU instructions per logit and
+        // made this kernel 100 % VALU-bound.  1 + ex is in [1, 2]: no denormal handling is needed.
+        const float ex = __builtin_amdgcn_exp2f(-1.44269504f * fabsf(u));
+        const float inv = __builtin_amdgcn_rcpf(1.f + ex);
+        const float sg = u >= 0.f ? inv : ex * inv;          // sigmoid(u) = 1 - p_t
+        const float sp = fmaxf(u, 0.f) + 0.69314718f * __builtin_amdgcn_logf(1.f + ex);   // softplus(u) = cross entropy
+        const float af = pos ? alpha : 1.f - alpha;
+        const float mod = G15 ? sg * __builtin_amdgcn_sqrtf(sg) : __powf(sg, gamma);
+        const float wgt = valid ? af * mod * inv_norm : 0.f;
+        loss_acc = fmaf(wgt, sp, loss_acc);
+        // d/du [sg^gamma * softplus(u)] = sg^gamma * (gamma*(1-sg)*sp + sg)
+        const float dldu = wgt * fmaf(gamma * (1.f - sg), sp, sg);
+        g[e] = pos ? -dldu : dldu;
+        db[e] += g[e];
+      }
+      store8<T>(dlogits + p * ld + j0, g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = xn[e];
+      t0 = t0n; t1 = t1n;
+      p = pn;
     }
   }
   __shared__ float red_loss;

@@ -997,7 +997,11 @@ int pwb_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, float* dweight
   // EDET_WGRAD_WGS overrides (lab switch, read per call).
   const char* wgs_env = getenv("EDET_WGRAD_WGS");
   const int wg_target = wgs_env ? atoi(wgs_env) : (kn >= 65536 ? 1024 : 512);
-  int S = (wg_target + ntile - 1) / ntile;
+  // rounded DOWN: two workgroups of this kernel are resident per compute unit (512 at a time), and a grid of 513 or
+  // 1026 (288 x 48: 3 tiles x 171 splits; 1152 x 320: 27 x 38) runs a last round for one or two stragglers
+  // (r03e: efficientdet-d7x 384x384x288->48 went from 0.93 to 1.19 ms per call when the target dropped to 512)
+  int S = wg_target / ntile;
+  if (S < 1) S = 1;
   const int max_by_rows = (a.M + 4 * BK - 1) / (4 * BK);
   if (S > max_by_rows) S = max_by_rows;
   const int64_t max_by_ws = (int64_t)(workspace_bytes / sizeof(float)) / kn;

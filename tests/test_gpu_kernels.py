@@ -737,10 +737,14 @@ def test_fuse(dt, case):
 
 # ------------------------------------------------------------------------------------ losses
 @pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
-def test_detection_loss(dt):
+@pytest.mark.parametrize('geom', [(2, 5, 4, 9, 90), (3, 7, 5, 9, 20), (2, 6, 3, 9, 3), (1, 4, 4, 3, 8)],
+                         ids=lambda g: 'x'.join(map(str, g)))
+def test_detection_loss(dt, geom=(2, 5, 4, 9, 90)):
+  """geom = (n, h, w, anchors, classes): 90 classes (COCO), 20 (an 8-element chunk crosses anchors more often), 3 (the
+  form for fewer than 8 classes: a chunk spans several anchors), 8 (a chunk is exactly one anchor)."""
   name, edt, tdt = dt
   rng = np.random.default_rng(5)
-  n, h, w, na, nc = 2, 5, 4, 9, 90
+  n, h, w, na, nc = geom
   logits = gu.rnd(rng, (n, h, w, na * nc), tdt, 2.0)
   box = gu.rnd(rng, (n, h, w, 4 * na), tdt, 0.3)
   ct = torch.from_numpy(rng.integers(-2, nc, (n, h, w, na)).astype(np.int32))
