@@ -241,5 +241,8 @@ __host__ __device__ inline int same_pad_before(int in, int k, int s) {
 int edet_reduce_partials(const float* ws, int P, int64_t n, float* dst, hipStream_t st);
 int edet_reduce_partials_set(const float* ws, int P, int64_t n, float* dst, hipStream_t st);
 
+// workgroups of kernel `fn` (block size `threads`, `lds` bytes of dynamic LDS) the device holds at once; 0 = unknown
+int edet_resident_wgs(const void* fn, int threads, size_t lds);
+
 static inline hipStream_t to_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -71,3 +71,35 @@ extern "C" int edet_debug_launch_names(char* buf, size_t capacity, size_t* neede
   }
   return 0;
 }
+
+// ---- resident workgroups of a kernel on the current device (occupancy x compute units), cached -------------------------
+// Launch planning uses it for the kernels whose workgroups each loop over a share of the work: a grid slightly larger than
+// what the chip holds at once runs a nearly empty last round (r03e: 513 workgroups on 512 slots cost 28 %).
+struct OccKey {
+  const void* fn;
+  int threads;
+  size_t lds;
+  bool operator<(const OccKey& o) const {
+    if (fn != o.fn) return fn < o.fn;
+    if (threads != o.threads) return threads < o.threads;
+    return lds < o.lds;
+  }
+};
+static std::mutex g_occ_mu;
+static std::map<OccKey, int> g_occ;
+
+int edet_resident_wgs(const void* fn, int threads, size_t lds) {
+  std::lock_guard<std::mutex> lock(g_occ_mu);
+  const OccKey key{fn, threads, lds};
+  auto it = g_occ.find(key);
+  if (it != g_occ.end()) return it->second;
+  int per_cu = 0, dev = 0, cus = 0;
+  int total = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) == hipSuccess && per_cu > 0 &&
+      hipGetDevice(&dev) == hipSuccess &&
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+    total = per_cu * cus;
+  (void)hipGetLastError();
+  g_occ[key] = total;      // 0 = unknown (callers keep their fixed targets)
+  return total;
+}

@@ -1437,6 +1437,8 @@ int pws_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
   // >= 4 super-tiles per wave (r03d lab, 24 pointwise layer shapes: 2 / 4 / 8 / 16 -> forward 4.85 / 4.79 / 4.82 / 4.87 ms)
   const int spw_min = env_int("EDET_PWS_SPW", 4);
   int grid = (nst + WAVES * spw_min - 1) / (WAVES * spw_min);
+  const int cap_fwd = env_int("EDET_PWS_FWD_CAP", EDET_MAX_PARTS);     // lab switch: workgroup cap (<= partial rows)
+  if (grid > cap_fwd) grid = cap_fwd;
   if (grid > EDET_MAX_PARTS) grid = EDET_MAX_PARTS;
   if (grid < 1) grid = 1;
   a.spw = (nst + grid * WAVES - 1) / (grid * WAVES);
@@ -1489,6 +1491,8 @@ int pws_try_dgrad(const edet_gview_t* dy, const void* w, int ldw, const edet_tvi
   const int nst = (a.M + TR * a.G - 1) / (TR * a.G);
   const int spw_min = env_int("EDET_PWS_SPW", 4);      // r03d lab: 2 / 4 / 8 -> backward 16.62 / 16.49 / 16.45 ms over 24 shapes
   int grid = (nst + WAVES * spw_min - 1) / (WAVES * spw_min);
+  const int cap_bwd = env_int("EDET_PWS_BWD_CAP", EDET_MAX_PARTS);     // lab switch
+  if (grid > cap_bwd) grid = cap_bwd;
   if (grid > EDET_MAX_PARTS) grid = EDET_MAX_PARTS;
   if (grid < 1) grid = 1;
   a.spw = (nst + grid * WAVES - 1) / (grid * WAVES);

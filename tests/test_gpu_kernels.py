@@ -739,7 +739,7 @@ def test_fuse(dt, case):
 @pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
 @pytest.mark.parametrize('geom', [(2, 5, 4, 9, 90), (3, 7, 5, 9, 20), (2, 6, 3, 9, 3), (1, 4, 4, 3, 8)],
                          ids=lambda g: 'x'.join(map(str, g)))
-def test_detection_loss(dt, geom=(2, 5, 4, 9, 90)):
+def test_detection_loss(dt, geom):
   """geom = (n, h, w, anchors, classes): 90 classes (COCO), 20 (an 8-element chunk crosses anchors more often), 3 (the
   form for fewer than 8 classes: a chunk spans several anchors), 8 (a chunk is exactly one anchor)."""
   name, edt, tdt = dt
