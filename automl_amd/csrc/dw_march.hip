@@ -1025,6 +1025,19 @@ inline void plan(Args& a, int C, int n, int space_w, int space_h, int max_p, int
   a.P = P;
 }
 
+// lab switch EDET_DWM_ROUNDS=r: persistent workgroups = r x what the chip holds of THIS kernel at once (occupancy query)
+inline void replan_rounds(Args& a, const void* fn, size_t lds, int max_p) {
+  const char* e = getenv("EDET_DWM_ROUNDS");
+  if (!e || !e[0]) return;
+  const int slots = edet_resident_wgs(fn, THREADS, lds);
+  if (slots <= 0) return;
+  int P = (int)(atof(e) * slots) / a.ngroups;
+  if (P < 1) P = 1;
+  if (P > max_p) P = max_p;
+  if (P > a.ntiles) P = a.ntiles;
+  a.P = P;
+}
+
 }  // namespace dwm
 
 // return 1 = handled, 0 = not applicable (caller falls back), < 0 = error
@@ -1043,6 +1056,7 @@ int dwm_try_fwd(const edet_tview_t* in, const float* weight, int k, int s, void*
     plan<CPT_>(a, in->c, in->n, a.ow, a.oh, EDET_MAX_PARTS, K_);                          \
     const size_t lds0 = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                  \
     const size_t ring = (size_t)2 * (a.TX * S_ + K_ - S_) * a.nch * CPT_ * sizeof(float); \
+    replan_rounds(a, reinterpret_cast<const void*>(&k_fwd_lx<K_, S_, CPT_, false>), lds0 + ring, EDET_MAX_PARTS); \
     if (oact) edet_launch(k_fwd_lx<K_, S_, CPT_, true>, dim3(a.P * a.ngroups), dim3(THREADS), lds0 + ring, st, a); \
     else edet_launch(k_fwd_lx<K_, S_, CPT_, false>, dim3(a.P * a.ngroups), dim3(THREADS), lds0 + ring, st, a); \
   } while (0)
@@ -1149,6 +1163,7 @@ int dwm_try_bwd_fused(const edet_gview_t* dy, const float* weight, int k, int s,
     plan<CPT_>(a, in->c, in->n, in->w, in->h, max_p, K_);                                 \
     const size_t lds = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                   \
     const size_t ring = (size_t)2 * (a.TX + K_ - 1) * a.nch * CPT_ * sizeof(float);       \
+    replan_rounds(a, reinterpret_cast<const void*>(&k_bwd_fused<K_, CPT_, true, false>), lds + ring, max_p); \
     const dim3 grid(a.P * a.ngroups), block(THREADS);                                     \
     if (gbn) { if (oact) edet_launch(k_bwd_fused<K_, CPT_, true, true>, grid, block, lds + ring, st, a); else edet_launch(k_bwd_fused<K_, CPT_, true, false>, grid, block, lds + ring, st, a); }             \
     else { if (oact) edet_launch(k_bwd_fused<K_, CPT_, false, true>, grid, block, lds + ring, st, a); else edet_launch(k_bwd_fused<K_, CPT_, false, false>, grid, block, lds + ring, st, a); }                \

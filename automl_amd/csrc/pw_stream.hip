@@ -1437,7 +1437,15 @@ int pws_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
   // >= 4 super-tiles per wave (r03d lab, 24 pointwise layer shapes: 2 / 4 / 8 / 16 -> forward 4.85 / 4.79 / 4.82 / 4.87 ms)
   const int spw_min = env_int("EDET_PWS_SPW", 4);
   int grid = (nst + WAVES * spw_min - 1) / (WAVES * spw_min);
-  const int cap_fwd = env_int("EDET_PWS_FWD_CAP", EDET_MAX_PARTS);     // lab switch: workgroup cap (<= partial rows)
+  // One round: at most as many workgroups as the chip holds at once (3 per compute unit for the 8-pass kernel, 2 for the
+  // 16-pass one).  r03h lab, caps of 1024 (the partial-row limit, round 2) / 768 / 512: 320x320x16->96 0.92 / 0.81 / 0.83
+  // ms, 160x160x24->144 0.39 / 0.33 / 0.36, 320x320x32->16 0.46 / 0.40 / 0.48, 80x80x64->64 62 / 55 / 60 us; the
+  // 144-channel inputs (2 per CU) 0.36 / 0.38 / 0.36: with 1024 workgroups on 768 slots the second round runs a third full.
+  const bool oact_ = in->act > EDET_ACT_SWISH;
+  const void* kfn = NS == 8 ? (oact_ ? reinterpret_cast<const void*>(&k_pw_fwd<8, true>) : reinterpret_cast<const void*>(&k_pw_fwd<8, false>))
+                            : (oact_ ? reinterpret_cast<const void*>(&k_pw_fwd<16, true>) : reinterpret_cast<const void*>(&k_pw_fwd<16, false>));
+  const int slots_fwd = edet_resident_wgs(kfn, THREADS, lds);
+  const int cap_fwd = env_int("EDET_PWS_FWD_CAP", slots_fwd > 0 ? slots_fwd : EDET_MAX_PARTS);     // lab switch overrides
   if (grid > cap_fwd) grid = cap_fwd;
   if (grid > EDET_MAX_PARTS) grid = EDET_MAX_PARTS;
   if (grid < 1) grid = 1;

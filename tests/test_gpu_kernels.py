@@ -776,7 +776,8 @@ def test_detection_loss(dt, geom):
   assert abs(float(s[1]) - float(box_loss)) <= 1e-3 * abs(float(box_loss)) + 1e-6, (float(s[1]), float(box_loss))
   gu.check(dl[..., :na * nc], lq.grad, name, 'dlogits', rtol=1e-2 if name == 'bf16' else 1e-4)
   gu.check(db[..., :4 * na], bq.grad, name, 'dbox', rtol=1e-2 if name == 'bf16' else 1e-4)
-  assert float(dl[..., na * nc:].abs().max()) == 0.0 and float(db[..., 4 * na:].abs().max()) == 0.0
+  for t, valid in ((dl, na * nc), (db, 4 * na)):      # padding columns (when the row has any) are written as zeros
+    assert t.shape[-1] == valid or float(t[..., valid:].abs().max()) == 0.0
   gu.check(dbias_c, lq.grad.sum((0, 1, 2)), name, 'class bias grad', rtol=2e-2 if name == 'bf16' else 1e-3)
   gu.check(dbias_b, bq.grad.sum((0, 1, 2)), name, 'box bias grad', rtol=2e-2 if name == 'bf16' else 1e-3)
 
