@@ -753,9 +753,15 @@ __global__ __launch_bounds__(16 * RED_SL) void k_reduce_partials(const float* __
   }
 }
 
-inline int ew_grid(int64_t total) {
+// grid of a grid-stride elementwise kernel: one thread per item up to one round of what the chip holds of the kernel
+inline int ew_grid(int64_t total, const void* fn = nullptr) {
   int64_t g = (total + THREADS - 1) / THREADS;
-  if (g > 4096) g = 4096;
+  int cap = 4096;
+  if (fn) {
+    const int slots = edet_resident_wgs(fn, THREADS, 0);
+    if (slots > 0) cap = slots;
+  }
+  if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -830,7 +836,7 @@ extern "C" int edet_bn_res(const edet_tview_t* y, const void* residual, void* ou
   EDET_CHECK(y && y->data && out, "edet_bn_res: null pointer");
   EDET_CHECK(y->c % 8 == 0 && y->ld % 8 == 0 && ldo % 8 == 0, "edet_bn_res: c/ld % 8");
   const int64_t rows = (int64_t)y->n * y->h * y->w;
-  const int grid = ew_grid(rows * (y->c / 8));
+  const int grid = ew_grid(rows * (y->c / 8), dtype == EDET_BF16 ? reinterpret_cast<const void*>(&k_bn_res<bf16_t>) : nullptr);
   if (dtype == EDET_BF16) edet_launch(k_bn_res<bf16_t>, grid, dim3(THREADS), 0, to_stream(stream), *y, (const bf16_t*)residual, (bf16_t*)out, ldo, rows);
   else if (dtype == EDET_F32) edet_launch(k_bn_res<float>, grid, dim3(THREADS), 0, to_stream(stream), *y, (const float*)residual, (float*)out, ldo, rows);
   else EDET_CHECK(false, "edet_bn_res: bad dtype %d", dtype);
@@ -842,7 +848,7 @@ extern "C" int edet_add(void* dst, const void* src, int64_t rows, int c, int ld,
                         int dtype, void* stream) {
   EDET_CHECK(dst && src, "edet_add: null pointer");
   EDET_CHECK(c % 8 == 0 && ld % 8 == 0, "edet_add: c/ld % 8");
-  const int grid = ew_grid(rows * (c / 8));
+  const int grid = ew_grid(rows * (c / 8), dtype == EDET_BF16 ? reinterpret_cast<const void*>(&k_add<bf16_t>) : nullptr);
   if (dtype == EDET_BF16) edet_launch(k_add<bf16_t>, grid, dim3(THREADS), 0, to_stream(stream), (bf16_t*)dst, (const bf16_t*)src, rows, c, ld, beta);
   else if (dtype == EDET_F32) edet_launch(k_add<float>, grid, dim3(THREADS), 0, to_stream(stream), (float*)dst, (const float*)src, rows, c, ld, beta);
   else EDET_CHECK(false, "edet_add: bad dtype %d", dtype);

@@ -362,9 +362,16 @@ __global__ void k_fuse_weights_bwd(const float* w0, const float* w1, const float
   }
 }
 
-inline int ew_grid(int64_t total) {
+// grid of a grid-stride elementwise kernel: one thread per item up to ONE ROUND of what the chip holds of this kernel
+// (occupancy query; 4096 when unknown) -- with more workgroups than resident slots the last round runs partly empty
+inline int ew_grid(int64_t total, const void* fn = nullptr, size_t lds = 0) {
   int64_t g = (total + THREADS - 1) / THREADS;
-  if (g > 4096) g = 4096;
+  int cap = 4096;
+  if (fn) {
+    const int slots = edet_resident_wgs(fn, THREADS, lds);
+    if (slots > 0) cap = slots;
+  }
+  if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -427,7 +434,7 @@ extern "C" int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, c
   FuseArgs a;
   if (int rc = fill_args(a, in0, in1, in2, modes, nin, wn, wc, act, oh, ow, ldo)) return rc;
   EDET_CHECK(out, "edet_fuse_fwd: null output");
-  const int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8));
+  const int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8), dtype == EDET_BF16 ? reinterpret_cast<const void*>(&k_fuse<bf16_t, false>) : nullptr);
   if (dtype == EDET_BF16) edet_launch(k_fuse<bf16_t, false>, grid, dim3(THREADS), 0, to_stream(stream), a, (bf16_t*)out, nullptr, nullptr, nullptr, nullptr);
   else if (dtype == EDET_F32) edet_launch(k_fuse<float, false>, grid, dim3(THREADS), 0, to_stream(stream), a, (float*)out, nullptr, nullptr, nullptr, nullptr);
   else EDET_CHECK(false, "edet_fuse_fwd: bad dtype %d", dtype);
@@ -442,8 +449,8 @@ extern "C" int edet_fuse_bwd_pre(const edet_tview_t* in0, const edet_tview_t* in
   FuseArgs a;
   if (int rc = fill_args(a, in0, in1, in2, modes, nin, wn, wc, act, oh, ow, ldo)) return rc;
   EDET_CHECK(dout && ds, "edet_fuse_bwd_pre: null pointer");
-  const int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8));
   const size_t lds = wc > 1 ? (size_t)3 * a.c * sizeof(float) : 0;
+  const int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8), dtype == EDET_BF16 ? reinterpret_cast<const void*>(&k_fuse<bf16_t, true>) : nullptr, lds);
   if (dtype == EDET_BF16) edet_launch(k_fuse<bf16_t, true>, grid, dim3(THREADS), lds, to_stream(stream), a, nullptr, (const bf16_t*)dout, (bf16_t*)ds, dwn, (unsigned char*)pool_argmax);
   else if (dtype == EDET_F32) edet_launch(k_fuse<float, true>, grid, dim3(THREADS), lds, to_stream(stream), a, nullptr, (const float*)dout, (float*)ds, dwn, (unsigned char*)pool_argmax);
   else EDET_CHECK(false, "edet_fuse_bwd_pre: bad dtype %d", dtype);
@@ -465,7 +472,7 @@ extern "C" int edet_fuse_bwd_input(const edet_tview_t* in, int mode, const float
     a.pad_t = same_pad_before(in->h, 3, 2);
     a.pad_l = same_pad_before(in->w, 3, 2);
   }
-  const int grid = ew_grid((int64_t)in->n * in->h * in->w * (in->c / 8));
+  const int grid = ew_grid((int64_t)in->n * in->h * in->w * (in->c / 8), dtype == EDET_BF16 ? reinterpret_cast<const void*>(&k_fuse_bwd_input<bf16_t>) : nullptr);
   const unsigned char* am = mode == EDET_RS_POOL ? reinterpret_cast<const unsigned char*>(pool_argmax) : nullptr;
   if (dtype == EDET_BF16) edet_launch(k_fuse_bwd_input<bf16_t>, grid, dim3(THREADS), 0, to_stream(stream), a, (const bf16_t*)ds, (bf16_t*)gout, am);
   else if (dtype == EDET_F32) edet_launch(k_fuse_bwd_input<float>, grid, dim3(THREADS), 0, to_stream(stream), a, (const float*)ds, (float*)gout, am);

@@ -375,10 +375,16 @@ extern "C" int edet_focal_loss(const void* logits, int ld, const int32_t* cls_ta
   const RowMap m = row_map_ld(ld);
   int64_t g = (positions + m.rpp - 1) / m.rpp;
   g = (g + 3) / 4;
-  if (g > 4096) g = 4096;
-  if (g < 1) g = 1;
   const size_t lds = (size_t)ld * sizeof(float);
   const bool g15 = gamma == 1.5f;
+  {   // one round of the workgroups the chip holds at once (the rows are strided over the grid)
+    const void* fn = dtype == EDET_BF16 ? (g15 ? reinterpret_cast<const void*>(&k_focal<bf16_t, true>) : reinterpret_cast<const void*>(&k_focal<bf16_t, false>))
+                                        : (g15 ? reinterpret_cast<const void*>(&k_focal<float, true>) : reinterpret_cast<const void*>(&k_focal<float, false>));
+    const int slots = edet_resident_wgs(fn, THREADS, lds);
+    const int64_t cap = slots > 0 ? slots : 4096;
+    if (g > cap) g = cap;
+  }
+  if (g < 1) g = 1;
 #define FOCAL_LAUNCH(T, G)                                                                            \
   edet_launch(k_focal<T, G>, dim3((int)g), dim3(THREADS), lds, to_stream(stream), (const T*)logits, ld, cls_targets, positions, \
       num_anchors, num_classes, alpha, gamma, inv_normalizer, norm_scale_dev, (T*)dlogits, dbias, sums, m)
