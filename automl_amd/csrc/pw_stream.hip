@@ -892,45 +892,55 @@ struct FusedArgs {
   edet_bwd_epi_t epi;
   float* ws;          // [grid][KO][R] fp32 partial weight gradients
   int M, R, KO, hw;
-  ColMap cr, cx;      // load mappings of dy and of x (the passes per tile are template parameters)
+  ColMap cr, cx;      // load mappings of dy and of x
   int SA, SX, SC, SW; // LDS row strides in bytes: Dt, Xt, C tile, weights
   int KOpad;          // KO rounded up to 32
   int TK, TN;         // 16-wide tiles of dW along k and n
-  int tpw, ksteps;    // tiles per wave; ceil(R / 16)
+  int tpw, ksteps;    // steps per wave; ceil(R / 16)
   int SG, kxsteps;    // NOY: LDS row stride of G in bytes, ceil(KOpad / 16)
+  int G;              // 32-row tiles per step: the loads of a whole step (32 G rows of dz, y, x) are in flight at once
 };
 
 // FT_S x FT_L = 16 x 16 tiles of dW kept per wave (min(TK, TN) <= FT_S, max(TK, TN) <= FT_L): 2 x 9 covers the expand
-// layers the host routes here (16..32 input channels, up to 144 output channels)
-template <int NSR, int NSX, bool GBN, int FT_S, int FT_L, bool NOY = false>
+// layers (16..32 input channels, up to 144 output channels), 3 x 9 the project layers (up to 144 -> 48), 4 x 4 the
+// 64 -> 64 layers of the BiFPN and the heads.
+// NSR / NSX: load passes per step of dy / x, all issued unconditionally (r03j: run-time guards around the loads cost
+// 30 % -- the waits degrade to vmcnt(0)); the host picks the instantiation that fits the step with the fewest rows
+// to spare.  The round-2 kernel had two pairs, (8, 1) and (12, 2): 8 passes of 32 rows each for a 16-channel gradient
+// whose 32-row tile needs one -- the reason the project layers measured slower in it.
+// NCH: 64-channel epilogue chunks (KOpad <= 64 NCH); the per-channel sums (BatchNorm backward, SE gate gradient)
+// are carried in registers across all tiles of the wave and reach LDS once per kernel (or once per image).
+// BETA: the instantiation can accumulate into gout (epi.beta; the old gradient rides along with x)
+template <int NSR, int NSX, bool GBN, int FT_S, int FT_L, bool NOY = false, int NCH = 1, bool BETA = true>
 __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) {
   static_assert(!NOY || GBN, "NOY is a form of the BatchNorm backward on load");
+  static_assert(!NOY || NCH == 1, "NOY: at most 32 input channels");
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int j = lane & 31, h = lane >> 5;
-  const bool has_beta = a.epi.beta != 0;
+  const bool has_beta = BETA && a.epi.beta != 0;
+  const int srows = TR * a.G;                                           // rows per step
   unsigned char* Wl = smem;                                             // [KOpad][SW]
   float* red = reinterpret_cast<float*>(Wl + (size_t)a.KOpad * a.SW);   // [2][KOpad] stats
   float* coefS = red + 2 * a.KOpad;                                     // [KOpad] scale, [KOpad] shift of the view
   float* coefH = coefS + a.KOpad;
-  const int d_alloc = NSR * a.cr.rp, x_alloc = NSX * a.cx.rp;           // >= 32 rows each (NSR / NSX load passes)
-  const size_t wave_bytes = (size_t)d_alloc * a.SA + (size_t)(has_beta ? 2 : 1) * x_alloc * a.SX +
+  const size_t wave_bytes = (size_t)srows * a.SA + (size_t)(has_beta ? 2 : 1) * srows * a.SX +
                             (size_t)TR * a.SC + (size_t)4 * a.KOpad * 4;
   float* vL = coefH + a.KOpad;                                          // NOY: [KOpad] v = c W^T
   unsigned char* Gl = reinterpret_cast<unsigned char*>(vL + (NOY ? a.KOpad : 0));      // NOY: [KOpad][SG] bf16 G
   unsigned char* wbase = Gl + (NOY ? (size_t)a.KOpad * a.SG : 0) + (size_t)wave * wave_bytes;
-  unsigned char* Dt = wbase;                                            // [d_alloc][SA] bf16 dy
-  unsigned char* Xt = Dt + (size_t)d_alloc * a.SA;                      // [x_alloc][SX] bf16 x, then act(x)
-  unsigned char* Ot = Xt + (size_t)x_alloc * a.SX;                      // [x_alloc][SX] bf16 old gout (beta only)
-  unsigned char* Ct = Ot + (has_beta ? (size_t)x_alloc * a.SX : 0);     // [32][SC] fp32
+  unsigned char* Dt = wbase;                                            // [srows][SA] bf16 dy
+  unsigned char* Xt = Dt + (size_t)srows * a.SA;                        // [srows][SX] bf16 x, then act(x)
+  unsigned char* Ot = Xt + (size_t)srows * a.SX;                        // [srows][SX] bf16 old gout (beta only)
+  unsigned char* Ct = Ot + (has_beta ? (size_t)srows * a.SX : 0);       // [32][SC] fp32
   float* wst = reinterpret_cast<float*>(Ct + TR * a.SC);                // [2][KOpad] sums (g, g*x) of this wave
-  float* wgt = wst + 2 * a.KOpad;                                       // [KOpad] dgate sums of the current image
+  float* wgt = wst + 2 * a.KOpad;                                       // [KOpad] dgate sums of one image
   float* gateL = wgt + a.KOpad;                                         // [KOpad] SE gate of the current image
   const bool want_stats = a.epi.stat_partials != nullptr;
   const bool want_gate = a.epi.dgate != nullptr;
   const bool swish = a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr, gated = a.tv.gate != nullptr;
 
-  // Nothing inside the tile loop may wait on a global load other than the prefetched tile (vmcnt is in order: a
+  // Nothing inside the tile loop may wait on a global load other than the prefetched step (vmcnt is in order: a
   // wait for a later small load would drain the whole prefetch): per-channel vectors live in LDS.
   for (int i = tid; i < 2 * a.KOpad; i += THREADS) red[i] = 0.f;
   for (int i = tid; i < a.KOpad; i += THREADS) {
@@ -939,7 +949,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
   }
   for (int i = lane; i < 3 * a.KOpad; i += 64) wst[i] = 0.f;
   for (int i = lane; i < a.KOpad; i += 64) gateL[i] = 1.f;
-  for (int i = lane; i < (int)(((size_t)d_alloc * a.SA + (size_t)x_alloc * a.SX) / 16); i += 64)
+  for (int i = lane; i < (int)(((size_t)srows * a.SA + (size_t)srows * a.SX) / 16); i += 64)
     reinterpret_cast<uint4*>(Dt)[i] = make_uint4(0, 0, 0, 0);
   {  // weights -> LDS (zero-filled beyond KO and beyond R)
     const int slots = a.SW / 16;
@@ -996,21 +1006,24 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
   const unsigned char* X = reinterpret_cast<const unsigned char*>(a.tv.data);
   bf16_t* GO = reinterpret_cast<bf16_t*>(a.epi.gout);
 
-  const int ntile = (a.M + TR - 1) / TR;
+  const int nstep = (a.M + srows - 1) / srows;
   const int gw = blockIdx.x * WAVES + wave;
-  const int t0 = min(ntile, gw * a.tpw), t1 = min(ntile, t0 + a.tpw);
+  const int t0 = min(nstep, gw * a.tpw), t1 = min(nstep, t0 + a.tpw);
 
   // native vector types: a HIP uint4 struct copied whole from a register array to LDS is not promoted to registers
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  uint4 rz[NSR], ry[(GBN && !NOY) ? NSR : 1];
-  u32x4 rx[NSX], ro[NSX];
+  u32x4 rz[NSR], ry[(GBN && !NOY) ? NSR : 1];
+  u32x4 rx[NSX], ro[BETA ? NSX : 1];
   auto issue = [&](int t) {
-    const int row0 = t * TR;
+    // every instantiated pass is issued, unconditionally and back to back (a load under a branch makes the compiler
+    // wait for ALL outstanding loads and stores wherever one of them is consumed); a pass that reaches beyond the step
+    // reads rows of the wave's NEXT step (they are in L2 when that step asks for them), rows past M re-read row M-1
+    const int row0 = t * srows;
 #pragma unroll
-    for (int i = 0; i < NSR; ++i) {   // rows past M re-read row M-1 (finite values; zeroed when they are staged)
+    for (int i = 0; i < NSR; ++i) {
       const size_t off = ((size_t)min(row0 + i * a.cr.rp + rsubR, a.M - 1) * a.gv.ld + colR * 8) * 2;
-      rz[i] = *reinterpret_cast<const uint4*>(DZ + off);
-      if (GBN && !NOY) ry[i] = *reinterpret_cast<const uint4*>(Y + off);
+      rz[i] = *reinterpret_cast<const u32x4*>(DZ + off);
+      if (GBN && !NOY) ry[i] = *reinterpret_cast<const u32x4*>(Y + off);
     }
 #pragma unroll
     for (int i = 0; i < NSX; ++i) {
@@ -1021,7 +1034,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
 #pragma unroll
       for (int i = 0; i < NSX; ++i) {
         const size_t off = ((size_t)min(row0 + i * a.cx.rp + rsubX, a.M - 1) * a.tv.ld + colX * 8) * 2;
-        ro[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(GO) + off);
+        ro[BETA ? i : 0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(GO) + off);
       }
     }
   };
@@ -1041,8 +1054,13 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
   if (GBN && !NOY) {
     loadf8(a.gv.a + colR * 8, ga); loadf8(a.gv.b + colR * 8, gb); loadf8(a.gv.cc + colR * 8, gc);
   }
-  // NOY: this lane's running column sums of x over all its tiles (KO <= 32: one epilogue chunk, the lane's 8 channels
-  // never change), added into wst once at the end
+  // this lane's running column sums over all its tiles (its 8 channels of every epilogue chunk never change):
+  // ra = sum g (BatchNorm backward) or sum d*act (SE gate gradient, per image), rb = sum g*x; NOY: xacc = sum x
+  float ra[NCH][8], rb[NCH][8];
+#pragma unroll
+  for (int ci = 0; ci < NCH; ++ci)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ra[ci][e] = rb[ci][e] = 0.f;
   float xacc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) xacc[e] = 0.f;
@@ -1056,227 +1074,244 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
       for (int e = 0; e < 4; ++e) accS[s][s2][e] = 0.f;
   const int ecol = lane & 7, erow = lane >> 3;     // epilogue mapping: 64-channel chunk, 8 lanes per row
   const int fi = lane & 15, fq = lane >> 4;        // 16x16x32 fragment coordinates
-  int gate_img = -1;                               // image whose dgate sums are in wgt
+  int gate_img = -1;                               // image whose dgate sums are in ra
   int gateL_img = -1;                              // image whose SE gate is in gateL
+  // SE gate gradient sums of image `gate_img`: registers -> wgt (8 row-lanes per column: LDS atomics) -> global
+  auto flush_gate = [&]() {
+#pragma unroll
+    for (int ci = 0; ci < NCH; ++ci) {
+      const int ch0 = ci * ECC + ecol * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (ch0 + e < a.KO) atomicAdd(&wgt[ch0 + e], ra[ci][e]);
+        ra[ci][e] = 0.f;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int c = lane; c < a.KO; c += 64) {
+      const float v = wgt[c];
+      if (v != 0.f) atomicAdd(&a.epi.dgate[(size_t)gate_img * a.KO + c], v);
+      wgt[c] = 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
   if (t0 < t1) issue(t0);
   for (int t = t0; t < t1; ++t) {
-    const int row0 = t * TR;
-    const int rows_valid = min(TR, a.M - row0);
+    const int rowS = t * srows;
+    const int rows_step = min(srows, a.M - rowS);
     // ---- stage dy = a*dz + b*y + c (bf16, zero beyond R and beyond M), raw x and the old gradient
 #pragma unroll
     for (int i = 0; i < NSR; ++i) {
-      const int r = i * a.cr.rp + rsubR;
-      if (NOY) {           // dz is the matrix-core operand as it is (R % 8 == 0 on this path: whole chunks)
-        *reinterpret_cast<uint4*>(Dt + r * a.SA + colR * 16) = r < rows_valid ? rz[i] : make_uint4(0, 0, 0, 0);
-        continue;
-      }
-      float x[8];
-      unpack8(rz[i], x);
-      if (GBN) {
-        float y[8];
-        unpack8(ry[i], y);
+      {
+        const int r = i * a.cr.rp + rsubR;
+        if (r < srows) {
+          if (NOY) {         // dz is the matrix-core operand as it is (R % 8 == 0 on this path: whole chunks)
+            u32x4 v = rz[i];
+            if (r >= rows_step) v = u32x4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(Dt + r * a.SA + colR * 16) = v;
+          } else {
+            float x[8];
+            unpack8(make_uint4(rz[i][0], rz[i][1], rz[i][2], rz[i][3]), x);
+            if (GBN) {
+              float y[8];
+              const u32x4 yv = ry[(GBN && !NOY) ? i : 0];
+              unpack8(make_uint4(yv[0], yv[1], yv[2], yv[3]), y);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = fmaf(ga[e], x[e], fmaf(gb[e], y[e], gc[e]));
-      }
-      if (kvalid < 8 || r >= rows_valid) {
+              for (int e = 0; e < 8; ++e) x[e] = fmaf(ga[e], x[e], fmaf(gb[e], y[e], gc[e]));
+            }
+            if (kvalid < 8 || r >= rows_step) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) if (e >= kvalid || r >= rows_valid) x[e] = 0.f;
+              for (int e = 0; e < 8; ++e) if (e >= kvalid || r >= rows_step) x[e] = 0.f;
+            }
+            *reinterpret_cast<uint4*>(Dt + r * a.SA + colR * 16) = pack8(x);
+          }
+        }
       }
-      *reinterpret_cast<uint4*>(Dt + r * a.SA + colR * 16) = pack8(x);
     }
 #pragma unroll
-    for (int i = 0; i < NSX; ++i)
-      *reinterpret_cast<u32x4*>(Xt + (i * a.cx.rp + rsubX) * a.SX + colX * 16) = rx[i];
-    if (has_beta) {
-#pragma unroll
-      for (int i = 0; i < NSX; ++i)
-        *reinterpret_cast<u32x4*>(Ot + (i * a.cx.rp + rsubX) * a.SX + colX * 16) = ro[i];
+    for (int i = 0; i < NSX; ++i) {
+      {
+        const int r = i * a.cx.rp + rsubX;
+        if (r < srows) {
+          *reinterpret_cast<u32x4*>(Xt + r * a.SX + colX * 16) = rx[i];
+          if (has_beta) *reinterpret_cast<u32x4*>(Ot + r * a.SX + colX * 16) = ro[BETA ? i : 0];
+        }
+      }
     }
     if (t + 1 < t1) issue(t + 1);
     __builtin_amdgcn_wave_barrier();
 
-    const int img0 = row0 / a.hw, img1 = (row0 + rows_valid - 1) / a.hw;
-    const bool one_img = img0 == img1;
-    // SE gate of the tile's image -> LDS (once per image and wave: this load does wait behind the prefetch)
-    if (gated && one_img && img0 != gateL_img) {
-      for (int c = lane; c < a.KO; c += 64) gateL[c] = a.tv.gate[(size_t)img0 * a.KO + c];
-      gateL_img = img0;
-      __builtin_amdgcn_wave_barrier();
-    }
-    // dgate bookkeeping: the sums in wgt belong to one image; a tile that straddles two images goes straight to
-    // global atomics
-    bool gate_direct = false;
-    if (want_gate) {
-      gate_direct = !one_img;
-      if (gate_img >= 0 && (gate_direct || img0 != gate_img)) {
-        for (int c = lane; c < a.KO; c += 64) {
-          const float v = wgt[c];
-          if (v != 0.f) atomicAdd(&a.epi.dgate[(size_t)gate_img * a.KO + c], v);
-          wgt[c] = 0.f;
+    for (int g = 0; g < a.G; ++g) {
+      const int row0 = rowS + g * TR;
+      if (row0 >= a.M) break;
+      const int rows_valid = min(TR, a.M - row0);
+      unsigned char* Dg = Dt + (size_t)g * TR * a.SA;
+      unsigned char* Xg = Xt + (size_t)g * TR * a.SX;
+      const unsigned char* Og = Ot + (size_t)g * TR * a.SX;
+      const int img0 = row0 / a.hw, img1 = (row0 + rows_valid - 1) / a.hw;
+      const bool one_img = img0 == img1;
+      // SE gate of the tile's image -> LDS (once per image and wave: this load does wait behind the prefetch)
+      if (gated && one_img && img0 != gateL_img) {
+        for (int c = lane; c < a.KO; c += 64) gateL[c] = a.tv.gate[(size_t)img0 * a.KO + c];
+        gateL_img = img0;
+        __builtin_amdgcn_wave_barrier();
+      }
+      // dgate bookkeeping: the sums in ra belong to one image; a tile that straddles two images goes straight to
+      // global atomics
+      bool gate_direct = false;
+      if (want_gate) {
+        gate_direct = !one_img;
+        if (gate_img >= 0 && (gate_direct || img0 != gate_img)) {
+          flush_gate();
+          gate_img = -1;
         }
-        gate_img = -1;
+        if (!gate_direct) gate_img = img0;
       }
-      if (!gate_direct) gate_img = img0;
-      __builtin_amdgcn_wave_barrier();
-    }
 
-    // ---- data gradient, 64 input channels at a time, and the activated operand for the weight gradient
-    const unsigned char* arow = Dt + (size_t)j * a.SA + h * 16;
-    for (int c0 = 0; c0 < a.KOpad; c0 += ECC) {
-      const int ccols = min(ECC, a.KOpad - c0);                // 32 or 64
-      const int ch0 = c0 + ecol * 8;                           // this lane's 8 channels
-      const bool col_ok = ch0 < a.KO && ecol * 8 < ccols;
-      float sc[8], sh[8], gt[8], s1[8], s2[8];
+      // ---- data gradient, 64 input channels at a time, and the activated operand for the weight gradient
+      const unsigned char* arow = Dg + (size_t)j * a.SA + h * 16;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; gt[e] = 1.f; s1[e] = s2[e] = 0.f; }
-      if (col_ok) {
-        loadf8(coefS + ch0, sc);
-        loadf8(coefH + ch0, sh);
-        if (gated && one_img) loadf8(gateL + ch0, gt);
-      }
-      for (int nt = 0; nt < ccols / 32; ++nt) {
-        f32x16 d = mma_tile(Wl + (size_t)(c0 + nt * 32 + j) * a.SW + h * 16, arow, a.ksteps);
-        if (NOY)           // + x G: the rows of Xt (raw x = the forward's operand on this path) against G
-          d = mma_tile_more(Gl + (size_t)(c0 + nt * 32 + j) * a.SG + h * 16, Xt + (size_t)j * a.SX + h * 16, a.kxsteps, d);
+      for (int ci = 0; ci < NCH; ++ci) {
+        const int c0 = ci * ECC;
+        if (c0 < a.KOpad) {
+          const int ccols = min(ECC, a.KOpad - c0);                // 32 or 64
+          const int ch0 = c0 + ecol * 8;                           // this lane's 8 channels
+          const bool col_ok = ch0 < a.KO && ecol * 8 < ccols;
+          float sc[8], sh[8], gt[8];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(Ct + j * a.SC + (nt * 32 + 8 * g + 4 * h) * 4) =
-              make_float4(d[4 * g + 0], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]);
-      }
-      __builtin_amdgcn_wave_barrier();
-      float vv[8];
-      if (NOY) {
+          for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; gt[e] = 1.f; }
+          if (col_ok) {
+            loadf8(coefS + ch0, sc);
+            loadf8(coefH + ch0, sh);
+            if (gated && one_img) loadf8(gateL + ch0, gt);
+          }
+          for (int nt = 0; nt < ccols / 32; ++nt) {
+            f32x16 d = mma_tile(Wl + (size_t)(c0 + nt * 32 + j) * a.SW + h * 16, arow, a.ksteps);
+            if (NOY)         // + x G: the rows of Xt (raw x = the forward's operand on this path) against G
+              d = mma_tile_more(Gl + (size_t)(c0 + nt * 32 + j) * a.SG + h * 16, Xg + (size_t)j * a.SX + h * 16, a.kxsteps, d);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) vv[e] = 0.f;
-        if (col_ok) loadf8(vL + ch0, vv);
-      }
+            for (int q = 0; q < 4; ++q)
+              *reinterpret_cast<float4*>(Ct + j * a.SC + (nt * 32 + 8 * q + 4 * h) * 4) =
+                  make_float4(d[4 * q + 0], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
+          }
+          __builtin_amdgcn_wave_barrier();
+          float vv[8];
+          if (NOY) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int r = p * 8 + erow;
-        if (col_ok) {
-          uint4* xslot = reinterpret_cast<uint4*>(Xt + r * a.SX + (c0 / 8 + ecol) * 16);
-          if (r < rows_valid) {
-            const float4 d0 = *reinterpret_cast<const float4*>(Ct + r * a.SC + ecol * 32);
-            const float4 d1 = *reinterpret_cast<const float4*>(Ct + r * a.SC + ecol * 32 + 16);
-            float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-            float x[8], g[8], av[8];
-            unpack8(*xslot, x);
-            if (NOY) {
+            for (int e = 0; e < 8; ++e) vv[e] = 0.f;
+            if (col_ok) loadf8(vL + ch0, vv);
+          }
 #pragma unroll
-              for (int e = 0; e < 8; ++e) { d[e] += vv[e]; xacc[e] += x[e]; }     // xacc: sum_p x (the s of dW)
-            }
-            // z (pre-activation), its activation av and the chained gradient g
-            if (swish) {
+          for (int p = 0; p < 4; ++p) {
+            const int r = p * 8 + erow;
+            if (col_ok) {
+              uint4* xslot = reinterpret_cast<uint4*>(Xg + r * a.SX + (c0 / 8 + ecol) * 16);
+              if (r < rows_valid) {
+                const float4 d0 = *reinterpret_cast<const float4*>(Ct + r * a.SC + ecol * 32);
+                const float4 d1 = *reinterpret_cast<const float4*>(Ct + r * a.SC + ecol * 32 + 16);
+                float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+                float x[8], gg[8], av[8];
+                unpack8(*xslot, x);
+                if (NOY) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const float z = fmaf(x[e], sc[e], sh[e]);
-                const float sg = sigmoidf_(z);
-                av[e] = z * sg;
-                g[e] = want_gate ? d[e] : d[e] * (sg * (1.0f + z * (1.0f - sg)));
-              }
-            } else {
+                  for (int e = 0; e < 8; ++e) { d[e] += vv[e]; xacc[e] += x[e]; }     // xacc: sum_p x (the s of dW)
+                }
+                // z (pre-activation), its activation av and the chained gradient gg
+                if (swish) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                av[e] = fmaf(x[e], sc[e], sh[e]);
-                g[e] = d[e];
-              }
-            }
-            if (want_gate) {
-              if (gate_direct) {
-                const int img = (row0 + r) / a.hw;
+                  for (int e = 0; e < 8; ++e) {
+                    const float z = fmaf(x[e], sc[e], sh[e]);
+                    const float sg = sigmoidf_(z);
+                    av[e] = z * sg;
+                    gg[e] = want_gate ? d[e] : d[e] * (sg * (1.0f + z * (1.0f - sg)));
+                  }
+                } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                  if (ch0 + e < a.KO) atomicAdd(&a.epi.dgate[(size_t)img * a.KO + ch0 + e], d[e] * av[e]);
+                  for (int e = 0; e < 8; ++e) {
+                    av[e] = fmaf(x[e], sc[e], sh[e]);
+                    gg[e] = d[e];
+                  }
+                }
+                if (want_gate) {
+                  if (gate_direct) {
+                    const int img = (row0 + r) / a.hw;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                      if (ch0 + e < a.KO) atomicAdd(&a.epi.dgate[(size_t)img * a.KO + ch0 + e], d[e] * av[e]);
+                  } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ra[ci][e] = fmaf(d[e], av[e], ra[ci][e]);
+                  }
+                }
+                if (gated) {
+                  if (!one_img) loadf8(a.tv.gate + (size_t)((row0 + r) / a.hw) * a.KO + ch0, gt);
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) av[e] *= gt[e];
+                }
+                if (has_beta) {
+                  float old[8];
+                  unpack8(*reinterpret_cast<const uint4*>(Og + r * a.SX + (c0 / 8 + ecol) * 16), old);
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) gg[e] += old[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (ch0 + e >= a.KO) { gg[e] = 0.f; av[e] = 0.f; }
+                *reinterpret_cast<uint4*>(GO + (size_t)(row0 + r) * a.tv.ld + ch0) = pack8(gg);
+                *xslot = pack8(av);
+                if (want_stats) {      // raw sums (g, g*x): sum g*(x-mean)*rstd is taken from the totals at the end
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) {
+                    ra[ci][e] += gg[e];
+                    rb[ci][e] = fmaf(gg[e], x[e], rb[ci][e]);
+                  }
+                }
               } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) s1[e] = fmaf(d[e], av[e], s1[e]);
+                *xslot = make_uint4(0, 0, 0, 0);          // rows past M do not contribute to dW
               }
             }
-            if (gated) {
-              if (!one_img) loadf8(a.tv.gate + (size_t)((row0 + r) / a.hw) * a.KO + ch0, gt);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) av[e] *= gt[e];
-            }
-            if (has_beta) {
-              float old[8];
-              unpack8(*reinterpret_cast<const uint4*>(Ot + r * a.SX + (c0 / 8 + ecol) * 16), old);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) g[e] += old[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) if (ch0 + e >= a.KO) { g[e] = 0.f; av[e] = 0.f; }
-            *reinterpret_cast<uint4*>(GO + (size_t)(row0 + r) * a.tv.ld + ch0) = pack8(g);
-            *xslot = pack8(av);
-            if (want_stats) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                s1[e] += g[e];
-                s2[e] = fmaf(g[e], x[e], s2[e]);
-              }
-            }
-          } else {
-            *xslot = make_uint4(0, 0, 0, 0);          // rows past M do not contribute to dW
           }
+          __builtin_amdgcn_wave_barrier();
         }
       }
-      __builtin_amdgcn_wave_barrier();
-      // chunk sums -> wave LDS accumulators (8 lanes share a column: LDS atomics); raw sums (g, g*x): the
-      // BatchNorm-backward form sum g*(x-mean)*rstd is taken from the totals at the end of the kernel
-      if (col_ok) {
-        if (want_stats) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            if (ch0 + e < a.KO) {
-              atomicAdd(&wst[ch0 + e], s1[e]);
-              atomicAdd(&wst[a.KOpad + ch0 + e], s2[e]);
-            }
-          }
-        }
-        if (want_gate && !gate_direct) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (ch0 + e < a.KO) atomicAdd(&wgt[ch0 + e], s1[e]);
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
 
-    // ---- weight gradient: dW[k][n] += sum over the tile's 32 rows of xa[row][k] * dy[row][n]
-    {
-      const unsigned char* St = ksmall ? Xt : Dt;      // small side: fragments kept in registers
-      const unsigned char* Lt = ksmall ? Dt : Xt;
-      const int sS = ksmall ? a.SX : a.SA, sL = ksmall ? a.SA : a.SX;
-      bf16x8 sf[FT_S];
-#pragma unroll
-      for (int s = 0; s < FT_S; ++s)
-        if (s < TS) sf[s] = column_frag(St, sS, fq * 8, s * 16 + fi);
-      if (NOY) {           // S = x^T x (ksmall on this path: sf are the fragments of x)
+      // ---- weight gradient: dW[k][n] += sum over the tile's 32 rows of xa[row][k] * dy[row][n]
+      {
+        const unsigned char* St = ksmall ? Xg : Dg;      // small side: fragments kept in registers
+        const unsigned char* Lt = ksmall ? Dg : Xg;
+        const int sS = ksmall ? a.SX : a.SA, sL = ksmall ? a.SA : a.SX;
+        bf16x8 sf[FT_S];
 #pragma unroll
         for (int s = 0; s < FT_S; ++s)
+          if (s < TS) sf[s] = column_frag(St, sS, fq * 8, s * 16 + fi);
+        if (NOY) {           // S = x^T x (ksmall on this path: sf are the fragments of x)
 #pragma unroll
-          for (int s2 = 0; s2 < FT_S; ++s2)
-            if (s < TS && s2 < TS)
-              accS[NOY ? s : 0][NOY ? s2 : 0] =
-                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf[s], sf[s2], accS[NOY ? s : 0][NOY ? s2 : 0], 0, 0, 0);
-      }
+          for (int s = 0; s < FT_S; ++s)
 #pragma unroll
-      for (int l = 0; l < FT_L; ++l) {
-        if (l < TL) {
-          const bf16x8 lf = column_frag(Lt, sL, fq * 8, l * 16 + fi);
+            for (int s2 = 0; s2 < FT_S; ++s2)
+              if (s < TS && s2 < TS)
+                accS[NOY ? s : 0][NOY ? s2 : 0] =
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf[s], sf[s2], accS[NOY ? s : 0][NOY ? s2 : 0], 0, 0, 0);
+        }
 #pragma unroll
-          for (int s = 0; s < FT_S; ++s) {
-            if (s < TS) {
-              // A = the k side (rows of dW), B = the n side (columns of dW)
-              if (ksmall) acc[s][l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf[s], lf, acc[s][l], 0, 0, 0);
-              else acc[s][l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lf, sf[s], acc[s][l], 0, 0, 0);
+        for (int l = 0; l < FT_L; ++l) {
+          if (l < TL) {
+            const bf16x8 lf = column_frag(Lt, sL, fq * 8, l * 16 + fi);
+#pragma unroll
+            for (int s = 0; s < FT_S; ++s) {
+              if (s < TS) {
+                // A = the k side (rows of dW), B = the n side (columns of dW)
+                if (ksmall) acc[s][l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf[s], lf, acc[s][l], 0, 0, 0);
+                else acc[s][l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lf, sf[s], acc[s][l], 0, 0, 0);
+              }
             }
           }
         }
       }
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
   }
   __builtin_amdgcn_wave_barrier();
+  if (want_gate && gate_img >= 0) flush_gate();
   if (NOY) {     // the lanes' column sums -> wst[0 .. KO) (8 row-lanes per column: LDS atomics, once per kernel)
     const int ch0 = ecol * 8;
     if (ch0 < a.KO) {
@@ -1287,13 +1322,19 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
     __builtin_amdgcn_wave_barrier();
   }
   const float xsum = (NOY && lane < a.KO) ? wst[lane] : 0.f;      // NOY: this wave's sum_p x[p][lane] (KO <= 32)
-  if (want_gate && gate_img >= 0) {
-    for (int c = lane; c < a.KO; c += 64) {
-      const float v = wgt[c];
-      if (v != 0.f) atomicAdd(&a.epi.dgate[(size_t)gate_img * a.KO + c], v);
-    }
-  }
   if (want_stats) {
+#pragma unroll
+    for (int ci = 0; ci < NCH; ++ci) {
+      const int ch0 = ci * ECC + ecol * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (ch0 + e < a.KO) {
+          atomicAdd(&wst[ch0 + e], ra[ci][e]);
+          atomicAdd(&wst[a.KOpad + ch0 + e], rb[ci][e]);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
     for (int c = lane; c < a.KO; c += 64) {
       atomicAdd(&red[c], wst[c]);
       atomicAdd(&red[a.KOpad + c], wst[a.KOpad + c]);
@@ -1571,27 +1612,34 @@ int pws_try_bwd_fused(const edet_gview_t* dy, const void* w, int ldw, const edet
   using namespace pws;
   const int R = dy->c, KO = in->c;
   if (!workspace || KO % 8 != 0 || dy->ld % 8 != 0 || in->ld % 8 != 0 || R > 160 || KO > 160) return 0;
+  if (epi->stat_partials && epi->dgate) return 0;     // one set of running sums per lane: BatchNorm backward OR gate
   FusedArgs a;
   memset(&a, 0, sizeof(a));
   a.gv = *dy; a.tv = *in; a.W = reinterpret_cast<const bf16_t*>(w); a.ldw = ldw; a.epi = *epi;
   a.ws = reinterpret_cast<float*>(workspace);
   a.M = in->n * in->h * in->w; a.R = R; a.KO = KO; a.hw = in->h * in->w;
   a.TK = (KO + 15) / 16; a.TN = (R + 15) / 16;
-  // Envelope: the "expand" shape, few input channels and many output channels (R >= 2 KO, dW <= 2 x 9 tiles of
-  // 16 x 16).  r02d, D0 640x640 batch 128, both gradients: 320x320x16->96 2.44 -> 1.95 ms, 160x160x24->144 1.45 ->
-  // 0.73 ms.  With one wave per SIMD the kernel is epilogue-bound on the K-heavy project layers (160x160x144->24:
-  // 1.79 ms against 1.83 ms for the two kernels; 160x160x96->24 and the 64->64 BiFPN / head layers are slower
-  // fused; r02l: 320x320x32->16 with the SE-gated view 2.64 ms fused against 1.79 ms), so those keep the two-kernel path.
-  if (R < 2 * KO || a.TK > 2 || a.TN > 9) return 0;
+  // Envelope = the instantiations below.  Class A, the "expand" shape (few input channels, many output channels:
+  // R >= 2 KO, dW <= 2 x 9 tiles of 16 x 16).  r02d, D0 640x640 batch 128, both gradients: 320x320x16->96 2.44 -> 1.95
+  // ms, 160x160x24->144 1.45 -> 0.73 ms.  Class B (r03): at most 64 output channels -- the project layers (dW <= 3 x 9
+  // tiles) and the 64 -> 64 layers (4 x 4) -- which the round-2 kernel ran slower than the two-kernel path because it
+  // issued 5-8x the gradient loads a tile needs (every instantiated pass) and paid 16-48 LDS atomics per tile for the
+  // per-channel sums; EDET_PWS_FUSED_WIDE=0 keeps class A only (lab switch, read per call).
+  const int tmin = a.TK < a.TN ? a.TK : a.TN, tmax = a.TK < a.TN ? a.TN : a.TK;
+  const bool class_a = R >= 2 * KO && a.TK <= 2 && a.TN <= 9;
+  int ft = 0;                                           // class B tile grid: 44 = 4 x 4, 39 = 3 x 9
+  if (!class_a) {
+    if (env_int("EDET_PWS_FUSED_WIDE", 1) == 0) return 0;
+    if (R > 64 || epi->beta) return 0;       // class B instantiations do not accumulate into gout
+    if (tmax <= 4 && KO <= 64) ft = 44;
+    else if (tmin <= 3 && tmax <= 9) ft = 39;
+    else return 0;
+    // r03k lab, 64 -> 64: 80x80 (819 K rows) 0.219 -> 0.165 ms, 40x40 (205 K rows) 0.071 -> 0.070, 20x20 0.030 -> 0.054:
+    // the prologue, the LDS reduction of dW and one wave per SIMD need ~250 K rows to pay off
+    if (a.M < env_int("EDET_PWS_FUSED_MINROWS", 262144)) return 0;
+  }
   a.cr = make_colmap(R);
   a.cx = make_colmap(KO);
-  const int pstR = (TR + a.cr.rp - 1) / a.cr.rp, pstX = (TR + a.cx.rp - 1) / a.cx.rp;
-  // (load passes of dy, of x) per 32-row tile, rounded up to an instantiated pair: the loops over the passes carry
-  // no run-time guard (a guarded register array lands in scratch memory)
-  int nsr, nsx;
-  if (pstR <= 8 && pstX <= 1) { nsr = 8; nsx = 1; }
-  else if (pstR <= 12 && pstX <= 2) { nsr = 12; nsx = 2; }
-  else return 0;
   const int Rp = (R + 7) / 8 * 8;
   a.ksteps = (R + 15) / 16;
   a.SA = frag_stride(Rp, Rp % 16 != 0);
@@ -1608,44 +1656,88 @@ int pws_try_bwd_fused(const edet_gview_t* dy, const void* w, int ldw, const edet
   // with one tile of loads in flight and is bound by that latency, not by bytes.  r03d, sums kept in registers across the
   // tiles: 1.90 -> 1.75 ms, 160x160x24->144 0.76 -> 0.68 ms (-8 / -10 %), with 43 % less traffic.
   const char* noy_env = getenv("EDET_PW_NOY");
-  const bool noy = gbn && (epi->flags & EDET_EPI_Y_IS_CONV_OF_INPUT) && dy->b && dy->cc && !in->scale && !in->gate &&
+  const bool noy = class_a && gbn && (epi->flags & EDET_EPI_Y_IS_CONV_OF_INPUT) && dy->b && dy->cc && !in->scale && !in->gate &&
                    in->act == EDET_ACT_NONE &&
                    !epi->stat_partials && !epi->dgate && R % 8 == 0 && KO <= 32 && !(noy_env && noy_env[0] == '0');
   a.SG = frag_stride(a.KOpad, false);
   a.kxsteps = (KO + 15) / 16;
   const size_t part = (size_t)KO * R + (noy ? (size_t)KO * KO + KO : 0);      // floats per workgroup partial
-  const size_t lds = (size_t)a.KOpad * a.SW + (size_t)4 * a.KOpad * 4 + (noy ? (size_t)a.KOpad * 4 + (size_t)a.KOpad * a.SG : 0) +
-                     (size_t)WAVES * ((size_t)nsr * a.cr.rp * a.SA + (size_t)(epi->beta ? 2 : 1) * nsx * a.cx.rp * a.SX +
+  // Rows in flight: G tiles of 32 rows per step, as many as an instantiated (NSR, NSX) pair of load passes covers
+  // without loading more than ~30 % past the step, the LDS (150 KB) and a budget of ~24 KB of loads per wave allow (the
+  // kernel runs one wave per SIMD: the bytes in flight per wave ARE the latency hiding).  EDET_PWS_FUSED_G caps it
+  // (lab switch).  r03j, D0 640x640 batch 128: 320x320x32->16 1.87 / 1.57 / 1.43 ms at G = 1 / 2 / 4.
+  static const int pairs_noy[][2] = {{13, 2}, {22, 4}};
+  static const int pairs_a[][2] = {{12, 4}};
+  static const int pairs_44[][2] = {{4, 8}, {8, 8}};
+  static const int pairs_39[][2] = {{2, 11}, {3, 11}, {4, 13}};
+  const int (*pairs)[2] = class_a ? (noy ? pairs_noy : pairs_a) : (ft == 44 ? pairs_44 : pairs_39);
+  const int npairs = class_a ? (noy ? 2 : 1) : (ft == 44 ? 2 : 3);
+  const int rbytes = ((gbn && !noy) ? 2 : 1) * Rp * 2, xbytes = (epi->beta ? 2 : 1) * KO * 2;
+  const int g_cap = env_int("EDET_PWS_FUSED_G", 4);
+  const int inflight = env_int("EDET_PWS_FUSED_INFLIGHT", 24 * 1024);
+  size_t lds = 0;
+  int pick = -1;
+  double pick_waste = 1e30;
+  a.G = 0;
+  for (int g = g_cap < 4 ? (g_cap < 1 ? 1 : g_cap) : 4; g >= 1; --g) {
+    const int nsr = (TR * g + a.cr.rp - 1) / a.cr.rp, nsx = (TR * g + a.cx.rp - 1) / a.cx.rp;
+    if (g > 1 && TR * g * (rbytes + xbytes) > inflight) continue;
+    const size_t l = (size_t)a.KOpad * a.SW + (size_t)4 * a.KOpad * 4 +
+                     (noy ? (size_t)a.KOpad * 4 + (size_t)a.KOpad * a.SG : 0) +
+                     (size_t)WAVES * ((size_t)TR * g * a.SA + (size_t)(epi->beta ? 2 : 1) * TR * g * a.SX +
                                       (size_t)TR * a.SC + (size_t)4 * a.KOpad * 4);
-  if (lds > 150 * 1024 || lds < (size_t)KO * R * 4) return 0;
-  const int ntile = (a.M + TR - 1) / TR;
-  // one workgroup per CU and wave (1 wave per SIMD); at least 4 tiles per wave, partials bounded by the workspace
+    if (l > 150 * 1024) continue;
+    for (int q = 0; q < npairs; ++q) {
+      if (pairs[q][0] < nsr || pairs[q][1] < nsx) continue;
+      const double waste = ((double)(pairs[q][0] * a.cr.rp - TR * g) * rbytes + (double)(pairs[q][1] * a.cx.rp - TR * g) * xbytes) /
+                           ((double)TR * g * (rbytes + xbytes));
+      if (waste < pick_waste - 1e-9 && (pick < 0 || pick_waste > 0.3)) {
+        pick = q; pick_waste = waste; a.G = g; lds = l;
+      }
+    }
+    if (pick >= 0 && pick_waste <= 0.3) break;
+  }
+  if (pick < 0 || lds < (size_t)KO * R * 4 + (noy ? (size_t)(KO * KO + KO) * 4 : 0)) return 0;
+  const int nstep = (a.M + TR * a.G - 1) / (TR * a.G);
   // one workgroup per compute unit, a single round (r03d lab: grids of 1024 / 512 / 256 -> 320x320x16->96 1.90 / 1.83 /
-  // 1.81 ms, 160x160x24->144 0.69 / 0.64 / 0.61 ms: every workgroup pays the prologue and the dW partial once)
+  // 1.81 ms, 160x160x24->144 0.69 / 0.64 / 0.61 ms: every workgroup pays the prologue and the dW partial once); at
+  // least 2 steps per wave, partials bounded by the workspace
   int grid = env_int("EDET_PWS_FUSED_GRID", 256);
   const int64_t max_by_ws = (int64_t)(workspace_bytes / sizeof(float)) / (int64_t)part - (noy ? 1 : 0);
   if (grid > max_by_ws) grid = (int)max_by_ws;
   if (grid > EDET_MAX_PARTS) grid = EDET_MAX_PARTS;
-  const int max_by_tiles = (ntile + WAVES * 4 - 1) / (WAVES * 4);
-  if (grid > max_by_tiles) grid = max_by_tiles;
+  const int max_by_steps = (nstep + WAVES * 2 - 1) / (WAVES * 2);
+  if (grid > max_by_steps) grid = max_by_steps;
   if (grid < 1) return 0;
-  a.tpw = (ntile + grid * WAVES - 1) / (grid * WAVES);
-  grid = (ntile + a.tpw * WAVES - 1) / (a.tpw * WAVES);
+  a.tpw = (nstep + grid * WAVES - 1) / (grid * WAVES);
+  grid = (nstep + a.tpw * WAVES - 1) / (a.tpw * WAVES);
   if (nparts_out) *nparts_out = grid;
-#define PWS_FUSED(NSR_, NSX_, GBN_, FS_, FL_, NOY_)                                                       \
-  do {                                                                                                    \
-    if (!allow_big_lds(&k_pw_bwd_fused<NSR_, NSX_, GBN_, FS_, FL_, NOY_>, lds)) return 0;                 \
-    edet_launch(k_pw_bwd_fused<NSR_, NSX_, GBN_, FS_, FL_, NOY_>, dim3(grid), dim3(THREADS), lds, st, a); \
+#define PWS_FUSED(NSR_, NSX_, GBN_, FS_, FL_, NOY_, NCH_, BETA_)                                                       \
+  do {                                                                                                                 \
+    if (!allow_big_lds(&k_pw_bwd_fused<NSR_, NSX_, GBN_, FS_, FL_, NOY_, NCH_, BETA_>, lds)) return 0;                 \
+    edet_launch(k_pw_bwd_fused<NSR_, NSX_, GBN_, FS_, FL_, NOY_, NCH_, BETA_>, dim3(grid), dim3(THREADS), lds, st, a); \
   } while (0)
-#define PWS_FUSED_G(NSR_, NSX_, FS_, FL_)                        \
-  do {                                                           \
-    if (noy) PWS_FUSED(NSR_, NSX_, true, FS_, FL_, true);        \
-    else if (gbn) PWS_FUSED(NSR_, NSX_, true, FS_, FL_, false);  \
-    else PWS_FUSED(NSR_, NSX_, false, FS_, FL_, false);          \
+#define PWS_FUSED_GB(NSR_, NSX_, FS_, FL_, NCH_, BETA_)                    \
+  do {                                                                     \
+    if (gbn) PWS_FUSED(NSR_, NSX_, true, FS_, FL_, false, NCH_, BETA_);    \
+    else PWS_FUSED(NSR_, NSX_, false, FS_, FL_, false, NCH_, BETA_);       \
   } while (0)
-  if (nsr == 8) PWS_FUSED_G(8, 1, 2, 9);
-  else PWS_FUSED_G(12, 2, 2, 9);
-#undef PWS_FUSED_G
+  if (class_a) {
+    if (noy) {
+      if (pick == 0) PWS_FUSED(13, 2, true, 2, 9, true, 1, true);
+      else PWS_FUSED(22, 4, true, 2, 9, true, 1, true);
+    } else {
+      PWS_FUSED_GB(12, 4, 2, 9, 1, true);
+    }
+  } else if (ft == 44) {
+    if (pick == 0) PWS_FUSED_GB(4, 8, 4, 4, 1, false);
+    else PWS_FUSED_GB(8, 8, 4, 4, 1, false);
+  } else {
+    if (pick == 0) PWS_FUSED_GB(2, 11, 3, 9, 3, false);
+    else if (pick == 1) PWS_FUSED_GB(3, 11, 3, 9, 3, false);
+    else PWS_FUSED_GB(4, 13, 3, 9, 3, false);
+  }
+#undef PWS_FUSED_GB
 #undef PWS_FUSED
   EDET_LAUNCH_CHECK("edet_pw_bwd(fused)");
   if (noy) {

@@ -253,7 +253,10 @@ def test_pw_bwd_data(dt, shape, mode, gbn, pw_impl, one_call=False, ws_mib=16, c
 
 PW_BWD_SHAPES = [(4, 33, 31, 16, 96), (2, 17, 19, 24, 144), (3, 11, 13, 8, 16), (2, 9, 9, 32, 64), (1, 23, 5, 16, 36),
                  (2, 9, 7, 24, 40), (3, 13, 11, 144, 24), (2, 12, 12, 96, 16), (3, 9, 9, 64, 64), (2, 5, 5, 64, 810),
-                 (1, 20, 20, 1152, 192)]
+                 (1, 20, 20, 1152, 192),
+                 # r03: the project / square layers inside the one-pass kernel (several steps per wave, several tiles per step)
+                 (2, 64, 64, 32, 16), (4, 48, 48, 64, 64), (8, 40, 40, 144, 24), (2, 40, 40, 96, 24), (2, 33, 31, 144, 40),
+                 (2, 20, 20, 64, 36), (2, 24, 24, 16, 96)]
 
 
 @pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
