@@ -268,7 +268,11 @@ def test_pw_bwd(dt, shape, mode, gbn, monkeypatch):
   2 cin: both load-pass instantiations, ragged maps, tiles that straddle images, cout % 8 != 0), the others outside
   (the entry point then runs the two separate kernels).  With a BatchNorm backward on dy both contracts are run: y is
   this convolution's own output and the call says so -- the plain-input cases inside the envelope then never read y
-  (EDET_PW_NOY=0 switches that off: also run) -- and y is an arbitrary tensor without the flag."""
+  (EDET_PW_NOY=0 switches that off: also run) -- and y is an arbitrary tensor without the flag.  The library sends
+  project / 64 -> 64 layers to the one-pass kernel only from ~250 K rows up (EDET_PWS_FUSED_MINROWS): the shapes here
+  are run once with the default (the two-kernel path) and then with that threshold at 0 (the one-pass kernel)."""
+  test_pw_bwd_data(dt, shape, mode, gbn, 'auto', one_call=True)
+  monkeypatch.setenv('EDET_PWS_FUSED_MINROWS', '0')
   test_pw_bwd_data(dt, shape, mode, gbn, 'auto', one_call=True)
   if gbn:
     test_pw_bwd_data(dt, shape, mode, gbn, 'auto', one_call=True, conv_y=False)
