@@ -174,8 +174,11 @@ __device__ __forceinline__ void column_stats(const unsigned char* Ct, int SC, in
 }
 
 // ------------------------------------------------------------------------------------ forward
-template <int NS, bool OACT>
-__global__ __launch_bounds__(THREADS, NS == 8 ? 3 : 2) void k_pw_fwd(const FwdArgs a) {
+// EXACT: every one of the NS load passes is issued and staged unconditionally (a.pst == NS).  A load under a run-time
+// guard makes every wait on the prefetched registers a wait for ALL outstanding loads and stores (r03j, the one-pass
+// backward: 30 %); the guarded form remains for the relu / relu6 / hswish instantiations.
+template <int NS, bool OACT, bool EXACT = false>
+__global__ __launch_bounds__(THREADS, NS <= 8 ? 3 : 2) void k_pw_fwd(const FwdArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int j = lane & 31, h = lane >> 5;
@@ -221,14 +224,27 @@ __global__ __launch_bounds__(THREADS, NS == 8 ? 3 : 2) void k_pw_fwd(const FwdAr
     const int row0 = st * a_rows;
     const unsigned char* base = reinterpret_cast<const unsigned char*>(A) + (size_t)row0 * a.tv.ld * 2;
     const bool full = row0 + a_alloc <= a.M;
+    if (EXACT) {
+      if (full) {
 #pragma unroll
-    for (int i = 0; i < NS; ++i) {
-      if (i < a.pst) {
-        if (full) {
-          raw[i] = *reinterpret_cast<const uint4*>(base + (size_t)i * pass_bytes + lane_off);
-        } else {  // tail: rows past M re-read row M-1 (finite values, never stored)
+        for (int i = 0; i < NS; ++i) raw[i] = *reinterpret_cast<const uint4*>(base + (size_t)i * pass_bytes + lane_off);
+      } else {  // tail: rows past M re-read row M-1 (finite values, never stored)
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
           const int r = min(row0 + i * a.ck.rp + rsub, a.M - 1);
           raw[i] = *reinterpret_cast<const uint4*>(A + (size_t)r * a.tv.ld + colK * 8);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        if (i < a.pst) {
+          if (full) {
+            raw[i] = *reinterpret_cast<const uint4*>(base + (size_t)i * pass_bytes + lane_off);
+          } else {
+            const int r = min(row0 + i * a.ck.rp + rsub, a.M - 1);
+            raw[i] = *reinterpret_cast<const uint4*>(A + (size_t)r * a.tv.ld + colK * 8);
+          }
         }
       }
     }
@@ -268,7 +284,7 @@ __global__ __launch_bounds__(THREADS, NS == 8 ? 3 : 2) void k_pw_fwd(const FwdAr
       }
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
-        if (i < a.pst) {
+        if (EXACT || i < a.pst) {
           const int r = i * a.ck.rp + rsub;
           if (per_row_gate) {
             const uint32_t rr = (uint32_t)min(row0 + r, a.M - 1);
@@ -1515,7 +1531,8 @@ int pws_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
   a.M = in->n * in->h * in->w; a.K = K; a.N = N; a.hw = in->h * in->w;
   a.stat_partials = stat_partials;
   a.ck = make_colmap(K);
-  const int NS = K > 128 ? 16 : 8;
+  const bool oact_ = in->act > EDET_ACT_SWISH;
+  int NS = K > 128 ? 16 : 8;
   a.ksteps = (K + 15) / 16;
   a.SA = frag_stride(K, K % 16 != 0);
   a.SW = a.SA;
@@ -1537,6 +1554,19 @@ int pws_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
     if (lds == 0 || a.NWC != a.Npad) lds = plan_lds(a.Npad, a.pst * a.ck.rp, a.SA, a.SW, 150 * 1024, &a.NWC, &a.SC);
     if (lds == 0) return 0;
   }
+  if (!oact_ && env_int("EDET_PWS_FWD_EXACT", 1)) {
+    // the instantiation with the fewest passes that covers the super-tile; its passes are all issued (rows beyond the
+    // super-tile are the wave's next rows) and staged, so the LDS tile holds NS * rp rows
+    static const int exact_ns[] = {4, 6, 7, 8, 11, 16};
+    int pick = 0;
+    for (int q = 0; q < 6; ++q) if (exact_ns[q] >= a.pst) { pick = exact_ns[q]; break; }
+    if (pick > 0) {
+      int nwc2 = 0, sc2 = 0;
+      const size_t cap = lds <= 53 * 1024 ? 53 * 1024 : (lds <= 80 * 1024 ? 80 * 1024 : 150 * 1024);
+      const size_t l2 = plan_lds(a.Npad, pick * a.ck.rp, a.SA, a.SW, cap, &nwc2, &sc2);
+      if (l2 != 0 && nwc2 == a.NWC) { NS = -pick; a.pst = pick; lds = l2; a.SC = sc2; }
+    }
+  }
   a.nwc = (a.Npad + a.NWC - 1) / a.NWC;
   if (a.nwc > 2) return 0;   // the big operand would be re-read too often: leave it to the tiled kernel
   const int nst = (a.M + TR * a.G - 1) / (TR * a.G);
@@ -1547,9 +1577,17 @@ int pws_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
   // 16-pass one).  r03h lab, caps of 1024 (the partial-row limit, round 2) / 768 / 512: 320x320x16->96 0.92 / 0.81 / 0.83
   // ms, 160x160x24->144 0.39 / 0.33 / 0.36, 320x320x32->16 0.46 / 0.40 / 0.48, 80x80x64->64 62 / 55 / 60 us; the
   // 144-channel inputs (2 per CU) 0.36 / 0.38 / 0.36: with 1024 workgroups on 768 slots the second round runs a third full.
-  const bool oact_ = in->act > EDET_ACT_SWISH;
-  const void* kfn = NS == 8 ? (oact_ ? reinterpret_cast<const void*>(&k_pw_fwd<8, true>) : reinterpret_cast<const void*>(&k_pw_fwd<8, false>))
-                            : (oact_ ? reinterpret_cast<const void*>(&k_pw_fwd<16, true>) : reinterpret_cast<const void*>(&k_pw_fwd<16, false>));
+  const void* kfn = nullptr;
+  switch (NS) {       // negative: the EXACT instantiation with -NS passes
+    case -4: kfn = reinterpret_cast<const void*>(&k_pw_fwd<4, false, true>); break;
+    case -6: kfn = reinterpret_cast<const void*>(&k_pw_fwd<6, false, true>); break;
+    case -7: kfn = reinterpret_cast<const void*>(&k_pw_fwd<7, false, true>); break;
+    case -8: kfn = reinterpret_cast<const void*>(&k_pw_fwd<8, false, true>); break;
+    case -11: kfn = reinterpret_cast<const void*>(&k_pw_fwd<11, false, true>); break;
+    case -16: kfn = reinterpret_cast<const void*>(&k_pw_fwd<16, false, true>); break;
+    case 8: kfn = oact_ ? reinterpret_cast<const void*>(&k_pw_fwd<8, true>) : reinterpret_cast<const void*>(&k_pw_fwd<8, false>); break;
+    default: kfn = oact_ ? reinterpret_cast<const void*>(&k_pw_fwd<16, true>) : reinterpret_cast<const void*>(&k_pw_fwd<16, false>); break;
+  }
   const int slots_fwd = edet_resident_wgs(kfn, THREADS, lds);
   const int cap_fwd = env_int("EDET_PWS_FWD_CAP", slots_fwd > 0 ? slots_fwd : EDET_MAX_PARTS);     // lab switch overrides
   if (grid > cap_fwd) grid = cap_fwd;
@@ -1558,14 +1596,21 @@ int pws_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
   a.spw = (nst + grid * WAVES - 1) / (grid * WAVES);
   grid = (nst + a.spw * WAVES - 1) / (a.spw * WAVES);
   if (nparts_out) *nparts_out = grid;
-#define PWS_FWD(NS_, OACT_)                                                      \
-  do {                                                                          \
-    if (!allow_big_lds(&k_pw_fwd<NS_, OACT_>, lds)) return 0;                   \
-    edet_launch(k_pw_fwd<NS_, OACT_>, dim3(grid), dim3(THREADS), lds, st, a);   \
+#define PWS_FWD(NS_, OACT_, EXACT_)                                                      \
+  do {                                                                                  \
+    if (!allow_big_lds(&k_pw_fwd<NS_, OACT_, EXACT_>, lds)) return 0;                   \
+    edet_launch(k_pw_fwd<NS_, OACT_, EXACT_>, dim3(grid), dim3(THREADS), lds, st, a);   \
   } while (0)
-  const bool oact = in->act > EDET_ACT_SWISH;      // relu / relu6 / hswish: the OACT instantiations
-  if (NS == 8) { if (oact) PWS_FWD(8, true); else PWS_FWD(8, false); }
-  else { if (oact) PWS_FWD(16, true); else PWS_FWD(16, false); }
+  switch (NS) {
+    case -4: PWS_FWD(4, false, true); break;
+    case -6: PWS_FWD(6, false, true); break;
+    case -7: PWS_FWD(7, false, true); break;
+    case -8: PWS_FWD(8, false, true); break;
+    case -11: PWS_FWD(11, false, true); break;
+    case -16: PWS_FWD(16, false, true); break;
+    case 8: if (oact_) PWS_FWD(8, true, false); else PWS_FWD(8, false, false); break;
+    default: if (oact_) PWS_FWD(16, true, false); else PWS_FWD(16, false, false); break;
+  }
 #undef PWS_FWD
   EDET_LAUNCH_CHECK("edet_pw_fwd(stream)");
   return 1;

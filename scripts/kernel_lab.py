@@ -87,8 +87,10 @@ def build_case(entry, shape):
     if entry == 'pw_fwd':
       wt = rand(cout, gu.pad8(cin)) * (1.0 / np.sqrt(cin))
       out = torch.empty(n, h, w, gu.pad8(cout), dtype=tdt, device=dev)
+      # EDET_LAB_NOSTATS=1 (read per call, so it can be the --ab variable): no BatchNorm statistic partials
       return (lambda: call('edet_pw_fwd', ctypes.byref(tv), ptr(wt), gu.pad8(cin), None, ptr(out), cout,
-                           gu.pad8(cout), ptr(parts), ctypes.byref(npart), edt, gu.stream())), nbytes
+                           gu.pad8(cout), None if os.environ.get('EDET_LAB_NOSTATS') == '1' else ptr(parts),
+                           ctypes.byref(npart), edt, gu.stream())), nbytes
     dz, y = rand(n, h, w, gu.pad8(cout)), rand(n, h, w, gu.pad8(cout))
     gv = gu.gview(dz, cout, y, vec(cout), vec(cout, -0.1, 0.1), vec(cout, -0.1, 0.1))
     if entry == 'pw_bwd_data':
