@@ -264,15 +264,20 @@ __global__ __launch_bounds__(THREADS) void k_fwd_lx(const Args a) {
 #pragma unroll
       for (int j = 0; j < S; ++j) fm[i][j] = raw_zero<CPT>();
     }
-    auto load_row = [&](int t, Raw<CPT> (&dst)[S], Raw<CPT>& hdst) {
-      const int r = t - a.pad_t;
-      if (t <= t_last && r >= 0 && r < H) {
-        const bf16_t* rp = ibase + (int64_t)r * W * a.in.ld;
+    // Every load of a step is issued on every step, at an in-range address (row, column and channel clamped): what
+    // lies outside the image / the channel range is zeroed where the row is consumed (mok / hok below).  A load under
+    // a branch turns every wait on the FIFO into a wait for ALL loads in flight -- the newest row included, i.e. the
+    // whole HBM latency once per row step (r03o: the waits of these kernels were all vmcnt(0)).
+    int64_t coff[S], hoff;
 #pragma unroll
-        for (int j = 0; j < S; ++j)
-          dst[j] = mok[j] ? raw_load<CPT>(rp + (int64_t)(wc0 + l.px * S + j) * a.in.ld) : raw_zero<CPT>();
-        if (HALO > 0) hdst = hok ? raw_load<CPT>(rp + (int64_t)ixh * a.in.ld) : raw_zero<CPT>();
-      }
+    for (int j = 0; j < S; ++j) coff[j] = (int64_t)min(max(wc0 + l.px * S + j, 0), W - 1) * a.in.ld;
+    hoff = hown ? (int64_t)min(max(ixh, 0), W - 1) * a.in.ld : coff[0];
+    const bf16_t* ibase_c = IN + ((int64_t)n * H * W * a.in.ld + (l.c < C ? l.c : 0));
+    auto load_row = [&](int t, Raw<CPT> (&dst)[S], Raw<CPT>& hdst) {
+      const bf16_t* rp = ibase_c + (int64_t)min(max(t - a.pad_t, 0), H - 1) * W * a.in.ld;
+#pragma unroll
+      for (int j = 0; j < S; ++j) dst[j] = raw_load<CPT>(rp + coff[j]);
+      if (HALO > 0) hdst = raw_load<CPT>(rp + hoff);
     };
 #pragma unroll
     for (int i = 0; i < PF; ++i) load_row(t0 + i, fm[i], fh[i]);
@@ -838,24 +843,18 @@ __global__ __launch_bounds__(THREADS, CPT * K >= 10 ? 2 : 3) void k_bwd_fused(co
       if (GBN) fy[i] = fhy[i] = raw_zero<CPT>();
     }
     if (!GBN) fy[0] = fhy[0] = raw_zero<CPT>();
+    // every load of a step is issued on every step at an in-range address (see k_fwd_lx); rows / columns / channels
+    // outside the tile or the image are zeroed where they are consumed (row_ok, qok, hok, xin below)
+    const int cc = l.c < C ? l.c : 0;
+    const int64_t qoff = (int64_t)min(q, W - 1), qhoff = hown ? (int64_t)min(max(qh, 0), W - 1) : qoff;
     auto load_step = [&](int t, Raw<CPT>& z, Raw<CPT>& y, Raw<CPT>& hz, Raw<CPT>& hy, Raw<CPT>& x) {
-      const int oy = r0 - PD + t;
-      z = hz = raw_zero<CPT>();
-      if (GBN) y = hy = raw_zero<CPT>();
-      if (t <= t_last && oy >= 0 && oy < H) {                  // uniform
-        const size_t rowoff = (img + (size_t)oy * W) * a.gy.ld + l.c;
-        if (qok) {
-          z = raw_load<CPT>(DZ + rowoff + (size_t)q * a.gy.ld);
-          if (GBN) y = raw_load<CPT>(YY + rowoff + (size_t)q * a.gy.ld);
-        }
-        if (hok) {
-          hz = raw_load<CPT>(DZ + rowoff + (size_t)qh * a.gy.ld);
-          if (GBN) hy = raw_load<CPT>(YY + rowoff + (size_t)qh * a.gy.ld);
-        }
-      }
-      const int iy = r0 + t;
-      x = raw_zero<CPT>();
-      if (iy < r1 && qok) x = raw_load<CPT>(X + (img + (size_t)iy * W + q) * a.in.ld + l.c);
+      const int oyc = min(max(r0 - PD + t, 0), H - 1);
+      const size_t rowoff = (img + (size_t)oyc * W) * a.gy.ld + cc;
+      z = raw_load<CPT>(DZ + rowoff + (size_t)qoff * a.gy.ld);
+      if (GBN) y = raw_load<CPT>(YY + rowoff + (size_t)qoff * a.gy.ld);
+      hz = raw_load<CPT>(DZ + rowoff + (size_t)qhoff * a.gy.ld);
+      if (GBN) hy = raw_load<CPT>(YY + rowoff + (size_t)qhoff * a.gy.ld);
+      x = raw_load<CPT>(X + (img + (size_t)min(r0 + t, H - 1) * W + qoff) * a.in.ld + cc);
     };
 #pragma unroll
     for (int i = 0; i < PF; ++i) load_step(i, fz[i], fy[GBN ? i : 0], fhz[i], fhy[GBN ? i : 0], fx[i]);
@@ -905,6 +904,9 @@ __global__ __launch_bounds__(THREADS, CPT * K >= 10 ? 2 : 3) void k_bwd_fused(co
             raw_unpack<CPT>(fy[0], y);
 #pragma unroll
             for (int e = 0; e < CPT; ++e) g[e] = qok ? fmaf(ga[e], g[e], fmaf(gb[e], y[e], gc[e])) : 0.f;
+          } else {
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) g[e] = qok ? g[e] : 0.f;
           }
           lds_put<CPT>(buf + (l.px + PD) * width + l.chunk * CPT, g);
           if (hown) {
@@ -914,6 +916,9 @@ __global__ __launch_bounds__(THREADS, CPT * K >= 10 ? 2 : 3) void k_bwd_fused(co
               raw_unpack<CPT>(fhy[0], y);
 #pragma unroll
               for (int e = 0; e < CPT; ++e) g[e] = hok ? fmaf(ga[e], g[e], fmaf(gb[e], y[e], gc[e])) : 0.f;
+            } else {
+#pragma unroll
+              for (int e = 0; e < CPT; ++e) g[e] = hok ? g[e] : 0.f;
             }
             lds_put<CPT>(buf + wch * width + l.chunk * CPT, g);
           }
