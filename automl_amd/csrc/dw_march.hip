@@ -206,11 +206,19 @@ template <int S, int CPT> struct PfDepth {
   static constexpr int dgrad = CPT == 4 ? (S == 1 ? 3 : 1) : (S == 1 ? 6 : 3);
 };
 
+__host__ __device__ constexpr int gcd_(int x, int y) { return y == 0 ? x : gcd_(y, x % y); }
+
 template <int K, int S, int CPT, bool OACT>
 __global__ __launch_bounds__(THREADS) void k_fwd_lx(const Args a) {
-  constexpr int PF = PfDepth<S, CPT>::fwd;
   constexpr int NSL = (K + S - 1) / S;   // output rows in flight
-  constexpr int U = S * NSL;             // static unroll of the row loop
+  constexpr int U0 = S * NSL;            // row steps after which the window slots repeat
+  // The FIFO of rows in flight is a ring of NF register sets addressed by static indices: no set is ever copied into
+  // its neighbour (r03q: the shift fm[i] = fm[i+1] at every step survived unrolling as NF moves per array and U0 steps,
+  // about as many VALU instructions as the 3x3 multiply-adds).  The row loop is unrolled over lcm(U0, NF) steps, so NF
+  // is chosen as a divisor or a small multiple of U0 near the depth the lab found best (6 rows at stride 1, 4 at 2).
+  constexpr int PF = U0 == 3 ? 5 : (U0 == 5 ? 4 : (U0 == 4 ? 3 : (U0 == 6 ? 5 : PfDepth<S, CPT>::fwd)));
+  constexpr int NF = PF + 1;
+  constexpr int U = U0 * NF / gcd_(U0, NF);   // static unroll of the row loop
   constexpr int HALO = K - S;            // window columns beyond TX * S
   extern __shared__ float red[];
   const int C = a.in.c, H = a.in.h, W = a.in.w;
@@ -256,8 +264,8 @@ __global__ __launch_bounds__(THREADS) void k_fwd_lx(const Args a) {
 #pragma unroll
       for (int e = 0; e < CPT; ++e) acc[s][e] = 0.f;
 
-    const int t0 = (oy0 * S / U) * U, t_last = (oy1 - 1) * S + K - 1;   // t = input row + pad_t
-    Raw<CPT> fm[PF + 1][S], fh[PF + 1];                     // fm[0] = row being consumed, fm[PF] = newest
+    const int t0 = (oy0 * S / U0) * U0, t_last = (oy1 - 1) * S + K - 1;   // t = input row + pad_t
+    Raw<CPT> fm[NF][S], fh[NF];                             // ring: step tt consumes set tt % NF, fills (tt + PF) % NF
 #pragma unroll
     for (int i = 0; i <= PF; ++i) {
       fh[i] = raw_zero<CPT>();
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(THREADS) void k_fwd_lx(const Args a) {
 #pragma unroll
       for (int tt = 0; tt < U; ++tt) {
         const int t = tb + tt;
-        load_row(t + PF, fm[PF], fh[PF]);                  // PF input rows in flight per thread
+        load_row(t + PF, fm[(tt + PF) % NF], fh[(tt + PF) % NF]);      // PF input rows in flight per thread
         const int r = t - a.pad_t;
         const bool row_ok = t <= t_last && r >= 0 && r < H;   // uniform over the workgroup
         float* buf = ring + (t & 1) * WIN * width;
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(THREADS) void k_fwd_lx(const Args a) {
 #pragma unroll
           for (int j = 0; j < S; ++j) {
             float x[CPT];
-            raw_unpack<CPT>(fm[0][j], x);
+            raw_unpack<CPT>(fm[tt % NF][j], x);
             view_act<CPT, OACT>(a.in, sc, sh, x);
             if (!mok[j]) {
 #pragma unroll
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(THREADS) void k_fwd_lx(const Args a) {
           }
           if (hown) {
             float x[CPT];
-            raw_unpack<CPT>(fh[0], x);
+            raw_unpack<CPT>(fh[tt % NF], x);
             view_act<CPT, OACT>(a.in, sc, sh, x);
             if (!hok) {
 #pragma unroll
@@ -344,12 +352,6 @@ __global__ __launch_bounds__(THREADS) void k_fwd_lx(const Args a) {
           }
 #pragma unroll
           for (int e = 0; e < CPT; ++e) acc[sl][e] = 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-          fh[i] = fh[i + 1];
-#pragma unroll
-          for (int j = 0; j < S; ++j) fm[i][j] = fm[i + 1][j];
         }
       }
     }
@@ -775,7 +777,12 @@ __global__ __launch_bounds__(THREADS, CPT * K >= 10 ? 2 : 3) void k_bwd_fused(co
   // rows of global loads in flight: 3 rows left the march latency-bound (a row step is ~0.2 us of work, HBM latency
   // under load ~2 us); r02i lab: 6 rows (4 with four channels per thread: register budget) 12.08 -> 11.44 ms over
   // the 15 depthwise layer shapes of D0 640x640 batch 128; 8 rows: 11.07 -> 10.92 ms (r02j), not worth the registers
-  constexpr int PF = CPT == 4 ? 4 : 6;
+  // ring of NF register sets with static indices (see k_fwd_lx): K = 3 -> 6 sets (5 rows ahead; 3 sets = 2 rows ahead
+  // with four channels per thread: register budget of the two-wave kernel), K = 5 -> 5 sets; the row loop is unrolled
+  // over lcm(K, NF) steps
+  constexpr int PF = K == 3 ? (CPT == 4 ? 2 : 5) : (K == 5 ? 4 : (CPT == 4 ? 4 : 6));
+  constexpr int NF = PF + 1;
+  constexpr int U = K * NF / gcd_(K, NF);
   constexpr int PD = (K - 1) / 2;             // 'SAME' padding of an odd kernel at stride 1
   extern __shared__ float red[];
   const int C = a.in.c, H = a.in.h, W = a.in.w;
@@ -836,7 +843,7 @@ __global__ __launch_bounds__(THREADS, CPT * K >= 10 ? 2 : 3) void k_bwd_fused(co
     }
     // step t: dy row oy = r0 - PD + t, newest x row iy = r0 + t, completed row iy = r0 - 2 PD + t
     const int t_last = (r1 - r0) - 1 + 2 * PD;
-    Raw<CPT> fz[PF + 1], fy[GBN ? PF + 1 : 1], fhz[PF + 1], fhy[GBN ? PF + 1 : 1], fx[PF + 1];
+    Raw<CPT> fz[NF], fy[GBN ? NF : 1], fhz[NF], fhy[GBN ? NF : 1], fx[NF];     // step tt consumes set tt % NF
 #pragma unroll
     for (int i = 0; i <= PF; ++i) {
       fz[i] = fhz[i] = fx[i] = raw_zero<CPT>();
@@ -858,11 +865,13 @@ __global__ __launch_bounds__(THREADS, CPT * K >= 10 ? 2 : 3) void k_bwd_fused(co
     };
 #pragma unroll
     for (int i = 0; i < PF; ++i) load_step(i, fz[i], fy[GBN ? i : 0], fhz[i], fhy[GBN ? i : 0], fx[i]);
-    for (int tb = 0; tb <= t_last; tb += K) {
+    for (int tb = 0; tb <= t_last; tb += U) {
 #pragma unroll
-      for (int tt = 0; tt < K; ++tt) {
+      for (int tt = 0; tt < U; ++tt) {
         const int t = tb + tt;
-        load_step(t + PF, fz[PF], fy[GBN ? PF : 0], fhz[PF], fhy[GBN ? PF : 0], fx[PF]);
+        constexpr int dummy0 = 0; (void)dummy0;
+        const int fc = tt % NF, fn = (tt + PF) % NF;       // set consumed / filled at this step
+        load_step(t + PF, fz[fn], fy[GBN ? fn : 0], fhz[fn], fhy[GBN ? fn : 0], fx[fn]);
         const int oy = r0 - PD + t;
         // ---- newest x row enters the window at slot (tt + K - 1) % K
         {
@@ -870,8 +879,8 @@ __global__ __launch_bounds__(THREADS, CPT * K >= 10 ? 2 : 3) void k_bwd_fused(co
           const int sl = slot_of(tt + K - 1, K);
           const int iy = r0 + t;
           float x[CPT], z[CPT];
-          raw_unpack<CPT>(fx[0], x);
-          xw[sl] = fx[0];
+          raw_unpack<CPT>(fx[fc], x);
+          xw[sl] = fx[fc];
           const bool xin = iy < r1 && qok;
 #pragma unroll
           for (int e = 0; e < CPT; ++e) z[e] = fmaf(x[e], sc[e], sh[e]);
@@ -898,10 +907,10 @@ __global__ __launch_bounds__(THREADS, CPT * K >= 10 ? 2 : 3) void k_bwd_fused(co
         float* buf = ring + (t & 1) * WIN * width;
         if (row_ok && in_tile) {
           float g[CPT];
-          raw_unpack<CPT>(fz[0], g);
+          raw_unpack<CPT>(fz[fc], g);
           if (GBN) {
             float y[CPT];
-            raw_unpack<CPT>(fy[0], y);
+            raw_unpack<CPT>(fy[GBN ? fc : 0], y);
 #pragma unroll
             for (int e = 0; e < CPT; ++e) g[e] = qok ? fmaf(ga[e], g[e], fmaf(gb[e], y[e], gc[e])) : 0.f;
           } else {
@@ -910,10 +919,10 @@ __global__ __launch_bounds__(THREADS, CPT * K >= 10 ? 2 : 3) void k_bwd_fused(co
           }
           lds_put<CPT>(buf + (l.px + PD) * width + l.chunk * CPT, g);
           if (hown) {
-            raw_unpack<CPT>(fhz[0], g);
+            raw_unpack<CPT>(fhz[fc], g);
             if (GBN) {
               float y[CPT];
-              raw_unpack<CPT>(fhy[0], y);
+              raw_unpack<CPT>(fhy[GBN ? fc : 0], y);
 #pragma unroll
               for (int e = 0; e < CPT; ++e) g[e] = hok ? fmaf(ga[e], g[e], fmaf(gb[e], y[e], gc[e])) : 0.f;
             } else {
@@ -967,11 +976,6 @@ __global__ __launch_bounds__(THREADS, CPT * K >= 10 ? 2 : 3) void k_bwd_fused(co
           }
 #pragma unroll
           for (int e = 0; e < CPT; ++e) dacc[sl][e] = 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-          fz[i] = fz[i + 1]; fhz[i] = fhz[i + 1]; fx[i] = fx[i + 1];
-          if (GBN) { fy[i] = fy[i + 1]; fhy[i] = fhy[i + 1]; }
         }
       }
     }
