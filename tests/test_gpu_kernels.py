@@ -256,7 +256,7 @@ PW_BWD_SHAPES = [(4, 33, 31, 16, 96), (2, 17, 19, 24, 144), (3, 11, 13, 8, 16), 
                  (1, 20, 20, 1152, 192),
                  # r03: the project / square layers inside the one-pass kernel (several steps per wave, several tiles per step)
                  (2, 64, 64, 32, 16), (4, 48, 48, 64, 64), (8, 40, 40, 144, 24), (2, 40, 40, 96, 24), (2, 33, 31, 144, 40),
-                 (2, 20, 20, 64, 36), (2, 24, 24, 16, 96)]
+                 (2, 20, 20, 64, 36), (2, 24, 24, 16, 96), (2, 40, 40, 40, 240), (1, 33, 17, 48, 256)]
 
 
 @pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
