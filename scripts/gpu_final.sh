@@ -5,10 +5,13 @@ mkdir -p gpurun_out
 T=${1:-final}
 STEPS_IN_PMC_RUN=6       # bench.py --steps 1 --warmup 1 in graph mode: 3 warm-up incl. capture, 1 profiled eager, 1 replay, 1 eager roofline step
 export TMPDIR=/tmp
-(timeout 2400 python -m pytest tests -m gpu -q --durations=8 2>&1 | cut -c1-3000 | tail -150) > gpurun_out/${T}_pytest_gpu.log
 (timeout 300 python __graft_entry__.py smoke 2>&1 | tail -4) > gpurun_out/${T}_smoke.log
 (timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${T} -o ${T} --output-format csv -- python bench.py --steps 3 --warmup 1 --no_cpu_baseline --no_other_configs 2>&1 | tail -3) > gpurun_out/${T}_prof.log
 find gpurun_out/prof_${T} -name "*kernel_trace.csv" -delete
+# the coverage test (tests/test_gpu_bench_shapes.py) reads the kernel statistics that profiles/CURRENT names: they must be
+# the ones of THIS tree, so the statistics are taken first and the parity run second
+cp gpurun_out/prof_${T}/${T}_kernel_stats.csv profiles/${T}_kernel_stats_b128.csv && echo ${T}_kernel_stats_b128.csv > profiles/CURRENT
+(timeout 2400 python -m pytest tests -m gpu -q --durations=8 2>&1 | cut -c1-3000 | tail -150) > gpurun_out/${T}_pytest_gpu.log
 run() {
   timeout 600 rocprofv3 --kernel-trace --pmc $2 -d gpurun_out/${T}_$1 -o $1 --output-format csv -- python bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_other_configs > gpurun_out/${T}_$1.log 2>&1
   python scripts/pmc_agg.py gpurun_out/${T}_$1 > gpurun_out/${T}_pmc_$1.txt 2>&1

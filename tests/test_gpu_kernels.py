@@ -482,7 +482,9 @@ def test_stem(dt, shape):
   dwd = torch.zeros(3, 3, 3, co, dtype=torch.float32, device=gu.DEV)
   call('edet_stem_bwd_weight', ptr(imgd), n, h, w, ctypes.byref(gv), ptr(dwd), edt, gu.stream())
   torch.cuda.synchronize()
-  gu.check(dwd, wq.grad, name, 'stem_bwd_weight %s' % (shape,), rtol=1e-3, atol=1e-3)
+  # bf16: dy = a*dz + b*y + c is rounded to bf16 for the matrix cores (as in every other weight-gradient kernel of the path)
+  wtol = 1e-3 if name == 'f32' else 1e-2
+  gu.check(dwd, wq.grad, name, 'stem_bwd_weight %s' % (shape,), rtol=wtol, atol=wtol)
 
 
 # ------------------------------------------------------------------------------------ BatchNorm
