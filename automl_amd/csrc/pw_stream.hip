@@ -177,7 +177,8 @@ __device__ __forceinline__ void column_stats(const unsigned char* Ct, int SC, in
 // EXACT: every one of the NS load passes is issued and staged unconditionally (a.pst == NS).  A load under a run-time
 // guard makes every wait on the prefetched registers a wait for ALL outstanding loads and stores (r03j, the one-pass
 // backward: 30 %); the guarded form remains for the relu / relu6 / hswish instantiations.
-template <int NS, bool OACT, bool EXACT = false>
+// (OACT stays the last template argument: tests/test_gpu_kernels.py reads it off the kernel symbol)
+template <int NS, bool EXACT, bool OACT>
 __global__ __launch_bounds__(THREADS, NS <= 8 ? 3 : 2) void k_pw_fwd(const FwdArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1579,14 +1580,14 @@ int pws_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
   // 144-channel inputs (2 per CU) 0.36 / 0.38 / 0.36: with 1024 workgroups on 768 slots the second round runs a third full.
   const void* kfn = nullptr;
   switch (NS) {       // negative: the EXACT instantiation with -NS passes
-    case -4: kfn = reinterpret_cast<const void*>(&k_pw_fwd<4, false, true>); break;
-    case -6: kfn = reinterpret_cast<const void*>(&k_pw_fwd<6, false, true>); break;
-    case -7: kfn = reinterpret_cast<const void*>(&k_pw_fwd<7, false, true>); break;
-    case -8: kfn = reinterpret_cast<const void*>(&k_pw_fwd<8, false, true>); break;
-    case -11: kfn = reinterpret_cast<const void*>(&k_pw_fwd<11, false, true>); break;
-    case -16: kfn = reinterpret_cast<const void*>(&k_pw_fwd<16, false, true>); break;
-    case 8: kfn = oact_ ? reinterpret_cast<const void*>(&k_pw_fwd<8, true>) : reinterpret_cast<const void*>(&k_pw_fwd<8, false>); break;
-    default: kfn = oact_ ? reinterpret_cast<const void*>(&k_pw_fwd<16, true>) : reinterpret_cast<const void*>(&k_pw_fwd<16, false>); break;
+    case -4: kfn = reinterpret_cast<const void*>(&k_pw_fwd<4, true, false>); break;
+    case -6: kfn = reinterpret_cast<const void*>(&k_pw_fwd<6, true, false>); break;
+    case -7: kfn = reinterpret_cast<const void*>(&k_pw_fwd<7, true, false>); break;
+    case -8: kfn = reinterpret_cast<const void*>(&k_pw_fwd<8, true, false>); break;
+    case -11: kfn = reinterpret_cast<const void*>(&k_pw_fwd<11, true, false>); break;
+    case -16: kfn = reinterpret_cast<const void*>(&k_pw_fwd<16, true, false>); break;
+    case 8: kfn = oact_ ? reinterpret_cast<const void*>(&k_pw_fwd<8, false, true>) : reinterpret_cast<const void*>(&k_pw_fwd<8, false, false>); break;
+    default: kfn = oact_ ? reinterpret_cast<const void*>(&k_pw_fwd<16, false, true>) : reinterpret_cast<const void*>(&k_pw_fwd<16, false, false>); break;
   }
   const int slots_fwd = edet_resident_wgs(kfn, THREADS, lds);
   const int cap_fwd = env_int("EDET_PWS_FWD_CAP", slots_fwd > 0 ? slots_fwd : EDET_MAX_PARTS);     // lab switch overrides
@@ -1598,8 +1599,8 @@ int pws_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
   if (nparts_out) *nparts_out = grid;
 #define PWS_FWD(NS_, OACT_, EXACT_)                                                      \
   do {                                                                                  \
-    if (!allow_big_lds(&k_pw_fwd<NS_, OACT_, EXACT_>, lds)) return 0;                   \
-    edet_launch(k_pw_fwd<NS_, OACT_, EXACT_>, dim3(grid), dim3(THREADS), lds, st, a);   \
+    if (!allow_big_lds(&k_pw_fwd<NS_, EXACT_, OACT_>, lds)) return 0;                   \
+    edet_launch(k_pw_fwd<NS_, EXACT_, OACT_>, dim3(grid), dim3(THREADS), lds, st, a);   \
   } while (0)
   switch (NS) {
     case -4: PWS_FWD(4, false, true); break;

@@ -105,10 +105,16 @@ def test_conv_bwd_at_v2s_224_shapes(layer):
 
 
 @pytest.mark.parametrize('layer', V2S_PW, ids=_pw_id)
-def test_pw_at_v2s_224_shapes(layer):
+def test_pw_at_v2s_224_shapes(layer, monkeypatch):
   h, cin, cout, view = layer
   shape = (N_IMG, h, h, cin, cout)
   tk.test_pw_fwd(BF16, shape, {'gate': 'bn_swish_gate'}.get(view, view), 'auto')
+  if cin <= 256:
+    # the library picks tiled / streaming by the row count: 2 images of the 56 / 28-row maps run the tiled kernel where
+    # the batch-256 forward streams (its instantiation depends on the channel counts only) -- run that one too
+    monkeypatch.setenv('EDET_PW_IMPL', 'stream')
+    tk.test_pw_fwd(BF16, shape, {'gate': 'bn_swish_gate'}.get(view, view), 'auto')
+    monkeypatch.delenv('EDET_PW_IMPL')
   tk.test_pw_bwd_data(BF16, shape, {'bn_swish': 'bn_swish_stats'}.get(view, view), True, 'auto', one_call=True,
                       ws_mib=ENGINE_WS_MIB)
 
