@@ -110,6 +110,16 @@ def ema_decay_dynamic(average_decay, num_updates):
   return min(average_decay, (1.0 + num_updates) / (10.0 + num_updates))
 
 
+def moving_normalizer_update(state, value, momentum):
+  """The loss normalizer as a moving average (train_lib.py:519-531, config.positives_momentum > 0): Keras'
+  moving_average_update on a variable that starts at 0.0 -- state <- state * momentum + value * (1 - momentum), with no
+  zero-debiasing, so the first steps divide the loss by a small number exactly as the reference does.  `state` is a python
+  float (returned) or a 0-d torch tensor (updated in place and returned: the device path, no host synchronisation)."""
+  if torch.is_tensor(state):
+    return state.mul_(momentum).add_(value, alpha=1.0 - momentum)
+  return state * momentum + float(value) * (1.0 - momentum)
+
+
 class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
   """EfficientDetNet plus the reference train_step.
 
@@ -138,6 +148,7 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
     self.use_dist = use_dist or process_group is not None
     self._lr_fn = None
     self.iterations = 0
+    self._moving_normalizer = None      # positives_momentum > 0: python float (host normalizer) or 0-d device tensor
 
   def set_optimizer_state(self, state):
     """Optimizer slots + iteration count; the count also drives the learning-rate schedule and the dynamic EMA decay
@@ -154,8 +165,6 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
       unsupported.append('iou_loss_type=%r (BoxIouLoss, train_lib.py:440-466)' % c.iou_loss_type)
     if getattr(c, 'label_smoothing', 0.0):
       unsupported.append('label_smoothing=%r (FocalLoss, train_lib.py:400-401)' % c.label_smoothing)
-    if getattr(c, 'positives_momentum', None):
-      unsupported.append('positives_momentum=%r (moving normalizer, train_lib.py:519-534)' % c.positives_momentum)
     if getattr(c, 'var_freeze_expr', None):
       unsupported.append('var_freeze_expr=%r (train_lib.py:478-484)' % c.var_freeze_expr)
     if str(getattr(c, 'optimizer', 'sgd')).lower() != 'sgd':
@@ -212,9 +221,10 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
         buf.copy_(labels[k], non_blocking=True)
     eng.set_hyper(lr, decay)
     if 'normalizer' in labels:                         # host value supplied by the caller
-      eng.hyper[2:3].copy_(torch.tensor([1.0 / float(labels['normalizer'])], dtype=torch.float32), non_blocking=True)
+      norm = self._host_normalizer(float(labels['normalizer']))
+      eng.hyper[2:3].copy_(torch.tensor([1.0 / norm], dtype=torch.float32), non_blocking=True)
     elif 'mean_num_positives' in g['labels']:
-      eng.set_normalizer(g['labels']['mean_num_positives'])
+      self._device_normalizer(eng, g['labels']['mean_num_positives'])
     else:
       raise KeyError("labels need 'mean_num_positives' (dataloader.py:393) or a host 'normalizer'")
     glabels = dict(g['labels'])
@@ -264,6 +274,45 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
       eng.arena.step_count += 1
     g['steps'] += 1
 
+  def _positives_momentum(self):
+    return float(getattr(self.config, 'positives_momentum', None) or 0.0)
+
+  def _host_normalizer(self, value):
+    """sum(mean_num_positives) + 1 as the reference uses it (train_lib.py:517-534): the moving average over the steps for
+    positives_momentum > 0, the mean over the replicas for positives_momentum < 0, the value itself otherwise."""
+    m = self._positives_momentum()
+    if m > 0:
+      self._moving_normalizer = moving_normalizer_update(
+          0.0 if self._moving_normalizer is None else float(self._moving_normalizer), value, m)
+      return self._moving_normalizer
+    if m < 0 and self.use_dist:
+      import torch.distributed as dist
+      t = torch.tensor([value], dtype=torch.float32)
+      if dist.get_backend(self.process_group) == 'nccl':
+        t = t.cuda()
+      dist.all_reduce(t, group=self.process_group)
+      return float(t.item()) / dist.get_world_size(self.process_group)
+    return value
+
+  def _device_normalizer(self, eng, mean_num_positives):
+    """The same on the device (no host synchronisation; runs eagerly in front of the replayed graph): hyper[2] =
+    1 / normalizer."""
+    m = self._positives_momentum()
+    if m == 0 or (m < 0 and not self.use_dist):
+      eng.set_normalizer(mean_num_positives)
+      return
+    s = mean_num_positives.reshape(-1).float().sum() + 1.0
+    if m > 0:
+      if not torch.is_tensor(self._moving_normalizer):
+        self._moving_normalizer = torch.full((), float(self._moving_normalizer or 0.0), dtype=torch.float32, device=s.device)
+      s = moving_normalizer_update(self._moving_normalizer, s, m)
+    else:
+      import torch.distributed as dist
+      s = s.clone()
+      dist.all_reduce(s, group=self.process_group)
+      s = s / dist.get_world_size(self.process_group)
+    torch.reciprocal(s, out=eng.hyper[2])
+
   def train_step(self, data, sync_loss=True):
     images, labels = data
     b, h, w = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
@@ -284,7 +333,12 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
       vals['learning_rate'] = lr
       return vals
     eng.forward(self._to_device_images(images, eng), training=True)
-    eng.loss_backward(self._labels_to_device(labels, eng))
+    dlabels = self._labels_to_device(labels, eng)
+    if self._positives_momentum() != 0:
+      # the eager path hands the engine a host normalizer: the moving average / replica mean is formed here
+      base = dlabels['normalizer'] if 'normalizer' in dlabels else float(dlabels['mean_num_positives'].sum().item()) + 1.0
+      dlabels['normalizer'] = self._host_normalizer(base)
+    eng.loss_backward(dlabels)
     decay = None
     if self.config.moving_average_decay:
       decay = ema_decay_dynamic(self.config.moving_average_decay, self.iterations)

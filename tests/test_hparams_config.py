@@ -96,7 +96,7 @@ def test_unbuilt_options_raise_instead_of_being_ignored():
   fail loudly (constructing the host objects needs no GPU)."""
   import pytest
   from automl_amd import efficientdet_net, train_lib
-  for override in ('iou_loss_type=ciou', 'label_smoothing=0.1', 'positives_momentum=0.9', 'var_freeze_expr=.*bn.*',
+  for override in ('iou_loss_type=ciou', 'label_smoothing=0.1', 'var_freeze_expr=.*bn.*',
                    'optimizer=adam', 'survival_prob=0.8'):
     config = hparams_config.get_efficientdet_config('efficientdet-d0')
     config.override(override)
@@ -107,6 +107,35 @@ def test_unbuilt_options_raise_instead_of_being_ignored():
   with pytest.raises(ValueError, match='not built'):
     efficientdet_net.EfficientDetNet(config=config)
   train_lib.EfficientDetNetTrain(config=hparams_config.get_efficientdet_config('efficientdet-d0'))   # defaults pass
+
+
+def test_positives_momentum_is_the_references_moving_normalizer():
+  """config.positives_momentum > 0 (tf2/train_lib.py:519-531): the loss normalizer sum(mean_num_positives) + 1 goes through
+  Keras' moving_average_update on a variable that starts at 0.0 -- v <- v * m + x * (1 - m), no zero-debiasing.  The host
+  path (python floats) and the device path (the same torch code on a 0-d tensor, in place) must both follow the closed
+  form v_t = (1 - m) * sum_k m^(t-k) x_k; constructing the host objects needs no GPU."""
+  import numpy as np
+  import torch
+  from automl_amd import train_lib
+  m = 0.9
+  xs = [101.0, 57.0, 230.5, 1.0, 88.0]
+  want, v = [], 0.0
+  for x in xs:
+    v = v - (v - x) * (1.0 - m)          # Keras: variable -= (variable - value) * (1 - momentum)
+    want.append(v)
+  closed = [(1 - m) * sum(m ** (t - k) * xs[k] for k in range(t + 1)) for t in range(len(xs))]
+  np.testing.assert_allclose(want, closed, rtol=1e-12)
+  config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  config.override('positives_momentum=%r' % m)
+  net = train_lib.EfficientDetNetTrain(config=config)
+  got = [net._host_normalizer(x) for x in xs]
+  np.testing.assert_allclose(got, want, rtol=1e-12)
+  state = torch.zeros((), dtype=torch.float32)
+  dev = [float(train_lib.moving_normalizer_update(state, torch.tensor(x), m)) for x in xs]
+  np.testing.assert_allclose(dev, want, rtol=1e-6)
+  # off by default: the value itself
+  net0 = train_lib.EfficientDetNetTrain(config=hparams_config.get_efficientdet_config('efficientdet-d0'))
+  assert net0._host_normalizer(101.0) == 101.0 and net0._moving_normalizer is None
 
 
 def test_config_pickle_and_copy_round_trip():
