@@ -14,6 +14,7 @@ Reference structure followed: efficientdet/tf2/efficientdet_keras.py:787-915 (Ef
 efficientdet/backbone/efficientnet_model.py:360-416,710-779, efficientdet/tf2/train_lib.py:493-684.
 """
 import ctypes
+import re
 import math
 import os
 
@@ -130,7 +131,34 @@ class ParamArena(object):
     self.seg_factor = torch.ones(self.nseg, dtype=torch.float32, device=dev)
     self.version = 0          # bumped whenever a variable changes: engines re-make their compute copies
     self.step_count = 0       # optimizer iterations applied to this arena
+    self.frozen_expr = None
+    self.frozen_ranges = []   # [begin, end) element ranges of the frozen variables in the flat arrays (set_frozen)
     self.set_params(values)
+
+  def set_frozen(self, expr):
+    """config.var_freeze_expr (tf2/train_lib.py:478-491): the trainable variables whose name -- with the ':0' TensorFlow
+    appends -- matches the expression from its start are left out of the L2 term, of the gradient list (per-tensor and
+    global clip norms) and of the update.  Here: their L2 flag is cleared and their gradient range is zeroed in front of
+    the optimizer kernels (Engine.optimizer_local), which makes them contribute nothing to the norms and keeps their
+    momentum slot -- cleared now -- and value where they are.  Returns the frozen names."""
+    pat = re.compile(expr)
+    frozen = [n for n in self.seg_names if pat.match(n + ':0')]
+    seg_index = {int(o): i for i, o in enumerate(self.seg_offsets.cpu().tolist()[:-1])}
+    flags = self.seg_flags.cpu().clone()
+    ranges = []
+    for n in frozen:
+      off, cnt, _, _ = self.offsets[n]
+      flags[seg_index[off]] = 0
+      if ranges and off - ranges[-1][1] <= 3:      # adjacent up to the alignment padding (zeros): one range
+        ranges[-1][1] = off + cnt
+      else:
+        ranges.append([off, off + cnt])
+    self.seg_flags.copy_(flags)
+    self.frozen_expr = expr
+    self.frozen_ranges = [(a, b) for a, b in ranges]
+    for a, b in self.frozen_ranges:
+      self.velocity[a:b].zero_()
+    return frozen
 
   def _slice(self, flat_train, flat_state, name):
     off, n, _, tr = self.offsets[name]
@@ -1093,6 +1121,8 @@ class Engine(object):
     scale_for_reduce applies the factors in place (the data-parallel path all-reduces the clipped gradient)."""
     c = self.config
     st = self.stream
+    for a, b in self.arena.frozen_ranges:          # var_freeze_expr: no gradient for these variables (ParamArena.set_frozen)
+      self.grads_flat[a:b].zero_()
     call('edet_opt_l2_norms', ptr(self.grads_flat), ptr(self.params_flat), ptr(self.seg_offsets),
          ptr(self.seg_flags), self.nseg, float(c.weight_decay), ptr(self.seg_sqnorm),
          ptr(self.loss_sums[2:]), st)

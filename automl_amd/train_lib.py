@@ -165,8 +165,6 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
       unsupported.append('iou_loss_type=%r (BoxIouLoss, train_lib.py:440-466)' % c.iou_loss_type)
     if getattr(c, 'label_smoothing', 0.0):
       unsupported.append('label_smoothing=%r (FocalLoss, train_lib.py:400-401)' % c.label_smoothing)
-    if getattr(c, 'var_freeze_expr', None):
-      unsupported.append('var_freeze_expr=%r (train_lib.py:478-484)' % c.var_freeze_expr)
     if str(getattr(c, 'optimizer', 'sgd')).lower() != 'sgd':
       unsupported.append('optimizer=%r (only SGD momentum, train_lib.py:183-185)' % c.optimizer)
     if unsupported:
@@ -273,6 +271,13 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
       eng.arena.version += 1        # what optimizer_apply does on the host when it is not replayed
       eng.arena.step_count += 1
     g['steps'] += 1
+
+  def _ensure_engine(self, batch, height, width):
+    eng = super()._ensure_engine(batch, height, width)
+    expr = getattr(self.config, 'var_freeze_expr', None)
+    if expr and eng.arena.frozen_expr != expr:
+      eng.arena.set_frozen(expr)         # tf2/train_lib.py:478-491: out of L2, gradients and updates
+    return eng
 
   def _positives_momentum(self):
     return float(getattr(self.config, 'positives_momentum', None) or 0.0)

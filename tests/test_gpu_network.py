@@ -161,8 +161,11 @@ def test_training_forward_matches_oracle_bf16_layer_by_layer(case):
   assert moving <= 2e-2, 'moving statistics differ: %g' % moving
 
 
+FREEZE_CASE = ('efficientdet-d0', 'var_freeze_expr=(efficientnet|fpn_cells|resample_p6)', 128, 2)   # finetune the heads
+
+
 @pytest.mark.parametrize('case', CASES[:2] + [('efficientdet-d1', '', 192, 2), CASES[3], ('efficientdet-d7x', '', 384, 2), CASES[4],
-                                               CASES[5], CASES[6]],
+                                               CASES[5], CASES[6], FREEZE_CASE],
                          ids=lambda c: '%s[%s]@%d' % (c[0], c[1], c[2]))
 def test_train_step_matches_oracle_fp32(case):
   """loss values, clipped gradients of every variable, and the updated variables after one step."""
@@ -251,6 +254,12 @@ def test_train_step_matches_oracle_fp32(case):
     assert len(bad) <= max(1, len(ref_grads) // 100) and all(e <= 5e-2 for _, e in bad), \
         'gradient mismatch in %d/%d tensors, worst: %s' % (len(bad), len(ref_grads), bad[:12])
   new = eng.get_params()
+  if 'var_freeze_expr' in override:
+    # tf2/train_lib.py:478-491: the frozen variables are out of the L2 term, the clip norms (both compared above through
+    # reg_l2_loss / gradient_norm / the clipped gradients of the others) and the update -- bit for bit where they were
+    frozen = [n for n in eng.seg_names if n not in ref_grads]
+    assert len(frozen) == 409 and len(ref_grads) == 84, (len(frozen), len(ref_grads))
+    assert all(np.array_equal(new[n], vals[n]) for n in frozen), [n for n in frozen if not np.array_equal(new[n], vals[n])][:5]
   worst = 0.0
   for name in ref_grads:
     want = oracle.params()[name].detach().numpy()

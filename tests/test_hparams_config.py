@@ -96,8 +96,7 @@ def test_unbuilt_options_raise_instead_of_being_ignored():
   fail loudly (constructing the host objects needs no GPU)."""
   import pytest
   from automl_amd import efficientdet_net, train_lib
-  for override in ('iou_loss_type=ciou', 'label_smoothing=0.1', 'var_freeze_expr=.*bn.*',
-                   'optimizer=adam', 'survival_prob=0.8'):
+  for override in ('iou_loss_type=ciou', 'label_smoothing=0.1', 'optimizer=adam', 'survival_prob=0.8'):
     config = hparams_config.get_efficientdet_config('efficientdet-d0')
     config.override(override)
     with pytest.raises(ValueError, match='not built'):
@@ -136,6 +135,50 @@ def test_positives_momentum_is_the_references_moving_normalizer():
   # off by default: the value itself
   net0 = train_lib.EfficientDetNetTrain(config=hparams_config.get_efficientdet_config('efficientdet-d0'))
   assert net0._host_normalizer(101.0) == 101.0 and net0._moving_normalizer is None
+
+
+def test_var_freeze_expr_in_the_arena_and_in_the_oracle():
+  """config.var_freeze_expr (tf2/train_lib.py:478-491): re.match on the variable name with TensorFlow's ':0'.  The
+  parameter arena (built on the CPU here: no kernel is launched) clears the L2 flag of the frozen variables and records
+  their element ranges -- the reference's finetuning expression freezes 409 of d0's 493 trainable variables, one contiguous
+  range -- and the oracle's train step leaves them out of L2, gradients and update."""
+  import numpy as np
+  import torch
+  from automl_amd import engine, netspec
+  from oracle import efficientdet_oracle as orc
+  from oracle.problems import perturbed_params
+  config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  config.override('image_size=64,var_freeze_expr=(efficientnet|fpn_cells|resample_p6)')
+  spec = netspec.NetSpec(config)
+  vals = perturbed_params(config, 3)
+  arena = engine.ParamArena(spec, 'cpu', vals)
+  l2_before = int(arena.seg_flags.sum())
+  arena.velocity.fill_(1.0)
+  frozen = arena.set_frozen(config.var_freeze_expr)
+  assert len(frozen) == 409 and all(n.startswith(('efficientnet', 'fpn_cells', 'resample_p6')) for n in frozen)
+  assert len(arena.frozen_ranges) == 1 and arena.frozen_ranges[0][0] == 0
+  end = arena.frozen_ranges[0][1]
+  assert end == max(arena.offsets[n][0] + arena.offsets[n][1] for n in frozen)
+  assert float(arena.velocity[:end].abs().max()) == 0.0 and float(arena.velocity[end:].min()) == 1.0
+  kept = [n for n in arena.seg_names if n not in frozen]
+  assert int(arena.seg_flags.sum()) == sum(1 for n in kept if orc.is_l2_regularised(n)) < l2_before
+  # the oracle's step
+  rng = np.random.default_rng(5)
+  images = torch.from_numpy(rng.standard_normal((1, 64, 64, 3)).astype(np.float32))
+  from tests.test_gpu_network import make_labels          # (label maps only: nothing of that module touches a GPU here)
+  labels = {k: torch.from_numpy(v) for k, v in make_labels(config, 1, 64, 7).items()}
+  oracle = orc.Oracle(config=config, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
+  with torch.no_grad():
+    oracle.forward(images, False)
+  out, grads = orc.train_step(oracle, images, labels, {}, 0.05, None)
+  assert sorted(grads) == sorted(kept)
+  want_l2 = config.weight_decay * sum(float((vals[n].astype(np.float64) ** 2).sum()) / 2 for n in kept if orc.is_l2_regularised(n))
+  assert abs(out['reg_l2_loss'] - want_l2) <= 1e-5 * want_l2
+  P = oracle.params()
+  assert all(np.array_equal(P[n].detach().numpy(), vals[n]) for n in frozen)
+  # (the per-level BatchNorm variables of the 1x1 / 2x2 levels of a 64-pixel image see no gradient: most, not all, move)
+  assert sum(1 for n in kept if not np.array_equal(P[n].detach().numpy(), vals[n])) >= len(kept) // 2
+  assert not np.array_equal(P['class_net/class-predict/bias'].detach().numpy(), vals['class_net/class-predict/bias'])
 
 
 def test_config_pickle_and_copy_round_trip():
