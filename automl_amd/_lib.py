@@ -101,6 +101,8 @@ SIGNATURES = {
                               c_void_p, c_int, c_void_p],
     'edet_focal_loss': [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float,
                         c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    'edet_focal_loss_smooth': [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float, c_float,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     'edet_box_loss': [c_void_p, c_int, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_void_p,
                       c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     'edet_opt_l2_norms': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,

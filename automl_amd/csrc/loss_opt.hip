@@ -23,12 +23,17 @@ inline RowMap row_map_ld(int ld) {
 // ce = softplus(u); loss = alpha_t * sigmoid(u)^gamma * softplus(u) / normalizer.  One exp, one rcp,
 // one log and one sqrt (gamma = 1.5) or exp2/log2 pair (general gamma) per logit; the anchor index is
 // advanced incrementally along the 8-wide chunk, so there is one integer division per 16 bytes.
-template <typename T, bool G15>
+// LS: label smoothing (tf2/train_lib.py:400-402): the cross entropy is taken against y*(1-ls) + ls/2 while alpha and the
+// modulating factor keep the hard label.  With u = -x for the positive class and x otherwise, ce_smoothed = softplus(u) -
+// (ls/2) u in both cases, so d/du [sg^gamma (sp - h u)] = sg^gamma (gamma (1-sg) (sp - h u) + sg - h), h = ls/2.  A
+// template parameter: the ls = 0 instantiations keep their instruction count (the kernel is VALU-bound).
+template <typename T, bool G15, bool LS = false>
 __global__ __launch_bounds__(THREADS) void k_focal(const T* __restrict__ logits, int ld,
                                                   const int32_t* __restrict__ tgt, int64_t positions,
                                                   int na, int nc, float alpha, float gamma, float inv_norm_h,
                                                   const float* __restrict__ norm_scale,
-                                                  T* __restrict__ dlogits, float* dbias, float* sums, RowMap m) {
+                                                  T* __restrict__ dlogits, float* dbias, float* sums, RowMap m,
+                                                  float half_ls) {
   const float inv_norm = norm_scale ? inv_norm_h * norm_scale[0] : inv_norm_h;
   const int tid = threadIdx.x;
   const int cv = tid % m.tpr, rr = tid / m.tpr;
@@ -56,11 +61,12 @@ __global__ __launch_bounds__(THREADS) void k_focal(const T* __restrict__ logits,
           const float ex = __builtin_amdgcn_exp2f(-1.44269504f * fabsf(u));
           const float inv = __builtin_amdgcn_rcpf(1.f + ex);
           const float sg = u >= 0.f ? inv : ex * inv;
-          const float sp = fmaxf(u, 0.f) + 0.69314718f * __builtin_amdgcn_logf(1.f + ex);
+          float sp = fmaxf(u, 0.f) + 0.69314718f * __builtin_amdgcn_logf(1.f + ex);
+          if (LS) sp = fmaf(-half_ls, u, sp);
           const float af = pos ? alpha : 1.f - alpha;
           const float mod = G15 ? sg * __builtin_amdgcn_sqrtf(sg) : __powf(sg, gamma);
           loss_acc = fmaf(af * mod, sp * inv_norm, loss_acc);
-          const float dldu = af * mod * fmaf(gamma * (1.f - sg), sp, sg) * inv_norm;
+          const float dldu = af * mod * fmaf(gamma * (1.f - sg), sp, LS ? sg - half_ls : sg) * inv_norm;
           g[e] = pos ? -dldu : dldu;
         }
         db[e] += g[e];
@@ -112,13 +118,14 @@ __global__ __launch_bounds__(THREADS) void k_focal(const T* __restrict__ logits,
         const float ex = __builtin_amdgcn_exp2f(-1.44269504f * fabsf(u));
         const float inv = __builtin_amdgcn_rcpf(1.f + ex);
         const float sg = u >= 0.f ? inv : ex * inv;          // sigmoid(u) = 1 - p_t
-        const float sp = fmaxf(u, 0.f) + 0.69314718f * __builtin_amdgcn_logf(1.f + ex);   // softplus(u) = cross entropy
+        float sp = fmaxf(u, 0.f) + 0.69314718f * __builtin_amdgcn_logf(1.f + ex);   // softplus(u) = cross entropy
+        if (LS) sp = fmaf(-half_ls, u, sp);                    // ... against the smoothed label
         const float af = pos ? alpha : 1.f - alpha;
         const float mod = G15 ? sg * __builtin_amdgcn_sqrtf(sg) : __powf(sg, gamma);
         const float wgt = valid ? af * mod * inv_norm : 0.f;
         loss_acc = fmaf(wgt, sp, loss_acc);
         // d/du [sg^gamma * softplus(u)] = sg^gamma * (gamma*(1-sg)*sp + sg)
-        const float dldu = wgt * fmaf(gamma * (1.f - sg), sp, sg);
+        const float dldu = wgt * fmaf(gamma * (1.f - sg), sp, LS ? sg - half_ls : sg);
         g[e] = pos ? -dldu : dldu;
         db[e] += g[e];
       }
@@ -364,19 +371,22 @@ __global__ __launch_bounds__(THREADS) void k_sgd_ema(float* params, float* grads
 
 }  // namespace
 
-extern "C" int edet_focal_loss(const void* logits, int ld, const int32_t* cls_targets,
-                               int64_t positions, int num_anchors, int num_classes,
-                               float alpha, float gamma, float inv_normalizer,
-                               const float* norm_scale_dev,
-                               void* dlogits, float* dbias, float* sums, int dtype, void* stream) {
+extern "C" int edet_focal_loss_smooth(const void* logits, int ld, const int32_t* cls_targets,
+                                      int64_t positions, int num_anchors, int num_classes,
+                                      float alpha, float gamma, float label_smoothing, float inv_normalizer,
+                                      const float* norm_scale_dev,
+                                      void* dlogits, float* dbias, float* sums, int dtype, void* stream) {
   EDET_CHECK(logits && cls_targets && dlogits && sums, "edet_focal_loss: null pointer");
   EDET_CHECK(ld % 8 == 0 && ld >= num_anchors * num_classes && ld <= 2048, "edet_focal_loss: bad ld %d", ld);
   EDET_CHECK(num_classes >= 1, "edet_focal_loss: num_classes must be positive");
+  EDET_CHECK(label_smoothing >= 0.f && label_smoothing <= 1.f, "edet_focal_loss: label_smoothing %g outside [0, 1]", (double)label_smoothing);
   const RowMap m = row_map_ld(ld);
   int64_t g = (positions + m.rpp - 1) / m.rpp;
   g = (g + 3) / 4;
   const size_t lds = (size_t)ld * sizeof(float);
   const bool g15 = gamma == 1.5f;
+  const bool ls = label_smoothing != 0.f;
+  const float half_ls = 0.5f * label_smoothing;
   {   // one round of the workgroups the chip holds at once (the rows are strided over the grid)
     const void* fn = dtype == EDET_BF16 ? (g15 ? reinterpret_cast<const void*>(&k_focal<bf16_t, true>) : reinterpret_cast<const void*>(&k_focal<bf16_t, false>))
                                         : (g15 ? reinterpret_cast<const void*>(&k_focal<float, true>) : reinterpret_cast<const void*>(&k_focal<float, false>));
@@ -385,15 +395,30 @@ extern "C" int edet_focal_loss(const void* logits, int ld, const int32_t* cls_ta
     if (g > cap) g = cap;
   }
   if (g < 1) g = 1;
-#define FOCAL_LAUNCH(T, G)                                                                            \
-  edet_launch(k_focal<T, G>, dim3((int)g), dim3(THREADS), lds, to_stream(stream), (const T*)logits, ld, cls_targets, positions, \
-      num_anchors, num_classes, alpha, gamma, inv_normalizer, norm_scale_dev, (T*)dlogits, dbias, sums, m)
-  if (dtype == EDET_BF16) { if (g15) FOCAL_LAUNCH(bf16_t, true); else FOCAL_LAUNCH(bf16_t, false); }
-  else if (dtype == EDET_F32) { if (g15) FOCAL_LAUNCH(float, true); else FOCAL_LAUNCH(float, false); }
+#define FOCAL_LAUNCH(T, G, L)                                                                         \
+  edet_launch(k_focal<T, G, L>, dim3((int)g), dim3(THREADS), lds, to_stream(stream), (const T*)logits, ld, cls_targets, positions, \
+      num_anchors, num_classes, alpha, gamma, inv_normalizer, norm_scale_dev, (T*)dlogits, dbias, sums, m, half_ls)
+#define FOCAL_LAUNCH_T(T)                                                  \
+  do {                                                                     \
+    if (g15) { if (ls) FOCAL_LAUNCH(T, true, true); else FOCAL_LAUNCH(T, true, false); }     \
+    else { if (ls) FOCAL_LAUNCH(T, false, true); else FOCAL_LAUNCH(T, false, false); }       \
+  } while (0)
+  if (dtype == EDET_BF16) FOCAL_LAUNCH_T(bf16_t);
+  else if (dtype == EDET_F32) FOCAL_LAUNCH_T(float);
+#undef FOCAL_LAUNCH_T
 #undef FOCAL_LAUNCH
   else EDET_CHECK(false, "edet_focal_loss: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_focal_loss");
   return 0;
+}
+
+extern "C" int edet_focal_loss(const void* logits, int ld, const int32_t* cls_targets,
+                               int64_t positions, int num_anchors, int num_classes,
+                               float alpha, float gamma, float inv_normalizer,
+                               const float* norm_scale_dev,
+                               void* dlogits, float* dbias, float* sums, int dtype, void* stream) {
+  return edet_focal_loss_smooth(logits, ld, cls_targets, positions, num_anchors, num_classes, alpha, gamma, 0.f,
+                                inv_normalizer, norm_scale_dev, dlogits, dbias, sums, dtype, stream);
 }
 
 extern "C" int edet_box_loss(const void* box_out, int ld, const float* box_targets,

@@ -1089,9 +1089,15 @@ class Engine(object):
       bt = labels['box_targets_%d' % level]
       assert ct.dtype == torch.int32 and ct.is_contiguous() and bt.dtype == torch.float32 and bt.is_contiguous()
       r = cv.raw
-      call('edet_focal_loss', ptr(r.data), r.ld, ptr(ct), r.rows, na, c.num_classes, c.alpha, c.gamma,
-           1.0 / normalizer, norm_dev, ptr(r.ensure_grad()), ptr(self.grad('class_net/class-predict/bias')),
-           ptr(self.loss_sums), self.dtype, self.stream, nbytes=2 * r.rows * r.c * self.esize)
+      ls = float(getattr(c, 'label_smoothing', 0.0) or 0.0)
+      if ls:      # FocalLoss(label_smoothing), train_lib.py:400-402
+        call('edet_focal_loss_smooth', ptr(r.data), r.ld, ptr(ct), r.rows, na, c.num_classes, c.alpha, c.gamma, ls,
+             1.0 / normalizer, norm_dev, ptr(r.ensure_grad()), ptr(self.grad('class_net/class-predict/bias')),
+             ptr(self.loss_sums), self.dtype, self.stream, nbytes=2 * r.rows * r.c * self.esize)
+      else:
+        call('edet_focal_loss', ptr(r.data), r.ld, ptr(ct), r.rows, na, c.num_classes, c.alpha, c.gamma,
+             1.0 / normalizer, norm_dev, ptr(r.ensure_grad()), ptr(self.grad('class_net/class-predict/bias')),
+             ptr(self.loss_sums), self.dtype, self.stream, nbytes=2 * r.rows * r.c * self.esize)
       r.grad_written = True
       rb = bv.raw
       call('edet_box_loss', ptr(rb.data), rb.ld, ptr(bt), rb.rows, 4 * na, c.delta, 1.0 / (normalizer * 4.0),

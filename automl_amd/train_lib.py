@@ -163,8 +163,6 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
     unsupported = []
     if getattr(c, 'iou_loss_type', None):
       unsupported.append('iou_loss_type=%r (BoxIouLoss, train_lib.py:440-466)' % c.iou_loss_type)
-    if getattr(c, 'label_smoothing', 0.0):
-      unsupported.append('label_smoothing=%r (FocalLoss, train_lib.py:400-401)' % c.label_smoothing)
     if str(getattr(c, 'optimizer', 'sgd')).lower() != 'sgd':
       unsupported.append('optimizer=%r (only SGD momentum, train_lib.py:183-185)' % c.optimizer)
     if unsupported:

@@ -326,6 +326,13 @@ int edet_focal_loss(const void* logits, int ld, const int32_t* cls_targets,
                     int64_t positions, int num_anchors, int num_classes,
                     float alpha, float gamma, float inv_normalizer, const float* norm_scale_dev,
                     void* dlogits, float* dbias, float* sums, int dtype, void* stream);
+/* the same with FocalLoss(label_smoothing) (train_lib.py:400-402, config.label_smoothing): the cross entropy is taken
+ * against y*(1 - label_smoothing) + label_smoothing/2, alpha and the modulating factor keep the hard label */
+int edet_focal_loss_smooth(const void* logits, int ld, const int32_t* cls_targets,
+                           int64_t positions, int num_anchors, int num_classes,
+                           float alpha, float gamma, float label_smoothing, float inv_normalizer,
+                           const float* norm_scale_dev,
+                           void* dlogits, float* dbias, float* sums, int dtype, void* stream);
 int edet_box_loss(const void* box_out, int ld, const float* box_targets,
                   int64_t positions, int nch, float delta, float inv_normalizer,
                   float grad_scale, const float* norm_scale_dev, void* dbox, float* dbias, float* sums,

@@ -748,7 +748,8 @@ def test_fuse(dt, case):
 @pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
 @pytest.mark.parametrize('geom', [(2, 5, 4, 9, 90), (3, 7, 5, 9, 20), (2, 6, 3, 9, 3), (1, 4, 4, 3, 8)],
                          ids=lambda g: 'x'.join(map(str, g)))
-def test_detection_loss(dt, geom):
+@pytest.mark.parametrize('smoothing', [0.0, 0.1], ids=['hard', 'ls0.1'])
+def test_detection_loss(dt, geom, smoothing):
   """geom = (n, h, w, anchors, classes): 90 classes (COCO), 20 (an 8-element chunk crosses anchors more often), 3 (the
   form for fewer than 8 classes: a chunk spans several anchors), 8 (a chunk is exactly one anchor)."""
   name, edt, tdt = dt
@@ -763,7 +764,7 @@ def test_detection_loss(dt, geom):
   norm = 37.0
   lq, bq = logits.clone().requires_grad_(True), box.clone().requires_grad_(True)
   onehot = torch.nn.functional.one_hot(torch.clamp(ct, min=0).long(), nc).float() * (ct >= 0).unsqueeze(-1)
-  fl = orc.focal_loss(lq, onehot.reshape(n, h, w, -1), 0.25, 1.5, norm).reshape(n, h, w, na, nc)
+  fl = orc.focal_loss(lq, onehot.reshape(n, h, w, -1), 0.25, 1.5, norm, smoothing).reshape(n, h, w, na, nc)
   cls_loss = (fl * (ct != -2).unsqueeze(-1)).sum()
   box_loss = (orc.huber(bq - bt, 0.1) * (bt != 0).float()).sum() / (norm * 4)
   (cls_loss + 50.0 * box_loss).backward()
@@ -775,8 +776,12 @@ def test_detection_loss(dt, geom):
   dbias_b = torch.zeros(4 * na, dtype=torch.float32, device=gu.DEV)
   # the normalizer reaches the kernels either as a host float or as a device scalar (graph replay): both ways
   inv_dev = torch.tensor([1.0 / norm], dtype=torch.float32, device=gu.DEV)
-  call('edet_focal_loss', ptr(ld), ld.shape[-1], ptr(ctd), n * h * w, na, nc, 0.25, 1.5, 1.0 / norm, None, ptr(dl),
-       ptr(dbias_c), ptr(sums), edt, gu.stream())
+  if smoothing:      # FocalLoss(label_smoothing), tf2/train_lib.py:400-402
+    call('edet_focal_loss_smooth', ptr(ld), ld.shape[-1], ptr(ctd), n * h * w, na, nc, 0.25, 1.5, smoothing, 1.0 / norm,
+         None, ptr(dl), ptr(dbias_c), ptr(sums), edt, gu.stream())
+  else:
+    call('edet_focal_loss', ptr(ld), ld.shape[-1], ptr(ctd), n * h * w, na, nc, 0.25, 1.5, 1.0 / norm, None, ptr(dl),
+         ptr(dbias_c), ptr(sums), edt, gu.stream())
   call('edet_box_loss', ptr(bd), bd.shape[-1], ptr(btd), n * h * w, 4 * na, 0.1, 0.25, 50.0, ptr(inv_dev), ptr(db),
        ptr(dbias_b), ptr(sums), edt, gu.stream())
   torch.cuda.synchronize()

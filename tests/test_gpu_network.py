@@ -162,10 +162,11 @@ def test_training_forward_matches_oracle_bf16_layer_by_layer(case):
 
 
 FREEZE_CASE = ('efficientdet-d0', 'var_freeze_expr=(efficientnet|fpn_cells|resample_p6)', 128, 2)   # finetune the heads
+SMOOTH_CASE = ('efficientdet-d0', 'label_smoothing=0.1', 128, 2)     # FocalLoss(label_smoothing), train_lib.py:400-402
 
 
 @pytest.mark.parametrize('case', CASES[:2] + [('efficientdet-d1', '', 192, 2), CASES[3], ('efficientdet-d7x', '', 384, 2), CASES[4],
-                                               CASES[5], CASES[6], FREEZE_CASE],
+                                               CASES[5], CASES[6], FREEZE_CASE, SMOOTH_CASE],
                          ids=lambda c: '%s[%s]@%d' % (c[0], c[1], c[2]))
 def test_train_step_matches_oracle_fp32(case):
   """loss values, clipped gradients of every variable, and the updated variables after one step."""

@@ -96,7 +96,7 @@ def test_unbuilt_options_raise_instead_of_being_ignored():
   fail loudly (constructing the host objects needs no GPU)."""
   import pytest
   from automl_amd import efficientdet_net, train_lib
-  for override in ('iou_loss_type=ciou', 'label_smoothing=0.1', 'optimizer=adam', 'survival_prob=0.8'):
+  for override in ('iou_loss_type=ciou', 'optimizer=adam', 'survival_prob=0.8'):
     config = hparams_config.get_efficientdet_config('efficientdet-d0')
     config.override(override)
     with pytest.raises(ValueError, match='not built'):

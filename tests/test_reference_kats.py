@@ -252,15 +252,14 @@ def test_losses_and_lr_schedules_equal_the_executed_reference_code():
   assert abs(float(cls_loss) - float(g['cls_loss'])) <= 2e-6 * float(g['cls_loss'])
   assert abs(float(box_loss) - float(g['box_loss'])) <= 2e-6 * float(g['box_loss'])
   assert abs(float(total) - float(g['det_loss'])) <= 2e-6 * float(g['det_loss'])
-  # focal loss is the reference's formula before label smoothing for the modulating factor; the oracle models
-  # label_smoothing = 0 (the detection default), so compare through the smoothing-free identity on a second case
+  # FocalLoss(alpha=0.25, gamma=2.0, label_smoothing=0.1) of the reference executed on a second case (normalizer 7): the
+  # modulating factor from the hard labels, the cross entropy from the smoothed ones -- the oracle's focal_loss with its
+  # label_smoothing argument (the device kernel edet_focal_loss_smooth is checked against it in tests/test_gpu_kernels.py)
   yt, yp = torch.from_numpy(g['fl_targets']), torch.from_numpy(g['fl_logits'])
-  p = torch.sigmoid(yp)
-  p_t = yt * p + (1 - yt) * (1 - p)
-  smooth = yt * 0.9 + 0.05
-  ce = torch.nn.functional.binary_cross_entropy_with_logits(yp, smooth, reduction='none')
-  want = (yt * 0.25 + (1 - yt) * 0.75) * (1 - p_t)**2.0 * ce / 7.0
+  want = orc.focal_loss(yp, yt, 0.25, 2.0, 7.0, 0.1)
   np.testing.assert_allclose(want.numpy(), g['fl_values'], rtol=2e-5, atol=1e-8)
+  hard = orc.focal_loss(yp, yt, 0.25, 2.0, 7.0)
+  assert float((hard - want).abs().max()) > 1e-4          # (the smoothing is visible in this case)
 
 
 def test_fusion_methods_equal_the_executed_reference_code():
