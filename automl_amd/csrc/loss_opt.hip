@@ -26,9 +26,10 @@ inline RowMap row_map_ld(int ld) {
 // LS: label smoothing (tf2/train_lib.py:400-402): the cross entropy is taken against y*(1-ls) + ls/2 while alpha and the
 // modulating factor keep the hard label.  With u = -x for the positive class and x otherwise, ce_smoothed = softplus(u) -
 // (ls/2) u in both cases, so d/du [sg^gamma (sp - h u)] = sg^gamma (gamma (1-sg) (sp - h u) + sg - h), h = ls/2.  A
-// template parameter: the ls = 0 instantiations keep their instruction count (the kernel is VALU-bound).
-template <typename T, bool G15, bool LS = false>
-__global__ __launch_bounds__(THREADS) void k_focal(const T* __restrict__ logits, int ld,
+// template parameter of the shared body: k_focal (ls = 0) keeps its instruction count (the kernel is VALU-bound) and
+// its symbol; k_focal_ls is the smoothed one.
+template <typename T, bool G15, bool LS>
+__device__ __forceinline__ void focal_body(const T* __restrict__ logits, int ld,
                                                   const int32_t* __restrict__ tgt, int64_t positions,
                                                   int na, int nc, float alpha, float gamma, float inv_norm_h,
                                                   const float* __restrict__ norm_scale,
@@ -152,6 +153,24 @@ __global__ __launch_bounds__(THREADS) void k_focal(const T* __restrict__ logits,
   if (tid == 0) atomicAdd(&sums[0], red_loss);
   if (dbias)
     for (int i = tid; i < nch; i += THREADS) atomicAdd(&dbias[i], red[i]);
+}
+
+template <typename T, bool G15>
+__global__ __launch_bounds__(THREADS) void k_focal(const T* __restrict__ logits, int ld,
+                                                  const int32_t* __restrict__ tgt, int64_t positions,
+                                                  int na, int nc, float alpha, float gamma, float inv_norm_h,
+                                                  const float* __restrict__ norm_scale,
+                                                  T* __restrict__ dlogits, float* dbias, float* sums, RowMap m) {
+  focal_body<T, G15, false>(logits, ld, tgt, positions, na, nc, alpha, gamma, inv_norm_h, norm_scale, dlogits, dbias, sums, m, 0.f);
+}
+template <typename T, bool G15>
+__global__ __launch_bounds__(THREADS) void k_focal_ls(const T* __restrict__ logits, int ld,
+                                                     const int32_t* __restrict__ tgt, int64_t positions,
+                                                     int na, int nc, float alpha, float gamma, float inv_norm_h,
+                                                     const float* __restrict__ norm_scale,
+                                                     T* __restrict__ dlogits, float* dbias, float* sums, RowMap m,
+                                                     float half_ls) {
+  focal_body<T, G15, true>(logits, ld, tgt, positions, na, nc, alpha, gamma, inv_norm_h, norm_scale, dlogits, dbias, sums, m, half_ls);
 }
 
 template <typename T>
@@ -395,17 +414,21 @@ extern "C" int edet_focal_loss_smooth(const void* logits, int ld, const int32_t*
     if (g > cap) g = cap;
   }
   if (g < 1) g = 1;
-#define FOCAL_LAUNCH(T, G, L)                                                                         \
-  edet_launch(k_focal<T, G, L>, dim3((int)g), dim3(THREADS), lds, to_stream(stream), (const T*)logits, ld, cls_targets, positions, \
+#define FOCAL_LAUNCH(T, G)                                                                            \
+  edet_launch(k_focal<T, G>, dim3((int)g), dim3(THREADS), lds, to_stream(stream), (const T*)logits, ld, cls_targets, positions, \
+      num_anchors, num_classes, alpha, gamma, inv_normalizer, norm_scale_dev, (T*)dlogits, dbias, sums, m)
+#define FOCAL_LAUNCH_LS(T, G)                                                                         \
+  edet_launch(k_focal_ls<T, G>, dim3((int)g), dim3(THREADS), lds, to_stream(stream), (const T*)logits, ld, cls_targets, positions, \
       num_anchors, num_classes, alpha, gamma, inv_normalizer, norm_scale_dev, (T*)dlogits, dbias, sums, m, half_ls)
 #define FOCAL_LAUNCH_T(T)                                                  \
   do {                                                                     \
-    if (g15) { if (ls) FOCAL_LAUNCH(T, true, true); else FOCAL_LAUNCH(T, true, false); }     \
-    else { if (ls) FOCAL_LAUNCH(T, false, true); else FOCAL_LAUNCH(T, false, false); }       \
+    if (g15) { if (ls) FOCAL_LAUNCH_LS(T, true); else FOCAL_LAUNCH(T, true); }     \
+    else { if (ls) FOCAL_LAUNCH_LS(T, false); else FOCAL_LAUNCH(T, false); }       \
   } while (0)
   if (dtype == EDET_BF16) FOCAL_LAUNCH_T(bf16_t);
   else if (dtype == EDET_F32) FOCAL_LAUNCH_T(float);
 #undef FOCAL_LAUNCH_T
+#undef FOCAL_LAUNCH_LS
 #undef FOCAL_LAUNCH
   else EDET_CHECK(false, "edet_focal_loss: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_focal_loss");
