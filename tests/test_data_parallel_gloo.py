@@ -119,3 +119,31 @@ def test_lr_schedules_match_reference_formulas():
   h = train_lib.learning_rate_schedule(dict(p))
   assert abs(h(15000) - 0.16 * (1 - 15000 / 30000.0)**0.9) < 1e-12
   assert train_lib.ema_decay_dynamic(0.9998, 0) == 0.1 and train_lib.ema_decay_dynamic(0.9998, 10**7) == 0.9998
+
+
+def _normalizer_worker(rank, world, port, tmp):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  config.override('positives_momentum=-1.0')
+  net = train_lib.EfficientDetNetTrain(config=config, use_dist=True)
+  got = net._host_normalizer(10.0 + 30.0 * rank)                # rank 0: 10, rank 1: 40 -> cross-replica mean 25
+  s = torch.tensor(got)
+  eng = type('E', (), {'hyper': torch.zeros(4), 'set_normalizer': None})()
+  net._device_normalizer(eng, torch.full((4,), 2.0 + rank))     # sum + 1 = 9 / 13 -> mean 11 -> hyper[2] = 1 / 11
+  torch.save({'host': s, 'inv': eng.hyper[2].clone()}, os.path.join(tmp, 'norm%d.pt' % rank))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_negative_positives_momentum_is_the_cross_replica_mean(tmp_path):
+  """config.positives_momentum < 0 (tf2/train_lib.py:532-533): the normalizer sum(mean_num_positives) + 1 becomes its
+  mean over the replicas (utils.cross_replica_mean) -- host path (a caller-supplied float) and device path (the tensor
+  the graph step reads), two gloo ranks on the CPU."""
+  world = 2
+  mp.spawn(_normalizer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+  for r in range(world):
+    d = torch.load(os.path.join(str(tmp_path), 'norm%d.pt' % r))
+    assert abs(float(d['host']) - 25.0) < 1e-6, d
+    assert abs(float(d['inv']) - 1.0 / 11.0) < 1e-7, d
