@@ -775,6 +775,10 @@ int pws_try_bwd_fused(const edet_gview_t* dy, const void* w, int ldw, const edet
                       const edet_bwd_epi_t* epi, int* nparts_out, float* dweight, void* workspace,
                       size_t workspace_bytes, hipStream_t st);
 
+// one-pass tiled data + weight gradient (pw_tile_bwd.hip); same return convention
+int pwt_try_bwd(const edet_gview_t* dy, const void* w, int ldw, const edet_tview_t* in, const edet_bwd_epi_t* epi,
+                int* nparts_out, float* dweight, void* workspace, size_t workspace_bytes, hipStream_t st);
+
 extern "C" int edet_pw_bwd(const edet_gview_t* dy, const void* w, int ldw, const edet_tview_t* in,
                            const edet_bwd_epi_t* epi, int* nparts_out, float* dweight, void* workspace,
                            size_t workspace_bytes, int dtype, void* stream) {
@@ -788,6 +792,12 @@ extern "C" int edet_pw_bwd(const edet_gview_t* dy, const void* w, int ldw, const
     if (impl == PW_AUTO || impl == PW_STREAM) {
       const int rc = pws_try_bwd_fused(dy, w, ldw, in, epi, nparts_out, dweight, workspace, workspace_bytes,
                                        to_stream(stream));
+      if (rc != 0) return rc < 0 ? rc : 0;
+    }
+    // the one-pass tiled kernel (pw_tile_bwd.hip): cout <= 128; EDET_PWT=0 switches it off (lab / test switch, read per call)
+    const char* pwt_env = getenv("EDET_PWT");
+    if (impl == PW_AUTO && !(pwt_env && pwt_env[0] == '0')) {
+      const int rc = pwt_try_bwd(dy, w, ldw, in, epi, nparts_out, dweight, workspace, workspace_bytes, to_stream(stream));
       if (rc != 0) return rc < 0 ? rc : 0;
     }
   }

@@ -38,6 +38,8 @@ PW_LAYERS = [
     ('b12_project', 20, 1152, 192, 'project'), ('b15_project', 20, 1152, 320, 'project'),
     ('fpn_80', 80, 64, 64, 'fpn'), ('fpn_40', 40, 64, 64, 'fpn'), ('fpn_20', 20, 64, 64, 'fpn'),
     ('fpn_10', 10, 64, 64, 'fpn'), ('fpn_5', 5, 64, 64, 'fpn'), ('cls_80', 80, 64, 810, 'fpn'),
+    ('rs_80', 80, 40, 64, 'fpn'), ('rs_40', 40, 112, 64, 'fpn'), ('rs_20', 20, 320, 64, 'fpn'), ('box_80', 80, 64, 36, 'fpn'),
+    ('b5_expand', 40, 40, 240, 'expand'), ('b3_expand', 80, 24, 144, 'expand'),
 ]
 # (name, H_in, C, K, S) of the depthwise convolutions
 DW_LAYERS = [
@@ -108,7 +110,13 @@ def build_case(entry, shape):
       gout = torch.empty(n, h, w, gu.pad8(cin), dtype=tdt, device=dev)
       mean, rstd = vec(cin, -0.2, 0.2), vec(cin)
       dwt = torch.zeros(cin, cout, dtype=torch.float32, device=dev)
-      if cin > cout:      # project layer: SE-gated view, the epilogue leaves D and the gate-gradient sums (engine._pw_bwd)
+      if cout in (64, 36):      # BiFPN / tower / resample layers: the input is a plain stored tensor, nothing to chain into
+        tv = gu.tview(x, cin)
+        if cout == 36:
+          gv = gu.gview(dz, cout)      # predict layer: no BatchNorm behind it
+        epi = BwdEpi(ptr(gout), 0, None, None, None, None)
+        keep = (wk, gout, dwt)
+      elif cin > cout:      # project layer: SE-gated view, the epilogue leaves D and the gate-gradient sums (engine._pw_bwd)
         dgate = torch.zeros(n, cin, dtype=torch.float32, device=dev)
         tv = gu.tview(x, cin, vec(cin), vec(cin, -0.3, 0.3), gate, _lib.ACT_SWISH)
         epi = BwdEpi(ptr(gout), 0, None, None, None, ptr(dgate))

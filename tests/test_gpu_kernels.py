@@ -154,6 +154,10 @@ def make_grad_view(rng, n, h, w, c, tdt, with_bn):
 @pytest.mark.parametrize('mode', ['plain', 'plain_beta', 'bn', 'bn_swish_stats', 'gate'])
 @pytest.mark.parametrize('gbn', [False, True])
 def test_pw_bwd_data(dt, shape, mode, gbn, pw_impl, one_call=False, ws_mib=16, conv_y=None):
+  pw_bwd_case(dt, shape, mode, gbn, pw_impl, one_call, ws_mib, conv_y)
+
+
+def pw_bwd_case(dt, shape, mode, gbn, pw_impl, one_call=False, ws_mib=16, conv_y=None):
   """one_call: through edet_pw_bwd (both gradients in one call; bf16: the fused kernel where the layer fits it), which
   must give the data gradient of edet_pw_bwd_data AND the weight gradient of edet_pw_bwd_weight.
   conv_y (default: on for one_call with a BatchNorm backward on dy): the saved tensor y behind dy IS the output of this
@@ -249,6 +253,9 @@ def test_pw_bwd_data(dt, shape, mode, gbn, pw_impl, one_call=False, ws_mib=16, c
     gq = want_g.to(tdt).float() if name == 'bf16' else want_g
     gu.check(s1, want_g.sum((0, 1, 2)), name, 'pw_bwd_data S1', rtol=3e-2 if name == 'bf16' else 1e-3)
     gu.check(s2, (gq * xh).sum((0, 1, 2)), name, 'pw_bwd_data S2', rtol=3e-2 if name == 'bf16' else 1e-3)
+  # the raw results (bit-for-bit comparisons of two runs)
+  return {'gout': gout[..., :cin].clone(), 'dweight': dwd.clone() if one_call else None, 'dgate': dgate.clone(),
+          'stats': parts[:npart.value * 2 * cin].clone() if stats else None}
 
 
 PW_BWD_SHAPES = [(4, 33, 31, 16, 96), (2, 17, 19, 24, 144), (3, 11, 13, 8, 16), (2, 9, 9, 32, 64), (1, 23, 5, 16, 36),
@@ -279,6 +286,38 @@ def test_pw_bwd(dt, shape, mode, gbn, monkeypatch):
     if mode.startswith('plain') and dt[0] == 'bf16':
       monkeypatch.setenv('EDET_PW_NOY', '0')         # the form that reads y, under the same contract
       test_pw_bwd_data(dt, shape, mode, gbn, 'auto', one_call=True)
+
+
+# r04: the one-pass TILED backward (pw_tile_bwd.hip).  Shapes for every (KT, NT) instantiation: K <= 64 / K in several
+# 128-channel slices with a ragged last slice, N <= 64 / <= 128, N % 8 != 0, maps whose pixel count is not a multiple of
+# the 64-row step (the gated steps are image-aligned), images that straddle row splits, more than 8 splits.
+PW_TILE_SHAPES = [(3, 9, 9, 64, 64), (4, 48, 48, 64, 64), (2, 20, 20, 672, 112), (3, 12, 12, 240, 80), (2, 10, 10, 480, 112),
+                  (5, 10, 10, 320, 64), (6, 10, 10, 144, 40), (2, 16, 16, 64, 112), (2, 20, 20, 64, 36), (2, 9, 7, 40, 64),
+                  (9, 24, 24, 112, 64), (2, 40, 40, 200, 128)]
+
+
+@pytest.mark.parametrize('shape', PW_TILE_SHAPES)
+@pytest.mark.parametrize('mode', ['plain', 'plain_beta', 'bn_swish_stats', 'gate'])
+@pytest.mark.parametrize('gbn', [False, True])
+def test_pw_bwd_tile(shape, mode, gbn, monkeypatch):
+  """edet_pw_bwd through the one-pass tiled kernel: results against the oracle (the body of test_pw_bwd_data), the launch
+  log shows the kernel that ran, and a second run of the same call gives every output BIT FOR BIT (no atomics: gate
+  sums, BatchNorm-backward sums and dW are combined in a fixed order)."""
+  bf16 = gu.DTYPES[1]
+  if shape[4] % 8 != 0 and gbn:
+    pytest.skip('predict layers carry no BatchNorm')
+  monkeypatch.setenv('EDET_PWS_FUSED_WIDE', '0')      # keep the wave-private one-pass kernel to its expand shapes
+  _lib.launch_log_start()
+  try:
+    first = pw_bwd_case(bf16, shape, mode, gbn, 'auto', one_call=True, conv_y=False)
+  finally:
+    log = _lib.launch_log_stop()
+  assert any('pwt::k_pw_bwd_tile' in k for k in log), sorted(log)
+  assert not any('atomic' in k for k in log)
+  second = pw_bwd_case(bf16, shape, mode, gbn, 'auto', one_call=True, conv_y=False)
+  for key, t in first.items():
+    if t is not None:
+      assert torch.equal(t, second[key]), 'run-to-run difference in %s' % key
 
 
 @pytest.mark.parametrize('dt', gu.DTYPES, ids=lambda d: d[0])
@@ -890,8 +929,8 @@ def test_tuned_kernels_with_the_other_activations(act, monkeypatch):
   generic = {k: v for k, v in log.items() if any(g in k for g in GENERIC_KERNELS)}
   assert not generic, 'fell back to the generic kernels: %s' % generic
   for family in ('pws::k_pw_fwd', 'pws::k_pw_dgrad', 'pws::k_pw_wgrad', 'pwb::k_big_gemm', 'pwb::k_big_wgrad',
-                 'dwm::k_fwd_lx', 'dwm::k_dgrad_lx', 'dwm::k_wgrad_lx', 'dwm::k_bwd_fused'):
+                 'pwt::k_pw_bwd_tile', 'dwm::k_fwd_lx', 'dwm::k_dgrad_lx', 'dwm::k_wgrad_lx', 'dwm::k_bwd_fused'):
     assert any(family in k for k in log), (family, sorted(log))
   # ... and every tuned kernel that ran is an OACT instantiation (last template argument)
-  tuned = [k for k in log if any(ns in k for ns in ('pws::k_', 'pwb::k_', 'dwm::k_')) and 'k_reduce' not in k]
+  tuned = [k for k in log if any(ns in k for ns in ('pws::k_', 'pwb::k_', 'pwt::k_pw_bwd', 'dwm::k_')) and 'k_reduce' not in k]
   assert tuned and all(', true>(' in k for k in tuned), [k for k in tuned if ', true>(' not in k]
