@@ -536,7 +536,12 @@ int pwt_try_bwd(const edet_gview_t* dy, const void* w, int ldw, const edet_tview
   const bool gbn = dy->a != nullptr;
   const bool xgen = in->scale || in->act != EDET_ACT_NONE || in->gate || epi->stat_partials || epi->dgate;
   const bool oact = in->act > EDET_ACT_SWISH;
-  const int kt = K <= 64 ? 64 : env_int("EDET_PWT_KT", 128), nt = N <= 64 ? 64 : 128;
+  // Slice width (r04b lab, D0 640x640 batch 128, KT = 64 against 128): with N > 64 the 128 x 128 tile holds one workgroup
+  // per compute unit (103 KB of LDS) and loses -- 672->112 0.435 against 0.652 ms, 480->112 0.225 / 0.240, 480->80 0.217 /
+  // 0.232, 240->80 0.119 / 0.129 --; with N <= 64 the wide slice wins on the large maps (80x80x240->40 0.296 against
+  // 0.357 ms) and is a wash on the small ones (20x20x320->64 0.0287 / 0.0270).  EDET_PWT_KT overrides (lab switch).
+  const int nt = N <= 64 ? 64 : 128;
+  const int kt = K <= 64 ? 64 : env_int("EDET_PWT_KT", (nt == 64 && a.M >= 400000) ? 128 : 64);
   int rc = 0;
 #define PWT_GO(KT_, NT_, GBN_, XGEN_, OACT_) rc = launch<KT_, NT_, GBN_, XGEN_, OACT_>(a, nparts_out, workspace_bytes, st)
 #define PWT_X(KT_, NT_, GBN_)                                     \
