@@ -98,10 +98,16 @@ constexpr int min_blocks(int KT, int NT, bool xgen) {
   return lds_bytes(KT, NT) > 80 * 1024 ? 1 : ((xgen || lds_bytes(KT, NT) > 53 * 1024) ? 2 : 3);
 }
 
-// XGEN = false: the input is a plain stored tensor (no BatchNorm / activation / gate on load, no statistic or gate
-// sums in the epilogue) -- the pointwise half of every SeparableConv2D of the BiFPN and the towers.
-template <int KT, int NT, bool GBN, bool XGEN, bool OACT>
-__global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XGEN)) void k_pw_bwd_tile(const Args a) {
+// XM = 0: the input is a plain stored tensor (no BatchNorm / activation / gate on load, no statistic or gate sums in the
+// epilogue) -- the pointwise half of every SeparableConv2D of the BiFPN and the towers.  XM = 1: the general view.
+// XM = 2: the SE-gated view of an MBConv projection with the gate-gradient sums in the epilogue (dgate[n][k] = sum_hw
+// d * act(z)): the data gradient is stored as it is and act(z) * gate is ALREADY in the LDS operand tile, so the epilogue
+// adds d * x~ from its own slot and the flush divides by the gate -- no second sigmoid per element, no raw x kept in
+// registers (the product is the bf16-rounded operand: 2^-9 relative noise per term of a sum over the image).
+template <int KT, int NT, bool GBN, int XM, bool OACT>
+__global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0)) void k_pw_bwd_tile(const Args a) {
+  constexpr bool XGEN = XM != 0;      // the input view carries BatchNorm / activation / gate, or the epilogue sums
+  constexpr bool XGATE = XM == 2;     // SE-gated input with gate-gradient sums: the epilogue needs no raw x
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int SX = KT * 2 + 16, SD = NT * 2 + 16, SW = NT * 2 + 16, SC = KT * 4 + 16;
   unsigned char* Xt = smem;
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XGEN)) void k_pw_bwd_ti
     geometry(t, img, r0, nvalid);
 
     // ---- stage step t: transformed operands -> LDS
-    uint4 xcur[XGEN ? NPX : 1];
+    uint4 xcur[(XGEN && !XGATE) ? NPX : 1];
     float gt[XGEN ? 8 : 1];
     float sc[XGEN ? 8 : 1], sh[XGEN ? 8 : 1];
     if constexpr (XGEN) {
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XGEN)) void k_pw_bwd_ti
       const int r = xr0 + RPPX * i;
       uint4 v = xn[i];
       if constexpr (XGEN) {
-        xcur[i] = xn[i];
+        if constexpr (!XGATE) xcur[i] = xn[i];
         if (affine || swish || other || gated) {
           float x[8];
           unpack8(v, x);
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XGEN)) void k_pw_bwd_ti
     __syncthreads();
 
     // ---- epilogue: the thread that loaded (row, chunk) of x finishes the same chunk of dx
-    if constexpr (XGEN) {
+    if constexpr (XGEN && !XGATE) {
       loadf8(cfx + xc * 8, sc);
       loadf8(cfx + KT + xc * 8, sh);
     }
@@ -359,7 +365,11 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XGEN)) void k_pw_bwd_ti
       const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
       float g[8];
       float x[XGEN ? 8 : 1];
-      if constexpr (XGEN) {
+      if constexpr (XGATE) {
+        unpack8(*reinterpret_cast<const uint4*>(Xt + r * SX + xc * 16), x);      // act(z) * gate, this thread's own slot
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] = fmaf(d[e], x[e], s1[e]); g[e] = d[e]; }
+      } else if constexpr (XGEN) {
         unpack8(xcur[i], x);
         if (want_gate) {
 #pragma unroll
@@ -392,7 +402,7 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XGEN)) void k_pw_bwd_ti
       unsigned char* dst = valid ? reinterpret_cast<unsigned char*>(GO + (size_t)r0 * ldx) + (uint32_t)((r * ldx + kx) * 2)
                                  : a.dump + tid * 16;
       *reinterpret_cast<uint4*>(dst) = pack8(g);
-      if constexpr (XGEN) {
+      if constexpr (XGEN && !XGATE) {
         if (want_stats) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) { s1[e] += g[e]; s2[e] = fmaf(g[e], x[e], s2[e]); }
@@ -412,6 +422,10 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XGEN)) void k_pw_bwd_ti
 #pragma unroll 8
           for (int rr = 0; rr < RPPX; ++rr) tot += red[rr * KT + tid];
           const int slot = split - (img * a.spi) / a.sps;
+          if constexpr (XGATE) {      // the sums were taken against act(z) * gate
+            const float gv = a.tv.gate[(size_t)img * a.K + k0 + tid];
+            tot = gv != 0.f ? tot / gv : 0.f;
+          }
           a.gate_ws[((size_t)slot * a.tv.n + img) * a.K + k0 + tid] = tot;
         }
         // (the next write of Ct comes after the next step's first barrier)
@@ -420,7 +434,7 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XGEN)) void k_pw_bwd_ti
   }
 
   // ---- BatchNorm-backward sums of this workgroup's rows: one partial row per split, columns of this slice
-  if constexpr (XGEN) {
+  if constexpr (XGEN && !XGATE) {
     if (want_stats) {
       __syncthreads();
       float* red = reinterpret_cast<float*>(Ct);        // [2][RPPX][KT]
@@ -473,9 +487,9 @@ inline int env_int(const char* name, int dflt) {
   return (e && e[0]) ? atoi(e) : dflt;
 }
 
-template <int KT, int NT, bool GBN, bool XGEN, bool OACT>
+template <int KT, int NT, bool GBN, int XM, bool OACT>
 int launch(Args& a, int* nparts_out, size_t workspace_bytes, hipStream_t st) {
-  auto kern = k_pw_bwd_tile<KT, NT, GBN, XGEN, OACT>;
+  auto kern = k_pw_bwd_tile<KT, NT, GBN, XM, OACT>;
   constexpr size_t lds = lds_bytes(KT, NT);
   static const bool lds_ok = lds <= 64 * 1024 ||
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
@@ -543,12 +557,15 @@ int pwt_try_bwd(const edet_gview_t* dy, const void* w, int ldw, const edet_tview
   const int nt = N <= 64 ? 64 : 128;
   const int kt = K <= 64 ? 64 : env_int("EDET_PWT_KT", (nt == 64 && a.M >= 400000) ? 128 : 64);
   int rc = 0;
-#define PWT_GO(KT_, NT_, GBN_, XGEN_, OACT_) rc = launch<KT_, NT_, GBN_, XGEN_, OACT_>(a, nparts_out, workspace_bytes, st)
+  const bool xgate = in->gate && epi->dgate && !epi->stat_partials && env_int("EDET_PWT_XGATE", 1);
+#define PWT_GO(KT_, NT_, GBN_, XM_, OACT_) rc = launch<KT_, NT_, GBN_, XM_, OACT_>(a, nparts_out, workspace_bytes, st)
 #define PWT_X(KT_, NT_, GBN_)                                     \
   do {                                                            \
-    if (!xgen) PWT_GO(KT_, NT_, GBN_, false, false);              \
-    else if (!oact) PWT_GO(KT_, NT_, GBN_, true, false);          \
-    else PWT_GO(KT_, NT_, GBN_, true, true);                      \
+    if (!xgen) PWT_GO(KT_, NT_, GBN_, 0, false);                  \
+    else if (xgate && !oact) PWT_GO(KT_, NT_, GBN_, 2, false);    \
+    else if (xgate) PWT_GO(KT_, NT_, GBN_, 2, true);              \
+    else if (!oact) PWT_GO(KT_, NT_, GBN_, 1, false);             \
+    else PWT_GO(KT_, NT_, GBN_, 1, true);                         \
   } while (0)
 #define PWT_G(KT_, NT_)                        \
   do {                                         \
