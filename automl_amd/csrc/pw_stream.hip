@@ -1746,6 +1746,14 @@ int pws_try_bwd_fused(const edet_gview_t* dy, const void* w, int ldw, const edet
     // a CU shuts out the small pyramid levels' chain on the second stream (the step did not move: 64.6 ms)
     if (KO < 2 * R) return 0;
     if (R > 64 || epi->beta) return 0;       // class B instantiations do not accumulate into gout
+    // r04: the one-pass TILED kernel (pw_tile_bwd.hip) takes the project layers from 96 input channels up -- lab, D0
+    // 640x640 batch 128: 160x160x96->24 0.436 against 0.582 ms here, 80x80x144->40 0.226 / 0.274, 160x160x144->24 0.803 /
+    // 0.796 (a tie, and the tiled kernel has no atomics); 320x320x32->16 stays here (0.787 against 0.841 ms).
+    // EDET_PWT=0 (the tiled kernel off) restores the round-3 envelope.
+    {
+      const char* pwt_env = getenv("EDET_PWT");
+      if (KO > 32 && !(pwt_env && pwt_env[0] == '0')) return 0;
+    }
     if (in->gate && a.hw % TR != 0) return 0;   // ... and take every 32-row tile to lie in one image where a gate is involved
     if (tmax <= 4 && KO <= 64) ft = 44;
     else if (tmin <= 3 && tmax <= 9) ft = 39;

@@ -91,11 +91,12 @@ __device__ __forceinline__ bf16x8 column_frag_tr(const unsigned char* tile, int 
   return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-constexpr int lds_bytes(int KT, int NT) {
-  return RS * (KT * 2 + 16) + RS * (NT * 2 + 16) + KT * (NT * 2 + 16) + RS * (KT * 4 + 16) + (2 * KT + 3 * NT) * 4;
+constexpr int lds_bytes(int KT, int NT, int NSL = 1, bool coefs = true) {
+  return RS * (KT * 2 + 16) + RS * (NT * 2 + 16) + KT * (NSL * NT * 2 + 16) + RS * (KT * 4 + 16) +
+         (coefs ? (2 * KT + 3 * NSL * NT) * 4 : 0);
 }
-constexpr int min_blocks(int KT, int NT, bool xgen) {
-  return lds_bytes(KT, NT) > 80 * 1024 ? 1 : ((xgen || lds_bytes(KT, NT) > 53 * 1024) ? 2 : 3);
+constexpr int min_blocks(int KT, int NT, bool xgen, int NSL = 1) {
+  return (lds_bytes(KT, NT, NSL) > 80 * 1024 || NSL > 3) ? 1 : ((xgen || NSL > 1 || lds_bytes(KT, NT, NSL) > 53 * 1024) ? 2 : 3);
 }
 
 // XM = 0: the input is a plain stored tensor (no BatchNorm / activation / gate on load, no statistic or gate sums in the
@@ -104,12 +105,19 @@ constexpr int min_blocks(int KT, int NT, bool xgen) {
 // d * act(z)): the data gradient is stored as it is and act(z) * gate is ALREADY in the LDS operand tile, so the epilogue
 // adds d * x~ from its own slot and the flush divides by the gate -- no second sigmoid per element, no raw x kept in
 // registers (the product is the bf16-rounded operand: 2^-9 relative noise per term of a sum over the image).
-template <int KT, int NT, bool GBN, int XM, bool OACT>
-__global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0)) void k_pw_bwd_tile(const Args a) {
+// NSL > 1 (r04): N up to NSL * 128 output channels in NSL column slices of the gradient per 64-row step -- the weight
+// slice [KT][N] stays resident, the data-gradient accumulators run over the slices of a step, the weight-gradient
+// accumulators (NSL sets) over the whole row range, one gradient slice is in flight while the previous one is on the
+// matrix cores.  The 20x20 projections (1152 -> 192 / 320), the 40 -> 240 expansion and the 810-column class-predict
+// layers (K = 64: 7 slices, 224 accumulator registers, one workgroup per compute unit).
+template <int KT, int NT, bool GBN, int XM, bool OACT, int NSL = 1>
+__global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0, NSL)) void k_pw_bwd_tile(const Args a) {
+  static_assert(NSL == 1 || NT == 128, "column slices are 128 channels wide");
   constexpr bool XGEN = XM != 0;      // the input view carries BatchNorm / activation / gate, or the epilogue sums
   constexpr bool XGATE = XM == 2;     // SE-gated input with gate-gradient sums: the epilogue needs no raw x
   extern __shared__ __align__(16) unsigned char smem[];
-  constexpr int SX = KT * 2 + 16, SD = NT * 2 + 16, SW = NT * 2 + 16, SC = KT * 4 + 16;
+  constexpr int SX = KT * 2 + 16, SD = NT * 2 + 16, SW = NSL * NT * 2 + 16, SC = KT * 4 + 16;
+  constexpr int NTT = NSL * NT;      // output channels covered
   unsigned char* Xt = smem;
   unsigned char* Dt = Xt + RS * SX;
   unsigned char* Wl = Dt + RS * SD;
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0)) void k_pw_bwd
   // per-channel coefficients (scale, shift | a, b, c): read from LDS where they are used, so that they do not occupy 40
   // registers across the matrix phase
   float* cfx = reinterpret_cast<float*>(Ct + RS * SC);     // [2][KT]
-  float* cfd = cfx + 2 * KT;                               // [3][NT]
+  float* cfd = cfx + 2 * KT;                               // [3][NTT]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
   // block -> (split, slice): the slices of one split back to back on one XCD (block b runs on XCD b % 8)
@@ -136,12 +144,18 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0)) void k_pw_bwd
   const int kx = k0 + xc * 8;
   const bool x_ok = kx < a.K;
   const int kxc = x_ok ? kx : 0;            // column actually addressed (loads are unconditional)
-  const int nd = dc * 8;
-  const bool d_ok = nd < a.N;
-  const int ndc = d_ok ? nd : 0;
-  // valid elements of the gradient chunk as a bit mask (all ones: the whole chunk; zero: a chunk past N) -- the padding
-  // columns of dy may hold anything
-  const uint4 dmask = d_ok ? keep_first(make_uint4(~0u, ~0u, ~0u, ~0u), a.N - nd) : make_uint4(0, 0, 0, 0);
+  const int nd = dc * 8;                     // channel of the gradient chunk within its column slice
+  // valid elements of the gradient chunk of slice j as a bit mask (all ones: the whole chunk; zero: a chunk past N) --
+  // the padding columns of dy may hold anything
+  auto slice_mask = [&](int j) {
+    const int n0 = j * NT + nd;
+    return n0 < a.N ? keep_first(make_uint4(~0u, ~0u, ~0u, ~0u), a.N - n0) : make_uint4(0, 0, 0, 0);
+  };
+  uint4 dmask[NSL <= 2 ? NSL : 1];           // (more slices: recomputed per slice, a handful of scalar-ish instructions)
+  if constexpr (NSL <= 2) {
+#pragma unroll
+    for (int j = 0; j < NSL; ++j) dmask[j] = slice_mask(j);
+  }
 
   const bf16_t* X = reinterpret_cast<const bf16_t*>(a.tv.data);
   const bf16_t* DZ = reinterpret_cast<const bf16_t*>(a.gv.dz);
@@ -158,8 +172,9 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0)) void k_pw_bwd
   const bool beta = a.epi.beta != 0;
 
   // ---- prologue: the weight slice -> LDS (rows past K and columns past N zero), per-channel coefficients -> registers
-  for (int idx = tid; idx < KT * CPRD; idx += THREADS) {
-    const int k = idx / CPRD, c = idx - k * CPRD;
+  constexpr int CPRW = NTT / 8;              // chunks per weight row
+  for (int idx = tid; idx < KT * CPRW; idx += THREADS) {
+    const int k = idx / CPRW, c = idx - k * CPRW;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (k0 + k < a.K && c * 8 < a.N) {
       v = *reinterpret_cast<const uint4*>(a.W + (size_t)(k0 + k) * a.ldw + c * 8);
@@ -175,24 +190,26 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0)) void k_pw_bwd
     }
   }
   if constexpr (GBN) {
-    for (int n = tid; n < NT; n += THREADS) {
+    for (int n = tid; n < NTT; n += THREADS) {
       const bool ok = n < a.N;
       cfd[n] = ok ? a.gv.a[n] : 0.f;
-      cfd[NT + n] = ok ? a.gv.b[n] : 0.f;
-      cfd[2 * NT + n] = ok ? a.gv.cc[n] : 0.f;
+      cfd[NTT + n] = ok ? a.gv.b[n] : 0.f;
+      cfd[2 * NTT + n] = ok ? a.gv.cc[n] : 0.f;
     }
   }
 
   // ---- accumulators
   constexpr int DT = KT / 64;                 // data-gradient column tiles per wave (row tile = wave & 1)
   constexpr int WKT = KT / 64, WNT = NT / 64; // weight-gradient tiles per wave: WKT x WNT
-  f32x16 accw[WKT][WNT];
+  f32x16 accw[NSL][WKT][WNT];
 #pragma unroll
-  for (int i = 0; i < WKT; ++i)
+  for (int sl = 0; sl < NSL; ++sl)
 #pragma unroll
-    for (int j = 0; j < WNT; ++j)
+    for (int i = 0; i < WKT; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) accw[i][j][e] = 0.f;
+      for (int j = 0; j < WNT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accw[sl][i][j][e] = 0.f;
   float s1[XGEN ? 8 : 1], s2[XGEN ? 8 : 1];      // BatchNorm-backward sums, or (s1) the SE gate sums: never both
   if constexpr (XGEN) {
 #pragma unroll
@@ -208,27 +225,33 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0)) void k_pw_bwd
     r0 = img * a.hwp + qs * RS;
     nvalid = min(RS, a.hwp - qs * RS);
   };
-  auto issue = [&](int t) {
+  auto issue_x = [&](int t) {
     int img, r0, nvalid;
     geometry(t, img, r0, nvalid);
     // one uniform 64-bit base per tensor and step + a 32-bit byte offset per lane
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(X + (size_t)r0 * ldx);
-    const unsigned char* zb = reinterpret_cast<const unsigned char*>(DZ + (size_t)r0 * ldd);
-    const unsigned char* yb = reinterpret_cast<const unsigned char*>(DY + (size_t)r0 * ldd);
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
       const int r = min(xr0 + RPPX * i, nvalid - 1);         // rows past the step re-read its last row
       xn[i] = *reinterpret_cast<const uint4*>(xb + (uint32_t)((r * ldx + kxc) * 2));
     }
+    if constexpr (XGEN) {
+      if (gated) loadf8(a.tv.gate + (size_t)img * a.K + kxc, gtn);
+    }
+  };
+  auto issue_d = [&](int t, int j) {      // column slice j of the gradient rows of step t
+    int img, r0, nvalid;
+    geometry(t, img, r0, nvalid);
+    const unsigned char* zb = reinterpret_cast<const unsigned char*>(DZ + (size_t)r0 * ldd);
+    const unsigned char* yb = reinterpret_cast<const unsigned char*>(DY + (size_t)r0 * ldd);
+    const int n0 = j * NT + nd;
+    const int ndc = n0 < a.N ? n0 : 0;                       // chunks past N re-read chunk 0 (masked where they are used)
 #pragma unroll
     for (int i = 0; i < NPD; ++i) {
       const int r = min(dr0 + RPPD * i, nvalid - 1);
       const uint32_t off = (uint32_t)((r * ldd + ndc) * 2);
       zn[i] = *reinterpret_cast<const uint4*>(zb + off);
       if constexpr (GBN) yn[i] = *reinterpret_cast<const uint4*>(yb + off);
-    }
-    if constexpr (XGEN) {
-      if (gated) loadf8(a.tv.gate + (size_t)img * a.K + kxc, gtn);
     }
   };
 
@@ -237,7 +260,7 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0)) void k_pw_bwd
   const int rt = wave & 1;                    // data gradient: row tile of this wave
   const int wkt0 = (wave & 1) * WKT, wnt0 = (wave >> 1) * WNT;
 
-  if (t0 < t1) issue(t0);
+  if (t0 < t1) { issue_x(t0); issue_d(t0, 0); }
   __syncthreads();                            // Wl complete
   for (int t = t0; t < t1; ++t) {
     int img, r0, nvalid;
@@ -273,35 +296,49 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0)) void k_pw_bwd
       if (!(x_ok && r < nvalid)) v = make_uint4(0, 0, 0, 0);
       *reinterpret_cast<uint4*>(Xt + r * SX + xc * 16) = v;
     }
-    float ga[GBN ? 8 : 1], gb[GBN ? 8 : 1], gc[GBN ? 8 : 1];
-    if constexpr (GBN) { loadf8(cfd + nd, ga); loadf8(cfd + NT + nd, gb); loadf8(cfd + 2 * NT + nd, gc); }
+    f32x16 accd[DT];
 #pragma unroll
-    for (int i = 0; i < NPD; ++i) {
-      const int r = dr0 + RPPD * i;
-      uint4 v = zn[i];
-      if constexpr (GBN) {
-        float g[8], y[8];
-        unpack8(zn[i], g);
-        unpack8(yn[i], y);
+    for (int i = 0; i < DT; ++i)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = fmaf(ga[e], g[e], fmaf(gb[e], y[e], gc[e]));
-        v = pack8(g);
+      for (int e = 0; e < 16; ++e) accd[i][e] = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) {
+      // ---- stage column slice sl of dy
+      {
+        float ga[GBN ? 8 : 1], gb[GBN ? 8 : 1], gc[GBN ? 8 : 1];
+        if constexpr (GBN) {
+          loadf8(cfd + sl * NT + nd, ga); loadf8(cfd + NTT + sl * NT + nd, gb); loadf8(cfd + 2 * NTT + sl * NT + nd, gc);
+        }
+        uint4 smask;
+        if constexpr (NSL <= 2) smask = dmask[sl]; else smask = slice_mask(sl);
+#pragma unroll
+        for (int i = 0; i < NPD; ++i) {
+          const int r = dr0 + RPPD * i;
+          uint4 v = zn[i];
+          if constexpr (GBN) {
+            float g[8], y[8];
+            unpack8(zn[i], g);
+            unpack8(yn[i], y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = fmaf(ga[e], g[e], fmaf(gb[e], y[e], gc[e]));
+            v = pack8(g);
+          }
+          const uint4 mk = r < nvalid ? smask : make_uint4(0, 0, 0, 0);
+          v = make_uint4(v.x & mk.x, v.y & mk.y, v.z & mk.z, v.w & mk.w);
+          *reinterpret_cast<uint4*>(Dt + r * SD + dc * 16) = v;
+        }
       }
-      const uint4 mk = r < nvalid ? dmask : make_uint4(0, 0, 0, 0);
-      v = make_uint4(v.x & mk.x, v.y & mk.y, v.z & mk.z, v.w & mk.w);
-      *reinterpret_cast<uint4*>(Dt + r * SD + dc * 16) = v;
-    }
-    // ---- request step t+1 (the last step re-requests itself: loads stay unconditional)
-    issue(min(t + 1, t1 - 1));
-    __syncthreads();
+      // ---- request what comes next: the next slice of this step, or step t+1 (the last step re-requests itself: the
+      // loads stay unconditional)
+      if (sl + 1 < NSL) {
+        issue_d(t, sl + 1);
+      } else {
+        issue_x(min(t + 1, t1 - 1));
+        issue_d(min(t + 1, t1 - 1), 0);
+      }
+      __syncthreads();
 
-    // ---- data gradient: C[row][k] = sum_n Dt[row][n] * Wl[k][n]  (D[i = k][j = row])
-    {
-      f32x16 accd[DT];
-#pragma unroll
-      for (int i = 0; i < DT; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) accd[i][e] = 0.f;
+      // ---- data gradient: C[row][k] += sum_n Dt[row][n] * Wl[k][sl*NT + n]  (D[i = k][j = row])
 #pragma unroll
       for (int kk = 0; kk < NT / 16; ++kk) {
         const int koff = (kk * 16 + h_lane * 8) * 2;
@@ -309,11 +346,11 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0)) void k_pw_bwd
 #pragma unroll
         for (int i = 0; i < DT; ++i) {
           const int ct = (wave >> 1) * DT + i;
-          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Wl + (ct * 32 + r_lane) * SW + koff);
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Wl + (ct * 32 + r_lane) * SW + sl * NT * 2 + koff);
           accd[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, accd[i], 0, 0, 0);
         }
       }
-      // ---- weight gradient: dW[k][n] += sum_rows Xt[row][k] * Dt[row][n]  (D[i = k][j = n])
+      // ---- weight gradient: dW[k][sl*NT + n] += sum_rows Xt[row][k] * Dt[row][n]  (D[i = k][j = n])
 #pragma unroll
       for (int ks = 0; ks < RS / 16; ++ks) {
         const int row0 = ks * 16 + h_lane * 8;
@@ -326,17 +363,18 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0)) void k_pw_bwd
         for (int i = 0; i < WKT; ++i)
 #pragma unroll
           for (int j = 0; j < WNT; ++j)
-            accw[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[i], df[j], accw[i][j], 0, 0, 0);
+            accw[sl][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[i], df[j], accw[sl][i][j], 0, 0, 0);
       }
-      // C tile: lane holds row rt*32 + r_lane, channels ct*32 + 8g + 4h .. +3
+      if (sl + 1 < NSL) __syncthreads();       // every wave is done with this slice of Dt
+    }
+    // C tile: lane holds row rt*32 + r_lane, channels ct*32 + 8g + 4h .. +3
 #pragma unroll
-      for (int i = 0; i < DT; ++i) {
-        const int ct = (wave >> 1) * DT + i;
+    for (int i = 0; i < DT; ++i) {
+      const int ct = (wave >> 1) * DT + i;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(Ct + (rt * 32 + r_lane) * SC + (ct * 32 + 8 * g + 4 * h_lane) * 4) =
-              make_float4(accd[i][4 * g + 0], accd[i][4 * g + 1], accd[i][4 * g + 2], accd[i][4 * g + 3]);
-      }
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(Ct + (rt * 32 + r_lane) * SC + (ct * 32 + 8 * g + 4 * h_lane) * 4) =
+            make_float4(accd[i][4 * g + 0], accd[i][4 * g + 1], accd[i][4 * g + 2], accd[i][4 * g + 3]);
     }
     // the previous contents of gout (accumulate): requested once the accumulators of the data gradient are dead, in
     // flight across the barrier
@@ -455,19 +493,21 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0)) void k_pw_bwd
     }
   }
 
-  // ---- dW partial of this split: lane holds n = nt*32 + r_lane, k = kt*32 + (e&3) + 8*(e>>2) + 4*h
+  // ---- dW partial of this split: lane holds n = sl*NT + nt*32 + r_lane, k = kt*32 + (e&3) + 8*(e>>2) + 4*h
   float* dst = a.ws + (size_t)split * a.K * a.N;
 #pragma unroll
-  for (int i = 0; i < WKT; ++i)
+  for (int sl = 0; sl < NSL; ++sl)
 #pragma unroll
-    for (int j = 0; j < WNT; ++j) {
-      const int n = (wnt0 + j) * 32 + r_lane;
+    for (int i = 0; i < WKT; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int k = k0 + (wkt0 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h_lane;
-        if (k < a.K && n < a.N) dst[(size_t)k * a.N + n] = accw[i][j][e];
+      for (int j = 0; j < WNT; ++j) {
+        const int n = sl * NT + (wnt0 + j) * 32 + r_lane;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int k = k0 + (wkt0 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h_lane;
+          if (k < a.K && n < a.N) dst[(size_t)k * a.N + n] = accw[sl][i][j][e];
+        }
       }
-    }
 }
 
 // dgate[img][k] += the slots of the workgroups that touched the image, in slot order
@@ -487,10 +527,10 @@ inline int env_int(const char* name, int dflt) {
   return (e && e[0]) ? atoi(e) : dflt;
 }
 
-template <int KT, int NT, bool GBN, int XM, bool OACT>
+template <int KT, int NT, bool GBN, int XM, bool OACT, int NSL = 1>
 int launch(Args& a, int* nparts_out, size_t workspace_bytes, hipStream_t st) {
-  auto kern = k_pw_bwd_tile<KT, NT, GBN, XM, OACT>;
-  constexpr size_t lds = lds_bytes(KT, NT);
+  auto kern = k_pw_bwd_tile<KT, NT, GBN, XM, OACT, NSL>;
+  constexpr size_t lds = lds_bytes(KT, NT, NSL, GBN || XM != 0);
   static const bool lds_ok = lds <= 64 * 1024 ||
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
   if (!lds_ok) return 0;
@@ -531,7 +571,7 @@ int pwt_try_bwd(const edet_gview_t* dy, const void* w, int ldw, const edet_tview
                 int* nparts_out, float* dweight, void* workspace, size_t workspace_bytes, hipStream_t st) {
   using namespace pwt;
   const int N = dy->c, K = in->c;
-  if (!workspace || K % 8 != 0 || in->ld % 8 != 0 || dy->ld % 8 != 0 || ldw % 8 != 0 || N > 128 || N < 1) return 0;
+  if (!workspace || K % 8 != 0 || in->ld % 8 != 0 || dy->ld % 8 != 0 || ldw % 8 != 0 || N > 896 || N < 1) return 0;
   // N % 8 != 0 (the 36-column box-predict layers): only without a BatchNorm backward on dy (its per-channel vectors
   // are read in chunks of 8); the straddling chunk of dy and of the weights is masked
   if (N % 8 != 0 && (dy->a || dy->ld < (N + 7) / 8 * 8 || ldw < (N + 7) / 8 * 8)) return 0;
@@ -572,7 +612,30 @@ int pwt_try_bwd(const edet_gview_t* dy, const void* w, int ldw, const edet_tview
     if (gbn) PWT_X(KT_, NT_, true);            \
     else PWT_X(KT_, NT_, false);               \
   } while (0)
-  if (kt == 64 && nt == 64) PWT_G(64, 64);
+  if (N > 128) {
+    // column-sliced instantiations (KT = 64, slices of 128): plain or SE-gated input, swish / linear; 7 slices only for
+    // the class-predict layers (no BatchNorm behind them).  EDET_PWT_NSL=0 switches them off (lab switch).
+    const int nsl = (N + 127) / 128;
+    if (oact || (xgen && !xgate) || !env_int("EDET_PWT_NSL", 1)) return 0;
+    if (nsl > 3 && (nsl > 7 || gbn || xgen || K > 64)) return 0;
+    // r04d lab (D0 640x640 batch 128): 80x80x40->240 0.437 -> 0.210 ms, 40x40x40->240 0.109 -> 0.055, 20x20x1152->192 0.417 ->
+    // 0.284, 20x20x672->192 0.266 -> 0.180; three slices hold one workgroup per compute unit (94 KB of LDS) and LOSE on
+    // the gated 20x20x1152->320 (0.571 -> 0.612 ms): off unless EDET_PWT_NSL3=1
+    if (nsl == 3 && xgate && !env_int("EDET_PWT_NSL3", 0)) return 0;
+#define PWT_N(NSL_, GBN_, XM_) rc = launch<64, 128, GBN_, XM_, false, NSL_>(a, nparts_out, workspace_bytes, st)
+#define PWT_NX(NSL_)                                   \
+  do {                                                 \
+    if (gbn && xgate) PWT_N(NSL_, true, 2);            \
+    else if (gbn) PWT_N(NSL_, true, 0);                \
+    else if (xgate) PWT_N(NSL_, false, 2);             \
+    else PWT_N(NSL_, false, 0);                        \
+  } while (0)
+    if (nsl == 2) PWT_NX(2);
+    else if (nsl == 3) PWT_NX(3);
+    else PWT_N(7, false, 0);
+#undef PWT_NX
+#undef PWT_N
+  } else if (kt == 64 && nt == 64) PWT_G(64, 64);
   else if (kt == 64) PWT_G(64, 128);
   else if (nt == 64) PWT_G(128, 64);
   else PWT_G(128, 128);

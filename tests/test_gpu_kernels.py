@@ -280,6 +280,7 @@ def test_pw_bwd(dt, shape, mode, gbn, monkeypatch):
   are run once with the default (the two-kernel path) and then with that threshold at 0 (the one-pass kernel)."""
   test_pw_bwd_data(dt, shape, mode, gbn, 'auto', one_call=True)
   monkeypatch.setenv('EDET_PWS_FUSED_MINROWS', '0')
+  monkeypatch.setenv('EDET_PWT', '0')       # r04: without the one-pass TILED kernel, which takes most of these shapes first
   test_pw_bwd_data(dt, shape, mode, gbn, 'auto', one_call=True)
   if gbn:
     test_pw_bwd_data(dt, shape, mode, gbn, 'auto', one_call=True, conv_y=False)
@@ -293,7 +294,9 @@ def test_pw_bwd(dt, shape, mode, gbn, monkeypatch):
 # the 64-row step (the gated steps are image-aligned), images that straddle row splits, more than 8 splits.
 PW_TILE_SHAPES = [(3, 9, 9, 64, 64), (4, 48, 48, 64, 64), (2, 20, 20, 672, 112), (3, 12, 12, 240, 80), (2, 10, 10, 480, 112),
                   (5, 10, 10, 320, 64), (6, 10, 10, 144, 40), (2, 16, 16, 64, 112), (2, 20, 20, 64, 36), (2, 9, 7, 40, 64),
-                  (9, 24, 24, 112, 64), (2, 40, 40, 200, 128)]
+                  (9, 24, 24, 112, 64), (2, 40, 40, 200, 128),
+                  # column-sliced instantiations (N > 128): 2 / 3 slices with a ragged last slice, 7 slices (class predict)
+                  (2, 10, 10, 672, 192), (3, 10, 10, 1152, 320), (2, 12, 12, 40, 240), (2, 9, 9, 64, 810), (1, 20, 20, 64, 810)]
 
 
 @pytest.mark.parametrize('shape', PW_TILE_SHAPES)
@@ -306,7 +309,10 @@ def test_pw_bwd_tile(shape, mode, gbn, monkeypatch):
   bf16 = gu.DTYPES[1]
   if shape[4] % 8 != 0 and gbn:
     pytest.skip('predict layers carry no BatchNorm')
+  if shape[4] > 128 and (mode == 'bn_swish_stats' or (shape[4] > 384 and mode == 'gate')):
+    pytest.skip('the column-sliced instantiations take plain and SE-gated inputs (7 slices: plain only)')
   monkeypatch.setenv('EDET_PWS_FUSED_WIDE', '0')      # keep the wave-private one-pass kernel to its expand shapes
+  monkeypatch.setenv('EDET_PWT_NSL3', '1')            # the three-slice gated instantiation is off by default (slower)
   _lib.launch_log_start()
   try:
     first = pw_bwd_case(bf16, shape, mode, gbn, 'auto', one_call=True, conv_y=False)
