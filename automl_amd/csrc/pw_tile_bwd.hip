@@ -617,7 +617,8 @@ int pwt_try_bwd(const edet_gview_t* dy, const void* w, int ldw, const edet_tview
     // the class-predict layers (no BatchNorm behind them).  EDET_PWT_NSL=0 switches them off (lab switch).
     const int nsl = (N + 127) / 128;
     if (oact || (xgen && !xgate) || !env_int("EDET_PWT_NSL", 1)) return 0;
-    if (nsl > 3 && (nsl > 7 || gbn || xgen || K > 64)) return 0;
+    const bool wide_expand = nsl > 3 && nsl <= 6 && gbn && !xgen && K <= 128 && env_int("EDET_PWT_WIDE", 1);
+    if (nsl > 3 && !wide_expand && (nsl > 7 || gbn || xgen || K > 64)) return 0;
     // r04d lab (D0 640x640 batch 128): 80x80x40->240 0.437 -> 0.210 ms, 40x40x40->240 0.109 -> 0.055, 20x20x1152->192 0.417 ->
     // 0.284, 20x20x672->192 0.266 -> 0.180; three slices hold one workgroup per compute unit (94 KB of LDS) and LOSE on
     // the gated 20x20x1152->320 (0.571 -> 0.612 ms): off unless EDET_PWT_NSL3=1
@@ -632,6 +633,8 @@ int pwt_try_bwd(const edet_gview_t* dy, const void* w, int ldw, const edet_tview
   } while (0)
     if (nsl == 2) PWT_NX(2);
     else if (nsl == 3) PWT_NX(3);
+    else if (wide_expand && nsl == 4) PWT_N(4, true, 0);
+    else if (wide_expand) PWT_N(6, true, 0);
     else PWT_N(7, false, 0);
 #undef PWT_NX
 #undef PWT_N

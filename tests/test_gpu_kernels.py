@@ -296,7 +296,9 @@ PW_TILE_SHAPES = [(3, 9, 9, 64, 64), (4, 48, 48, 64, 64), (2, 20, 20, 672, 112),
                   (5, 10, 10, 320, 64), (6, 10, 10, 144, 40), (2, 16, 16, 64, 112), (2, 20, 20, 64, 36), (2, 9, 7, 40, 64),
                   (9, 24, 24, 112, 64), (2, 40, 40, 200, 128),
                   # column-sliced instantiations (N > 128): 2 / 3 slices with a ragged last slice, 7 slices (class predict)
-                  (2, 10, 10, 672, 192), (3, 10, 10, 1152, 320), (2, 12, 12, 40, 240), (2, 9, 9, 64, 810), (1, 20, 20, 64, 810)]
+                  (2, 10, 10, 672, 192), (3, 10, 10, 1152, 320), (2, 12, 12, 40, 240), (2, 9, 9, 64, 810), (1, 20, 20, 64, 810),
+                  # 4 / 6 slices: the 40x40 expansions (plain input, BatchNorm behind the convolution, two K slices)
+                  (2, 12, 12, 80, 480), (2, 10, 10, 112, 672)]
 
 
 @pytest.mark.parametrize('shape', PW_TILE_SHAPES)
@@ -310,7 +312,9 @@ def test_pw_bwd_tile(shape, mode, gbn, monkeypatch):
   if shape[4] % 8 != 0 and gbn:
     pytest.skip('predict layers carry no BatchNorm')
   if shape[4] > 128 and (mode == 'bn_swish_stats' or (shape[4] > 384 and mode == 'gate')):
-    pytest.skip('the column-sliced instantiations take plain and SE-gated inputs (7 slices: plain only)')
+    pytest.skip('the column-sliced instantiations take plain and SE-gated inputs (4+ slices: plain only)')
+  if 384 < shape[4] <= 768 and not gbn:
+    pytest.skip('4 / 6 slices: instantiated for the MBConv expansions only (BatchNorm behind the convolution)')
   monkeypatch.setenv('EDET_PWS_FUSED_WIDE', '0')      # keep the wave-private one-pass kernel to its expand shapes
   monkeypatch.setenv('EDET_PWT_NSL3', '1')            # the three-slice gated instantiation is off by default (slower)
   _lib.launch_log_start()
