@@ -61,7 +61,7 @@ SIGNATURES = {
     'edet_cast_batch': [c_void_p, c_int, c_int, c_int, c_void_p],
     'edet_stem_fwd': [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, PI,
                       c_int, c_void_p],
-    'edet_stem_bwd_weight': [c_void_p, c_int, c_int, c_int, PG, c_void_p, c_int, c_void_p],
+    'edet_stem_bwd_weight': [c_void_p, c_int, c_int, c_int, PG, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],
     'edet_pw_fwd': [PT, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, PI, c_int, c_void_p],
     'edet_pw_bwd_data': [PG, c_void_p, c_int, PT, PE, PI, c_int, c_void_p],
     'edet_pw_bwd_weight': [PT, PG, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],
@@ -94,17 +94,17 @@ SIGNATURES = {
     'edet_fuse_fwd': [PT, PT, PT, PI, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
                       c_void_p],
     'edet_fuse_bwd_pre': [PT, PT, PT, PI, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
-                          c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+                          c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],
     'edet_fuse_bwd_input': [PT, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                             c_int, c_int, c_void_p],
     'edet_fuse_weights_bwd': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_int, c_void_p],
     'edet_focal_loss': [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float,
-                        c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],
     'edet_focal_loss_smooth': [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float, c_float,
-                               c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],
     'edet_box_loss': [c_void_p, c_int, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_void_p,
-                      c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+                      c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],
     'edet_opt_l2_norms': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
                           c_void_p],
     'edet_opt_clip_factors': [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p],

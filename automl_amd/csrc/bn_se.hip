@@ -101,15 +101,34 @@ __global__ void k_bn_eval(int c, const float* gamma, const float* beta, float ep
 }
 
 // ------------------------------------------------------------------ backward reduce / finalize
+// The per-channel sums of a workgroup WITHOUT LDS atomics (r04: run-to-run identical results): the row-lanes (rr) of a
+// channel chunk park their 8 + 8 sums in scr[2][THREADS * 8] and the first tpr * 8 threads add them in row-lane order
+// into red[cb ..] / red[c + cb ..].  Called by every thread of the workgroup (two barriers).
+__device__ __forceinline__ void rowlane_sums(float* scr, const RowMap& m, int cv, int rr, bool ok, const float (&s1)[8],
+                                             const float (&s2)[8], float* red, int cb, int c) {
+  const int width = m.tpr * 8;
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    scr[rr * width + cv * 8 + e] = ok ? s1[e] : 0.f;
+    scr[THREADS * 8 + rr * width + cv * 8 + e] = ok ? s2[e] : 0.f;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < width; t += THREADS) {
+    float u = 0.f, v = 0.f;
+    for (int r = 0; r < m.rpp; ++r) { u += scr[r * width + t]; v += scr[THREADS * 8 + r * width + t]; }
+    if (cb + t < c) { red[cb + t] = u; red[c + cb + t] = v; }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(THREADS) void k_bn_bwd_reduce(const T* __restrict__ dz, const T* __restrict__ y,
                                                           int64_t rows, int c, int ld, const float* mean,
                                                           const float* rstd, float* partials, RowMap m) {
   const int tid = threadIdx.x;
   const int cv = tid % m.tpr, rr = tid / m.tpr;
-  extern __shared__ float red[];  // [2][c]
-  for (int i = tid; i < 2 * c; i += THREADS) red[i] = 0.f;
-  __syncthreads();
+  extern __shared__ float red[];  // [2][c] + scratch [2][THREADS * 8]
+  float* scr = red + 2 * c;
   // channel blocks of tpr*8 (<= 2048) channels: one iteration for every layer up to 2048 channels, two for the
   // widest EfficientNet-B3..B7 stages
   for (int cb = 0; cb < c; cb += m.tpr * 8) {
@@ -143,9 +162,8 @@ __global__ __launch_bounds__(THREADS) void k_bn_bwd_reduce(const T* __restrict__
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s1[e] += g[e]; s2[e] += g[e] * (x[e] - mu[e]) * rs[e]; }
       }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { atomicAdd(&red[c0 + e], s1[e]); atomicAdd(&red[c + c0 + e], s2[e]); }
     }
+    rowlane_sums(scr, m, cv, rr, ok, s1, s2, red, cb, c);
   }
   __syncthreads();
   for (int i = tid; i < 2 * c; i += THREADS) partials[(size_t)blockIdx.x * 2 * c + i] = red[i];
@@ -587,46 +605,55 @@ __global__ __launch_bounds__(THREADS) void k_se_fc_bwd_img2(const float* __restr
   }
 }
 
-// parameter gradients.  Workgroup = 64 channels i x 4 hidden-unit groups, for one slice of the images
-// (blockIdx.y) and one block of SE_JB hidden units (blockIdx.z); thread (i, jg) owns the (i, j) pairs with
-// j % 4 == jg and sums over its images (loads coalesced along i); the image slices are combined with fp32
-// atomics (<= SE_SPLIT per address).
+// parameter gradients.  Workgroup = 64 channels i x 4 hidden-unit groups for one block of SE_JB hidden units
+// (blockIdx.z); thread (i, jg) owns the (i, j) pairs with j % 4 == jg and sums over ALL images, in image order: every
+// address is written by exactly one thread, so there are no atomics and the result is the same on every run (r04; the
+// round-2 version split the images over blockIdx.y and combined the slices with fp32 atomics).  The per-image operands
+// of a chunk of SE_NB images -- pooled / dpre2 for the 64 channels, dpre1 / hact for the hidden units -- are staged in
+// LDS by all 256 threads at once (coalesced, every load of the chunk in flight together), which is what the image
+// split was there for.
 //   dw1[i][j] += sum_n pooled[n][i]*inv_hw * dpre1[n][j];  dw2[j][i] += sum_n hact[n][j] * dpre2[n][i]
 constexpr int SE_MAX_JPT = 12;           // hidden units per thread
 constexpr int SE_JB = 4 * SE_MAX_JPT;    // hidden units per workgroup (48)
 constexpr int SE_NB = 64;                // images per LDS chunk
-constexpr int SE_SPLIT = 8;              // image slices
 __global__ __launch_bounds__(THREADS) void k_se_fc_bwd_par(const float* __restrict__ pooled,
                                                           const float* __restrict__ scratch, int nimg, int c,
                                                           int se, float inv_hw, float* dw1, float* db1,
-                                                          float* dw2, float* db2, int per_split) {
-  extern __shared__ float sm[];  // dpre1 [NB][jb], hact [NB][jb] for the current chunk of images
+                                                          float* dw2, float* db2) {
+  extern __shared__ float sm[];  // dpre1 [NB][jb], hact [NB][jb], pooled [NB][64], dpre2 [NB][64] of the current chunk
   const float* dpre2 = scratch;
   const float* dpre1_g = scratch + (size_t)nimg * c;
   const float* hact_g = scratch + (size_t)nimg * (c + se);
   const int j0 = blockIdx.z * SE_JB, jb = min(SE_JB, se - j0);
   float* d1 = sm;
   float* ha = sm + (size_t)SE_NB * SE_JB;
+  float* pls = ha + (size_t)SE_NB * SE_JB;
+  float* d2s = pls + (size_t)SE_NB * 64;
   const int tid = threadIdx.x;
-  const int i = blockIdx.x * 64 + (tid & 63), jg = tid >> 6;
-  const int nbeg = blockIdx.y * per_split, nend = min(nimg, nbeg + per_split);
+  const int il = tid & 63, i0 = blockIdx.x * 64, i = i0 + il, jg = tid >> 6;
   float a1[SE_MAX_JPT], a2[SE_MAX_JPT];
 #pragma unroll
   for (int t = 0; t < SE_MAX_JPT; ++t) a1[t] = a2[t] = 0.f;
   float sb2 = 0.f, sb1 = 0.f;
-  for (int n0 = nbeg; n0 < nend; n0 += SE_NB) {
-    const int nb = min(SE_NB, nend - n0);
+  for (int n0 = 0; n0 < nimg; n0 += SE_NB) {
+    const int nb = min(SE_NB, nimg - n0);
     __syncthreads();
     for (int q = tid; q < nb * jb; q += THREADS) {
       const int n = q / jb, j = q - n * jb;
       d1[q] = dpre1_g[(size_t)(n0 + n) * se + j0 + j];
       ha[q] = hact_g[(size_t)(n0 + n) * se + j0 + j];
     }
+    for (int q = tid; q < nb * 64; q += THREADS) {
+      const int n = q >> 6, ii = q & 63;
+      const bool ok = i0 + ii < c;
+      pls[q] = ok ? pooled[(size_t)(n0 + n) * c + i0 + ii] * inv_hw : 0.f;
+      d2s[q] = ok ? dpre2[(size_t)(n0 + n) * c + i0 + ii] : 0.f;
+    }
     __syncthreads();
     if (i < c) {
       for (int n = 0; n < nb; ++n) {
-        const float pl = pooled[(size_t)(n0 + n) * c + i] * inv_hw;
-        const float d2 = dpre2[(size_t)(n0 + n) * c + i];
+        const float pl = pls[n * 64 + il];
+        const float d2 = d2s[n * 64 + il];
         sb2 += d2;
 #pragma unroll
         for (int t = 0; t < SE_MAX_JPT; ++t) {
@@ -641,15 +668,15 @@ __global__ __launch_bounds__(THREADS) void k_se_fc_bwd_par(const float* __restri
     if (blockIdx.x == 0 && tid < jb)
       for (int n = 0; n < nb; ++n) sb1 += d1[n * jb + tid];
   }
-  if (blockIdx.x == 0 && tid < jb) atomicAdd(&db1[j0 + tid], sb1);
+  if (blockIdx.x == 0 && tid < jb) db1[j0 + tid] += sb1;
   if (i < c) {
-    if (jg == 0 && blockIdx.z == 0) atomicAdd(&db2[i], sb2);
+    if (jg == 0 && blockIdx.z == 0) db2[i] += sb2;
 #pragma unroll
     for (int t = 0; t < SE_MAX_JPT; ++t) {
       const int j = jg + 4 * t;
       if (j < jb) {
-        atomicAdd(&dw1[(size_t)i * se + j0 + j], a1[t]);
-        atomicAdd(&dw2[(size_t)(j0 + j) * c + i], a2[t]);
+        dw1[(size_t)i * se + j0 + j] += a1[t];
+        dw2[(size_t)(j0 + j) * c + i] += a2[t];
       }
     }
   }
@@ -665,9 +692,8 @@ __global__ __launch_bounds__(THREADS) void k_se_gate_bwd(const edet_tview_t in, 
   const int n = blockIdx.x / wg_per_img, part = blockIdx.x % wg_per_img;
   const int cv = tid % m.tpr, rr = tid / m.tpr;
   const int hw = in.h * in.w;
-  extern __shared__ float red[];  // [2][c]
-  for (int i = tid; i < 2 * in.c; i += THREADS) red[i] = 0.f;
-  __syncthreads();
+  extern __shared__ float red[];  // [2][c] + scratch [2][THREADS * 8]
+  float* scr = red + 2 * in.c;
   for (int cb = 0; cb < in.c; cb += m.tpr * 8) {     // channel blocks of <= 2048 channels
   const int c0 = cb + cv * 8;
   const bool ok = c0 < in.c;
@@ -718,9 +744,8 @@ __global__ __launch_bounds__(THREADS) void k_se_gate_bwd(const edet_tview_t in, 
       chain(d, x);
       store8<T>(g + off, d);
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { atomicAdd(&red[c0 + e], s1[e]); atomicAdd(&red[in.c + c0 + e], s2[e]); }
   }
+  rowlane_sums(scr, m, cv, rr, ok, s1, s2, red, cb, in.c);
   }
   __syncthreads();
   for (int i = tid; i < 2 * in.c; i += THREADS) partials[(size_t)blockIdx.x * 2 * in.c + i] = red[i];
@@ -805,11 +830,11 @@ extern "C" int edet_bn_bwd_reduce(const void* dz, const void* y, int64_t rows, i
                                   const float* mean, const float* rstd, float* stat_partials,
                                   int* nparts_out, int dtype, void* stream) {
   EDET_CHECK(dz && y && mean && rstd && stat_partials, "edet_bn_bwd_reduce: null pointer");
-  EDET_CHECK(c % 8 == 0 && ld % 8 == 0 && c <= 8192, "edet_bn_bwd_reduce: c/ld must be multiples of 8, c <= 8192");
+  EDET_CHECK(c % 8 == 0 && ld % 8 == 0 && c <= 6144, "edet_bn_bwd_reduce: c/ld must be multiples of 8, c <= 6144");
   const RowMap m = row_map(c);
   const int grid = persistent_grid(rows, m.rpp, 512);
   if (nparts_out) *nparts_out = grid;
-  const size_t lds = (size_t)2 * c * sizeof(float);
+  const size_t lds = (size_t)(2 * c + 2 * THREADS * 8) * sizeof(float);
   if (dtype == EDET_BF16)
     edet_launch(k_bn_bwd_reduce<bf16_t>, grid, dim3(THREADS), lds, to_stream(stream), (const bf16_t*)dz, (const bf16_t*)y, rows, c, ld, mean, rstd, stat_partials, m);
   else if (dtype == EDET_F32)
@@ -966,10 +991,9 @@ extern "C" int edet_se_fc_bwd(const float* pooled_sum, const float* hidden_pre, 
   } else {
     edet_launch(k_se_fc_bwd_img, dim3(n), dim3(c >= 512 ? SE_FC_THREADS : THREADS), (size_t)(c + se) * sizeof(float), to_stream(stream), hidden_pre, gate, dgate, n, c, se, inv_hw, w1, w2, dpool, scratch, act);
   }
-  const int nsplit = n >= 2 * SE_SPLIT ? SE_SPLIT : 1;
-  const int per_split = cdiv(n, nsplit);
-  edet_launch(k_se_fc_bwd_par, dim3(cdiv(c, 64), cdiv(n, per_split), cdiv(se, SE_JB)), dim3(THREADS), (size_t)2 * SE_NB * SE_JB * sizeof(float), to_stream(stream), 
-      pooled_sum, scratch, n, c, se, inv_hw, dw1, db1, dw2, db2, per_split);
+  edet_launch(k_se_fc_bwd_par, dim3(cdiv(c, 64), 1, cdiv(se, SE_JB)), dim3(THREADS),
+              (size_t)2 * SE_NB * (SE_JB + 64) * sizeof(float), to_stream(stream), pooled_sum, scratch, n, c, se, inv_hw,
+              dw1, db1, dw2, db2);
   EDET_LAUNCH_CHECK("edet_se_fc_bwd");
   return 0;
 }
@@ -978,13 +1002,13 @@ extern "C" int edet_se_gate_bwd(const edet_tview_t* in, void* g, const float* dp
                                 const float* mean, const float* rstd,
                                 float* stat_partials, int* nparts_out, int dtype, void* stream) {
   EDET_CHECK(in && in->data && in->gate && g && dpool && mean && rstd && stat_partials, "edet_se_gate_bwd: null pointer");
-  EDET_CHECK(in->c % 8 == 0 && in->ld % 8 == 0 && in->c <= 8192, "edet_se_gate_bwd: c/ld");
+  EDET_CHECK(in->c % 8 == 0 && in->ld % 8 == 0 && in->c <= 6144, "edet_se_gate_bwd: c/ld (c <= 6144)");
   const RowMap m = row_map(in->c);
   int wpi = se_wg_per_img(in->n, in->h * in->w, m.rpp);
   while (in->n * wpi > EDET_MAX_PARTS && wpi > 1) --wpi;
   EDET_CHECK(in->n * wpi <= EDET_MAX_PARTS, "edet_se_gate_bwd: batch %d exceeds %d partial rows", in->n, EDET_MAX_PARTS);
   if (nparts_out) *nparts_out = in->n * wpi;
-  const size_t lds = (size_t)2 * in->c * sizeof(float);
+  const size_t lds = (size_t)(2 * in->c + 2 * THREADS * 8) * sizeof(float);
   const bool other = in->act > EDET_ACT_SWISH;
   if (dtype == EDET_BF16 && !other) edet_launch(k_se_gate_bwd<bf16_t, false>, dim3(in->n * wpi), dim3(THREADS), lds, to_stream(stream), *in, (bf16_t*)g, dpool, mean, rstd, stat_partials, wpi, m);
   else if (dtype == EDET_BF16) edet_launch(k_se_gate_bwd<bf16_t, true>, dim3(in->n * wpi), dim3(THREADS), lds, to_stream(stream), *in, (bf16_t*)g, dpool, mean, rstd, stat_partials, wpi, m);

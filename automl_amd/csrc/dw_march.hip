@@ -126,8 +126,8 @@ __device__ __forceinline__ void view_act(const edet_tview_t& v, const float sc[C
 
 // workgroup reduction of per-thread channel sums into one partial row: partials[(p*nrow + row)*C + c].
 // One round per row: every thread parks its CPT values in LDS ([px][chunk][e] = thread-major), then
-// thread (col, slice) sums the pixels px = slice, slice + nsl, ... of column col and the few slices of a
-// column are combined with LDS atomics (nsl-way only).
+// thread (col, slice) sums the pixels px = slice, slice + nsl, ... of column col into its own slot and the
+// few slices of a column are added in slice order (r04: no LDS atomics -- the same sums on every run).
 template <int CPT, int NROW>
 __device__ __forceinline__ void block_channel_sums(const Args& a, const Lane& l, int C, const float (&s)[NROW][CPT],
                                                    float* dst_rows, float* red /* LDS [THREADS*CPT + width] */) {
@@ -141,17 +141,18 @@ __device__ __forceinline__ void block_channel_sums(const Args& a, const Lane& l,
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < CPT; ++e) red[threadIdx.x * CPT + e] = (l.active && threadIdx.x < nthr) ? s[r][e] : 0.f;
-    if (threadIdx.x < width) out[threadIdx.x] = 0.f;
     __syncthreads();
     if (slice < nsl) {
       float t = 0.f;
       for (int px = slice; px < a.TX; px += nsl) t += red[px * width + col];
-      atomicAdd(&out[col], t);
+      out[slice * width + col] = t;
     }
     __syncthreads();
     if (threadIdx.x < width) {
       const int c = l.g * width + threadIdx.x;
-      if (c < C) dst_rows[((size_t)l.p * NROW + r) * C + c] = out[threadIdx.x];
+      float t = 0.f;
+      for (int q = 0; q < nsl; ++q) t += out[q * width + threadIdx.x];
+      if (c < C) dst_rows[((size_t)l.p * NROW + r) * C + c] = t;
     }
   }
 }
@@ -192,7 +193,7 @@ template <> __device__ __forceinline__ void lds_get<2>(const float* p, float x[2
 }
 
 // floats of LDS in front of the row ring (block_channel_sums scratch)
-__host__ __device__ inline int red_floats(int nch, int cpt) { return THREADS * cpt + nch * cpt; }
+__host__ __device__ inline int red_floats(int nch, int cpt) { return THREADS * cpt + THREADS; }
 
 // PF = rows of global loads in flight per thread ahead of the row being consumed (register FIFO).  With two
 // rows the march was latency-bound: a row step (~0.3 us of work) had to wait for a load issued only two

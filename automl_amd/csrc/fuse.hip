@@ -86,7 +86,8 @@ __device__ __forceinline__ void sample_input(const FuseArgs& a, int i, const Vie
 template <typename T, bool BWD>
 __global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restrict__ out,
                                                  const T* __restrict__ dout, T* __restrict__ ds,
-                                                 float* dwn, unsigned char* __restrict__ pool_argmax) {
+                                                 float* dwn, unsigned char* __restrict__ pool_argmax,
+                                                 float* dwn_parts = nullptr) {
   const int nvec = a.c / 8;
   const int64_t total = (int64_t)a.n * a.oh * a.ow * nvec;
   const bool per_ch = a.wc > 1;                      // channel_attn / channel_fastattn: one weight per channel
@@ -173,17 +174,41 @@ __global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restric
     __syncthreads();
     for (int i = threadIdx.x; i < a.nin * a.c; i += THREADS) atomicAdd(&dwn[i], redc[i]);   // dwn [3][wc], wc == c
   } else if (BWD && dwn) {
-    __shared__ float red[3];
-    if (threadIdx.x < 3) red[threadIdx.x] = 0.f;
-    __syncthreads();
+    // scalar fusion weights: wave shuffles, then the waves in order (r04: no LDS atomics); with a partial buffer the
+    // workgroup's three sums go to its row there and k_fuse_dwn_finish adds the rows in order -- the same gradient on
+    // every run -- without one they are added into dwn with global atomics as before
+    __shared__ float red[THREADS / 64][4];
     for (int i = 0; i < a.nin; ++i) {
       float v = dw_acc[i];
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-      if ((threadIdx.x & 63) == 0) atomicAdd(&red[i], v);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
     }
     __syncthreads();
-    if (threadIdx.x < a.nin) atomicAdd(&dwn[threadIdx.x], red[threadIdx.x]);
+    if (threadIdx.x < 3) {
+      float t = 0.f;
+      if (threadIdx.x < a.nin)
+        for (int w = 0; w < THREADS / 64; ++w) t += red[w][threadIdx.x];
+      if (dwn_parts) dwn_parts[(size_t)blockIdx.x * 4 + threadIdx.x] = t;
+      else if (threadIdx.x < a.nin) atomicAdd(&dwn[threadIdx.x], t);
+    }
+  }
+}
+
+// dwn[i] += the workgroup rows of k_fuse<.., true>, in row order (i < 3)
+__global__ __launch_bounds__(256) void k_fuse_dwn_finish(const float* __restrict__ parts, int G, float* dwn) {
+  __shared__ float red[256][3];
+  float t[3] = {0.f, 0.f, 0.f};
+  // thread q adds the rows q*per .. (q+1)*per - 1 in order, thread 0 then adds the 256 chunk sums in order
+  const int per = (G + 255) / 256;
+  for (int g = threadIdx.x * per; g < min(G, (threadIdx.x + 1) * per); ++g)
+    for (int i = 0; i < 3; ++i) t[i] += parts[(size_t)g * 4 + i];
+  for (int i = 0; i < 3; ++i) red[threadIdx.x][i] = t[i];
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float s = 0.f;
+    for (int q = 0; q < 256; ++q) s += red[q][threadIdx.x];
+    dwn[threadIdx.x] += s;
   }
 }
 
@@ -435,8 +460,8 @@ extern "C" int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, c
   if (int rc = fill_args(a, in0, in1, in2, modes, nin, wn, wc, act, oh, ow, ldo)) return rc;
   EDET_CHECK(out, "edet_fuse_fwd: null output");
   const int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8), dtype == EDET_BF16 ? reinterpret_cast<const void*>(&k_fuse<bf16_t, false>) : nullptr);
-  if (dtype == EDET_BF16) edet_launch(k_fuse<bf16_t, false>, grid, dim3(THREADS), 0, to_stream(stream), a, (bf16_t*)out, nullptr, nullptr, nullptr, nullptr);
-  else if (dtype == EDET_F32) edet_launch(k_fuse<float, false>, grid, dim3(THREADS), 0, to_stream(stream), a, (float*)out, nullptr, nullptr, nullptr, nullptr);
+  if (dtype == EDET_BF16) edet_launch(k_fuse<bf16_t, false>, grid, dim3(THREADS), 0, to_stream(stream), a, (bf16_t*)out, nullptr, nullptr, nullptr, nullptr, nullptr);
+  else if (dtype == EDET_F32) edet_launch(k_fuse<float, false>, grid, dim3(THREADS), 0, to_stream(stream), a, (float*)out, nullptr, nullptr, nullptr, nullptr, nullptr);
   else EDET_CHECK(false, "edet_fuse_fwd: bad dtype %d", dtype);
   EDET_LAUNCH_CHECK("edet_fuse_fwd");
   return 0;
@@ -445,15 +470,19 @@ extern "C" int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, c
 extern "C" int edet_fuse_bwd_pre(const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
                                  const int* modes, int nin, const float* wn, int wc, int act,
                                  const void* dout, int oh, int ow, int ldo,
-                                 void* ds, float* dwn, void* pool_argmax, int dtype, void* stream) {
+                                 void* ds, float* dwn, void* pool_argmax, void* workspace, size_t workspace_bytes,
+                                 int dtype, void* stream) {
   FuseArgs a;
   if (int rc = fill_args(a, in0, in1, in2, modes, nin, wn, wc, act, oh, ow, ldo)) return rc;
   EDET_CHECK(dout && ds, "edet_fuse_bwd_pre: null pointer");
   const size_t lds = wc > 1 ? (size_t)3 * a.c * sizeof(float) : 0;
   const int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8), dtype == EDET_BF16 ? reinterpret_cast<const void*>(&k_fuse<bf16_t, true>) : nullptr, lds);
-  if (dtype == EDET_BF16) edet_launch(k_fuse<bf16_t, true>, grid, dim3(THREADS), lds, to_stream(stream), a, nullptr, (const bf16_t*)dout, (bf16_t*)ds, dwn, (unsigned char*)pool_argmax);
-  else if (dtype == EDET_F32) edet_launch(k_fuse<float, true>, grid, dim3(THREADS), lds, to_stream(stream), a, nullptr, (const float*)dout, (float*)ds, dwn, (unsigned char*)pool_argmax);
+  // scalar fusion weights: ordered partial rows [grid][4] through the workspace (else: atomic adds into dwn)
+  float* parts = (dwn && wc == 1 && workspace && workspace_bytes >= (size_t)grid * 4 * sizeof(float)) ? reinterpret_cast<float*>(workspace) : nullptr;
+  if (dtype == EDET_BF16) edet_launch(k_fuse<bf16_t, true>, grid, dim3(THREADS), lds, to_stream(stream), a, nullptr, (const bf16_t*)dout, (bf16_t*)ds, dwn, (unsigned char*)pool_argmax, parts);
+  else if (dtype == EDET_F32) edet_launch(k_fuse<float, true>, grid, dim3(THREADS), lds, to_stream(stream), a, nullptr, (const float*)dout, (float*)ds, dwn, (unsigned char*)pool_argmax, parts);
   else EDET_CHECK(false, "edet_fuse_bwd_pre: bad dtype %d", dtype);
+  if (parts) edet_launch(k_fuse_dwn_finish, dim3(1), dim3(256), 0, to_stream(stream), (const float*)parts, grid, dwn);
   EDET_LAUNCH_CHECK("edet_fuse_bwd_pre");
   return 0;
 }

@@ -28,12 +28,58 @@ inline RowMap row_map_ld(int ld) {
 // (ls/2) u in both cases, so d/du [sg^gamma (sp - h u)] = sg^gamma (gamma (1-sg) (sp - h u) + sg - h), h = ls/2.  A
 // template parameter of the shared body: k_focal (ls = 0) keeps its instruction count (the kernel is VALU-bound) and
 // its symbol; k_focal_ls is the smoothed one.
+// Tail of the two loss kernels: the workgroup's loss sum and its per-channel bias-gradient sums.  r04: combined in a fixed
+// order (wave shuffles, waves in order, row-lanes in order through LDS -- no LDS atomics); with a partial buffer the
+// workgroup writes its row [1 + nch] there and k_loss_finish adds the rows in order (the same loss and bias gradient on
+// every run), without one it adds into the destinations with global atomics as before.
+// LDS: scr[THREADS * 8] floats (dynamic).
+__device__ __forceinline__ void loss_tail(float loss_acc, const float (&db)[8], bool ok, int nch, const RowMap& m, float* scr,
+                                          float* part, float* sum_dst, float* dbias) {
+  __shared__ float wsum[THREADS / 64];
+  const int tid = threadIdx.x;
+  const int cv = tid % m.tpr, rr = tid / m.tpr;
+  const int width = m.tpr * 8;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) loss_acc += __shfl_down(loss_acc, off, 64);
+  if ((tid & 63) == 0) wsum[tid >> 6] = loss_acc;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) scr[rr * width + cv * 8 + e] = ok ? db[e] : 0.f;
+  __syncthreads();
+  float* row = part ? part + (size_t)blockIdx.x * (1 + nch) : nullptr;
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < THREADS / 64; ++w) t += wsum[w];
+    if (row) row[0] = t; else atomicAdd(sum_dst, t);
+  }
+  if (dbias || row) {
+    for (int i = tid; i < nch; i += THREADS) {
+      float t = 0.f;
+      for (int r = 0; r < m.rpp; ++r) t += scr[r * width + i];
+      if (row) row[1 + i] = t; else atomicAdd(&dbias[i], t);
+    }
+  }
+}
+
+// dst[0] += sum of column 0, dbias[i] += sum of column 1 + i over the G partial rows, in row order
+__global__ __launch_bounds__(256) void k_loss_finish(const float* __restrict__ part, int G, int nch, float* sum_dst,
+                                                     float* dbias) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i > nch) return;
+  float t0 = 0.f, t1 = 0.f;
+  int g = 0;
+  for (; g + 1 < G; g += 2) { t0 += part[(size_t)g * (1 + nch) + i]; t1 += part[(size_t)(g + 1) * (1 + nch) + i]; }
+  if (g < G) t0 += part[(size_t)g * (1 + nch) + i];
+  const float t = t0 + t1;
+  if (i == 0) sum_dst[0] += t;
+  else if (dbias) dbias[i - 1] += t;
+}
+
 template <typename T, bool G15, bool LS>
 __device__ __forceinline__ void focal_body(const T* __restrict__ logits, int ld,
                                                   const int32_t* __restrict__ tgt, int64_t positions,
                                                   int na, int nc, float alpha, float gamma, float inv_norm_h,
                                                   const float* __restrict__ norm_scale,
-                                                  T* __restrict__ dlogits, float* dbias, float* sums, RowMap m,
+                                                  T* __restrict__ dlogits, float* dbias, float* sums, float* part, RowMap m,
                                                   float half_ls) {
   const float inv_norm = norm_scale ? inv_norm_h * norm_scale[0] : inv_norm_h;
   const int tid = threadIdx.x;
@@ -137,22 +183,8 @@ __device__ __forceinline__ void focal_body(const T* __restrict__ logits, int ld,
       p = pn;
     }
   }
-  __shared__ float red_loss;
-  extern __shared__ float red[];  // [ld]
-  if (tid == 0) red_loss = 0.f;
-  for (int i = tid; i < ld; i += THREADS) red[i] = 0.f;
-  __syncthreads();
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) loss_acc += __shfl_down(loss_acc, off, 64);
-  if ((tid & 63) == 0) atomicAdd(&red_loss, loss_acc);
-  if (ok && dbias) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(&red[j0 + e], db[e]);
-  }
-  __syncthreads();
-  if (tid == 0) atomicAdd(&sums[0], red_loss);
-  if (dbias)
-    for (int i = tid; i < nch; i += THREADS) atomicAdd(&dbias[i], red[i]);
+  extern __shared__ float red[];  // [THREADS * 8]
+  loss_tail(loss_acc, db, ok, nch, m, red, part, &sums[0], dbias);
 }
 
 template <typename T, bool G15>
@@ -160,17 +192,17 @@ __global__ __launch_bounds__(THREADS) void k_focal(const T* __restrict__ logits,
                                                   const int32_t* __restrict__ tgt, int64_t positions,
                                                   int na, int nc, float alpha, float gamma, float inv_norm_h,
                                                   const float* __restrict__ norm_scale,
-                                                  T* __restrict__ dlogits, float* dbias, float* sums, RowMap m) {
-  focal_body<T, G15, false>(logits, ld, tgt, positions, na, nc, alpha, gamma, inv_norm_h, norm_scale, dlogits, dbias, sums, m, 0.f);
+                                                  T* __restrict__ dlogits, float* dbias, float* sums, float* part, RowMap m) {
+  focal_body<T, G15, false>(logits, ld, tgt, positions, na, nc, alpha, gamma, inv_norm_h, norm_scale, dlogits, dbias, sums, part, m, 0.f);
 }
 template <typename T, bool G15>
 __global__ __launch_bounds__(THREADS) void k_focal_ls(const T* __restrict__ logits, int ld,
                                                      const int32_t* __restrict__ tgt, int64_t positions,
                                                      int na, int nc, float alpha, float gamma, float inv_norm_h,
                                                      const float* __restrict__ norm_scale,
-                                                     T* __restrict__ dlogits, float* dbias, float* sums, RowMap m,
+                                                     T* __restrict__ dlogits, float* dbias, float* sums, float* part, RowMap m,
                                                      float half_ls) {
-  focal_body<T, G15, true>(logits, ld, tgt, positions, na, nc, alpha, gamma, inv_norm_h, norm_scale, dlogits, dbias, sums, m, half_ls);
+  focal_body<T, G15, true>(logits, ld, tgt, positions, na, nc, alpha, gamma, inv_norm_h, norm_scale, dlogits, dbias, sums, part, m, half_ls);
 }
 
 template <typename T>
@@ -178,7 +210,7 @@ __global__ __launch_bounds__(THREADS) void k_box(const T* __restrict__ out, int 
                                                 const float* __restrict__ tgt, int64_t positions, int nch,
                                                 float delta, float inv_norm_h, float grad_scale,
                                                 const float* __restrict__ norm_scale,
-                                                T* __restrict__ dbox, float* dbias, float* sums, RowMap m) {
+                                                T* __restrict__ dbox, float* dbias, float* sums, float* part, RowMap m) {
   const float inv_norm = norm_scale ? inv_norm_h * norm_scale[0] : inv_norm_h;
   const int tid = threadIdx.x;
   const int cv = tid % m.tpr, rr = tid / m.tpr;
@@ -210,22 +242,8 @@ __global__ __launch_bounds__(THREADS) void k_box(const T* __restrict__ out, int 
       store8<T>(dbox + p * ld + j0, g);
     }
   }
-  __shared__ float red_loss;
-  extern __shared__ float red[];
-  if (tid == 0) red_loss = 0.f;
-  for (int i = tid; i < ld; i += THREADS) red[i] = 0.f;
-  __syncthreads();
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) loss_acc += __shfl_down(loss_acc, off, 64);
-  if ((tid & 63) == 0) atomicAdd(&red_loss, loss_acc);
-  if (ok && dbias) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(&red[j0 + e], db[e]);
-  }
-  __syncthreads();
-  if (tid == 0) atomicAdd(&sums[1], red_loss);
-  if (dbias)
-    for (int i = tid; i < nch; i += THREADS) atomicAdd(&dbias[i], red[i]);
+  extern __shared__ float red[];  // [THREADS * 8]
+  loss_tail(loss_acc, db, ok, nch, m, red, part, &sums[1], dbias);
 }
 
 // ----------------------------------------------------------------------------------- optimizer
@@ -394,7 +412,8 @@ extern "C" int edet_focal_loss_smooth(const void* logits, int ld, const int32_t*
                                       int64_t positions, int num_anchors, int num_classes,
                                       float alpha, float gamma, float label_smoothing, float inv_normalizer,
                                       const float* norm_scale_dev,
-                                      void* dlogits, float* dbias, float* sums, int dtype, void* stream) {
+                                      void* dlogits, float* dbias, float* sums, void* workspace, size_t workspace_bytes,
+                                      int dtype, void* stream) {
   EDET_CHECK(logits && cls_targets && dlogits && sums, "edet_focal_loss: null pointer");
   EDET_CHECK(ld % 8 == 0 && ld >= num_anchors * num_classes && ld <= 2048, "edet_focal_loss: bad ld %d", ld);
   EDET_CHECK(num_classes >= 1, "edet_focal_loss: num_classes must be positive");
@@ -402,7 +421,7 @@ extern "C" int edet_focal_loss_smooth(const void* logits, int ld, const int32_t*
   const RowMap m = row_map_ld(ld);
   int64_t g = (positions + m.rpp - 1) / m.rpp;
   g = (g + 3) / 4;
-  const size_t lds = (size_t)ld * sizeof(float);
+  const size_t lds = (size_t)THREADS * 8 * sizeof(float);
   const bool g15 = gamma == 1.5f;
   const bool ls = label_smoothing != 0.f;
   const float half_ls = 0.5f * label_smoothing;
@@ -414,12 +433,15 @@ extern "C" int edet_focal_loss_smooth(const void* logits, int ld, const int32_t*
     if (g > cap) g = cap;
   }
   if (g < 1) g = 1;
+  // ordered partial rows [g][1 + nch] when the workspace holds them (else: global atomics)
+  const int nch_ = num_anchors * num_classes;
+  float* part = (workspace && workspace_bytes >= (size_t)g * (1 + nch_) * sizeof(float)) ? reinterpret_cast<float*>(workspace) : nullptr;
 #define FOCAL_LAUNCH(T, G)                                                                            \
   edet_launch(k_focal<T, G>, dim3((int)g), dim3(THREADS), lds, to_stream(stream), (const T*)logits, ld, cls_targets, positions, \
-      num_anchors, num_classes, alpha, gamma, inv_normalizer, norm_scale_dev, (T*)dlogits, dbias, sums, m)
+      num_anchors, num_classes, alpha, gamma, inv_normalizer, norm_scale_dev, (T*)dlogits, dbias, sums, part, m)
 #define FOCAL_LAUNCH_LS(T, G)                                                                         \
   edet_launch(k_focal_ls<T, G>, dim3((int)g), dim3(THREADS), lds, to_stream(stream), (const T*)logits, ld, cls_targets, positions, \
-      num_anchors, num_classes, alpha, gamma, inv_normalizer, norm_scale_dev, (T*)dlogits, dbias, sums, m, half_ls)
+      num_anchors, num_classes, alpha, gamma, inv_normalizer, norm_scale_dev, (T*)dlogits, dbias, sums, part, m, half_ls)
 #define FOCAL_LAUNCH_T(T)                                                  \
   do {                                                                     \
     if (g15) { if (ls) FOCAL_LAUNCH_LS(T, true); else FOCAL_LAUNCH(T, true); }     \
@@ -431,6 +453,7 @@ extern "C" int edet_focal_loss_smooth(const void* logits, int ld, const int32_t*
 #undef FOCAL_LAUNCH_LS
 #undef FOCAL_LAUNCH
   else EDET_CHECK(false, "edet_focal_loss: bad dtype %d", dtype);
+  if (part) edet_launch(k_loss_finish, dim3((nch_ + 256) / 256), dim3(256), 0, to_stream(stream), (const float*)part, (int)g, nch_, &sums[0], dbias);
   EDET_LAUNCH_CHECK("edet_focal_loss");
   return 0;
 }
@@ -439,15 +462,17 @@ extern "C" int edet_focal_loss(const void* logits, int ld, const int32_t* cls_ta
                                int64_t positions, int num_anchors, int num_classes,
                                float alpha, float gamma, float inv_normalizer,
                                const float* norm_scale_dev,
-                               void* dlogits, float* dbias, float* sums, int dtype, void* stream) {
+                               void* dlogits, float* dbias, float* sums, void* workspace, size_t workspace_bytes,
+                               int dtype, void* stream) {
   return edet_focal_loss_smooth(logits, ld, cls_targets, positions, num_anchors, num_classes, alpha, gamma, 0.f,
-                                inv_normalizer, norm_scale_dev, dlogits, dbias, sums, dtype, stream);
+                                inv_normalizer, norm_scale_dev, dlogits, dbias, sums, workspace, workspace_bytes, dtype,
+                                stream);
 }
 
 extern "C" int edet_box_loss(const void* box_out, int ld, const float* box_targets,
                              int64_t positions, int nch, float delta, float inv_normalizer,
                              float grad_scale, const float* norm_scale_dev, void* dbox, float* dbias,
-                             float* sums, int dtype, void* stream) {
+                             float* sums, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
   EDET_CHECK(box_out && box_targets && dbox && sums, "edet_box_loss: null pointer");
   EDET_CHECK(ld % 8 == 0 && ld >= nch && ld <= 2048, "edet_box_loss: bad ld %d", ld);
   const RowMap m = row_map_ld(ld);
@@ -455,12 +480,14 @@ extern "C" int edet_box_loss(const void* box_out, int ld, const float* box_targe
   g = (g + 3) / 4;
   if (g > 2048) g = 2048;
   if (g < 1) g = 1;
-  const size_t lds = (size_t)ld * sizeof(float);
+  const size_t lds = (size_t)THREADS * 8 * sizeof(float);
+  float* part = (workspace && workspace_bytes >= (size_t)g * (1 + nch) * sizeof(float)) ? reinterpret_cast<float*>(workspace) : nullptr;
   if (dtype == EDET_BF16)
-    edet_launch(k_box<bf16_t>, dim3((int)g), dim3(THREADS), lds, to_stream(stream), (const bf16_t*)box_out, ld, box_targets, positions, nch, delta, inv_normalizer, grad_scale, norm_scale_dev, (bf16_t*)dbox, dbias, sums, m);
+    edet_launch(k_box<bf16_t>, dim3((int)g), dim3(THREADS), lds, to_stream(stream), (const bf16_t*)box_out, ld, box_targets, positions, nch, delta, inv_normalizer, grad_scale, norm_scale_dev, (bf16_t*)dbox, dbias, sums, part, m);
   else if (dtype == EDET_F32)
-    edet_launch(k_box<float>, dim3((int)g), dim3(THREADS), lds, to_stream(stream), (const float*)box_out, ld, box_targets, positions, nch, delta, inv_normalizer, grad_scale, norm_scale_dev, (float*)dbox, dbias, sums, m);
+    edet_launch(k_box<float>, dim3((int)g), dim3(THREADS), lds, to_stream(stream), (const float*)box_out, ld, box_targets, positions, nch, delta, inv_normalizer, grad_scale, norm_scale_dev, (float*)dbox, dbias, sums, part, m);
   else EDET_CHECK(false, "edet_box_loss: bad dtype %d", dtype);
+  if (part) edet_launch(k_loss_finish, dim3((nch + 256) / 256), dim3(256), 0, to_stream(stream), (const float*)part, (int)g, nch, &sums[1], dbias);
   EDET_LAUNCH_CHECK("edet_box_loss");
   return 0;
 }

@@ -186,18 +186,18 @@ __global__ __launch_bounds__(THREADS, NS <= 8 ? 3 : 2) void k_pw_fwd(const FwdAr
   // LDS carve-up
   unsigned char* Wl = smem;                                        // [NWC][SW]
   float* biasL = reinterpret_cast<float*>(Wl + (size_t)a.NWC * a.SW);   // [Npad]
-  float* red = biasL + a.Npad;                                     // [2][Npad]
+  float* red = biasL + a.Npad;                                     // [WAVES][2][Npad]: one set of column sums per wave
   const int a_rows = TR * a.G;                                     // rows per super-tile
   const int a_alloc = a.pst * a.ck.rp;                             // >= a_rows: every load pass lands in-bounds
   const size_t wave_bytes = (size_t)a_alloc * a.SA + (size_t)TR * a.SC + (size_t)2 * a.NWC * 4;
-  unsigned char* wbase = reinterpret_cast<unsigned char*>(red + 2 * a.Npad) + (size_t)wave * wave_bytes;
+  unsigned char* wbase = reinterpret_cast<unsigned char*>(red + 2 * WAVES * a.Npad) + (size_t)wave * wave_bytes;
   unsigned char* At = wbase;                                       // [32*G][SA]
   unsigned char* Ct = wbase + (size_t)a_alloc * a.SA;              // [32][SC]
   float* wst = reinterpret_cast<float*>(Ct + TR * a.SC);           // [2][NWC] this wave's column sums
   const bool want_stats = a.stat_partials != nullptr;
 
   for (int i = tid; i < a.Npad; i += THREADS) biasL[i] = (a.bias && i < a.N) ? a.bias[i] : 0.f;
-  for (int i = tid; i < 2 * a.Npad; i += THREADS) red[i] = 0.f;
+  for (int i = tid; i < 2 * WAVES * a.Npad; i += THREADS) red[i] = 0.f;
   // zero this wave's A buffer once: the bytes after column K stay zero (k-step overhang)
   for (int i = lane; i < a_alloc * a.SA / 16; i += 64) reinterpret_cast<uint4*>(At)[i] = make_uint4(0, 0, 0, 0);
 
@@ -349,10 +349,13 @@ __global__ __launch_bounds__(THREADS, NS <= 8 ? 3 : 2) void k_pw_fwd(const FwdAr
     }
     if (want_stats) {
       __builtin_amdgcn_wave_barrier();
+      // into this wave's own set (r04: no LDS atomics; the four sets are added in wave order at the end, so the
+      // statistics are the same on every run)
+      float* redw = red + (size_t)wave * 2 * a.Npad;
       for (int c = lane; c < nrows; c += 64) {
         if (n0 + c < a.N) {
-          atomicAdd(&red[n0 + c], wst[c]);
-          atomicAdd(&red[a.Npad + n0 + c], wst[a.NWC + c]);
+          redw[n0 + c] += wst[c];
+          redw[a.Npad + n0 + c] += wst[a.NWC + c];
         }
       }
     }
@@ -362,7 +365,10 @@ __global__ __launch_bounds__(THREADS, NS <= 8 ? 3 : 2) void k_pw_fwd(const FwdAr
     float* dst = a.stat_partials + (size_t)blockIdx.x * 2 * a.N;
     for (int i = tid; i < 2 * a.N; i += THREADS) {
       const int which = i / a.N, col = i - which * a.N;
-      dst[i] = red[which * a.Npad + col];
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) t += red[(size_t)w * 2 * a.Npad + which * a.Npad + col];
+      dst[i] = t;
     }
   }
 }
@@ -373,7 +379,7 @@ inline size_t plan_lds(int Npad, int a_rows, int SA, int SW, size_t cap, int* NW
   for (int nwcr = Npad; nwcr >= 32; nwcr -= 32) {
     const int ccols = nwcr < NCC ? nwcr : NCC;
     const int SC = ctile_stride(ccols);
-    const size_t total = (size_t)nwcr * SW + (size_t)3 * Npad * 4 +
+    const size_t total = (size_t)nwcr * SW + (size_t)(1 + 2 * WAVES) * Npad * 4 +
                          (size_t)WAVES * ((size_t)a_rows * SA + (size_t)TR * SC + (size_t)2 * nwcr * 4);
     if (total <= cap) {
       *NWC_out = nwcr;
@@ -1417,11 +1423,16 @@ __global__ __launch_bounds__(THREADS, 1) void k_pw_bwd_fused(const FusedArgs a) 
       }
     }
     __builtin_amdgcn_wave_barrier();
-    for (int c = lane; c < a.KO; c += 64) {
-      atomicAdd(&red[c], wst[c]);
-      atomicAdd(&red[a.KOpad + c], wst[a.KOpad + c]);
+    // the four waves in wave order (r04: no cross-wave LDS atomics -- the same sums on every run)
+    for (int w = 0; w < WAVES; ++w) {
+      if (wave == w) {
+        for (int c = lane; c < a.KO; c += 64) {
+          red[c] += wst[c];
+          red[a.KOpad + c] += wst[a.KOpad + c];
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
     float* dst = a.epi.stat_partials + (size_t)blockIdx.x * 2 * a.KO;
     for (int c = tid; c < a.KO; c += THREADS) {
       const float sg = red[c], sgx = red[a.KOpad + c];
@@ -1752,7 +1763,9 @@ int pws_try_bwd_fused(const edet_gview_t* dy, const void* w, int ldw, const edet
     // EDET_PWT=0 (the tiled kernel off) restores the round-3 envelope.
     {
       const char* pwt_env = getenv("EDET_PWT");
-      if (KO > 32 && !(pwt_env && pwt_env[0] == '0')) return 0;
+      // ... and every SE-gated projection: this kernel adds its gate-gradient sums into dgate with global atomics, the
+      // tiled kernel in a fixed order (320x320x32->16: 0.84 against 0.79 ms here -- the price of a reproducible step)
+      if ((KO > 32 || in->gate) && !(pwt_env && pwt_env[0] == '0')) return 0;
     }
     if (in->gate && a.hw % TR != 0) return 0;   // ... and take every 32-row tile to lie in one image where a gate is involved
     if (tmax <= 4 && KO <= 64) ft = 44;

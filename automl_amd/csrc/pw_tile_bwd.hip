@@ -618,11 +618,15 @@ int pwt_try_bwd(const edet_gview_t* dy, const void* w, int ldw, const edet_tview
     const int nsl = (N + 127) / 128;
     if (oact || (xgen && !xgate) || !env_int("EDET_PWT_NSL", 1)) return 0;
     const bool wide_expand = nsl > 3 && nsl <= 6 && gbn && !xgen && K <= 128 && env_int("EDET_PWT_WIDE", 1);
-    if (nsl > 3 && !wide_expand && (nsl > 7 || gbn || xgen || K > 64)) return 0;
+    // 7 slices (class predict): up to two K slices (efficientdet-d0 .. d2: 64 / 88 / 112 filters) -- every further slice
+    // re-reads the 810-column gradient --, and any K on the small maps, where the two-kernel path would run the generic
+    // weight gradient (fp32 atomics) and the re-reads cost nothing
+    if (nsl > 3 && !wide_expand && (nsl > 7 || gbn || xgen || (K > 128 && a.M >= 65536))) return 0;
     // r04d lab (D0 640x640 batch 128): 80x80x40->240 0.437 -> 0.210 ms, 40x40x40->240 0.109 -> 0.055, 20x20x1152->192 0.417 ->
     // 0.284, 20x20x672->192 0.266 -> 0.180; three slices hold one workgroup per compute unit (94 KB of LDS) and LOSE on
-    // the gated 20x20x1152->320 (0.571 -> 0.612 ms): off unless EDET_PWT_NSL3=1
-    if (nsl == 3 && xgate && !env_int("EDET_PWT_NSL3", 0)) return 0;
+    // the gated 20x20x1152->320 (0.571 -> 0.612 ms) -- kept all the same: the two-kernel path adds the SE gate-gradient
+    // sums with global atomics, this one in a fixed order (EDET_PWT_NSL3=0 switches it off)
+    if (nsl == 3 && xgate && !env_int("EDET_PWT_NSL3", 1)) return 0;
 #define PWT_N(NSL_, GBN_, XM_) rc = launch<64, 128, GBN_, XM_, false, NSL_>(a, nparts_out, workspace_bytes, st)
 #define PWT_NX(NSL_)                                   \
   do {                                                 \

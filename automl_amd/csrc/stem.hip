@@ -21,6 +21,7 @@ struct StemArgs {
   float* stat_partials;
   edet_gview_t gy;
   float* dweight;
+  float* ws;        // weight gradient: per-workgroup partials [P][27 * cout] (NULL: atomic adds into dweight)
   int tiles_y, tiles_x, nsp, P;
 };
 
@@ -170,10 +171,25 @@ __global__ __launch_bounds__(THREADS) void k_stem_fwd_mfma(const StemArgs a) {
         float u = s1[ct][t], w = s2[ct][t];
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) { u += __shfl_down(u, off, 64); w += __shfl_down(w, off, 64); }
-        const int ch = ct * 32 + (t >> 3) * 16 + h * 8 + (t & 7);
-        if (j == 0 && ch < cout) { atomicAdd(&red[ch], u); atomicAdd(&red[64 + ch], w); }
+        s1[ct][t] = u;
+        s2[ct][t] = w;
       }
-    __syncthreads();
+    // the four waves add their sums in wave order (r04: no LDS atomics -- the same statistics on every run)
+    for (int wv = 0; wv < THREADS / 64; ++wv) {
+      if (wave == wv && j == 0) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const int ch = ct * 32 + (t >> 3) * 16 + h * 8 + (t & 7);
+            if (ch < cout) {
+              red[ch] = (wv == 0 ? 0.f : red[ch]) + s1[ct][t];
+              red[64 + ch] = (wv == 0 ? 0.f : red[64 + ch]) + s2[ct][t];
+            }
+          }
+      }
+      __syncthreads();
+    }
     for (int i = tid; i < 2 * cout; i += THREADS) {
       const int which = i / cout, c = i - which * cout;
       a.stat_partials[(size_t)blockIdx.x * 2 * cout + i] = red[which * 64 + c];
@@ -282,18 +298,25 @@ __global__ __launch_bounds__(THREADS) void k_stem_bwd_weight_mfma(const StemArgs
     }
   }
   // lane (channel j = lane & 31, half h) holds k = (t & 3) + 8 (t >> 2) + 4 h: the four waves are combined in LDS
-  __syncthreads();
+  // (r04: in wave order, no LDS atomics; with a workspace the workgroup's partial goes there and edet_reduce_partials
+  // adds the partials in order -- the same gradient on every run)
+  for (int wv = 0; wv < THREADS / 64; ++wv) {
+    __syncthreads();
+    if (wave == wv) {
 #pragma unroll
-  for (int ct = 0; ct < NCT; ++ct)
+      for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int k = (t & 3) + 8 * (t >> 2) + 4 * h, ch = ct * 32 + i;
-      if (k < 27 && ch < cout) atomicAdd(&red[k * 64 + ch], acc[ct][t]);
+        for (int t = 0; t < 16; ++t) {
+          const int k = (t & 3) + 8 * (t >> 2) + 4 * h, ch = ct * 32 + i;
+          if (k < 27 && ch < cout) red[k * 64 + ch] += acc[ct][t];
+        }
     }
+  }
   __syncthreads();
   for (int q = tid; q < 27 * cout; q += THREADS) {
     const int k = q / cout, ch = q - k * cout;
-    atomicAdd(&a.dweight[q], red[k * 64 + ch]);
+    if (a.ws) a.ws[(size_t)blockIdx.x * 27 * cout + q] = red[k * 64 + ch];
+    else atomicAdd(&a.dweight[q], red[k * 64 + ch]);
   }
 }
 
@@ -499,6 +522,7 @@ int stem_launch(bool fwd, StemArgs& a, hipStream_t st) {
     if (a.cout <= 32) edet_launch(k_stem_bwd_weight_mfma<1>, dim3(a.P), dim3(THREADS), 0, st, a);
     else edet_launch(k_stem_bwd_weight_mfma<2>, dim3(a.P), dim3(THREADS), 0, st, a);
     EDET_LAUNCH_CHECK("edet_stem_bwd_weight");
+    if (a.ws && edet_reduce_partials(a.ws, a.P, (int64_t)27 * a.cout, a.dweight, st) != 0) return -2;
     return 0;
   }
   if (fwd && sizeof(T) == 2) {
@@ -562,7 +586,8 @@ extern "C" int edet_stem_fwd(const void* images, int n, int h, int w, const floa
 }
 
 extern "C" int edet_stem_bwd_weight(const void* images, int n, int h, int w,
-                                    const edet_gview_t* dy, float* dweight, int dtype, void* stream) {
+                                    const edet_gview_t* dy, float* dweight, void* workspace, size_t workspace_bytes,
+                                    int dtype, void* stream) {
   EDET_CHECK(images && dy && dy->dz && dweight, "edet_stem_bwd_weight: null pointer");
   EDET_CHECK(dy->c % 8 == 0 && dy->ld % 8 == 0, "edet_stem_bwd_weight: dy c/ld % 8");
   StemArgs a;
@@ -570,6 +595,9 @@ extern "C" int edet_stem_bwd_weight(const void* images, int n, int h, int w,
   a.img = images; a.n = n; a.h = h; a.w = w; a.cout = dy->c; a.gy = *dy; a.dweight = dweight;
   stem_geometry(a);
   EDET_CHECK(a.oh == dy->h && a.ow == dy->w, "edet_stem_bwd_weight: dy geometry mismatch");
+  // bf16: ordered partial sums through the workspace when it holds EDET_MAX_PARTS of them
+  if (dtype == EDET_BF16 && workspace && workspace_bytes >= (size_t)EDET_MAX_PARTS * 27 * dy->c * sizeof(float))
+    a.ws = reinterpret_cast<float*>(workspace);
   if (dtype == EDET_BF16) return stem_launch<bf16_t>(false, a, to_stream(stream));
   if (dtype == EDET_F32) return stem_launch<float>(false, a, to_stream(stream));
   EDET_CHECK(false, "edet_stem_bwd_weight: bad dtype %d", dtype);

@@ -167,7 +167,8 @@ class V2Engine(engine_lib.Engine):
 
       def stem_bwd():
         g = self._gview(v0)
-        call('edet_stem_bwd_weight', ptr(images), n, h, w, ctypes.byref(g), ptr(self.grad(wstem)), self.dtype,
+        call('edet_stem_bwd_weight', ptr(images), n, h, w, ctypes.byref(g), ptr(self.grad(wstem)), ptr(self.workspace),
+             self.workspace.numel() * 4, self.dtype,
              self.stream, nbytes=(n * h * w * 3 + y0.rows * y0.c) * self.esize)
       self.tape.append(stem_bwd)
     if training or spec.blocks[0].has_residual or spec.blocks[0].conv_type == 1:

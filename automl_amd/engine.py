@@ -818,7 +818,8 @@ class Engine(object):
         tv2 = [v.tview() for v in inputs]
         tvp2 = [ctypes.byref(t) for t in tv2] + [None] * (3 - nin)
         call('edet_fuse_bwd_pre', tvp2[0], tvp2[1], tvp2[2], marr, nin, ptr(wn), wc, act, ptr(out.grad), oh, ow,
-             out.ld, ptr(ds), ptr(dwn), ptr(amax), self.dtype, self.stream, nbytes=fbytes + out.rows * c * self.esize)
+             out.ld, ptr(ds), ptr(dwn), ptr(amax), ptr(self.workspace), self.workspace.numel() * 4, self.dtype, self.stream,
+             nbytes=fbytes + out.rows * c * self.esize)
         plane = 0
         for i, v in enumerate(inputs):
           am = None
@@ -890,7 +891,8 @@ class Engine(object):
 
       def stem_bwd():
         g = self._gview(v0)
-        call('edet_stem_bwd_weight', ptr(images), n, h, w, ctypes.byref(g), ptr(self.grad(wstem)), self.dtype,
+        call('edet_stem_bwd_weight', ptr(images), n, h, w, ctypes.byref(g), ptr(self.grad(wstem)), ptr(self.workspace),
+             self.workspace.numel() * 4, self.dtype,
              self.stream, nbytes=(n * h * w * 3 + y0.rows * y0.c) * self.esize)
       self.tape.append(stem_bwd)
     # ---- MBConv blocks
@@ -1093,16 +1095,18 @@ class Engine(object):
       if ls:      # FocalLoss(label_smoothing), train_lib.py:400-402
         call('edet_focal_loss_smooth', ptr(r.data), r.ld, ptr(ct), r.rows, na, c.num_classes, c.alpha, c.gamma, ls,
              1.0 / normalizer, norm_dev, ptr(r.ensure_grad()), ptr(self.grad('class_net/class-predict/bias')),
-             ptr(self.loss_sums), self.dtype, self.stream, nbytes=2 * r.rows * r.c * self.esize)
+             ptr(self.loss_sums), ptr(self.workspace), self.workspace.numel() * 4, self.dtype, self.stream,
+             nbytes=2 * r.rows * r.c * self.esize)
       else:
         call('edet_focal_loss', ptr(r.data), r.ld, ptr(ct), r.rows, na, c.num_classes, c.alpha, c.gamma,
              1.0 / normalizer, norm_dev, ptr(r.ensure_grad()), ptr(self.grad('class_net/class-predict/bias')),
-             ptr(self.loss_sums), self.dtype, self.stream, nbytes=2 * r.rows * r.c * self.esize)
+             ptr(self.loss_sums), ptr(self.workspace), self.workspace.numel() * 4, self.dtype, self.stream,
+             nbytes=2 * r.rows * r.c * self.esize)
       r.grad_written = True
       rb = bv.raw
       call('edet_box_loss', ptr(rb.data), rb.ld, ptr(bt), rb.rows, 4 * na, c.delta, 1.0 / (normalizer * 4.0),
            float(c.box_loss_weight), norm_dev, ptr(rb.ensure_grad()), ptr(self.grad('box_net/box-predict/bias')),
-           ptr(self.loss_sums), self.dtype, self.stream)
+           ptr(self.loss_sums), ptr(self.workspace), self.workspace.numel() * 4, self.dtype, self.stream)
       rb.grad_written = True
     self.backward()
 

@@ -148,8 +148,12 @@ int edet_cast_batch(const edet_cast_item_t* items_dev, int count, int max_blocks
 int edet_stem_fwd(const void* images, int n, int h, int w, const float* weight,
                   void* out, int cout, int ldo, float* stat_partials, int* nparts_out,
                   int dtype, void* stream);
+/* dweight [3,3,3,cout] fp32 is accumulated into.  workspace: caller-owned device scratch for the per-workgroup
+ * partial sums (27 * cout floats each, at most EDET_MAX_PARTS of them), added in a fixed order -- the same
+ * gradient on every run; may be NULL, then the partials are combined with atomic adds.  */
 int edet_stem_bwd_weight(const void* images, int n, int h, int w,
-                         const edet_gview_t* dy, float* dweight, int dtype, void* stream);
+                         const edet_gview_t* dy, float* dweight, void* workspace, size_t workspace_bytes,
+                         int dtype, void* stream);
 
 /* ---- pointwise (1x1) convolution = GEMM on the matrix cores ----------------
  * Conv2D 1x1 call sites: efficientnet_model.py:304-312,345-353;
@@ -297,13 +301,17 @@ int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, const edet_t
                   const int* modes, int nin, const float* wn, int wc, int act,
                   void* out, int oh, int ow, int ldo, int dtype, void* stream);
 /* ds = dout * act'(s) (s recomputed) written to `ds`; dwn[i] += sum ds * x_i.
+ * workspace (may be NULL): caller-owned scratch for the per-workgroup partial sums of the scalar fusion weights
+ * (16 bytes per workgroup: 64 KiB is enough), added in a fixed order -- the same dwn on every run; NULL or
+ * per-channel weights: atomic adds.
  * pool_argmax (may be NULL): caller-owned bytes [npool][n][oh][ow][c], one plane per EDET_RS_POOL
  * input in input order; receives the winning tap (ky*3+kx, first maximum of the row-major scan) of
  * every pooled element so that edet_fuse_bwd_input does not have to recompute the 3x3 windows.  */
 int edet_fuse_bwd_pre(const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
                       const int* modes, int nin, const float* wn, int wc, int act,
                       const void* dout, int oh, int ow, int ldo,
-                      void* ds, float* dwn, void* pool_argmax, int dtype, void* stream);
+                      void* ds, float* dwn, void* pool_argmax, void* workspace, size_t workspace_bytes,
+                      int dtype, void* stream);
 /* gradient of one fusion input: gout (+)= wn[i] * resample_i^T(ds).  pool_argmax: this input's
  * plane written by edet_fuse_bwd_pre (EDET_RS_POOL only; NULL -> the windows are recomputed).  */
 int edet_fuse_bwd_input(const edet_tview_t* in, int mode, const float* wn, int wc, int idx,
@@ -321,22 +329,27 @@ int edet_fuse_weights_bwd(const float* w0, const float* w1, const float* w2, int
  * cls_targets int32 [n,h,w,a] (-1 background, -2 ignore).
  * norm_scale_dev (may be NULL): device scalar multiplied into inv_normalizer at run time, so that a
  * captured hipGraph of the step can be replayed with the next batch's normalizer
- * (sum(mean_num_positives) + 1, train_lib.py:517).  */
+ * (sum(mean_num_positives) + 1, train_lib.py:517).
+ * workspace: caller-owned device scratch for the per-workgroup partial rows (loss sum + bias gradient), added in a
+ * fixed order -- the same loss and bias gradient on every run; (a few thousand rows of 1 + channels floats: 8 MiB
+ * covers every EfficientDet head); NULL or too small: the partials are combined with atomic adds.  */
 int edet_focal_loss(const void* logits, int ld, const int32_t* cls_targets,
                     int64_t positions, int num_anchors, int num_classes,
                     float alpha, float gamma, float inv_normalizer, const float* norm_scale_dev,
-                    void* dlogits, float* dbias, float* sums, int dtype, void* stream);
+                    void* dlogits, float* dbias, float* sums, void* workspace, size_t workspace_bytes,
+                    int dtype, void* stream);
 /* the same with FocalLoss(label_smoothing) (train_lib.py:400-402, config.label_smoothing): the cross entropy is taken
  * against y*(1 - label_smoothing) + label_smoothing/2, alpha and the modulating factor keep the hard label */
 int edet_focal_loss_smooth(const void* logits, int ld, const int32_t* cls_targets,
                            int64_t positions, int num_anchors, int num_classes,
                            float alpha, float gamma, float label_smoothing, float inv_normalizer,
                            const float* norm_scale_dev,
-                           void* dlogits, float* dbias, float* sums, int dtype, void* stream);
+                           void* dlogits, float* dbias, float* sums, void* workspace, size_t workspace_bytes,
+                           int dtype, void* stream);
 int edet_box_loss(const void* box_out, int ld, const float* box_targets,
                   int64_t positions, int nch, float delta, float inv_normalizer,
                   float grad_scale, const float* norm_scale_dev, void* dbox, float* dbias, float* sums,
-                  int dtype, void* stream);
+                  void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
 /* ---- optimizer -----------------------------------------------------------------
  * train_lib.py:486-491 (L2), :675-682 (per-tensor clip_by_norm then

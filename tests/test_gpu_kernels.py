@@ -528,12 +528,19 @@ def test_stem(dt, shape):
   gu.check(s1, out.sum((0, 1, 2)), name, 'stem sum', rtol=srt, atol=srt * n * oh * ow, scale_by_max=False)
   dzd, yd = gu.to_dev(dz, tdt), gu.to_dev(y, tdt)
   gv = gu.gview(dzd, co, yd, ga, gb, gcc)
-  dwd = torch.zeros(3, 3, 3, co, dtype=torch.float32, device=gu.DEV)
-  call('edet_stem_bwd_weight', ptr(imgd), n, h, w, ctypes.byref(gv), ptr(dwd), edt, gu.stream())
-  torch.cuda.synchronize()
   # bf16: dy = a*dz + b*y + c is rounded to bf16 for the matrix cores (as in every other weight-gradient kernel of the path)
   wtol = 1e-3 if name == 'f32' else 1e-2
-  gu.check(dwd, wq.grad, name, 'stem_bwd_weight %s' % (shape,), rtol=wtol, atol=wtol)
+  runs = []
+  for wsp in (torch.empty(_lib.MAX_PARTS * 27 * co, dtype=torch.float32, device=gu.DEV), None):
+    for _ in range(2):
+      dwd = torch.zeros(3, 3, 3, co, dtype=torch.float32, device=gu.DEV)
+      call('edet_stem_bwd_weight', ptr(imgd), n, h, w, ctypes.byref(gv), ptr(dwd), ptr(wsp),
+           wsp.numel() * 4 if wsp is not None else 0, edt, gu.stream())
+      torch.cuda.synchronize()
+      gu.check(dwd, wq.grad, name, 'stem_bwd_weight %s' % (shape,), rtol=wtol, atol=wtol)
+      runs.append(dwd)
+  if name == 'bf16':      # with the workspace: ordered partial sums, the same bits on every run
+    assert torch.equal(runs[0], runs[1])
 
 
 # ------------------------------------------------------------------------------------ BatchNorm
@@ -768,8 +775,18 @@ def test_fuse(dt, case):
   dwn = torch.zeros(max(4, 3 * wc), dtype=torch.float32, device=gu.DEV)
   npool = sum(1 for m in ins if m[0] == _lib.RS_POOL)
   amax = torch.full((max(npool, 1), n, oh, ow, c), 255, dtype=torch.uint8, device=gu.DEV)
-  call('edet_fuse_bwd_pre', tvp[0], tvp[1], tvp[2], modes, nin, ptr(wn), wc, act, ptr(dd), oh, ow, c, ptr(ds),
-       ptr(dwn), ptr(amax) if npool else None, edt, gu.stream())
+  # with a workspace the scalar fusion-weight sums are added in a fixed order: two runs give the same bits
+  wsp = torch.empty(64 * 1024, dtype=torch.float32, device=gu.DEV)
+  dwn_runs = []
+  for use_ws in (False, True, True):
+    dwn.zero_()
+    call('edet_fuse_bwd_pre', tvp[0], tvp[1], tvp[2], modes, nin, ptr(wn), wc, act, ptr(dd), oh, ow, c, ptr(ds),
+         ptr(dwn), ptr(amax) if npool else None, ptr(wsp) if use_ws else None, wsp.numel() * 4 if use_ws else 0, edt,
+         gu.stream())
+    torch.cuda.synchronize()
+    dwn_runs.append(dwn.clone())
+  if wc == 1:
+    assert torch.equal(dwn_runs[1], dwn_runs[2])
   plane = 0
   for i in range(nin):
     planes = [None]
@@ -798,7 +815,8 @@ def test_fuse(dt, case):
 @pytest.mark.parametrize('geom', [(2, 5, 4, 9, 90), (3, 7, 5, 9, 20), (2, 6, 3, 9, 3), (1, 4, 4, 3, 8)],
                          ids=lambda g: 'x'.join(map(str, g)))
 @pytest.mark.parametrize('smoothing', [0.0, 0.1], ids=['hard', 'ls0.1'])
-def test_detection_loss(dt, geom, smoothing):
+@pytest.mark.parametrize('use_ws', [True, False], ids=['workspace', 'atomics'])
+def test_detection_loss(dt, geom, smoothing, use_ws):
   """geom = (n, h, w, anchors, classes): 90 classes (COCO), 20 (an 8-element chunk crosses anchors more often), 3 (the
   form for fewer than 8 classes: a chunk spans several anchors), 8 (a chunk is exactly one anchor)."""
   name, edt, tdt = dt
@@ -825,15 +843,26 @@ def test_detection_loss(dt, geom, smoothing):
   dbias_b = torch.zeros(4 * na, dtype=torch.float32, device=gu.DEV)
   # the normalizer reaches the kernels either as a host float or as a device scalar (graph replay): both ways
   inv_dev = torch.tensor([1.0 / norm], dtype=torch.float32, device=gu.DEV)
-  if smoothing:      # FocalLoss(label_smoothing), tf2/train_lib.py:400-402
-    call('edet_focal_loss_smooth', ptr(ld), ld.shape[-1], ptr(ctd), n * h * w, na, nc, 0.25, 1.5, smoothing, 1.0 / norm,
-         None, ptr(dl), ptr(dbias_c), ptr(sums), edt, gu.stream())
-  else:
-    call('edet_focal_loss', ptr(ld), ld.shape[-1], ptr(ctd), n * h * w, na, nc, 0.25, 1.5, 1.0 / norm, None, ptr(dl),
-         ptr(dbias_c), ptr(sums), edt, gu.stream())
-  call('edet_box_loss', ptr(bd), bd.shape[-1], ptr(btd), n * h * w, 4 * na, 0.1, 0.25, 50.0, ptr(inv_dev), ptr(db),
-       ptr(dbias_b), ptr(sums), edt, gu.stream())
-  torch.cuda.synchronize()
+  # workspace: ordered partial sums (the same loss / bias gradient on every run); None: atomic adds
+  wsp = torch.empty(2 * 1024 * 1024, dtype=torch.float32, device=gu.DEV) if use_ws else None
+  wsb = wsp.numel() * 4 if use_ws else 0
+
+  def run():
+    sums.zero_(), dbias_c.zero_(), dbias_b.zero_()
+    if smoothing:      # FocalLoss(label_smoothing), tf2/train_lib.py:400-402
+      call('edet_focal_loss_smooth', ptr(ld), ld.shape[-1], ptr(ctd), n * h * w, na, nc, 0.25, 1.5, smoothing, 1.0 / norm,
+           None, ptr(dl), ptr(dbias_c), ptr(sums), ptr(wsp), wsb, edt, gu.stream())
+    else:
+      call('edet_focal_loss', ptr(ld), ld.shape[-1], ptr(ctd), n * h * w, na, nc, 0.25, 1.5, 1.0 / norm, None, ptr(dl),
+           ptr(dbias_c), ptr(sums), ptr(wsp), wsb, edt, gu.stream())
+    call('edet_box_loss', ptr(bd), bd.shape[-1], ptr(btd), n * h * w, 4 * na, 0.1, 0.25, 50.0, ptr(inv_dev), ptr(db),
+         ptr(dbias_b), ptr(sums), ptr(wsp), wsb, edt, gu.stream())
+    torch.cuda.synchronize()
+    return sums.clone(), dbias_c.clone(), dbias_b.clone()
+  first = run()
+  if use_ws:
+    for a, b in zip(first, run()):
+      assert torch.equal(a, b), 'run-to-run difference in the loss sums / bias gradients'
   s = sums.cpu()
   assert abs(float(s[0]) - float(cls_loss)) <= 1e-3 * abs(float(cls_loss)) + 1e-5, (float(s[0]), float(cls_loss))
   assert abs(float(s[1]) - float(box_loss)) <= 1e-3 * abs(float(box_loss)) + 1e-6, (float(s[1]), float(box_loss))
@@ -942,5 +971,8 @@ def test_tuned_kernels_with_the_other_activations(act, monkeypatch):
                  'pwt::k_pw_bwd_tile', 'dwm::k_fwd_lx', 'dwm::k_dgrad_lx', 'dwm::k_wgrad_lx', 'dwm::k_bwd_fused'):
     assert any(family in k for k in log), (family, sorted(log))
   # ... and every tuned kernel that ran is an OACT instantiation (last template argument)
-  tuned = [k for k in log if any(ns in k for ns in ('pws::k_', 'pwb::k_', 'pwt::k_pw_bwd', 'dwm::k_')) and 'k_reduce' not in k]
+  tuned = [k for k in log if any(ns in k for ns in ('pws::k_', 'pwb::k_', 'dwm::k_')) and 'k_reduce' not in k]
   assert tuned and all(', true>(' in k for k in tuned), [k for k in tuned if ', true>(' not in k]
+  # (the one-pass tiled kernel carries OACT as its fifth template argument, in front of the slice count)
+  tiled = [k for k in log if 'pwt::k_pw_bwd_tile' in k]
+  assert tiled and all(k.split('<')[1].split(',')[4].strip() == 'true' for k in tiled), tiled

@@ -312,6 +312,41 @@ def test_train_step_bf16_tracks_the_oracle():
   assert cos >= 0.9, cos
 
 
+@pytest.mark.parametrize('model,size,batch', [('efficientdet-d0', 640, 8), ('efficientdet-d1', 256, 3)])
+def test_train_step_is_bit_reproducible(model, size, batch):
+  """r04: the bf16 training step has no floating-point atomics left on its path (BatchNorm partial rows, SE pooling / FC /
+  gate gradients, loss sums and bias gradients, fusion-weight gradients, stem / depthwise / pointwise weight gradients
+  are all combined in a fixed order), so the same step run twice -- two engines built from the same variables, the same
+  batch, the same stochastic-depth draws -- gives the gradient arena, the updated variables, the EMA shadows and the
+  BatchNorm moving statistics BIT FOR BIT.  d0 at the benchmark's 640 x 640 (batch 8) and d1 (stochastic depth).  The
+  one exception is documented: the reported L2 loss VALUE is still summed with atomics (it feeds nothing)."""
+  config = hparams_config.get_efficientdet_config(model)
+  vals = perturbed_params(config, 11)
+  rng = np.random.default_rng(97)
+  images = torch.from_numpy(rng.standard_normal((batch, size, size, 3)).astype(np.float32))
+  labels = make_labels(config, batch, size, 101)
+  runs = []
+  for _ in range(2):
+    net = train_lib.EfficientDetNetTrain(config=config, dtype='bf16', params=vals, seed=5)
+    eng = net._ensure_engine(batch, size, size)
+    for _step in range(2):
+      eng.refresh_drop_masks()
+      eng.forward(net._to_device_images(images, eng), training=True)
+      eng.loss_backward(net._labels_to_device(labels, eng))
+      grads = eng.grads_flat.clone()
+      eng.optimizer_step(0.02, 0.9)
+    torch.cuda.synchronize()
+    lv = eng.loss_values()
+    runs.append((grads, eng.params_flat.clone(), eng.ema.clone(), eng.state_flat.clone(), lv))
+    del net, eng
+  (g0, p0, e0, s0, l0), (g1, p1, e1, s1, l1) = runs
+  assert torch.equal(g0, g1), 'gradient arena differs between two runs: %d elements' % int((g0 != g1).sum())
+  assert torch.equal(p0, p1) and torch.equal(e0, e1), 'updated variables / EMA shadows differ between two runs'
+  assert torch.equal(s0, s1), 'BatchNorm moving statistics differ between two runs'
+  for k in ('cls_loss', 'box_loss', 'gradient_norm'):
+    assert l0[k] == l1[k], (k, l0[k], l1[k])
+
+
 def test_two_steps_decrease_loss_and_are_deterministic_in_shape():
   """EfficientDetNetTrain.train_step end to end twice (API level), d0 at 128."""
   config = hparams_config.get_efficientdet_config('efficientdet-d0')
