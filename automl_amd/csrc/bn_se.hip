@@ -605,55 +605,53 @@ __global__ __launch_bounds__(THREADS) void k_se_fc_bwd_img2(const float* __restr
   }
 }
 
-// parameter gradients.  Workgroup = 64 channels i x 4 hidden-unit groups for one block of SE_JB hidden units
-// (blockIdx.z); thread (i, jg) owns the (i, j) pairs with j % 4 == jg and sums over ALL images, in image order: every
-// address is written by exactly one thread, so there are no atomics and the result is the same on every run (r04; the
-// round-2 version split the images over blockIdx.y and combined the slices with fp32 atomics).  The per-image operands
-// of a chunk of SE_NB images -- pooled / dpre2 for the 64 channels, dpre1 / hact for the hidden units -- are staged in
-// LDS by all 256 threads at once (coalesced, every load of the chunk in flight together), which is what the image
-// split was there for.
+// parameter gradients.  Workgroup = 64 channels i x 4 hidden-unit groups, for one slice of the images
+// (blockIdx.y) and one block of SE_JB hidden units (blockIdx.z); thread (i, jg) owns the (i, j) pairs with
+// j % 4 == jg and sums over its images (loads coalesced along i).  r04: every image slice writes its sums to its own
+// partial [dw1 | dw2 | db1 | db2] in the scratch and k_se_fc_bwd_sum adds the SE_SPLIT partials in slice order -- the
+// same gradients on every run (rounds 2-3 combined the slices with fp32 atomics; summing all images in one workgroup
+// instead was measured at twice the time: 45 -> 89 us per call over the 16 blocks of D0).
 //   dw1[i][j] += sum_n pooled[n][i]*inv_hw * dpre1[n][j];  dw2[j][i] += sum_n hact[n][j] * dpre2[n][i]
 constexpr int SE_MAX_JPT = 12;           // hidden units per thread
 constexpr int SE_JB = 4 * SE_MAX_JPT;    // hidden units per workgroup (48)
 constexpr int SE_NB = 64;                // images per LDS chunk
+constexpr int SE_SPLIT = 8;              // image slices
 __global__ __launch_bounds__(THREADS) void k_se_fc_bwd_par(const float* __restrict__ pooled,
                                                           const float* __restrict__ scratch, int nimg, int c,
-                                                          int se, float inv_hw, float* dw1, float* db1,
-                                                          float* dw2, float* db2) {
-  extern __shared__ float sm[];  // dpre1 [NB][jb], hact [NB][jb], pooled [NB][64], dpre2 [NB][64] of the current chunk
+                                                          int se, float inv_hw, float* __restrict__ parts,
+                                                          int per_split) {
+  extern __shared__ float sm[];  // dpre1 [NB][jb], hact [NB][jb] for the current chunk of images
   const float* dpre2 = scratch;
   const float* dpre1_g = scratch + (size_t)nimg * c;
   const float* hact_g = scratch + (size_t)nimg * (c + se);
   const int j0 = blockIdx.z * SE_JB, jb = min(SE_JB, se - j0);
   float* d1 = sm;
   float* ha = sm + (size_t)SE_NB * SE_JB;
-  float* pls = ha + (size_t)SE_NB * SE_JB;
-  float* d2s = pls + (size_t)SE_NB * 64;
   const int tid = threadIdx.x;
-  const int il = tid & 63, i0 = blockIdx.x * 64, i = i0 + il, jg = tid >> 6;
+  const int i = blockIdx.x * 64 + (tid & 63), jg = tid >> 6;
+  const int nbeg = blockIdx.y * per_split, nend = min(nimg, nbeg + per_split);
+  const size_t cs = (size_t)c * se;
+  float* pw1 = parts + (size_t)blockIdx.y * (2 * cs + se + c);      // this slice's partial: dw1 [c][se]
+  float* pw2 = pw1 + cs;                                             // dw2 [se][c]
+  float* pb1 = pw2 + cs;                                             // db1 [se]
+  float* pb2 = pb1 + se;                                             // db2 [c]
   float a1[SE_MAX_JPT], a2[SE_MAX_JPT];
 #pragma unroll
   for (int t = 0; t < SE_MAX_JPT; ++t) a1[t] = a2[t] = 0.f;
   float sb2 = 0.f, sb1 = 0.f;
-  for (int n0 = 0; n0 < nimg; n0 += SE_NB) {
-    const int nb = min(SE_NB, nimg - n0);
+  for (int n0 = nbeg; n0 < nend; n0 += SE_NB) {
+    const int nb = min(SE_NB, nend - n0);
     __syncthreads();
     for (int q = tid; q < nb * jb; q += THREADS) {
       const int n = q / jb, j = q - n * jb;
       d1[q] = dpre1_g[(size_t)(n0 + n) * se + j0 + j];
       ha[q] = hact_g[(size_t)(n0 + n) * se + j0 + j];
     }
-    for (int q = tid; q < nb * 64; q += THREADS) {
-      const int n = q >> 6, ii = q & 63;
-      const bool ok = i0 + ii < c;
-      pls[q] = ok ? pooled[(size_t)(n0 + n) * c + i0 + ii] * inv_hw : 0.f;
-      d2s[q] = ok ? dpre2[(size_t)(n0 + n) * c + i0 + ii] : 0.f;
-    }
     __syncthreads();
     if (i < c) {
       for (int n = 0; n < nb; ++n) {
-        const float pl = pls[n * 64 + il];
-        const float d2 = d2s[n * 64 + il];
+        const float pl = pooled[(size_t)(n0 + n) * c + i] * inv_hw;
+        const float d2 = dpre2[(size_t)(n0 + n) * c + i];
         sb2 += d2;
 #pragma unroll
         for (int t = 0; t < SE_MAX_JPT; ++t) {
@@ -668,18 +666,32 @@ __global__ __launch_bounds__(THREADS) void k_se_fc_bwd_par(const float* __restri
     if (blockIdx.x == 0 && tid < jb)
       for (int n = 0; n < nb; ++n) sb1 += d1[n * jb + tid];
   }
-  if (blockIdx.x == 0 && tid < jb) db1[j0 + tid] += sb1;
+  if (blockIdx.x == 0 && tid < jb) pb1[j0 + tid] = sb1;
   if (i < c) {
-    if (jg == 0 && blockIdx.z == 0) db2[i] += sb2;
+    if (jg == 0 && blockIdx.z == 0) pb2[i] = sb2;
 #pragma unroll
     for (int t = 0; t < SE_MAX_JPT; ++t) {
       const int j = jg + 4 * t;
       if (j < jb) {
-        dw1[(size_t)i * se + j0 + j] += a1[t];
-        dw2[(size_t)(j0 + j) * c + i] += a2[t];
+        pw1[(size_t)i * se + j0 + j] = a1[t];
+        pw2[(size_t)(j0 + j) * c + i] = a2[t];
       }
     }
   }
+}
+
+// (dw1, dw2, db1, db2) += the nsplit partials, in slice order
+__global__ __launch_bounds__(THREADS) void k_se_fc_bwd_sum(const float* __restrict__ parts, int nsplit, int c, int se,
+                                                          float* dw1, float* db1, float* dw2, float* db2) {
+  const size_t cs = (size_t)c * se, total = 2 * cs + se + c;
+  const size_t q = (size_t)blockIdx.x * THREADS + threadIdx.x;
+  if (q >= total) return;
+  float t = 0.f;
+  for (int p = 0; p < nsplit; ++p) t += parts[(size_t)p * total + q];
+  if (q < cs) dw1[q] += t;
+  else if (q < 2 * cs) dw2[q - cs] += t;
+  else if (q < 2 * cs + se) db1[q - 2 * cs] += t;
+  else db2[q - 2 * cs - se] += t;
 }
 
 // g (in place, holds D) -> dz = (D*gate + dpool)*act'(z); BN backward stat partials.  OTHER: an activation beyond
@@ -755,7 +767,8 @@ __global__ __launch_bounds__(THREADS) void k_se_gate_bwd(const edet_tview_t in, 
 // sl, sl+64, ... with two independent loads in flight, the 64 slices are combined through LDS.
 constexpr int RED_SL = 64;      // row slices per element: 16 elements x 64 slices = 1024 lanes
 __global__ __launch_bounds__(16 * RED_SL) void k_reduce_partials(const float* __restrict__ ws, int P, int64_t n,
-                                                                float* __restrict__ dst, int accumulate) {
+                                                                float* __restrict__ dst, int accumulate,
+                                                                int64_t n_a = -1, float* __restrict__ dst_b = nullptr) {
   __shared__ float red[RED_SL][17];
   const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int64_t i = (int64_t)blockIdx.x * 16 + e;
@@ -774,7 +787,9 @@ __global__ __launch_bounds__(16 * RED_SL) void k_reduce_partials(const float* __
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < RED_SL; ++k) t += red[k][e];
-    dst[i] = accumulate ? dst[i] + t : t;
+    // two destinations (edet_reduce_partials2): columns [0, n_a) -> dst (may be NULL: dropped), [n_a, n) -> dst_b
+    float* d = (n_a < 0 || i < n_a) ? (dst ? dst + i : nullptr) : dst_b + (i - n_a);
+    if (d) *d = accumulate ? *d + t : t;
   }
 }
 
@@ -793,14 +808,20 @@ inline int ew_grid(int64_t total, const void* fn = nullptr) {
 
 }  // namespace
 
+// dst_a[i] += column i (i < n_a; dst_a may be NULL), dst_b[i - n_a] += column i (n_a <= i < n)
+int edet_reduce_partials2(const float* ws, int P, int64_t n, float* dst_a, int64_t n_a, float* dst_b, hipStream_t st) {
+  edet_launch(k_reduce_partials, dim3((unsigned)((n + 15) / 16)), dim3(16 * RED_SL), 0, st, ws, P, n, dst_a, 1, n_a, dst_b);
+  EDET_LAUNCH_CHECK("edet_reduce_partials2");
+  return 0;
+}
 int edet_reduce_partials(const float* ws, int P, int64_t n, float* dst, hipStream_t st) {
-  edet_launch(k_reduce_partials, dim3((unsigned)((n + 15) / 16)), dim3(16 * RED_SL), 0, st, ws, P, n, dst, 1);
+  edet_launch(k_reduce_partials, dim3((unsigned)((n + 15) / 16)), dim3(16 * RED_SL), 0, st, ws, P, n, dst, 1, (int64_t)-1, (float*)nullptr);
   EDET_LAUNCH_CHECK("edet_reduce_partials");
   return 0;
 }
 // dst[i] = sum of the partial rows (no accumulation)
 int edet_reduce_partials_set(const float* ws, int P, int64_t n, float* dst, hipStream_t st) {
-  edet_launch(k_reduce_partials, dim3((unsigned)((n + 15) / 16)), dim3(16 * RED_SL), 0, st, ws, P, n, dst, 0);
+  edet_launch(k_reduce_partials, dim3((unsigned)((n + 15) / 16)), dim3(16 * RED_SL), 0, st, ws, P, n, dst, 0, (int64_t)-1, (float*)nullptr);
   EDET_LAUNCH_CHECK("edet_reduce_partials");
   return 0;
 }
@@ -991,8 +1012,15 @@ extern "C" int edet_se_fc_bwd(const float* pooled_sum, const float* hidden_pre, 
   } else {
     edet_launch(k_se_fc_bwd_img, dim3(n), dim3(c >= 512 ? SE_FC_THREADS : THREADS), (size_t)(c + se) * sizeof(float), to_stream(stream), hidden_pre, gate, dgate, n, c, se, inv_hw, w1, w2, dpool, scratch, act);
   }
-  edet_launch(k_se_fc_bwd_par, dim3(cdiv(c, 64), 1, cdiv(se, SE_JB)), dim3(THREADS),
-              (size_t)2 * SE_NB * (SE_JB + 64) * sizeof(float), to_stream(stream), pooled_sum, scratch, n, c, se, inv_hw,
+  const int nsplit = n >= 2 * SE_SPLIT ? SE_SPLIT : 1;
+  const int per_split = cdiv(n, nsplit);
+  const int nsl = cdiv(n, per_split);
+  // the image slices' partials live behind the per-image vectors of the scratch (see the header for its size)
+  float* parts = scratch + (size_t)n * (c + (2 + cdiv(c, 128)) * se);
+  edet_launch(k_se_fc_bwd_par, dim3(cdiv(c, 64), nsl, cdiv(se, SE_JB)), dim3(THREADS), (size_t)2 * SE_NB * SE_JB * sizeof(float),
+              to_stream(stream), pooled_sum, (const float*)scratch, n, c, se, inv_hw, parts, per_split);
+  const size_t total = (size_t)2 * c * se + se + c;
+  edet_launch(k_se_fc_bwd_sum, dim3(cdiv(total, THREADS)), dim3(THREADS), 0, to_stream(stream), (const float*)parts, nsl, c, se,
               dw1, db1, dw2, db2);
   EDET_LAUNCH_CHECK("edet_se_fc_bwd");
   return 0;

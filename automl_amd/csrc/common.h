@@ -240,6 +240,8 @@ __host__ __device__ inline int same_pad_before(int in, int k, int s) {
 // dst[i] += sum_p ws[p*n + i]  (p < P): 16 elements x 16 partial-row slices per workgroup (bn_se.hip)
 int edet_reduce_partials(const float* ws, int P, int64_t n, float* dst, hipStream_t st);
 int edet_reduce_partials_set(const float* ws, int P, int64_t n, float* dst, hipStream_t st);
+// two destinations: dst_a[i] += column i for i < n_a (dst_a may be NULL), dst_b[i - n_a] += column i for n_a <= i < n
+int edet_reduce_partials2(const float* ws, int P, int64_t n, float* dst_a, int64_t n_a, float* dst_b, hipStream_t st);
 
 // workgroups of kernel `fn` (block size `threads`, `lds` bytes of dynamic LDS) the device holds at once; 0 = unknown
 int edet_resident_wgs(const void* fn, int threads, size_t lds);

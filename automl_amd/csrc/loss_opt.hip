@@ -30,7 +30,7 @@ inline RowMap row_map_ld(int ld) {
 // its symbol; k_focal_ls is the smoothed one.
 // Tail of the two loss kernels: the workgroup's loss sum and its per-channel bias-gradient sums.  r04: combined in a fixed
 // order (wave shuffles, waves in order, row-lanes in order through LDS -- no LDS atomics); with a partial buffer the
-// workgroup writes its row [1 + nch] there and k_loss_finish adds the rows in order (the same loss and bias gradient on
+// workgroup writes its row [nch | 1] there and edet_reduce_partials2 adds the rows in order (the same loss and bias gradient on
 // every run), without one it adds into the destinations with global atomics as before.
 // LDS: scr[THREADS * 8] floats (dynamic).
 __device__ __forceinline__ void loss_tail(float loss_acc, const float (&db)[8], bool ok, int nch, const RowMap& m, float* scr,
@@ -45,33 +45,19 @@ __device__ __forceinline__ void loss_tail(float loss_acc, const float (&db)[8], 
 #pragma unroll
   for (int e = 0; e < 8; ++e) scr[rr * width + cv * 8 + e] = ok ? db[e] : 0.f;
   __syncthreads();
-  float* row = part ? part + (size_t)blockIdx.x * (1 + nch) : nullptr;
+  float* row = part ? part + (size_t)blockIdx.x * (1 + nch) : nullptr;      // [bias gradient (nch) | loss]
   if (tid == 0) {
     float t = 0.f;
     for (int w = 0; w < THREADS / 64; ++w) t += wsum[w];
-    if (row) row[0] = t; else atomicAdd(sum_dst, t);
+    if (row) row[nch] = t; else atomicAdd(sum_dst, t);
   }
   if (dbias || row) {
     for (int i = tid; i < nch; i += THREADS) {
       float t = 0.f;
       for (int r = 0; r < m.rpp; ++r) t += scr[r * width + i];
-      if (row) row[1 + i] = t; else atomicAdd(&dbias[i], t);
+      if (row) row[i] = t; else atomicAdd(&dbias[i], t);
     }
   }
-}
-
-// dst[0] += sum of column 0, dbias[i] += sum of column 1 + i over the G partial rows, in row order
-__global__ __launch_bounds__(256) void k_loss_finish(const float* __restrict__ part, int G, int nch, float* sum_dst,
-                                                     float* dbias) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i > nch) return;
-  float t0 = 0.f, t1 = 0.f;
-  int g = 0;
-  for (; g + 1 < G; g += 2) { t0 += part[(size_t)g * (1 + nch) + i]; t1 += part[(size_t)(g + 1) * (1 + nch) + i]; }
-  if (g < G) t0 += part[(size_t)g * (1 + nch) + i];
-  const float t = t0 + t1;
-  if (i == 0) sum_dst[0] += t;
-  else if (dbias) dbias[i - 1] += t;
 }
 
 template <typename T, bool G15, bool LS>
@@ -453,7 +439,7 @@ extern "C" int edet_focal_loss_smooth(const void* logits, int ld, const int32_t*
 #undef FOCAL_LAUNCH_LS
 #undef FOCAL_LAUNCH
   else EDET_CHECK(false, "edet_focal_loss: bad dtype %d", dtype);
-  if (part) edet_launch(k_loss_finish, dim3((nch_ + 256) / 256), dim3(256), 0, to_stream(stream), (const float*)part, (int)g, nch_, &sums[0], dbias);
+  if (part && edet_reduce_partials2(part, (int)g, 1 + nch_, dbias, nch_, &sums[0], to_stream(stream)) != 0) return -2;
   EDET_LAUNCH_CHECK("edet_focal_loss");
   return 0;
 }
@@ -487,7 +473,7 @@ extern "C" int edet_box_loss(const void* box_out, int ld, const float* box_targe
   else if (dtype == EDET_F32)
     edet_launch(k_box<float>, dim3((int)g), dim3(THREADS), lds, to_stream(stream), (const float*)box_out, ld, box_targets, positions, nch, delta, inv_normalizer, grad_scale, norm_scale_dev, (float*)dbox, dbias, sums, part, m);
   else EDET_CHECK(false, "edet_box_loss: bad dtype %d", dtype);
-  if (part) edet_launch(k_loss_finish, dim3((nch + 256) / 256), dim3(256), 0, to_stream(stream), (const float*)part, (int)g, nch, &sums[1], dbias);
+  if (part && edet_reduce_partials2(part, (int)g, 1 + nch, dbias, nch, &sums[1], to_stream(stream)) != 0) return -2;
   EDET_LAUNCH_CHECK("edet_box_loss");
   return 0;
 }

@@ -697,7 +697,8 @@ class Engine(object):
     v.consumers += 1
     if self.training:
       dpool = self.buf(key + ':dpool', (n, c), torch.float32)
-      scratch = self.buf(key + ':scr', (n * (c + (2 + (c + 127) // 128) * se_filters),), torch.float32)
+      scratch = self.buf(key + ':scr', (n * (c + (2 + (c + 127) // 128) * se_filters) +
+                                        8 * (2 * c * se_filters + c + se_filters),), torch.float32)
 
       def bwd():
         call('edet_se_fc_bwd', ptr(pooled), ptr(hidden), ptr(gate), ptr(vg.dgate), n, c, se_filters, inv_hw,

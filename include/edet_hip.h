@@ -277,7 +277,8 @@ int edet_se_squeeze_excite(const edet_tview_t* in, void* scratch, size_t scratch
                            const float* w1, const float* b1, const float* w2, const float* b2,
                            float* pooled_sum, float* hidden_pre, float* gate, int act, int dtype, void* stream);
 /* dgate [n,c] -> dpool [n,c] (already divided by H*W), parameter gradients.
- * scratch: caller-owned fp32 workspace of n * (c + (2 + ceil(c / 128)) * se) elements.  */
+ * scratch: caller-owned fp32 workspace of n * (c + (2 + ceil(c / 128)) * se) + 8 * (2 * c * se + c + se) elements
+ * (the second term: the parameter gradients of 8 image slices, added in slice order -- no atomics).  */
 int edet_se_fc_bwd(const float* pooled_sum, const float* hidden_pre, const float* gate,
                    const float* dgate, int n, int c, int se, float inv_hw,
                    const float* w1, const float* w2,

@@ -683,7 +683,7 @@ def test_squeeze_excite(dt, shape):
   dgate = gu.fdev((dout * a.detach()).sum((1, 2)))
   grads = [torch.zeros_like(t) for t in (w1d, b1d, w2d, b2d)]
   dpool = torch.zeros(n, c, dtype=torch.float32, device=gu.DEV)
-  scratch = torch.zeros(n * (c + (2 + (c + 127) // 128) * se), dtype=torch.float32, device=gu.DEV)
+  scratch = torch.zeros(n * (c + (2 + (c + 127) // 128) * se) + 8 * (2 * c * se + c + se), dtype=torch.float32, device=gu.DEV)
   call('edet_se_fc_bwd', ptr(pd), ptr(hd), ptr(gd), ptr(dgate), n, c, se, 1.0 / (h * w), ptr(w1d), ptr(w2d),
        ptr(grads[0]), ptr(grads[1]), ptr(grads[2]), ptr(grads[3]), ptr(dpool), ptr(scratch), ACT_SWISH, gu.stream())
   parts = partial_buf(c)
