@@ -593,9 +593,11 @@ int pwt_try_bwd(const edet_gview_t* dy, const void* w, int ldw, const edet_tview
   // Slice width (r04b lab, D0 640x640 batch 128, KT = 64 against 128): with N > 64 the 128 x 128 tile holds one workgroup
   // per compute unit (103 KB of LDS) and loses -- 672->112 0.435 against 0.652 ms, 480->112 0.225 / 0.240, 480->80 0.217 /
   // 0.232, 240->80 0.119 / 0.129 --; with N <= 64 the wide slice wins on the large maps (80x80x240->40 0.296 against
-  // 0.357 ms) and is a wash on the small ones (20x20x320->64 0.0287 / 0.0270).  EDET_PWT_KT overrides (lab switch).
+  // 0.357 ms) and is a wash on the small ones (20x20x320->64 0.0287 / 0.0270): wide from 80 x 80 pixels per image up.
+  // EDET_PWT_KT overrides (lab switch).
   const int nt = N <= 64 ? 64 : 128;
-  const int kt = K <= 64 ? 64 : env_int("EDET_PWT_KT", (nt == 64 && a.M >= 400000) ? 128 : 64);
+  // (decided by the map, not by the batch: the 2-image parity runs then launch the instantiations of the batch-128 step)
+  const int kt = K <= 64 ? 64 : env_int("EDET_PWT_KT", (nt == 64 && in->h * in->w >= 3200) ? 128 : 64);
   int rc = 0;
   const bool xgate = in->gate && epi->dgate && !epi->stat_partials && env_int("EDET_PWT_XGATE", 1);
 #define PWT_GO(KT_, NT_, GBN_, XM_, OACT_) rc = launch<KT_, NT_, GBN_, XM_, OACT_>(a, nparts_out, workspace_bytes, st)
