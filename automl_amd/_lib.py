@@ -16,6 +16,7 @@ ACT_CODES = {'swish': ACT_SWISH, 'silu': ACT_SWISH, 'swish_native': ACT_SWISH, '
 RS_IDENTITY, RS_UP2, RS_POOL = 0, 1, 2
 MAX_PARTS = 1024
 OPT_SPLIT = 16   # EDET_OPT_SPLIT: partial squared norms per tensor segment
+SEG_L2, SEG_FROZEN = 1, 2   # EDET_SEG_L2 / EDET_SEG_FROZEN bits of seg_flags
 
 c_void_p, c_int, c_float, c_double, c_int64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
                                                ctypes.c_double, ctypes.c_int64)
@@ -105,11 +106,10 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],
     'edet_box_loss': [c_void_p, c_int, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_void_p,
                       c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],
-    'edet_opt_l2_norms': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
-                          c_void_p],
-    'edet_opt_clip_factors': [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    'edet_opt_l2_norms': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p],
+    'edet_opt_clip_factors': [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     'edet_opt_scale': [c_void_p, c_void_p, c_void_p, c_int, c_void_p],
-    'edet_opt_sgd_ema': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+    'edet_opt_sgd_ema': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                          c_float, c_void_p],
     'edet_pre_nms': [c_void_p, c_void_p, PI, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                      c_void_p, c_void_p],

@@ -260,14 +260,18 @@ __device__ __forceinline__ bool slice_range(const int64_t* seg_off, int s, int j
 
 __global__ __launch_bounds__(THREADS) void k_l2_norms(float* grads, const float* params,
                                                      const int64_t* seg_off, const int32_t* seg_flags,
-                                                     float wd, float* seg_sqnorm, float* l2_sum) {
+                                                     float wd, float* seg_sqnorm, int nseg) {
   __shared__ float sh[THREADS / 64];
   const int s = blockIdx.x, j = blockIdx.y;
   int64_t b, e;
   const bool any = slice_range(seg_off, s, j, b, e);
-  const bool reg = (seg_flags[s] & 1) != 0;
+  const bool frozen = (seg_flags[s] & EDET_SEG_FROZEN) != 0;
+  const bool reg = (seg_flags[s] & EDET_SEG_L2) != 0 && !frozen;
   float gsq = 0.f, wsq = 0.f;
-  if (any) {
+  if (any && frozen) {
+    // a frozen variable (config.var_freeze_expr) has no gradient: zeroed here, no share in the norms, skipped by the update
+    for (int64_t i = b + threadIdx.x; i < e; i += THREADS) grads[i] = 0.f;
+  } else if (any) {
     if ((b & 3) == 0) {
       const int64_t nv = (e - b) >> 2;
       float4* g4 = reinterpret_cast<float4*>(grads + b);
@@ -299,19 +303,23 @@ __global__ __launch_bounds__(THREADS) void k_l2_norms(float* grads, const float*
   const float tw = block_sum(wsq, sh);
   if (threadIdx.x == 0) {
     seg_sqnorm[(size_t)s * OPT_SPLIT + j] = tg;
-    if (any && reg && l2_sum) atomicAdd(l2_sum, 0.5f * wd * tw);
+    // this slice's share of the L2 loss, summed in a fixed order by k_clip_factors (r04: no atomics)
+    seg_sqnorm[((size_t)nseg + s) * OPT_SPLIT + j] = (any && reg) ? 0.5f * wd * tw : 0.f;
   }
 }
 
 // tf.clip_by_norm per tensor, then tf.clip_by_global_norm over the clipped tensors
 __global__ __launch_bounds__(THREADS) void k_clip_factors(const float* seg_sqnorm, int nseg, float clip,
-                                                         float* seg_factor, float* gnorm_out) {
+                                                         float* seg_factor, float* gnorm_out, float* l2_sum) {
   __shared__ float sh[THREADS / 64];
-  float acc = 0.f;
+  float acc = 0.f, l2 = 0.f;
   for (int s = threadIdx.x; s < nseg; s += THREADS) {
     float sq = 0.f;
 #pragma unroll
-    for (int j = 0; j < OPT_SPLIT; ++j) sq += seg_sqnorm[(size_t)s * OPT_SPLIT + j];
+    for (int j = 0; j < OPT_SPLIT; ++j) {
+      sq += seg_sqnorm[(size_t)s * OPT_SPLIT + j];
+      l2 += seg_sqnorm[((size_t)nseg + s) * OPT_SPLIT + j];
+    }
     const float nrm = sqrtf(sq);
     float f = 1.f;
     if (clip > 0.f) f = clip / fmaxf(nrm, clip);
@@ -320,6 +328,8 @@ __global__ __launch_bounds__(THREADS) void k_clip_factors(const float* seg_sqnor
     acc = fmaf(cn, cn, acc);
   }
   const float tot = block_sum(acc, sh);
+  const float l2tot = block_sum(l2, sh);
+  if (threadIdx.x == 0 && l2_sum) l2_sum[0] += l2tot;
   const float gn = sqrtf(tot);
   float f2 = 1.f;
   if (clip > 0.f) f2 = clip / fmaxf(gn, clip);
@@ -357,10 +367,13 @@ __device__ __forceinline__ void sgd1(float g, float& v, float& w, float& em, flo
 
 __global__ __launch_bounds__(THREADS) void k_sgd_ema(float* params, float* grads, float* vel, float* ema,
                                                     const int64_t* seg_off, const float* seg_factor,
-                                                    const float* hyper, float momentum) {
+                                                    const int32_t* seg_flags, const float* hyper, float momentum) {
   const int s = blockIdx.x;
   int64_t b, e;
   if (!slice_range(seg_off, s, blockIdx.y, b, e)) return;
+  // frozen variables are not in the optimizer's variable list (tf2/train_lib.py:478-491,683): value, momentum slot and
+  // EMA shadow stay exactly as they are
+  if (seg_flags && (seg_flags[s] & EDET_SEG_FROZEN)) return;
   const float f = seg_factor ? seg_factor[s] : 1.f;
   const float lr = hyper[0], decay = hyper[1];
   const bool has_ema = ema != nullptr;
@@ -480,17 +493,17 @@ extern "C" int edet_box_loss(const void* box_out, int ld, const float* box_targe
 
 extern "C" int edet_opt_l2_norms(float* grads, const float* params, const int64_t* seg_offsets,
                                  const int32_t* seg_flags, int nseg, float weight_decay,
-                                 float* seg_sqnorm, float* l2_sum, void* stream) {
+                                 float* seg_sqnorm, void* stream) {
   EDET_CHECK(grads && params && seg_offsets && seg_flags && seg_sqnorm && nseg > 0, "edet_opt_l2_norms: bad arguments");
-  edet_launch(k_l2_norms, dim3(nseg, OPT_SPLIT), dim3(THREADS), 0, to_stream(stream), grads, params, seg_offsets, seg_flags, weight_decay, seg_sqnorm, l2_sum);
+  edet_launch(k_l2_norms, dim3(nseg, OPT_SPLIT), dim3(THREADS), 0, to_stream(stream), grads, params, seg_offsets, seg_flags, weight_decay, seg_sqnorm, nseg);
   EDET_LAUNCH_CHECK("edet_opt_l2_norms");
   return 0;
 }
 
 extern "C" int edet_opt_clip_factors(const float* seg_sqnorm, int nseg, float clip_norm,
-                                     float* seg_factor, float* global_norm_out, void* stream) {
+                                     float* seg_factor, float* global_norm_out, float* l2_sum, void* stream) {
   EDET_CHECK(seg_sqnorm && seg_factor && nseg > 0, "edet_opt_clip_factors: bad arguments");
-  edet_launch(k_clip_factors, dim3(1), dim3(THREADS), 0, to_stream(stream), seg_sqnorm, nseg, clip_norm, seg_factor, global_norm_out);
+  edet_launch(k_clip_factors, dim3(1), dim3(THREADS), 0, to_stream(stream), seg_sqnorm, nseg, clip_norm, seg_factor, global_norm_out, l2_sum);
   EDET_LAUNCH_CHECK("edet_opt_clip_factors");
   return 0;
 }
@@ -504,10 +517,10 @@ extern "C" int edet_opt_scale(float* grads, const int64_t* seg_offsets, const fl
 }
 
 extern "C" int edet_opt_sgd_ema(float* params, float* grads, float* velocity, float* ema,
-                                const int64_t* seg_offsets, const float* seg_factor, int nseg,
+                                const int64_t* seg_offsets, const float* seg_factor, const int32_t* seg_flags, int nseg,
                                 const float* hyper_dev, float momentum, void* stream) {
   EDET_CHECK(params && grads && velocity && seg_offsets && hyper_dev && nseg > 0, "edet_opt_sgd_ema: bad arguments");
-  edet_launch(k_sgd_ema, dim3(nseg, OPT_SPLIT), dim3(THREADS), 0, to_stream(stream), params, grads, velocity, ema, seg_offsets, seg_factor, hyper_dev, momentum);
+  edet_launch(k_sgd_ema, dim3(nseg, OPT_SPLIT), dim3(THREADS), 0, to_stream(stream), params, grads, velocity, ema, seg_offsets, seg_factor, seg_flags, hyper_dev, momentum);
   EDET_LAUNCH_CHECK("edet_opt_sgd_ema");
   return 0;
 }

@@ -127,7 +127,8 @@ class ParamArena(object):
     self.seg_offsets = torch.tensor(seg, dtype=torch.int64, device=dev)
     self.seg_flags = torch.tensor(flags, dtype=torch.int32, device=dev)
     self.nseg = len(flags)
-    self.seg_sqnorm = torch.zeros(self.nseg * _lib.OPT_SPLIT, dtype=torch.float32, device=dev)
+    self._l2_flags = list(flags)          # as built: set_frozen starts from these every time
+    self.seg_sqnorm = torch.zeros(2 * self.nseg * _lib.OPT_SPLIT, dtype=torch.float32, device=dev)   # norms | L2 partials
     self.seg_factor = torch.ones(self.nseg, dtype=torch.float32, device=dev)
     self.version = 0          # bumped whenever a variable changes: engines re-make their compute copies
     self.step_count = 0       # optimizer iterations applied to this arena
@@ -138,23 +139,27 @@ class ParamArena(object):
   def set_frozen(self, expr):
     """config.var_freeze_expr (tf2/train_lib.py:478-491): the trainable variables whose name -- with the ':0' TensorFlow
     appends -- matches the expression from its start are left out of the L2 term, of the gradient list (per-tensor and
-    global clip norms) and of the update.  Here: their L2 flag is cleared and their gradient range is zeroed in front of
-    the optimizer kernels (Engine.optimizer_local), which makes them contribute nothing to the norms and keeps their
-    momentum slot -- cleared now -- and value where they are.  Returns the frozen names."""
-    pat = re.compile(expr)
-    frozen = [n for n in self.seg_names if pat.match(n + ':0')]
+    global clip norms) and of the update.  Here: their segment carries EDET_SEG_FROZEN instead of the L2 flag -- the
+    optimizer kernels zero their gradient, count nothing of them in the norms and never touch their value, momentum
+    slot or EMA shadow (so an optimizer state restored from an un-frozen run cannot move them either).  The flags are
+    rebuilt from the arena's original ones on every call: another expression un-freezes what no longer matches, an
+    empty one un-freezes everything.  Returns the frozen names."""
+    frozen = []
+    if expr:
+      pat = re.compile(expr)
+      frozen = [n for n in self.seg_names if pat.match(n + ':0')]
     seg_index = {int(o): i for i, o in enumerate(self.seg_offsets.cpu().tolist()[:-1])}
-    flags = self.seg_flags.cpu().clone()
+    flags = list(self._l2_flags)
     ranges = []
     for n in frozen:
       off, cnt, _, _ = self.offsets[n]
-      flags[seg_index[off]] = 0
+      flags[seg_index[off]] = _lib.SEG_FROZEN
       if ranges and off - ranges[-1][1] <= 3:      # adjacent up to the alignment padding (zeros): one range
         ranges[-1][1] = off + cnt
       else:
         ranges.append([off, off + cnt])
-    self.seg_flags.copy_(flags)
-    self.frozen_expr = expr
+    self.seg_flags.copy_(torch.tensor(flags, dtype=torch.int32))
+    self.frozen_expr = expr or None
     self.frozen_ranges = [(a, b) for a, b in ranges]
     for a, b in self.frozen_ranges:
       self.velocity[a:b].zero_()
@@ -1132,14 +1137,12 @@ class Engine(object):
     scale_for_reduce applies the factors in place (the data-parallel path all-reduces the clipped gradient)."""
     c = self.config
     st = self.stream
-    for a, b in self.arena.frozen_ranges:          # var_freeze_expr: no gradient for these variables (ParamArena.set_frozen)
-      self.grads_flat[a:b].zero_()
+    # (frozen variables -- ParamArena.set_frozen -- are handled by the kernels through their segment flag)
     call('edet_opt_l2_norms', ptr(self.grads_flat), ptr(self.params_flat), ptr(self.seg_offsets),
-         ptr(self.seg_flags), self.nseg, float(c.weight_decay), ptr(self.seg_sqnorm),
-         ptr(self.loss_sums[2:]), st)
+         ptr(self.seg_flags), self.nseg, float(c.weight_decay), ptr(self.seg_sqnorm), st)
     clip = abs(c.clip_gradients_norm) if c.clip_gradients_norm else 0.0
     call('edet_opt_clip_factors', ptr(self.seg_sqnorm), self.nseg, float(clip), ptr(self.seg_factor),
-         ptr(self.gnorm), st)
+         ptr(self.gnorm), ptr(self.loss_sums[2:]), st)
     if scale_for_reduce:
       call('edet_opt_scale', ptr(self.grads_flat), ptr(self.seg_offsets), ptr(self.seg_factor), self.nseg, st)
 
@@ -1147,7 +1150,7 @@ class Engine(object):
     """SGD momentum + EMA (train_lib.py:176-199) with lr / decay from self.hyper (set_hyper)."""
     call('edet_opt_sgd_ema', ptr(self.params_flat), ptr(self.grads_flat), ptr(self.velocity),
          ptr(self.ema) if use_ema else None, ptr(self.seg_offsets),
-         None if already_scaled else ptr(self.seg_factor), self.nseg, ptr(self.hyper),
+         None if already_scaled else ptr(self.seg_factor), ptr(self.seg_flags), self.nseg, ptr(self.hyper),
          float(self.config.momentum), self.stream)
     self.arena.version += 1
     self.arena.step_count += 1

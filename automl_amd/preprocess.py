@@ -35,6 +35,9 @@ def preprocess_infer(raw_images, image_size, mean_rgb, stddev_rgb, dtype=torch.f
 F = np.float32
 
 
+MAX_BOXES = 1024      # PREP_MAX_BOXES of csrc/preprocess.hip
+
+
 class DetectionInputProcessor(object):
   """``dataloader.DetectionInputProcessor`` (dataloader.py:144-200, base class :36-141) for a BATCH of equally sized raw
   images, same method names and call order as ``InputReader.process_example`` uses them (:321-336)::
@@ -76,6 +79,10 @@ class DetectionInputProcessor(object):
     if boxes is not None:
       self._boxes = torch.as_tensor(boxes, dtype=torch.float32).reshape(b, -1, 4).cuda().contiguous()
       m = int(self._boxes.shape[1])
+      if m > MAX_BOXES:
+        raise ValueError('at most %d boxes per image (edet_preprocess_train keeps them in LDS), got %d' % (MAX_BOXES, m))
+      if classes is None:      # the reference's constructor allows it (dataloader.py:146): boxes without labels
+        classes = torch.zeros(b, m, dtype=torch.float32)
       self._classes = torch.as_tensor(classes, dtype=torch.float32).reshape(b, m).cuda().contiguous()
       self._counts = (torch.full((b,), m, dtype=torch.int32) if counts is None
                       else torch.as_tensor(counts).to(torch.int32)).cuda().contiguous()

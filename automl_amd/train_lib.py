@@ -272,9 +272,9 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
 
   def _ensure_engine(self, batch, height, width):
     eng = super()._ensure_engine(batch, height, width)
-    expr = getattr(self.config, 'var_freeze_expr', None)
-    if expr and eng.arena.frozen_expr != expr:
-      eng.arena.set_frozen(expr)         # tf2/train_lib.py:478-491: out of L2, gradients and updates
+    expr = getattr(self.config, 'var_freeze_expr', None) or None
+    if eng.arena.frozen_expr != expr:
+      eng.arena.set_frozen(expr)         # tf2/train_lib.py:478-491: out of L2, gradients and updates (None: un-freeze)
     return eng
 
   def _positives_momentum(self):

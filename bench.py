@@ -318,6 +318,9 @@ def main():
   ap.add_argument('--no_other_configs', action='store_true',
                   help='skip the V2-S / D7x side measurements (they run at N = 1 on the headline workload only)')
   ap.add_argument('--dump_launches', default='', help='write the per-(kernel, shape) launch table of one step here')
+  ap.add_argument('--force_dist', action='store_true',
+                  help='world size 1 through the data-parallel path all the same: RCCL communicator, the gradient '
+                       'all-reduce between the two captured graphs (rehearsal of the multi-GPU launch structure on one GPU)')
   ap.add_argument('--graph', type=int, default=int(os.environ.get('EDET_GRAPH', '1')),
                   help='1: the timed steps replay the step captured as a hipGraph; 0: eager launches')
   args = ap.parse_args()
@@ -337,9 +340,11 @@ def main():
   device = 'cuda:%d' % local_rank
   torch.cuda.set_device(device)
   dist = None
-  if world > 1:
+  use_dist = world > 1 or args.force_dist
+  if use_dist:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29541')
     if backend == 'nccl':
       dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device))
     else:
@@ -348,7 +353,7 @@ def main():
   config = hparams_config.get_efficientdet_config(args.model)
   config.override('image_size=%d' % args.image_size)
   net = train_lib.EfficientDetNetTrain(config=config, dtype=args.dtype, device=device, seed=0,
-                                       global_batch_size=args.batch * world, use_dist=world > 1,
+                                       global_batch_size=args.batch * world, use_dist=use_dist,
                                        steps_per_epoch=1000, use_graph=bool(args.graph))
   eng = net._ensure_engine(args.batch, args.image_size, args.image_size)
   images, labels = synth_batch(config, args.batch, args.image_size, 3 + rank, device, eng.tdtype)
@@ -419,6 +424,8 @@ def main():
     dist.all_reduce(ones, op=dist.ReduceOp.SUM)          # through the same RCCL communicator as the gradients
     ranks_seen = int(ones.item())
   losses = eng.loss_values()
+  import zlib
+  param_crc = zlib.crc32(eng.params_flat.detach().cpu().numpy().tobytes()) & 0xffffffff      # the variables after every step of this run
 
   if rank == 0:
     ms_per_step = elapsed / args.steps * 1e3
@@ -440,7 +447,8 @@ def main():
                                    'BASELINE configs[2]' if is_headline else
                                    ('BASELINE configs[4] per-GPU leg' if 'd7x' in args.model else 'not a BASELINE config')),
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'ranks_seen': ranks_seen,
-                   'loss': losses.get('loss'),
+                   'loss': losses.get('loss'), 'param_crc32': param_crc,
+                   'collectives': (dist.get_backend() if dist is not None else None),
                    'launch': 'hipGraph replay of the captured step' if args.graph else 'eager',
                    'host_enqueue_ms_per_step': host_enqueue / args.steps * 1e3,
                    'eager_ms_per_step': eager_ms_per_step},

@@ -356,24 +356,30 @@ int edet_box_loss(const void* box_out, int ld, const float* box_targets,
  * train_lib.py:486-491 (L2), :675-682 (per-tensor clip_by_norm then
  * clip_by_global_norm), Keras SGD momentum, TFA MovingAverage (:176-199).
  * All parameters live in one flat fp32 arena; seg_offsets[nseg+1] delimits the
- * tensors, seg_flags bit0 = L2-regularised (kernel/weight variables).  */
-/* seg_sqnorm holds EDET_OPT_SPLIT partial squared norms per tensor ([nseg][EDET_OPT_SPLIT], written by
- * edet_opt_l2_norms in a fixed order, summed by edet_opt_clip_factors): large tensors are processed by
- * up to EDET_OPT_SPLIT workgroups.  */
+ * tensors, seg_flags bit0 (EDET_SEG_L2) = L2-regularised (kernel/weight variables), bit1 (EDET_SEG_FROZEN) =
+ * frozen by config.var_freeze_expr (tf2/train_lib.py:478-491: out of the L2 term, of the gradient list and of the
+ * update -- its gradient is zeroed, it adds nothing to the norms, value / momentum / EMA shadow are never touched).  */
+#define EDET_SEG_L2 1
+#define EDET_SEG_FROZEN 2
+/* seg_sqnorm: [2][nseg][EDET_OPT_SPLIT] floats -- EDET_OPT_SPLIT partial squared gradient norms per tensor and, behind
+ * them, the tensors' partial L2 losses; written by edet_opt_l2_norms, summed in a fixed order by
+ * edet_opt_clip_factors (large tensors are processed by up to EDET_OPT_SPLIT workgroups).  */
 #define EDET_OPT_SPLIT 16
 int edet_opt_l2_norms(float* grads, const float* params, const int64_t* seg_offsets,
                       const int32_t* seg_flags, int nseg, float weight_decay,
-                      float* seg_sqnorm, float* l2_sum, void* stream);
-/* seg_factor[s] = clip_by_norm factor * clip_by_global_norm factor; global_norm_out = norm after clipping */
+                      float* seg_sqnorm, void* stream);
+/* seg_factor[s] = clip_by_norm factor * clip_by_global_norm factor; global_norm_out = norm after clipping;
+ * l2_sum[0] += the L2 loss (either may be NULL) */
 int edet_opt_clip_factors(const float* seg_sqnorm, int nseg, float clip_norm,
-                          float* seg_factor, float* global_norm_out, void* stream);
+                          float* seg_factor, float* global_norm_out, float* l2_sum, void* stream);
 /* grads[s] *= seg_factor[s]  (data-parallel path: clip locally, then all-reduce, train_lib.py:675-683) */
 int edet_opt_scale(float* grads, const int64_t* seg_offsets, const float* seg_factor,
                    int nseg, void* stream);
 /* hyper_dev = device float[2] {learning_rate, ema_decay}; seg_factor may be NULL (already scaled);
- * ema may be NULL.  v = momentum*v - lr*g; w += v; ema -= (1-decay)*(ema - w).  */
+ * ema may be NULL; seg_flags may be NULL (no frozen variables).  v = momentum*v - lr*g; w += v;
+ * ema -= (1-decay)*(ema - w); segments flagged EDET_SEG_FROZEN are skipped.  */
 int edet_opt_sgd_ema(float* params, float* grads, float* velocity, float* ema,
-                     const int64_t* seg_offsets, const float* seg_factor, int nseg,
+                     const int64_t* seg_offsets, const float* seg_factor, const int32_t* seg_flags, int nseg,
                      const float* hyper_dev, float momentum, void* stream);
 
 /* ---- detection post-processing -------------------------------

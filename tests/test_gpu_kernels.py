@@ -878,7 +878,7 @@ def test_detection_loss(dt, geom, smoothing, use_ws):
 def test_optimizer():
   rng = np.random.default_rng(11)
   sizes = [7, 64, 1, 1000, 33, 4096, 40003, 3, 65536]   # unaligned, multi-slice and vectorised segments
-  flags = [1, 0, 0, 1, 1, 0, 1, 1, 1]
+  flags = [1, 0, 0, 1, _lib.SEG_FROZEN, 0, 1, _lib.SEG_FROZEN, 1]     # L2 flag / frozen (var_freeze_expr): two of those
   offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
   tot = int(offs[-1])
   p = torch.from_numpy(rng.standard_normal(tot).astype(np.float32))
@@ -891,7 +891,9 @@ def test_optimizer():
   l2 = 0.0
   for i in range(len(sizes)):
     sl = slice(int(offs[i]), int(offs[i + 1]))
-    if flags[i]:
+    if flags[i] == _lib.SEG_FROZEN:      # no gradient, no L2 term, no share in the norms
+      g2[sl] = 0.0
+    elif flags[i]:
       g2[sl] += wd * p[sl]
       l2 += 0.5 * wd * float((p[sl]**2).sum())
   for i in range(len(sizes)):
@@ -902,19 +904,27 @@ def test_optimizer():
   v2 = mom * v - lr * g2
   p2 = p + v2
   e2 = ema - (1 - decay) * (ema - p2)
+  for i in range(len(sizes)):      # frozen: value, momentum slot (even a non-zero one) and EMA shadow stay bit for bit
+    if flags[i] == _lib.SEG_FROZEN:
+      sl = slice(int(offs[i]), int(offs[i + 1]))
+      v2[sl], p2[sl], e2[sl] = v[sl], p[sl], ema[sl]
   pd, gd, vd, ed = (t.to(gu.DEV) for t in (p, g, v, ema))
   od = torch.from_numpy(offs).to(gu.DEV)
   fd = torch.tensor(flags, dtype=torch.int32, device=gu.DEV)
-  sq = torch.zeros(len(sizes) * _lib.OPT_SPLIT, dtype=torch.float32, device=gu.DEV)
+  sq = torch.zeros(2 * len(sizes) * _lib.OPT_SPLIT, dtype=torch.float32, device=gu.DEV)
   fac = torch.zeros(len(sizes), dtype=torch.float32, device=gu.DEV)
   l2d = torch.zeros(1, dtype=torch.float32, device=gu.DEV)
   gnd = torch.zeros(1, dtype=torch.float32, device=gu.DEV)
   hyper = torch.tensor([lr, decay], dtype=torch.float32, device=gu.DEV)
-  call('edet_opt_l2_norms', ptr(gd), ptr(pd), ptr(od), ptr(fd), len(sizes), wd, ptr(sq), ptr(l2d), gu.stream())
-  call('edet_opt_clip_factors', ptr(sq), len(sizes), clip, ptr(fac), ptr(gnd), gu.stream())
-  call('edet_opt_sgd_ema', ptr(pd), ptr(gd), ptr(vd), ptr(ed), ptr(od), ptr(fac), len(sizes), ptr(hyper), mom,
+  call('edet_opt_l2_norms', ptr(gd), ptr(pd), ptr(od), ptr(fd), len(sizes), wd, ptr(sq), gu.stream())
+  call('edet_opt_clip_factors', ptr(sq), len(sizes), clip, ptr(fac), ptr(gnd), ptr(l2d), gu.stream())
+  call('edet_opt_sgd_ema', ptr(pd), ptr(gd), ptr(vd), ptr(ed), ptr(od), ptr(fac), ptr(fd), len(sizes), ptr(hyper), mom,
        gu.stream())
   torch.cuda.synchronize()
+  for i in range(len(sizes)):
+    if flags[i] == _lib.SEG_FROZEN:
+      sl = slice(int(offs[i]), int(offs[i + 1]))
+      assert torch.equal(pd[sl].cpu(), p[sl]) and torch.equal(vd[sl].cpu(), v[sl]) and torch.equal(ed[sl].cpu(), ema[sl])
   assert abs(float(l2d) - l2) <= 1e-4 * l2
   assert abs(float(gnd) - float(g2.norm())) <= 1e-4 * float(g2.norm())
   gu.check(pd, p2, 'f32', 'sgd params', rtol=1e-5, atol=1e-6)
@@ -922,8 +932,8 @@ def test_optimizer():
   gu.check(ed, e2, 'f32', 'ema', rtol=1e-5, atol=1e-6)
   # data-parallel path: scale first, then update with factor == NULL
   gd2 = g.to(gu.DEV)
-  call('edet_opt_l2_norms', ptr(gd2), ptr(p.to(gu.DEV)), ptr(od), ptr(fd), len(sizes), wd, ptr(sq), None, gu.stream())
-  call('edet_opt_clip_factors', ptr(sq), len(sizes), clip, ptr(fac), None, gu.stream())
+  call('edet_opt_l2_norms', ptr(gd2), ptr(p.to(gu.DEV)), ptr(od), ptr(fd), len(sizes), wd, ptr(sq), gu.stream())
+  call('edet_opt_clip_factors', ptr(sq), len(sizes), clip, ptr(fac), None, None, gu.stream())
   call('edet_opt_scale', ptr(gd2), ptr(od), ptr(fac), len(sizes), gu.stream())
   torch.cuda.synchronize()
   gu.check(gd2, g2, 'f32', 'scaled grads', rtol=1e-5, atol=1e-6)

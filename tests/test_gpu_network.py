@@ -312,6 +312,36 @@ def test_train_step_bf16_tracks_the_oracle():
   assert cos >= 0.9, cos
 
 
+def test_frozen_variables_survive_a_restored_optimizer_state():
+  """the fine-tune flow builds the model with config.var_freeze_expr and THEN restores an optimizer state
+  saved by an un-frozen run -- non-zero momentum and EMA shadows over the frozen ranges.  The reference keeps frozen
+  variables out of apply_gradients (tf2/train_lib.py:478-491,683): value and slots never change.  Here the optimizer
+  kernels skip the segments flagged EDET_SEG_FROZEN, whatever the slots hold."""
+  config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  config.override('var_freeze_expr=(efficientnet|fpn_cells|resample_p6)')
+  size, batch = 128, 2
+  vals = perturbed_params(config, 7)
+  rng = np.random.default_rng(3)
+  images = rng.standard_normal((batch, size, size, 3)).astype(np.float32)
+  labels = make_labels(config, batch, size, 5)
+  net = train_lib.EfficientDetNetTrain(config=config, dtype='bf16', params=vals, steps_per_epoch=10, global_batch_size=64)
+  eng = net._ensure_engine(batch, size, size)
+  assert eng.arena.frozen_ranges
+  state = net.get_optimizer_state()
+  state['velocity'] = np.full_like(state['velocity'], 0.25)          # as saved by a run that trained everything
+  state['ema'] = state['ema'] + 0.5
+  net.set_optimizer_state(state)
+  before = (eng.params_flat.clone(), eng.velocity.clone(), eng.ema.clone())
+  for _ in range(2):
+    net.train_step((images, labels))
+  torch.cuda.synchronize()
+  for a, b in eng.arena.frozen_ranges:
+    for was, now in zip(before, (eng.params_flat, eng.velocity, eng.ema)):
+      assert torch.equal(was[a:b], now[a:b])
+  a, b = eng.arena.frozen_ranges[-1][1], eng.n_train_elems
+  assert not torch.equal(before[0][a:b], eng.params_flat[a:b])        # the heads did train
+
+
 @pytest.mark.parametrize('model,size,batch', [('efficientdet-d0', 640, 8), ('efficientdet-d1', 256, 3)])
 def test_train_step_is_bit_reproducible(model, size, batch):
   """r04: the bf16 training step has no floating-point atomics left on its path (BatchNorm partial rows, SE pooling / FC /
@@ -565,3 +595,41 @@ def test_bench_spawns_two_ranks_and_reports_them(tmp_path):
     assert line['n_gpus'] == 2 and line['config']['ranks_seen'] == 2 and line['config']['global_batch'] == 16, line['config']
     assert line['steps'] == 3 and line['value'] > 0 and abs(line['value'] - 16 * 3 / (line['ms_per_step'] * 3e-3)) < 1e-6 * line['value']
     assert line['scaling'] == 'weak' and line['config']['parallelism'] == 'dp2' and np.isfinite(line['config']['loss'])
+
+
+def test_rccl_path_on_the_device_at_world_size_one(tmp_path):
+  """The data-parallel launch structure on the real device, as the driver's scaling run starts it: `python -m
+  torch.distributed.run --nproc-per-node 1 bench.py --force_dist` = backend nccl (RCCL), communicator bound to cuda:0,
+  the first step eager, then TWO captured graphs with the SUM all-reduce of the gradient arena between them
+  (capture_error_mode thread_local next to the RCCL watchdog thread), `ranks_seen` counted through the same
+  communicator.  The training step is bit-reproducible (r04), so the variables after the run must equal those of the
+  plain single-process run BIT FOR BIT (crc32 of the parameter arena): a world-size-1 all-reduce is the identity."""
+  import json
+  import os
+  import socket
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ)
+  for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'EDET_BENCH_SAME_DEVICE', 'EDET_BENCH_BACKEND'):
+    env.pop(k, None)
+  with socket.socket() as sk:
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+  common = [os.path.join(root, 'bench.py'), '--gpus', '1', '--batch', '8', '--steps', '3', '--warmup', '3',
+            '--image_size', '256', '--no_cpu_baseline', '--no_other_configs']
+  lines = {}
+  for name, cmd in (('plain', [sys.executable] + common),
+                    ('rccl', [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+                              '--master-addr', '127.0.0.1', '--master-port', str(port)] + common + ['--force_dist'])):
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, (name, r.stdout[-2000:], r.stderr[-3000:])
+    out = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(out) == 1, (name, r.stdout[-2000:])
+    lines[name] = json.loads(out[0])
+  plain, rccl = lines['plain'], lines['rccl']
+  assert rccl['config']['collectives'] == 'nccl' and rccl['config']['ranks_seen'] == 1 and rccl['n_gpus'] == 1, rccl['config']
+  assert rccl['config']['launch'].startswith('hipGraph') and np.isfinite(rccl['config']['loss'])
+  assert plain['config']['collectives'] is None
+  assert rccl['config']['param_crc32'] == plain['config']['param_crc32'], (plain['config'], rccl['config'])
+  assert rccl['config']['loss'] == plain['config']['loss']

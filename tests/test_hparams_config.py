@@ -152,7 +152,8 @@ def test_var_freeze_expr_in_the_arena_and_in_the_oracle():
   spec = netspec.NetSpec(config)
   vals = perturbed_params(config, 3)
   arena = engine.ParamArena(spec, 'cpu', vals)
-  l2_before = int(arena.seg_flags.sum())
+  flags_before = arena.seg_flags.clone()
+  l2_before = int((arena.seg_flags & 1).sum())
   arena.velocity.fill_(1.0)
   frozen = arena.set_frozen(config.var_freeze_expr)
   assert len(frozen) == 409 and all(n.startswith(('efficientnet', 'fpn_cells', 'resample_p6')) for n in frozen)
@@ -161,7 +162,15 @@ def test_var_freeze_expr_in_the_arena_and_in_the_oracle():
   assert end == max(arena.offsets[n][0] + arena.offsets[n][1] for n in frozen)
   assert float(arena.velocity[:end].abs().max()) == 0.0 and float(arena.velocity[end:].min()) == 1.0
   kept = [n for n in arena.seg_names if n not in frozen]
-  assert int(arena.seg_flags.sum()) == sum(1 for n in kept if orc.is_l2_regularised(n)) < l2_before
+  assert int((arena.seg_flags & 1).sum()) == sum(1 for n in kept if orc.is_l2_regularised(n)) < l2_before
+  assert int((arena.seg_flags & 2).ne(0).sum()) == len(frozen)        # EDET_SEG_FROZEN: the optimizer kernels skip these
+  # another expression starts from the arena's own flags: what no longer matches is trainable again, with
+  # its L2 flag; an empty expression un-freezes everything
+  again = arena.set_frozen('(efficientnet)')
+  assert 0 < len(again) < len(frozen) and int((arena.seg_flags & 2).ne(0).sum()) == len(again)
+  assert int((arena.seg_flags & 1).sum()) == sum(1 for n in arena.seg_names if n not in again and orc.is_l2_regularised(n))
+  assert arena.set_frozen(None) == [] and torch.equal(arena.seg_flags, flags_before) and arena.frozen_ranges == []
+  frozen = arena.set_frozen(config.var_freeze_expr)
   # the oracle's step
   rng = np.random.default_rng(5)
   images = torch.from_numpy(rng.standard_normal((1, 64, 64, 3)).astype(np.float32))
