@@ -335,9 +335,14 @@ def test_frozen_variables_survive_a_restored_optimizer_state():
   for _ in range(2):
     net.train_step((images, labels))
   torch.cuda.synchronize()
-  for a, b in eng.arena.frozen_ranges:
+  import re
+  pat = re.compile(config.var_freeze_expr)
+  frozen = [n for n in eng.seg_names if pat.match(n + ':0')]
+  assert len(frozen) == 409
+  for n in frozen:      # (per variable: the alignment padding between two tensors is nobody's variable)
+    off, cnt, _, _ = eng.offsets[n]
     for was, now in zip(before, (eng.params_flat, eng.velocity, eng.ema)):
-      assert torch.equal(was[a:b], now[a:b])
+      assert torch.equal(was[off:off + cnt], now[off:off + cnt]), n
   a, b = eng.arena.frozen_ranges[-1][1], eng.n_train_elems
   assert not torch.equal(before[0][a:b], eng.params_flat[a:b])        # the heads did train
 
