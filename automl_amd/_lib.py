@@ -64,6 +64,7 @@ SIGNATURES = {
                       c_int, c_void_p],
     'edet_stem_bwd_weight': [c_void_p, c_int, c_int, c_int, PG, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],
     'edet_pw_fwd': [PT, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, PI, c_int, c_void_p],
+    'edet_pw_fwd_f32out': [PT, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p],
     'edet_pw_bwd_data': [PG, c_void_p, c_int, PT, PE, PI, c_int, c_void_p],
     'edet_pw_bwd_weight': [PT, PG, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],
     'edet_pw_bwd': [PG, c_void_p, c_int, PT, PE, PI, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],

@@ -108,8 +108,12 @@ __device__ __forceinline__ void mma_stage(const unsigned char* As, const unsigne
 
 // OACT: the view's activation is relu / relu6 / hswish (utils.activation_fn; a.tv.act carries the code) -- a template
 // parameter, so that the swish / linear instantiations keep their code and registers
-template <bool BWD, bool GBN, bool CONV = false, bool OACT = false>
+// F32OUT (forward only, r04): the output is stored as fp32 -- the class / box predict layers of the INFERENCE forward, whose
+// bf16 storage alone costs 3e-3 of the logit range (scripts/precision_sweep.py); a.out then points at floats, ldo in
+// floats, no statistics.
+template <bool BWD, bool GBN, bool CONV = false, bool OACT = false, bool F32OUT = false>
 __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
+  static_assert(!F32OUT || (!BWD && !CONV), "fp32 output: plain forward only");
   // CONV && BWD: data gradient of the dense convolution -- rows = INPUT pixels, the streamed operand dy is
   // gathered at (iy + pad - ky) / s when that is an integer inside the dy image, reduction index (ky*k+kx)*cout+co
   extern __shared__ __align__(16) unsigned char smem[];
@@ -326,7 +330,40 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
 
     // ---------------------------------------------------------------- epilogue through LDS
     const int r = lane & 31, h = lane >> 5;
-    if (!BWD) {
+    if constexpr (F32OUT) {
+      // C tile as fp32 [BM][LDC_F32], bias added; stored unrounded
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ch = wj * 64 + nj * 32 + 8 * g + 4 * h;
+          float b4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (a.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (j0 + ch + e < a.J) b4[e] = a.bias[j0 + ch + e];
+          }
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            *reinterpret_cast<float4*>(smem + (wm * 64 + mi * 32 + r) * LDC_F32 + ch * 4) =
+                make_float4(acc[nj][mi][4 * g + 0] + b4[0], acc[nj][mi][4 * g + 1] + b4[1], acc[nj][mi][4 * g + 2] + b4[2],
+                            acc[nj][mi][4 * g + 3] + b4[3]);
+        }
+      __syncthreads();
+      if (mt + 1 < mt_end) { setup(mt + 1); issue(0); prefetched = true; } else prefetched = false;
+      float* OF = reinterpret_cast<float*>(a.out);
+#pragma unroll
+      for (int i = 0; i < BM / 16; ++i) {
+        const int row = er + 16 * i;
+        const int m = m0 + row;
+        if (ecol_ok && m < a.M) {
+          const float4 d0 = *reinterpret_cast<const float4*>(smem + row * LDC_F32 + ec * 32);
+          const float4 d1 = *reinterpret_cast<const float4*>(smem + row * LDC_F32 + ec * 32 + 16);
+          *reinterpret_cast<float4*>(OF + (size_t)m * a.ldo + ej) = d0;
+          *reinterpret_cast<float4*>(OF + (size_t)m * a.ldo + ej + 4) = d1;
+        }
+      }
+    } else if (!BWD) {
       // C tile as bf16 [BM][LDC_BF]: bias added, rounded once
 #pragma unroll
       for (int nj = 0; nj < 2; ++nj) {
@@ -907,6 +944,31 @@ int pwb_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
   if (in->act > EDET_ACT_SWISH) edet_launch(k_big_gemm<false, false, false, true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
   else edet_launch(k_big_gemm<false, false>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
   EDET_LAUNCH_CHECK("edet_pw_fwd(big)");
+  return 1;
+}
+
+// forward with fp32 output [rows][ldo] (ldo in floats, >= cout rounded up to 8); no statistics
+int pwb_fwd_f32out(const edet_tview_t* in, const void* wt, int ldw, const float* bias, float* out, int cout, int ldo,
+                   hipStream_t st) {
+  using namespace pwb;
+  const int K = in->c, N = cout;
+  if (K % 8 != 0 || in->ld % 8 != 0 || ldw % 8 != 0 || ldo % 4 != 0 || ldo < (N + 7) / 8 * 8) return 0;
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tv = *in;
+  a.Bm = reinterpret_cast<const bf16_t*>(wt); a.ldb = ldw;
+  a.M = in->n * in->h * in->w; a.R = K; a.J = N; a.hw = in->h * in->w;
+  a.bias = bias; a.out = reinterpret_cast<bf16_t*>(out); a.ldo = ldo;
+  a.ntm = (a.M + BM - 1) / BM; a.ntj = (N + BJ - 1) / BJ;
+  a.tpw = big_tpw(a.ntm);
+  a.ngrp = (a.ntm + a.tpw - 1) / a.tpw;
+  static const bool ok = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<false, false, false, false, true>)) &&
+                         big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<false, false, false, true, true>));
+  if (!ok) return 0;
+  const int grid = (a.ngrp + 7) / 8 * 8 * a.ntj;
+  if (in->act > EDET_ACT_SWISH) edet_launch(k_big_gemm<false, false, false, true, true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
+  else edet_launch(k_big_gemm<false, false, false, false, true>, dim3(grid), dim3(THREADS), SMEM_BYTES, st, a);
+  EDET_LAUNCH_CHECK("edet_pw_fwd_f32out");
   return 1;
 }
 

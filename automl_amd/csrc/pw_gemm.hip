@@ -712,6 +712,20 @@ extern "C" int edet_pw_fwd(const edet_tview_t* in, const void* wt, int ldw, cons
   EDET_CHECK(false, "edet_pw_fwd: bad dtype %d", dtype);
 }
 
+int pwb_fwd_f32out(const edet_tview_t* in, const void* wt, int ldw, const float* bias, float* out, int cout, int ldo,
+                   hipStream_t st);
+
+extern "C" int edet_pw_fwd_f32out(const edet_tview_t* in, const void* wt, int ldw, const float* bias, float* out,
+                                  int cout, int ldo, void* stream) {
+  EDET_CHECK(in && in->data && wt && out, "edet_pw_fwd_f32out: null pointer");
+  EDET_CHECK(in->c % 8 == 0 && in->ld % 8 == 0 && ldw % 8 == 0 && ldw >= in->c && ldo % 8 == 0 && ldo >= cout,
+             "edet_pw_fwd_f32out: channel counts / strides must be multiples of 8 (c=%d ld=%d ldo=%d ldw=%d)", in->c, in->ld,
+             ldo, ldw);
+  const int rc = pwb_fwd_f32out(in, wt, ldw, bias, out, cout, ldo, to_stream(stream));
+  EDET_CHECK(rc != 0, "edet_pw_fwd_f32out: shape outside the tiled kernel's envelope");
+  return rc < 0 ? rc : 0;
+}
+
 extern "C" int edet_pw_bwd_data(const edet_gview_t* dy, const void* w, int ldw,
                                 const edet_tview_t* in, const edet_bwd_epi_t* epi, int* nparts_out,
                                 int dtype, void* stream) {

@@ -35,11 +35,11 @@ def _pad8(c):
 class Raw(object):
   """A stored NHWC tensor and (lazily) its gradient buffer."""
 
-  def __init__(self, eng, key, n, h, w, c, ld=None, needs_grad=True):
+  def __init__(self, eng, key, n, h, w, c, ld=None, needs_grad=True, dtype=None):
     self.eng, self.key = eng, key
     self.n, self.h, self.w, self.c = n, h, w, c
     self.ld = ld or _pad8(c)
-    self.data = eng.buf(key, (n, h, w, self.ld), eng.tdtype)
+    self.data = eng.buf(key, (n, h, w, self.ld), dtype or eng.tdtype)
     self.needs_grad = needs_grad
     self.grad = None
     self.grad_written = False
@@ -292,6 +292,10 @@ class Engine(object):
     self._cast_items = {}      # weight name -> descriptors of its compute copies (filled by the first pass)
     self._cast_table = None
     self.batched_casts = True    # every compute copy of a step in one edet_cast_batch launch
+    # inference forward with bf16 storage: the class / box logits are stored as fp32 (edet_pw_fwd_f32out) -- rounding them to
+    # bf16 is 3e-3 of their range and the whole of what separated the path from the 1e-3 of north_star
+    # (scripts/precision_sweep.py); the training step keeps bf16 logits (they only feed the loss)
+    self.logits_f32 = os.environ.get('EDET_LOGITS_F32', '1') != '0'
     self.fused_dw_bwd = True     # one edet_dw_bwd call per stride-1 layer
     self.fused_pw_bwd = True     # one edet_pw_bwd call per pointwise layer whose input needs a gradient
     # cross-replica BatchNorm (utils.SyncBatchNormalization / TpuBatchNormalization, utils.py:166-241):
@@ -545,11 +549,19 @@ class Engine(object):
     return epi, fused
 
   # ------------------------------------------------------------------ layers
-  def pw(self, key, vin, wname, cout, bias=None, bn=None, act=ACT_NONE, ld=None):
-    """1x1 conv (+bias) [-> BN -> act as a view]."""
+  def pw(self, key, vin, wname, cout, bias=None, bn=None, act=ACT_NONE, ld=None, f32out=False):
+    """1x1 conv (+bias) [-> BN -> act as a view].  f32out (inference, bf16 storage): the output is stored as fp32 --
+    the class / box logits, whose bf16 rounding alone is 3e-3 of their range (Engine.logits_f32)."""
     r = vin.raw
     cin = r.c
     wt, ldk, w, ldn = self._pw_copies(wname, cin, cout)
+    if f32out and not self.training and self.dtype == EDET_BF16 and bn is None:
+      out = Raw(self, key + ':f32', r.n, r.h, r.w, cout, ld, needs_grad=False, dtype=torch.float32)
+      call('edet_pw_fwd_f32out', ctypes.byref(vin.tview()), ptr(wt), ldk, ptr(self.param(bias)) if bias else None,
+           ptr(out.data), cout, out.ld, self.stream, nbytes=r.rows * (cin * 2 + cout * 4),
+           tag='%dx%dx%d->%d f32' % (r.h, r.w, cin, cout))
+      vin.consumers += 1
+      return View(out, None, act)
     out = Raw(self, key, r.n, r.h, r.w, cout, ld)
     bnl = self.get_bn(bn, cout) if bn else None
     stats = ptr(self.partials) if (bnl and self.training) else None
@@ -1018,7 +1030,7 @@ class Engine(object):
     s = '%s/%s-predict' % (net, prefix)
     key = '%s:l%d' % (s, level)
     d = self.dw(key + ':dw', x, s + '/depthwise_kernel', 3, 1)
-    return self.pw(key + ':pw', d, s + '/pointwise_kernel', out_ch, bias=s + '/bias')
+    return self.pw(key + ':pw', d, s + '/pointwise_kernel', out_ch, bias=s + '/bias', f32out=self.logits_f32)
 
   def _head(self, feats, net, prefix, out_ch):
     return [self._head_level(feat, self.config.min_level + li, net, prefix, out_ch) for li, feat in enumerate(feats)]

@@ -163,6 +163,11 @@ int edet_stem_bwd_weight(const void* images, int n, int h, int w,
 int edet_pw_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bias,
                 void* out, int cout, int ldo, float* stat_partials, int* nparts_out,
                 int dtype, void* stream);
+/* the same 1x1 convolution of a bf16 view with the output stored as fp32 [rows][ldo] (ldo in floats, a multiple of 8,
+ * >= cout), no statistics: the class / box predict layers of the inference forward (efficientdet_keras.py:459-464,
+ * 546-556) -- rounding the logits to bf16 alone costs 3e-3 of their range, the convolution itself 1e-4 */
+int edet_pw_fwd_f32out(const edet_tview_t* in, const void* wt, int ldw, const float* bias, float* out,
+                       int cout, int ldo, void* stream);
 /* d(in) from dy: w is the compute copy [cin][ldw] (Cout contiguous).  */
 int edet_pw_bwd_data(const edet_gview_t* dy, const void* w, int ldw,
                      const edet_tview_t* in, const edet_bwd_epi_t* epi, int* nparts_out,

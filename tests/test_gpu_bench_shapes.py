@@ -194,7 +194,10 @@ def test_d0_512_batch1_forward_equals_oracle(dtype):
     cref, bref = _oracle(config, vals, 'f32').forward(images, False)
   e32 = _level_errs(cls, cref) + _level_errs(box, bref)
   print('d0-512 forward %s vs fp32 oracle: %s' % (dtype, e32))
-  assert max(e32) <= (TOL['f32'] if dtype == 'f32' else TOL['bf16_vs_f32']), e32
+  # r04: north_star's 1e-3 ("box/class logits within 1e-3 rel of the TF CPU reference") holds for the bf16 path too -- the
+  # inference forward stores the logits as fp32 (Engine.logits_f32); what is left is the bf16 rounding of the matrix-core
+  # operands (scripts/precision_sweep.py: 7e-5 class / 8e-4 box at 640x640)
+  assert max(e32) <= TOL['f32'], e32
   if dtype == 'bf16':
     with torch.no_grad():
       cemu, bemu = _oracle(config, vals, 'bf16').forward(images, False)
