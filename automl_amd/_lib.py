@@ -75,6 +75,9 @@ SIGNATURES = {
     'edet_dw_bwd_data': [PG, c_void_p, c_int, c_int, PT, PE, PI, c_int, c_void_p],
     'edet_dw_bwd_weight': [PT, PG, c_int, c_int, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],
     'edet_dw_bwd': [PG, c_void_p, c_int, c_int, PT, PE, PI, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],
+    'edet_reduce_defer': [c_void_p, c_int],
+    'edet_reduce_flush': [c_void_p],
+    'edet_reduce_deferred_end': [c_void_p, ctypes.POINTER(c_void_p)],
     'edet_bn_finalize': [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_float, c_float, c_int,
                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     'edet_bn_eval': [c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],

@@ -4,6 +4,10 @@
 // Reference: efficientdet/utils.py:166-266 (BatchNorm classes, eps 1e-3, momentum 0.99),
 // efficientdet/tf2/util_keras.py:29-66, efficientdet/backbone/efficientnet_model.py:153-195 (SE),
 // :393-410 (project BN + identity skip).
+#include <algorithm>
+#include <map>
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -808,6 +812,139 @@ inline int ew_grid(int64_t total, const void* fn = nullptr) {
 
 }  // namespace
 
+// ---- deferred, batched partial-sum reductions (r04) -----------------------------------------------------------------
+// Every weight-gradient kernel of the backward pass ends in "dst += sum of my P partial rows": 192 launches of ~7 us per
+// D0 step, each a kernel boundary on the critical chain.  With deferral on for a stream (edet_reduce_defer),
+// edet_reduce_partials records (ws, P, n, dst) instead of launching; edet_reduce_flush launches ONE kernel over the
+// recorded table (passed by value as kernel arguments, <= RED_BATCH entries per launch: nothing is copied to the device,
+// so a flush is legal inside a hipGraph capture).  Entries with the same destination (the tower kernels shared by the
+// pyramid levels) form a group that one set of workgroups adds in recording order: a fixed summation order (the same bits on
+// every run), though not the immediate kernel's.  The caller keeps the partial regions intact until the flush (edet_reduce_deferred_end tells it how
+// far they reach).
+namespace {
+
+constexpr int RED_BATCH = 96;
+struct RedItem { const float* ws; float* dst; int P; int n; };
+struct RedBatch {
+  RedItem it[RED_BATCH];
+  unsigned short gfirst[RED_BATCH + 1];     // group g = items gfirst[g] .. gfirst[g+1]-1 (same dst, same n)
+  int gblock[RED_BATCH + 1];                // prefix sum of the groups' 64-element blocks
+  int ngroups;
+};
+
+// Workgroup = 64 consecutive elements x 4 row slices: every row is read in whole 256-byte segments (the immediate kernel
+// reads 64-byte ones), thread (e, sl) adds the rows sl, sl + 4, ... with four independent running sums, the four slices
+// are combined in slice order.  A fixed order -- the same bits on every run -- but not the immediate kernel's order.
+constexpr int RB_E = 64, RB_S = 4;
+__global__ __launch_bounds__(RB_E * RB_S) void k_reduce_batch(const RedBatch b) {
+  __shared__ float red[RB_S][RB_E];
+  int g = 0;
+  while (g + 1 < b.ngroups && (int)blockIdx.x >= b.gblock[g + 1]) ++g;
+  const int e = threadIdx.x & (RB_E - 1), sl = threadIdx.x / RB_E;
+  const int64_t n = b.it[b.gfirst[g]].n;
+  const int64_t i = (int64_t)(blockIdx.x - b.gblock[g]) * RB_E + e;
+  const bool ok = i < n;
+  float acc = 0.f;
+  float* dst = b.it[b.gfirst[g]].dst;
+  if (sl == 0 && ok) acc = dst[i];
+  for (int m = b.gfirst[g]; m < b.gfirst[g + 1]; ++m) {
+    const float* ws = b.it[m].ws + (ok ? i : 0);
+    const int P = b.it[m].P;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = sl;
+    for (; p + 3 * RB_S < P; p += 4 * RB_S) {
+      s0 += ws[(size_t)p * n];
+      s1 += ws[(size_t)(p + RB_S) * n];
+      s2 += ws[(size_t)(p + 2 * RB_S) * n];
+      s3 += ws[(size_t)(p + 3 * RB_S) * n];
+    }
+    for (; p < P; p += RB_S) s0 += ws[(size_t)p * n];
+    __syncthreads();
+    red[sl][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0) acc += (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+  }
+  if (sl == 0 && ok) dst[i] = acc;
+}
+
+struct DeferState {
+  bool on = false;
+  std::vector<RedItem> items;
+  const unsigned char* hi = nullptr;
+};
+std::map<hipStream_t, DeferState>& defer_map() {
+  static std::map<hipStream_t, DeferState> m;
+  return m;
+}
+
+int flush_stream(hipStream_t st, DeferState& d) {
+  std::vector<RedItem> items;
+  items.swap(d.items);
+  d.hi = nullptr;
+  // groups: entries with the same destination, members in recording order, groups in order of first appearance
+  std::vector<std::vector<RedItem>> groups;
+  for (const RedItem& r : items) {
+    size_t g = 0;
+    while (g < groups.size() && groups[g][0].dst != r.dst) ++g;
+    if (g == groups.size()) groups.emplace_back();
+    groups[g].push_back(r);
+  }
+  RedBatch b;
+  int ni = 0, ng = 0, nblocks = 0;
+  auto launch = [&]() -> int {
+    if (ni == 0) return 0;
+    b.gfirst[ng] = (unsigned short)ni;
+    b.gblock[ng] = nblocks;
+    b.ngroups = ng;
+    edet_launch(k_reduce_batch, dim3((unsigned)nblocks), dim3(RB_E * RB_S), 0, st, b);
+    EDET_LAUNCH_CHECK("edet_reduce_flush");
+    ni = ng = nblocks = 0;
+    return 0;
+  };
+  memset(&b, 0, sizeof(b));
+  for (const std::vector<RedItem>& grp : groups) {
+    size_t pos = 0;
+    while (pos < grp.size()) {
+      const size_t left = grp.size() - pos;
+      size_t take = left < (size_t)(RED_BATCH - ni) ? left : (size_t)(RED_BATCH - ni);
+      // a group is split over two launches (stream order keeps the sum order) only when it alone exceeds a batch
+      if (take == 0 || (take < left && ni > 0)) {
+        if (int rc = launch()) return rc;
+        continue;
+      }
+      b.gfirst[ng] = (unsigned short)ni;
+      b.gblock[ng] = nblocks;
+      for (size_t k = 0; k < take; ++k) b.it[ni++] = grp[pos + k];
+      nblocks += (grp[0].n + RB_E - 1) / RB_E;
+      ++ng;
+      pos += take;
+    }
+  }
+  return launch();
+}
+
+}  // namespace
+
+extern "C" int edet_reduce_defer(void* stream, int enable) {
+  DeferState& d = defer_map()[to_stream(stream)];
+  if (!enable && d.on && !d.items.empty()) {
+    if (int rc = flush_stream(to_stream(stream), d)) return rc;
+  }
+  d.on = enable != 0;
+  return 0;
+}
+extern "C" int edet_reduce_flush(void* stream) {
+  auto it = defer_map().find(to_stream(stream));
+  if (it == defer_map().end() || it->second.items.empty()) return 0;
+  return flush_stream(to_stream(stream), it->second);
+}
+extern "C" int edet_reduce_deferred_end(void* stream, const void** hi_out) {
+  EDET_CHECK(hi_out, "edet_reduce_deferred_end: null pointer");
+  auto it = defer_map().find(to_stream(stream));
+  *hi_out = it == defer_map().end() ? nullptr : it->second.hi;
+  return 0;
+}
+
 // dst_a[i] += column i (i < n_a; dst_a may be NULL), dst_b[i - n_a] += column i (n_a <= i < n)
 int edet_reduce_partials2(const float* ws, int P, int64_t n, float* dst_a, int64_t n_a, float* dst_b, hipStream_t st) {
   edet_launch(k_reduce_partials, dim3((unsigned)((n + 15) / 16)), dim3(16 * RED_SL), 0, st, ws, P, n, dst_a, 1, n_a, dst_b);
@@ -815,6 +952,18 @@ int edet_reduce_partials2(const float* ws, int P, int64_t n, float* dst_a, int64
   return 0;
 }
 int edet_reduce_partials(const float* ws, int P, int64_t n, float* dst, hipStream_t st) {
+  {
+    auto it = defer_map().find(st);
+    if (it != defer_map().end() && it->second.on && n < (int64_t)1 << 31) {
+      DeferState& d = it->second;
+      RedItem r;
+      r.ws = ws; r.dst = dst; r.P = P; r.n = (int)n;
+      d.items.push_back(r);
+      const unsigned char* end = reinterpret_cast<const unsigned char*>(ws) + (size_t)P * n * sizeof(float);
+      if (!d.hi || end > d.hi) d.hi = end;
+      return 0;
+    }
+  }
   edet_launch(k_reduce_partials, dim3((unsigned)((n + 15) / 16)), dim3(16 * RED_SL), 0, st, ws, P, n, dst, 1, (int64_t)-1, (float*)nullptr);
   EDET_LAUNCH_CHECK("edet_reduce_partials");
   return 0;

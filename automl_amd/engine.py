@@ -240,6 +240,7 @@ class Branch(object):
 
   def __init__(self, stream, partials, workspace, grads=None):
     self.stream, self.partials, self.workspace, self.grads = stream, partials, workspace, grads
+    self.ws_off = 0       # bytes of the workspace that hold partial sums of deferred reductions (Engine._ws_mark)
 
 
 class Engine(object):
@@ -271,8 +272,14 @@ class Engine(object):
     self._build_params(params, seed, arena)
     cmax = max([p.shape[0] for p in self.spec.params if len(p.shape) == 1] + [64])
     self._cmax = cmax
+    # batched weight-gradient reductions (see _ws): EDET_DEFER_REDUCE=0 = one reduction launch per layer, as in round 3
+    self.defer_reduce = os.environ.get('EDET_DEFER_REDUCE', '1') != '0'
+    self._deferring = False
+    self._defer_streams = set()
+    ws_floats = (64 if self.defer_reduce else 16) * 1024 * 1024      # 256 MiB with deferral (64 MiB: the round-3 scratch)
+    self._ws_floats = ws_floats
     self._main = self._branch = Branch(None, torch.empty(_lib.MAX_PARTS * 2 * cmax, dtype=torch.float32, device=self.device),
-                                       torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=self.device))  # 64 MiB scratch
+                                       torch.empty(ws_floats, dtype=torch.float32, device=self.device))
     self._side = None
     # The class / box towers of the SMALL pyramid levels (20x20 and below: ~300 latency-bound launches per step that
     # each use a fraction of the chip) run as one chain on a second HIP stream, forked and joined with events (a
@@ -323,6 +330,46 @@ class Engine(object):
   def workspace(self):
     return self._branch.workspace
 
+  # ---- deferred weight-gradient reductions (edet_reduce_defer): the backward pass records the ~190 "dW += partial sums"
+  # of a step and adds them in a handful of batched launches; until a flush every call gets the workspace BEHIND the
+  # partial sums still waiting there
+  WS_RESERVE = 64 * 1024 * 1024       # what a single call may need (the round-3 workspace size)
+
+  def _ws(self):
+    """(pointer, bytes) of the free part of the current chain's workspace."""
+    b = self._branch
+    return b.workspace.data_ptr() + b.ws_off, b.workspace.numel() * 4 - b.ws_off
+
+  def _ws_mark(self):
+    """After a call that may have left partial sums for a deferred reduction: the next call starts behind them."""
+    if not self._deferring:
+      return
+    b = self._branch
+    hi = ctypes.c_void_p()
+    call('edet_reduce_deferred_end', self.stream, ctypes.byref(hi))
+    if hi.value:
+      b.ws_off = (hi.value - b.workspace.data_ptr() + 255) // 256 * 256
+      if b.workspace.numel() * 4 - b.ws_off < self.WS_RESERVE:
+        call('edet_reduce_flush', self.stream)
+        b.ws_off = 0
+
+  def _defer_begin(self):
+    if self.defer_reduce and not self._deferring:
+      self._deferring = True
+      self._defer_streams = set()
+    if self._deferring and self.stream not in self._defer_streams:
+      call('edet_reduce_defer', self.stream, 1)
+      self._defer_streams.add(self.stream)
+
+  def _defer_end(self):
+    """Flushes what the current chain recorded and returns its stream to the immediate mode."""
+    if self._deferring and self.stream in self._defer_streams:
+      call('edet_reduce_defer', self.stream, 0)
+      self._defer_streams.discard(self.stream)
+      self._branch.ws_off = 0
+      if not self._defer_streams:
+        self._deferring = False
+
   # ------------------------------------------------------------------ a second chain on its own stream
   def _side_branch(self):
     if self._side is None:
@@ -333,7 +380,7 @@ class Engine(object):
       self._side_grads = torch.zeros(self.n_train_elems, dtype=torch.float32, device=self.device)
       self._side = Branch(torch.cuda.Stream(device=self.device),
                           torch.empty(_lib.MAX_PARTS * 2 * self._cmax, dtype=torch.float32, device=self.device),
-                          torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=self.device),   # 64 MiB, as the main one
+                          torch.empty(self._ws_floats, dtype=torch.float32, device=self.device),   # as the main one
                           self._side_grads)
     return self._side
 
@@ -587,14 +634,16 @@ class Engine(object):
       if no_bias:
         epi.flags = _lib.EPI_Y_IS_CONV_OF_INPUT      # y = view(x) W exactly: the library need not read it
       call('edet_pw_bwd', ctypes.byref(g), ptr(w), ldn, ctypes.byref(vin.tview()), ctypes.byref(epi),
-           ctypes.byref(self._nparts), ptr(self.grad(wname)), ptr(self.workspace), self.workspace.numel() * 4,
+           ctypes.byref(self._nparts), ptr(self.grad(wname)), *self._ws(),
            self.dtype, self.stream, nbytes=2 * nb, tag=tag)
+      self._ws_mark()
       vin.raw.grad_written = True
       if fused:
         self._bn_bwd_finalize(vin.bn, self._nparts.value)
       return
     call('edet_pw_bwd_weight', ctypes.byref(vin.tview()), ctypes.byref(g), ptr(self.grad(wname)),
-         ptr(self.workspace), self.workspace.numel() * 4, self.dtype, self.stream, nbytes=nb, tag=tag)
+         *self._ws(), self.dtype, self.stream, nbytes=nb, tag=tag)
+    self._ws_mark()
     if vin.raw.needs_grad:
       dgate = vin.dgate if vin.gate is not None else None
       epi, fused = self._epi(vin, dgate)
@@ -640,7 +689,8 @@ class Engine(object):
     nb = (vin.raw.rows * cin + vout.raw.rows * cout) * self.esize
     tag = '%dx%dx%d->%d k%ds%d' % (vin.raw.h, vin.raw.w, cin, cout, k, stride)
     call('edet_conv_bwd_weight', ctypes.byref(vin.tview()), ctypes.byref(g), k, stride, ptr(self.grad(wname)),
-         ptr(self.workspace), self.workspace.numel() * 4, self.dtype, self.stream, nbytes=nb, tag=tag)
+         *self._ws(), self.dtype, self.stream, nbytes=nb, tag=tag)
+    self._ws_mark()
     if vin.raw.needs_grad:
       # compute copy for the data gradient: HWIO -> [cin][k][k][cout] (reduction index (tap, co) contiguous)
       wperm = self.buf('wtd:' + wname, (cin, k * k * cout), self.tdtype)
@@ -678,14 +728,15 @@ class Engine(object):
     if vin.raw.needs_grad and stride == 1 and self.fused_dw_bwd:
       epi, fused = self._epi(vin)
       call('edet_dw_bwd', ctypes.byref(g), ptr(self.param(wname)), k, stride, ctypes.byref(vin.tview()),
-           ctypes.byref(epi), ctypes.byref(self._nparts), ptr(self.grad(wname)), ptr(self.workspace),
-           self.workspace.numel() * 4, self.dtype, self.stream, nbytes=2 * nb, tag=tag)
+           ctypes.byref(epi), ctypes.byref(self._nparts), ptr(self.grad(wname)), *self._ws(), self.dtype, self.stream, nbytes=2 * nb, tag=tag)
+      self._ws_mark()
       vin.raw.grad_written = True
       if fused:
         self._bn_bwd_finalize(vin.bn, self._nparts.value)
       return
     call('edet_dw_bwd_weight', ctypes.byref(vin.tview()), ctypes.byref(g), k, stride, ptr(self.grad(wname)),
-         ptr(self.workspace), self.workspace.numel() * 4, self.dtype, self.stream, nbytes=nb, tag=tag)
+         *self._ws(), self.dtype, self.stream, nbytes=nb, tag=tag)
+    self._ws_mark()
     if vin.raw.needs_grad:
       epi, fused = self._epi(vin)
       call('edet_dw_bwd_data', ctypes.byref(g), ptr(self.param(wname)), k, stride, ctypes.byref(vin.tview()),
@@ -836,7 +887,7 @@ class Engine(object):
         tv2 = [v.tview() for v in inputs]
         tvp2 = [ctypes.byref(t) for t in tv2] + [None] * (3 - nin)
         call('edet_fuse_bwd_pre', tvp2[0], tvp2[1], tvp2[2], marr, nin, ptr(wn), wc, act, ptr(out.grad), oh, ow,
-             out.ld, ptr(ds), ptr(dwn), ptr(amax), ptr(self.workspace), self.workspace.numel() * 4, self.dtype, self.stream,
+             out.ld, ptr(ds), ptr(dwn), ptr(amax), *self._ws(), self.dtype, self.stream,
              nbytes=fbytes + out.rows * c * self.esize)
         plane = 0
         for i, v in enumerate(inputs):
@@ -909,9 +960,9 @@ class Engine(object):
 
       def stem_bwd():
         g = self._gview(v0)
-        call('edet_stem_bwd_weight', ptr(images), n, h, w, ctypes.byref(g), ptr(self.grad(wstem)), ptr(self.workspace),
-             self.workspace.numel() * 4, self.dtype,
+        call('edet_stem_bwd_weight', ptr(images), n, h, w, ctypes.byref(g), ptr(self.grad(wstem)), *self._ws(), self.dtype,
              self.stream, nbytes=(n * h * w * 3 + y0.rows * y0.c) * self.esize)
+        self._ws_mark()
       self.tape.append(stem_bwd)
     # ---- MBConv blocks
     reds = []
@@ -1069,8 +1120,13 @@ class Engine(object):
       def bwd():
         def replay(which):
           def job():
-            for fn in reversed(tapes[which]):
-              fn()
+            self._defer_begin()        # (the side chain records on its own stream and flushes before the join)
+            try:
+              for fn in reversed(tapes[which]):
+                fn()
+            finally:
+              if which == 'side':
+                self._defer_end()
           return job
         self._fork_join(replay('main'), replay('side'))
         self._side_pending = True
@@ -1113,24 +1169,28 @@ class Engine(object):
       if ls:      # FocalLoss(label_smoothing), train_lib.py:400-402
         call('edet_focal_loss_smooth', ptr(r.data), r.ld, ptr(ct), r.rows, na, c.num_classes, c.alpha, c.gamma, ls,
              1.0 / normalizer, norm_dev, ptr(r.ensure_grad()), ptr(self.grad('class_net/class-predict/bias')),
-             ptr(self.loss_sums), ptr(self.workspace), self.workspace.numel() * 4, self.dtype, self.stream,
+             ptr(self.loss_sums), *self._ws(), self.dtype, self.stream,
              nbytes=2 * r.rows * r.c * self.esize)
       else:
         call('edet_focal_loss', ptr(r.data), r.ld, ptr(ct), r.rows, na, c.num_classes, c.alpha, c.gamma,
              1.0 / normalizer, norm_dev, ptr(r.ensure_grad()), ptr(self.grad('class_net/class-predict/bias')),
-             ptr(self.loss_sums), ptr(self.workspace), self.workspace.numel() * 4, self.dtype, self.stream,
+             ptr(self.loss_sums), *self._ws(), self.dtype, self.stream,
              nbytes=2 * r.rows * r.c * self.esize)
       r.grad_written = True
       rb = bv.raw
       call('edet_box_loss', ptr(rb.data), rb.ld, ptr(bt), rb.rows, 4 * na, c.delta, 1.0 / (normalizer * 4.0),
            float(c.box_loss_weight), norm_dev, ptr(rb.ensure_grad()), ptr(self.grad('box_net/box-predict/bias')),
-           ptr(self.loss_sums), ptr(self.workspace), self.workspace.numel() * 4, self.dtype, self.stream)
+           ptr(self.loss_sums), *self._ws(), self.dtype, self.stream)
       rb.grad_written = True
     self.backward()
 
   def backward(self):
-    for fn in reversed(self.tape):
-      fn()
+    self._defer_begin()          # the weight-gradient sums of this pass: recorded, added in a few batched launches
+    try:
+      for fn in reversed(self.tape):
+        fn()
+    finally:
+      self._defer_end()
     self.tape = []
     self._join_side()
 

@@ -228,6 +228,19 @@ int edet_dw_bwd(const edet_gview_t* dy, const float* weight, int k, int stride,
                 const edet_tview_t* in, const edet_bwd_epi_t* epi, int* nparts_out,
                 float* dweight, void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
+/* ---- deferred weight-gradient reductions -------------------------------------------------
+ * Every weight-gradient entry point above that takes a workspace ends in "dweight += sum of the partial sums it left
+ * there" (a small kernel per call: ~190 of them per EfficientDet-D0 step).  edet_reduce_defer(stream, 1): from now on those
+ * sums on `stream` are recorded instead of launched; edet_reduce_flush(stream) adds everything recorded in ONE launch
+ * (same destinations in recording order -- a fixed summation order, the same result on every run; legal inside a
+ * stream capture).  Between a call and the flush the caller must not reuse the part of the workspace that holds its partial
+ * sums: edet_reduce_deferred_end gives the highest address of the recorded partial regions (NULL: nothing recorded), so a
+ * caller can hand the next call the workspace from there on.  edet_reduce_defer(stream, 0) flushes and returns to the
+ * immediate mode.  Host-side state per stream; not thread safe.  */
+int edet_reduce_defer(void* stream, int enable);
+int edet_reduce_flush(void* stream);
+int edet_reduce_deferred_end(void* stream, const void** hi_out);
+
 /* ---- BatchNorm statistics --------------------------------------------------
  * utils.py:244-266 / util_keras.py:29-66 (eps 1e-3, momentum 0.99).
  * finalize: partial sums -> batch mean / biased variance -> scale, shift, mean,
