@@ -619,6 +619,10 @@ int pwt_try_bwd(const edet_gview_t* dy, const void* w, int ldw, const edet_tview
     // the class-predict layers (no BatchNorm behind them).  EDET_PWT_NSL=0 switches them off (lab switch).
     const int nsl = (N + 127) / 128;
     if (oact || (xgen && !xgate) || !env_int("EDET_PWT_NSL", 1)) return 0;
+    // Every K slice re-reads the whole N-wide gradient pair: with more than two slices that only pays on the small maps,
+    // where the re-reads come out of the L2 / MALL (r04k, efficientdet-d7x 1536x1536 batch 8: 384->384 at 192x192 10.4 ->
+    // 14.7 ms over 18 layers, at 96x96 4.0 -> 5.8, at 24x24 0.92 -> 0.78; D0 20x20x1152->192 0.417 -> 0.284 ms)
+    if (K > 128 && a.M > env_int("EDET_PWT_NSL_MAXROWS", 65536)) return 0;
     const bool wide_expand = nsl > 3 && nsl <= 6 && gbn && !xgen && K <= 128 && env_int("EDET_PWT_WIDE", 1);
     // 7 slices (class predict): up to two K slices (efficientdet-d0 .. d2: 64 / 88 / 112 filters) -- every further slice
     // re-reads the 810-column gradient --, and any K on the small maps, where the two-kernel path would run the generic
