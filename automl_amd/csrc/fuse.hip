@@ -22,6 +22,11 @@ struct FuseArgs {
   int wc;
   int act;
   int n, oh, ow, c, ldo;
+  // backward, r04: gradient buffers of EDET_RS_IDENTITY inputs that the kernel writes itself (NULL: left to
+  // edet_fuse_bwd_input), accumulate flags, and whether ds has to be stored at all (another input still reads it)
+  void* gin[3];
+  int gbeta[3];
+  int write_ds;
 };
 
 // affine-only view value (fusion inputs never carry an activation or gate)
@@ -156,7 +161,33 @@ __global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restric
 #pragma unroll
         for (int e = 0; e < 8; ++e) d[e] *= act_other_grad_(a.act, s[e]);
       }
-      store8<T>(ds + off, d);
+      if (a.write_ds) store8<T>(ds + off, d);
+      // identity inputs: g_i (+)= wn_i * ds at the same pixel, from the value ds is stored as (rounded to the storage
+      // type first: the same bits edet_fuse_bwd_input would produce from the stored tensor)
+      for (int i = 0; i < a.nin; ++i) {
+        if (a.gin[i]) {
+          float g[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] = to_f<T>(from_f<T>(d[e]));
+          if (per_ch) {
+            float wv[8];
+            loadf8(a.wn + (size_t)i * a.wc + c0, wv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] *= wv[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] *= wn[i];
+          }
+          T* gp = reinterpret_cast<T*>(a.gin[i]) + opix * a.in[i].ld + c0;
+          if (a.gbeta[i]) {
+            float old[8];
+            load8<T>(gp, old);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] += old[e];
+          }
+          store8<T>(gp, g);
+        }
+      }
       for (int i = 0; i < a.nin; ++i) {
         if (per_ch) {
           if (dwn) {
@@ -470,11 +501,17 @@ extern "C" int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, c
 extern "C" int edet_fuse_bwd_pre(const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
                                  const int* modes, int nin, const float* wn, int wc, int act,
                                  const void* dout, int oh, int ow, int ldo,
-                                 void* ds, float* dwn, void* pool_argmax, void* workspace, size_t workspace_bytes,
-                                 int dtype, void* stream) {
+                                 void* ds, float* dwn, void* pool_argmax, void* const* gin, const int* gbeta,
+                                 int write_ds, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
   FuseArgs a;
   if (int rc = fill_args(a, in0, in1, in2, modes, nin, wn, wc, act, oh, ow, ldo)) return rc;
   EDET_CHECK(dout && ds, "edet_fuse_bwd_pre: null pointer");
+  a.write_ds = write_ds;
+  for (int i = 0; i < nin; ++i) {
+    a.gin[i] = gin ? gin[i] : nullptr;
+    a.gbeta[i] = (gin && gbeta) ? gbeta[i] : 0;
+    EDET_CHECK(!a.gin[i] || modes[i] == EDET_RS_IDENTITY, "edet_fuse_bwd_pre: gin[%d] given for a resampled input", i);
+  }
   const size_t lds = wc > 1 ? (size_t)3 * a.c * sizeof(float) : 0;
   const int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8), dtype == EDET_BF16 ? reinterpret_cast<const void*>(&k_fuse<bf16_t, true>) : nullptr, lds);
   // scalar fusion weights: ordered partial rows [grid][4] through the workspace (else: atomic adds into dwn)

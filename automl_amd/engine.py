@@ -303,6 +303,7 @@ class Engine(object):
     # bf16 is 3e-3 of their range and the whole of what separated the path from the 1e-3 of north_star
     # (scripts/precision_sweep.py); the training step keeps bf16 logits (they only feed the loss)
     self.logits_f32 = os.environ.get('EDET_LOGITS_F32', '1') != '0'
+    self.fuse_merge_identity = os.environ.get('EDET_FUSE_MERGE', '1') != '0'   # BiFPN backward: see Engine.fuse
     self.fused_dw_bwd = True     # one edet_dw_bwd call per stride-1 layer
     self.fused_pw_bwd = True     # one edet_pw_bwd call per pointwise layer whose input needs a gradient
     # cross-replica BatchNorm (utils.SyncBatchNormalization / TpuBatchNormalization, utils.py:166-241):
@@ -886,8 +887,19 @@ class Engine(object):
         assert out.grad_written, key
         tv2 = [v.tview() for v in inputs]
         tvp2 = [ctypes.byref(t) for t in tv2] + [None] * (3 - nin)
+        # identity inputs that need a gradient: written by the fusion kernel itself (no edet_fuse_bwd_input launch, no
+        # second read of ds); ds is stored only when a resampled input still has to read it
+        merged = [self.fuse_merge_identity and modes[i] == RS_IDENTITY and v.raw.needs_grad for i, v in enumerate(inputs)]
+        gin = (ctypes.c_void_p * 3)()
+        gbeta = (ctypes.c_int * 3)()
+        for i, v in enumerate(inputs):
+          if merged[i]:
+            gin[i] = ptr(v.raw.ensure_grad())
+            gbeta[i] = 1 if v.raw.grad_written else 0
+            v.raw.grad_written = True
+        write_ds = 1 if any(v.raw.needs_grad and not merged[i] for i, v in enumerate(inputs)) else 0
         call('edet_fuse_bwd_pre', tvp2[0], tvp2[1], tvp2[2], marr, nin, ptr(wn), wc, act, ptr(out.grad), oh, ow,
-             out.ld, ptr(ds), ptr(dwn), ptr(amax), *self._ws(), self.dtype, self.stream,
+             out.ld, ptr(ds), ptr(dwn), ptr(amax), gin, gbeta, write_ds, *self._ws(), self.dtype, self.stream,
              nbytes=fbytes + out.rows * c * self.esize)
         plane = 0
         for i, v in enumerate(inputs):
@@ -895,7 +907,7 @@ class Engine(object):
           if modes[i] == RS_POOL and amax is not None:
             am = amax[plane].data_ptr()
             plane += 1
-          if not v.raw.needs_grad:
+          if not v.raw.needs_grad or merged[i]:
             continue
           g = v.raw.ensure_grad()
           call('edet_fuse_bwd_input', ctypes.byref(tv2[i]), modes[i], ptr(wn), wc, i, ptr(ds), oh, ow, out.ld, am,

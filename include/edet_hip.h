@@ -320,6 +320,9 @@ int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, const edet_t
                   const int* modes, int nin, const float* wn, int wc, int act,
                   void* out, int oh, int ow, int ldo, int dtype, void* stream);
 /* ds = dout * act'(s) (s recomputed) written to `ds`; dwn[i] += sum ds * x_i.
+ * gin / gbeta (may be NULL): per input, the gradient buffer of an EDET_RS_IDENTITY input that this call writes itself
+ * (gin[i] (+)= wn[i] * ds when gbeta[i]; exactly what edet_fuse_bwd_input gives) -- saves that launch and its read of
+ * ds; write_ds = 0 when no other input needs the stored ds.
  * workspace (may be NULL): caller-owned scratch for the per-workgroup partial sums of the scalar fusion weights
  * (16 bytes per workgroup: 64 KiB is enough), added in a fixed order -- the same dwn on every run; NULL or
  * per-channel weights: atomic adds.
@@ -329,8 +332,8 @@ int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, const edet_t
 int edet_fuse_bwd_pre(const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
                       const int* modes, int nin, const float* wn, int wc, int act,
                       const void* dout, int oh, int ow, int ldo,
-                      void* ds, float* dwn, void* pool_argmax, void* workspace, size_t workspace_bytes,
-                      int dtype, void* stream);
+                      void* ds, float* dwn, void* pool_argmax, void* const* gin, const int* gbeta, int write_ds,
+                      void* workspace, size_t workspace_bytes, int dtype, void* stream);
 /* gradient of one fusion input: gout (+)= wn[i] * resample_i^T(ds).  pool_argmax: this input's
  * plane written by edet_fuse_bwd_pre (EDET_RS_POOL only; NULL -> the windows are recomputed).  */
 int edet_fuse_bwd_input(const edet_tview_t* in, int mode, const float* wn, int wc, int idx,

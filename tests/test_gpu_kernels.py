@@ -781,12 +781,37 @@ def test_fuse(dt, case):
   for use_ws in (False, True, True):
     dwn.zero_()
     call('edet_fuse_bwd_pre', tvp[0], tvp[1], tvp[2], modes, nin, ptr(wn), wc, act, ptr(dd), oh, ow, c, ptr(ds),
-         ptr(dwn), ptr(amax) if npool else None, ptr(wsp) if use_ws else None, wsp.numel() * 4 if use_ws else 0, edt,
-         gu.stream())
+         ptr(dwn), ptr(amax) if npool else None, None, None, 1, ptr(wsp) if use_ws else None,
+         wsp.numel() * 4 if use_ws else 0, edt, gu.stream())
     torch.cuda.synchronize()
     dwn_runs.append(dwn.clone())
   if wc == 1:
     assert torch.equal(dwn_runs[1], dwn_runs[2])
+  # r04: the identity inputs' gradients written by the fusion kernel itself (gin / gbeta) must equal, bit for bit, what
+  # edet_fuse_bwd_input makes of the stored ds -- with and without accumulation
+  ds_ref = ds.clone()
+  for beta in (0, 1):
+    gin = (ctypes.c_void_p * 3)()
+    gbeta = (ctypes.c_int * 3)()
+    merged, wants = {}, {}
+    for i in range(nin):
+      if ins[i][0] == _lib.RS_IDENTITY:
+        start = gu.to_dev(gu.rnd(np.random.default_rng(i), tuple(xd[i].shape), tdt), tdt) if beta else torch.full_like(xd[i], float('nan'))
+        merged[i] = start.clone()
+        wants[i] = start.clone()
+        gin[i] = merged[i].data_ptr()
+        gbeta[i] = beta
+        call('edet_fuse_bwd_input', ctypes.byref(tvs[i]), ins[i][0], ptr(wn), wc, i, ptr(ds_ref), oh, ow, c, None,
+             ptr(wants[i]), beta, edt, gu.stream())
+    if merged:
+      ds.fill_(float('nan'))
+      call('edet_fuse_bwd_pre', tvp[0], tvp[1], tvp[2], modes, nin, ptr(wn), wc, act, ptr(dd), oh, ow, c, ptr(ds),
+           ptr(dwn.clone()), ptr(amax) if npool else None, gin, gbeta, 0, None, 0, edt, gu.stream())
+      torch.cuda.synchronize()
+      for i in merged:
+        assert torch.equal(merged[i][..., :c], wants[i][..., :c]), 'merged identity gradient %d (beta %d)' % (i, beta)
+      assert bool(torch.isnan(ds.float()).all())      # write_ds = 0: nothing stored
+  ds.copy_(ds_ref)
   plane = 0
   for i in range(nin):
     planes = [None]
