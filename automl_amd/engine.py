@@ -304,6 +304,7 @@ class Engine(object):
     # (scripts/precision_sweep.py); the training step keeps bf16 logits (they only feed the loss)
     self.logits_f32 = os.environ.get('EDET_LOGITS_F32', '1') != '0'
     self.fuse_merge_identity = os.environ.get('EDET_FUSE_MERGE', '1') != '0'   # BiFPN backward: see Engine.fuse
+    self.overlap_s2_wgrad = os.environ.get('EDET_S2_OVERLAP', '0') == '1'
     self.fused_dw_bwd = True     # one edet_dw_bwd call per stride-1 layer
     self.fused_pw_bwd = True     # one edet_pw_bwd call per pointwise layer whose input needs a gradient
     # cross-replica BatchNorm (utils.SyncBatchNormalization / TpuBatchNormalization, utils.py:166-241):
@@ -735,16 +736,36 @@ class Engine(object):
       if fused:
         self._bn_bwd_finalize(vin.bn, self._nparts.value)
       return
-    call('edet_dw_bwd_weight', ctypes.byref(vin.tview()), ctypes.byref(g), k, stride, ptr(self.grad(wname)),
-         *self._ws(), self.dtype, self.stream, nbytes=nb, tag=tag)
-    self._ws_mark()
-    if vin.raw.needs_grad:
+    gptr = ptr(self.grad(wname))
+
+    def wgrad():
+      call('edet_dw_bwd_weight', ctypes.byref(vin.tview()), ctypes.byref(g), k, stride, gptr,
+           *self._ws(), self.dtype, self.stream, nbytes=nb, tag=tag)
+      self._ws_mark()
+
+    def dgrad():
       epi, fused = self._epi(vin)
       call('edet_dw_bwd_data', ctypes.byref(g), ptr(self.param(wname)), k, stride, ctypes.byref(vin.tview()),
            ctypes.byref(epi), ctypes.byref(self._nparts), self.dtype, self.stream, nbytes=nb, tag=tag)
       vin.raw.grad_written = True
       if fused:
         self._bn_bwd_finalize(vin.bn, self._nparts.value)
+
+    if vin.raw.needs_grad and self.overlap_s2_wgrad and self.training and self.sync_bn is None and self._branch is self._main:
+      # Stride-2 layer: the weight-gradient kernel (nothing on the chain waits for it) on the side stream NEXT TO the
+      # data-gradient kernel -- both march over the same (dz, y, x), the second reader finds them in the L2 / MALL
+      # (Engine.overlap_s2_wgrad; the side chain records its reduction on its own stream and flushes before the join)
+      def side_job():
+        self._defer_begin()
+        try:
+          wgrad()
+        finally:
+          self._defer_end()
+      self._fork_join(dgrad, side_job)
+      return
+    wgrad()
+    if vin.raw.needs_grad:
+      dgrad()
 
   def se(self, key, v, scope, se_filters):
     """Squeeze-and-excitation: returns the gated view of v (efficientnet_model.py:183-195)."""
