@@ -110,8 +110,9 @@ constexpr int min_blocks(int KT, int NT, bool xgen, int NSL = 1) {
 // accumulators (NSL sets) over the whole row range, one gradient slice is in flight while the previous one is on the
 // matrix cores.  The 20x20 projections (1152 -> 192 / 320), the 40 -> 240 expansion and the 810-column class-predict
 // layers (K = 64: 7 slices, 224 accumulator registers, one workgroup per compute unit).
-template <int KT, int NT, bool GBN, int XM, bool OACT, int NSL = 1>
+template <int KT, int NT, bool GBN, int XM, bool OACT, int NSL = 1, int PF = 1>
 __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0, NSL)) void k_pw_bwd_tile(const Args a) {
+  static_assert(PF == 1 || PF == 2, "one or two steps of loads in flight");
   static_assert(NSL == 1 || NT == 128, "column slices are 128 channels wide");
   constexpr bool XGEN = XM != 0;      // the input view carries BatchNorm / activation / gate, or the epilogue sums
   constexpr bool XGATE = XM == 2;     // SE-gated input with gate-gradient sums: the epilogue needs no raw x
@@ -217,15 +218,20 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0, NSL)) void k_p
   }
 
   // ---- loads in flight (one step ahead)
-  uint4 xn[NPX], zn[NPD], yn[GBN ? NPD : 1];
-  float gtn[XGEN ? 8 : 1];
+  // a register set of loads in flight: PF = 1 one set (step t+1 requested while step t is worked on), PF = 2 two sets used
+  // alternately (step t+2 requested at step t: twice the bytes in flight per workgroup)
+  struct LoadSet {
+    uint4 x[NPX], z[NPD], y[GBN ? NPD : 1];
+    float g[XGEN ? 8 : 1];
+  };
+  LoadSet LA, LB;
   auto geometry = [&](int t, int& img, int& r0, int& nvalid) {
     img = t / a.spi;
     const int qs = t - img * a.spi;
     r0 = img * a.hwp + qs * RS;
     nvalid = min(RS, a.hwp - qs * RS);
   };
-  auto issue_x = [&](int t) {
+  auto issue_x = [&](int t, LoadSet& L) {
     int img, r0, nvalid;
     geometry(t, img, r0, nvalid);
     // one uniform 64-bit base per tensor and step + a 32-bit byte offset per lane
@@ -233,13 +239,13 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0, NSL)) void k_p
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
       const int r = min(xr0 + RPPX * i, nvalid - 1);         // rows past the step re-read its last row
-      xn[i] = *reinterpret_cast<const uint4*>(xb + (uint32_t)((r * ldx + kxc) * 2));
+      L.x[i] = *reinterpret_cast<const uint4*>(xb + (uint32_t)((r * ldx + kxc) * 2));
     }
     if constexpr (XGEN) {
-      if (gated) loadf8(a.tv.gate + (size_t)img * a.K + kxc, gtn);
+      if (gated) loadf8(a.tv.gate + (size_t)img * a.K + kxc, L.g);
     }
   };
-  auto issue_d = [&](int t, int j) {      // column slice j of the gradient rows of step t
+  auto issue_d = [&](int t, int j, LoadSet& L) {      // column slice j of the gradient rows of step t
     int img, r0, nvalid;
     geometry(t, img, r0, nvalid);
     const unsigned char* zb = reinterpret_cast<const unsigned char*>(DZ + (size_t)r0 * ldd);
@@ -250,8 +256,8 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0, NSL)) void k_p
     for (int i = 0; i < NPD; ++i) {
       const int r = min(dr0 + RPPD * i, nvalid - 1);
       const uint32_t off = (uint32_t)((r * ldd + ndc) * 2);
-      zn[i] = *reinterpret_cast<const uint4*>(zb + off);
-      if constexpr (GBN) yn[i] = *reinterpret_cast<const uint4*>(yb + off);
+      L.z[i] = *reinterpret_cast<const uint4*>(zb + off);
+      if constexpr (GBN) L.y[i] = *reinterpret_cast<const uint4*>(yb + off);
     }
   };
 
@@ -260,9 +266,13 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0, NSL)) void k_p
   const int rt = wave & 1;                    // data gradient: row tile of this wave
   const int wkt0 = (wave & 1) * WKT, wnt0 = (wave >> 1) * WNT;
 
-  if (t0 < t1) { issue_x(t0); issue_d(t0, 0); }
+  if (t0 < t1) {
+    issue_x(t0, LA); issue_d(t0, 0, LA);
+    if constexpr (PF == 2) { issue_x(min(t0 + 1, t1 - 1), LB); issue_d(min(t0 + 1, t1 - 1), 0, LB); }
+  }
   __syncthreads();                            // Wl complete
-  for (int t = t0; t < t1; ++t) {
+  // one step: the loads of step t are in L; the same set then receives the loads of step tn
+  auto step = [&](int t, int tn, LoadSet& L) {
     int img, r0, nvalid;
     geometry(t, img, r0, nvalid);
 
@@ -272,16 +282,16 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0, NSL)) void k_p
     float sc[XGEN ? 8 : 1], sh[XGEN ? 8 : 1];
     if constexpr (XGEN) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) gt[e] = gated ? gtn[e] : 1.f;
+      for (int e = 0; e < 8; ++e) gt[e] = gated ? L.g[e] : 1.f;
       loadf8(cfx + xc * 8, sc);
       loadf8(cfx + KT + xc * 8, sh);
     }
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
       const int r = xr0 + RPPX * i;
-      uint4 v = xn[i];
+      uint4 v = L.x[i];
       if constexpr (XGEN) {
-        if constexpr (!XGATE) xcur[i] = xn[i];
+        if constexpr (!XGATE) xcur[i] = L.x[i];
         if (affine || swish || other || gated) {
           float x[8];
           unpack8(v, x);
@@ -314,11 +324,11 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0, NSL)) void k_p
 #pragma unroll
         for (int i = 0; i < NPD; ++i) {
           const int r = dr0 + RPPD * i;
-          uint4 v = zn[i];
+          uint4 v = L.z[i];
           if constexpr (GBN) {
             float g[8], y[8];
-            unpack8(zn[i], g);
-            unpack8(yn[i], y);
+            unpack8(L.z[i], g);
+            unpack8(L.y[i], y);
 #pragma unroll
             for (int e = 0; e < 8; ++e) g[e] = fmaf(ga[e], g[e], fmaf(gb[e], y[e], gc[e]));
             v = pack8(g);
@@ -331,10 +341,10 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0, NSL)) void k_p
       // ---- request what comes next: the next slice of this step, or step t+1 (the last step re-requests itself: the
       // loads stay unconditional)
       if (sl + 1 < NSL) {
-        issue_d(t, sl + 1);
+        issue_d(t, sl + 1, L);
       } else {
-        issue_x(min(t + 1, t1 - 1));
-        issue_d(min(t + 1, t1 - 1), 0);
+        issue_x(min(tn, t1 - 1), L);
+        issue_d(min(tn, t1 - 1), 0, L);
       }
       __syncthreads();
 
@@ -469,6 +479,14 @@ __global__ __launch_bounds__(THREADS, min_blocks(KT, NT, XM != 0, NSL)) void k_p
         // (the next write of Ct comes after the next step's first barrier)
       }
     }
+  };
+  if constexpr (PF == 1) {
+    for (int t = t0; t < t1; ++t) step(t, t + 1, LA);
+  } else {
+    for (int t = t0; t < t1; t += 2) {
+      step(t, t + 2, LA);
+      if (t + 1 < t1) step(t + 1, t + 3, LB);
+    }
   }
 
   // ---- BatchNorm-backward sums of this workgroup's rows: one partial row per split, columns of this slice
@@ -527,9 +545,9 @@ inline int env_int(const char* name, int dflt) {
   return (e && e[0]) ? atoi(e) : dflt;
 }
 
-template <int KT, int NT, bool GBN, int XM, bool OACT, int NSL = 1>
+template <int KT, int NT, bool GBN, int XM, bool OACT, int NSL = 1, int PF = 1>
 int launch(Args& a, int* nparts_out, size_t workspace_bytes, hipStream_t st) {
-  auto kern = k_pw_bwd_tile<KT, NT, GBN, XM, OACT, NSL>;
+  auto kern = k_pw_bwd_tile<KT, NT, GBN, XM, OACT, NSL, PF>;
   constexpr size_t lds = lds_bytes(KT, NT, NSL, GBN || XM != 0);
   static const bool lds_ok = lds <= 64 * 1024 ||
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
@@ -600,6 +618,8 @@ int pwt_try_bwd(const edet_gview_t* dy, const void* w, int ldw, const edet_tview
   const int kt = K <= 64 ? 64 : env_int("EDET_PWT_KT", (nt == 64 && in->h * in->w >= 3200) ? 128 : 64);
   int rc = 0;
   const bool xgate = in->gate && epi->dgate && !epi->stat_partials && env_int("EDET_PWT_XGATE", 1);
+  // (PF = 2, two steps of loads in flight, is not instantiated: r04n lab, +-1 % on every layer shape -- these kernels
+  // are not short of bytes in flight)
 #define PWT_GO(KT_, NT_, GBN_, XM_, OACT_) rc = launch<KT_, NT_, GBN_, XM_, OACT_>(a, nparts_out, workspace_bytes, st)
 #define PWT_X(KT_, NT_, GBN_)                                     \
   do {                                                            \
