@@ -42,7 +42,7 @@ ENTRY_KERNELS = {
     'edet_dw_bwd': ['dwm::k_bwd_fused'],
     'edet_pw_bwd_weight': ['pws::k_pw_wgrad', 'pwb::k_big_wgrad', 'k_wgrad<unsigned short'],
     'edet_pw_bwd_data': ['pws::k_pw_dgrad', 'pwb::k_big_gemm<true', 'k_gemm<unsigned short, 8, true', 'k_gemm<unsigned short, 4, true', 'k_gemm<unsigned short, 2, true'],
-    'edet_pw_bwd': ['pws::k_pw_bwd_fused', 'pws::k_pw_wgrad', 'pwb::k_big_wgrad', 'k_wgrad<unsigned short', 'pws::k_pw_dgrad',
+    'edet_pw_bwd': ['pwt::k_pw_bwd_tile', 'pwt::k_gate_finish', 'pws::k_pw_bwd_fused', 'pws::k_noy_apply', 'pws::k_pw_wgrad', 'pwb::k_big_wgrad', 'k_wgrad<unsigned short', 'pws::k_pw_dgrad',
                     'pwb::k_big_gemm<true', 'k_gemm<unsigned short, 8, true', 'k_gemm<unsigned short, 4, true',
                     'k_gemm<unsigned short, 2, true'],
     'edet_pw_fwd': ['pws::k_pw_fwd', 'pwb::k_big_gemm<false', 'k_gemm<unsigned short, 8, false', 'k_gemm<unsigned short, 4, false'],
