@@ -1154,8 +1154,11 @@ int dwm_try_bwd_fused(const edet_gview_t* dy, const float* weight, int k, int s,
                       size_t workspace_bytes, hipStream_t st) {
   using namespace dwm;
   // k = 3: 4 channels per thread (8-byte loads, 2 waves/SIMD) wins on the large maps, 2 channels per thread
-  // (3-4 waves/SIMD) on the small ones (measured: 320x320x32 1.08 vs 1.55 ms, 40x40x64 1.25 vs 1.05 ms)
-  const bool k3c4 = (int64_t)in->h * in->w >= 128 * 128;
+  // (3-4 waves/SIMD) on the small ones (measured r02: 320x320x32 1.08 vs 1.55 ms, 40x40x64 1.25 vs 1.05 ms)
+  const char* c4_env = getenv("EDET_DWM_C4_MINHW");      // lab switch
+  // r04 lab (D0 640x640 batch 128, 64 channels): 80x80 0.147 (2 channels) -> 0.137 ms (4), 40x40 0.0485 -> 0.0480 with the
+  // threshold at 80x80, 0.057 with 4 channels there too
+  const bool k3c4 = (int64_t)in->h * in->w >= (c4_env && c4_env[0] ? atoi(c4_env) : 80 * 80);
   if (s != 1 || (k != 3 && k != 5) || in->gate || epi->dgate || in->c % 8 != 0 || !workspace) return 0;
   Args a;
   memset(&a, 0, sizeof(a));

@@ -13,6 +13,7 @@ Design:
 Reference structure followed: efficientdet/tf2/efficientdet_keras.py:787-915 (EfficientDetNet),
 efficientdet/backbone/efficientnet_model.py:360-416,710-779, efficientdet/tf2/train_lib.py:493-684.
 """
+import contextlib
 import ctypes
 import re
 import math
@@ -303,6 +304,7 @@ class Engine(object):
     # bf16 is 3e-3 of their range and the whole of what separated the path from the 1e-3 of north_star
     # (scripts/precision_sweep.py); the training step keeps bf16 logits (they only feed the loss)
     self.logits_f32 = os.environ.get('EDET_LOGITS_F32', '1') != '0'
+    self._f32_island = False
     self.fuse_merge_identity = os.environ.get('EDET_FUSE_MERGE', '1') != '0'   # BiFPN backward: see Engine.fuse
     self.overlap_s2_wgrad = os.environ.get('EDET_S2_OVERLAP', '0') == '1'
     self.fused_dw_bwd = True     # one edet_dw_bwd call per stride-1 layer
@@ -493,15 +495,35 @@ class Engine(object):
   def _pw_copies(self, name, cin, cout):
     """(Wt [cout][ldk], ldk, W [cin][ldn], ldn) compute-dtype copies of an HWIO 1x1 kernel."""
     ldk, ldn = _pad8(cin), _pad8(cout)
-    wt = self.buf('wt:' + name, (cout, ldk), self.tdtype)
-    w = self.buf('w:' + name, (cin, ldn), self.tdtype)
-    if name not in self._cast_done:
+    sfx = ':f32' if self._f32_island else ''      # fp32 copies of a layer that runs in fp32 inside a bf16 engine
+    wt = self.buf('wt:' + name + sfx, (cout, ldk), self.tdtype)
+    w = self.buf('w:' + name + sfx, (cin, ldn), self.tdtype)
+    if name + sfx not in self._cast_done:
       src = ptr(self.param(name))
       call('edet_cast_matrix', src, ptr(wt), cin, cout, ldk, 1, self.dtype, self.stream)
       call('edet_cast_matrix', src, ptr(w), cin, cout, ldn, 0, self.dtype, self.stream)
-      self._cast_done.add(name)
-      self._cast_items[name] = [(src, ptr(wt), cin, cout, ldk, 1), (src, ptr(w), cin, cout, ldn, 0)]
+      self._cast_done.add(name + sfx)
+      if not sfx:        # (the batched re-cast of a step makes the engine's own compute type only)
+        self._cast_items[name] = [(src, ptr(wt), cin, cout, ldk, 1), (src, ptr(w), cin, cout, ldn, 0)]
     return wt, ldk, w, ldn
+
+  @contextlib.contextmanager
+  def _fp32_island(self):
+    """Layers built inside run through the fp32 kernels of the library although the engine stores bf16 (their inputs
+    must be fp32 tensors: Engine._to_f32).  Inference only -- the box-predict layer, see _head_level."""
+    saved = (self.dtype, self.tdtype, self._f32_island)
+    self.dtype, self.tdtype, self._f32_island = EDET_F32, torch.float32, True
+    try:
+      yield
+    finally:
+      self.dtype, self.tdtype, self._f32_island = saved
+
+  def _to_f32(self, key, v):
+    """fp32 copy of a stored tensor, same view (BatchNorm / activation are applied on load by the fp32 kernels)."""
+    r = v.raw
+    out = Raw(self, key, r.n, r.h, r.w, r.c, r.ld, needs_grad=False, dtype=torch.float32)
+    out.data.copy_(r.data)
+    return View(out, v.bn, v.act, v.gate)
 
   def _cast_all(self):
     """Every compute copy recorded by an earlier pass, re-made in one launch (edet_cast_batch)."""
@@ -1113,6 +1135,14 @@ class Engine(object):
                   bn='%s/%s-%d-bn-%d' % (net, prefix, i, level), act=self.act)
     s = '%s/%s-predict' % (net, prefix)
     key = '%s:l%d' % (s, level)
+    if net == 'box_net' and self.logits_f32 and not self.training and self.dtype == EDET_BF16:
+      # Inference, bf16 storage: the BOX-predict layer (depthwise 3x3 + 64 -> 36 pointwise) runs in fp32.  Error budget
+      # of the box logits against the fp32 oracle (scripts/precision_sweep.py, d0 640x640): bf16 matrix-core operands of
+      # this one layer 1.1e-3 of the range, its depthwise output stored as bf16 6.1e-4, everything else together 3e-4
+      # -- the class logits are at 1e-4 with bf16 operands and need no such treatment.
+      with self._fp32_island():
+        d = self.dw(key + ':dw:f32', self._to_f32(key + ':x:f32', x), s + '/depthwise_kernel', 3, 1)
+        return self.pw(key + ':pw:f32', d, s + '/pointwise_kernel', out_ch, bias=s + '/bias')
     d = self.dw(key + ':dw', x, s + '/depthwise_kernel', 3, 1)
     return self.pw(key + ':pw', d, s + '/pointwise_kernel', out_ch, bias=s + '/bias', f32out=self.logits_f32)
 

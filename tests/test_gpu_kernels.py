@@ -1011,8 +1011,11 @@ def test_tuned_kernels_with_the_other_activations(act, monkeypatch):
                  'pwt::k_pw_bwd_tile', 'dwm::k_fwd_lx', 'dwm::k_dgrad_lx', 'dwm::k_wgrad_lx', 'dwm::k_bwd_fused'):
     assert any(family in k for k in log), (family, sorted(log))
   # ... and every tuned kernel that ran is an OACT instantiation (last template argument)
-  tuned = [k for k in log if any(ns in k for ns in ('pws::k_', 'pwb::k_', 'dwm::k_')) and 'k_reduce' not in k]
-  assert tuned and all(', true>(' in k for k in tuned), [k for k in tuned if ', true>(' not in k]
-  # (the one-pass tiled kernel carries OACT as its fifth template argument, in front of the slice count)
-  tiled = [k for k in log if 'pwt::k_pw_bwd_tile' in k]
-  assert tiled and all(k.split('<')[1].split(',')[4].strip() == 'true' for k in tiled), tiled
+  # (OACT is the last template argument, except: pwb::k_big_gemm carries it fourth -- in front of F32OUT --, the one-pass
+  # tiled kernel fifth -- in front of the slice count)
+  def oact_of(k):
+    targs = [t.strip() for t in k.split('<', 1)[1].rsplit('>(', 1)[0].split(',')]
+    return targs[3] if 'pwb::k_big_gemm' in k else (targs[4] if 'pwt::k_pw_bwd_tile' in k else targs[-1])
+  tuned = [k for k in log if any(ns in k for ns in ('pws::k_', 'pwb::k_', 'pwt::k_pw_bwd', 'dwm::k_')) and 'k_reduce' not in k]
+  assert tuned and all(oact_of(k) == 'true' for k in tuned), [k for k in tuned if oact_of(k) != 'true']
+  assert any('pwt::k_pw_bwd_tile' in k for k in tuned)
