@@ -108,7 +108,10 @@ typedef struct edet_bwd_epi {
  * edet_pw_fwd stored it.  With this bit set the pointwise backward entry points may apply the b*y term of the
  * BatchNorm backward through the convolution INPUT (dx = dz (W diag a)^T + x~ (W diag(b) W^T) + c W^T, dW = (x~^T dz)
  * diag a + (x~^T x~) W diag b + (sum x~) c^T) and never read y: for an MBConv expansion that is 43 % less HBM traffic.
- * Without it they read y.  */
+ * Without it they read y.  Valid only while the stored y is exactly what edet_pw_fwd wrote from THIS input view and THIS
+ * kernel (no in-place modification of x, W or y in between); the recomputed product is not rounded to the storage type,
+ * so the gradients differ from the read-y form by the rounding of y (2^-9 relative per element, zero mean) --
+ * tests/test_gpu_kernels.py::test_pw_bwd runs both forms (EDET_PW_NOY=0 / 1) against the oracle under this contract.  */
 #define EDET_EPI_Y_IS_CONV_OF_INPUT 1
 
 const char* edet_last_error(void);
