@@ -96,11 +96,11 @@ SIGNATURES = {
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     'edet_se_gate_bwd': [PT, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, PI, c_int, c_void_p],
     'edet_fuse_weights': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p],
-    'edet_fuse_fwd': [PT, PT, PT, PI, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
-                      c_void_p],
+    'edet_fuse_fwd': [PT, PT, PT, PI, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                      ctypes.POINTER(c_void_p), c_int, c_int, c_void_p],
     'edet_fuse_bwd_pre': [PT, PT, PT, PI, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
                           c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), PI, c_int, c_void_p, ctypes.c_size_t,
-                          c_int, c_void_p],
+                          ctypes.POINTER(c_void_p), c_int, ctypes.POINTER(c_void_p), c_int, c_void_p],
     'edet_fuse_bwd_input': [PT, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                             c_int, c_int, c_void_p],
     'edet_fuse_weights_bwd': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,

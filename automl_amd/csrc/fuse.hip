@@ -27,7 +27,53 @@ struct FuseArgs {
   void* gin[3];
   int gbeta[3];
   int write_ds;
+  // r04: the raw scalar fusion variables (wc == 1).  Forward: every workgroup normalises them itself (three scalars)
+  // and workgroup 0 stores the result in wn_out for the backward kernels -- no k_fuse_weights launch.
+  const float* wraw[3];
+  float* wn_out;
+  int method;
 };
+
+// normalised fusion weights of one channel from the raw variables (efficientdet_keras.py:84-113): method 1 = 'sum' (ones),
+// 2 = 'attn' (softmax), otherwise 'fastattn' (relu / (sum + 1e-4)).  One code path for k_fuse_weights and k_fuse.
+__device__ __forceinline__ void normalise_weights(const float (&w)[3], int nin, int method, float (&wn)[3]) {
+  if (method == 1) {
+    for (int i = 0; i < nin; ++i) wn[i] = 1.f;
+    return;
+  }
+  if (method == 2) {      // 'attn': softmax over the inputs (efficientdet_keras.py:84-88)
+    float m = w[0], e[3], s = 0.f;
+    for (int i = 1; i < nin; ++i) m = fmaxf(m, w[i]);
+    for (int i = 0; i < nin; ++i) { e[i] = expf(w[i] - m); s += e[i]; }
+    for (int i = 0; i < nin; ++i) wn[i] = e[i] / s;
+    return;
+  }
+  float r[3], s = 0.f;
+  for (int i = 0; i < nin; ++i) { r[i] = fmaxf(w[i], 0.f); s += r[i]; }
+  for (int i = 0; i < nin; ++i) wn[i] = r[i] / (s + 0.0001f);
+}
+
+// d(raw variables) += backward of normalise_weights given d(normalised weights) (method 1: nothing to do)
+__device__ __forceinline__ void normalise_weights_bwd(const float (&w)[3], int nin, int method, const float (&dwn)[3],
+                                                      float (&dw)[3]) {
+  for (int i = 0; i < 3; ++i) dw[i] = 0.f;
+  if (method == 1) return;
+  if (method == 2) {      // softmax backward: dw_i = p_i * (dwn_i - sum_j dwn_j p_j)
+    float m = w[0], p[3], s = 0.f, dot = 0.f;
+    for (int i = 1; i < nin; ++i) m = fmaxf(m, w[i]);
+    for (int i = 0; i < nin; ++i) { p[i] = expf(w[i] - m); s += p[i]; }
+    for (int i = 0; i < nin; ++i) { p[i] /= s; dot += dwn[i] * p[i]; }
+    for (int i = 0; i < nin; ++i) dw[i] = p[i] * (dwn[i] - dot);
+    return;
+  }
+  float r[3], s = 0.0001f, dot = 0.f;
+  for (int i = 0; i < nin; ++i) { r[i] = fmaxf(w[i], 0.f); s += r[i]; }
+  for (int i = 0; i < nin; ++i) dot += dwn[i] * r[i];
+  for (int i = 0; i < nin; ++i) {
+    const float dr = dwn[i] / s - dot / (s * s);
+    if (w[i] > 0.f) dw[i] = dr;
+  }
+}
 
 // affine-only view value (fusion inputs never carry an activation or gate)
 __device__ __forceinline__ void affine8(const edet_tview_t& v, const ViewCoef& k, float x[8]) {
@@ -98,8 +144,15 @@ __global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restric
   const bool per_ch = a.wc > 1;                      // channel_attn / channel_fastattn: one weight per channel
   extern __shared__ float redc[];                    // per_ch && BWD: [3][c] dwn sums of this workgroup
   float wn[3] = {0.f, 0.f, 0.f};
-  if (!per_ch)
+  if (!BWD && !per_ch && a.wn_out) {
+    float w[3] = {0.f, 0.f, 0.f};
+    if (a.method != 1)
+      for (int i = 0; i < a.nin; ++i) w[i] = a.wraw[i][0];
+    normalise_weights(w, a.nin, a.method, wn);
+    if (blockIdx.x == 0 && threadIdx.x < a.nin) a.wn_out[threadIdx.x] = wn[threadIdx.x];
+  } else if (!per_ch) {
     for (int i = 0; i < a.nin; ++i) wn[i] = a.wn[i];
+  }
   float dw_acc[3] = {0.f, 0.f, 0.f};
   if (BWD && per_ch && dwn) {
     for (int i = threadIdx.x; i < 3 * a.c; i += THREADS) redc[i] = 0.f;
@@ -226,9 +279,16 @@ __global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restric
   }
 }
 
-// dwn[i] += the workgroup rows of k_fuse<.., true>, in row order (i < 3)
-__global__ __launch_bounds__(256) void k_fuse_dwn_finish(const float* __restrict__ parts, int G, float* dwn) {
+// dwn[i] += the workgroup rows of k_fuse<.., true>, in row order (i < 3); with the raw variables (r04) also their
+// gradient dw_i += backward of the normalisation -- k_fuse_weights_bwd's arithmetic without its launch
+struct FuseWBwd {
+  const float* w[3];
+  float* dw[3];
+  int nin, method;
+};
+__global__ __launch_bounds__(256) void k_fuse_dwn_finish(const float* __restrict__ parts, int G, float* dwn, FuseWBwd wb) {
   __shared__ float red[256][3];
+  __shared__ float tot[3];
   float t[3] = {0.f, 0.f, 0.f};
   // thread q adds the rows q*per .. (q+1)*per - 1 in order, thread 0 then adds the 256 chunk sums in order
   const int per = (G + 255) / 256;
@@ -240,6 +300,16 @@ __global__ __launch_bounds__(256) void k_fuse_dwn_finish(const float* __restrict
     float s = 0.f;
     for (int q = 0; q < 256; ++q) s += red[q][threadIdx.x];
     dwn[threadIdx.x] += s;
+    tot[threadIdx.x] = dwn[threadIdx.x];
+  }
+  if (wb.nin == 0 || wb.method == 1) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float w[3] = {0.f, 0.f, 0.f}, d[3] = {tot[0], tot[1], tot[2]}, dw[3];
+    for (int i = 0; i < wb.nin; ++i) w[i] = wb.w[i][0];
+    normalise_weights_bwd(w, wb.nin, wb.method, d, dw);
+    for (int i = 0; i < wb.nin; ++i)
+      if (wb.method == 2 || w[i] > 0.f) wb.dw[i][0] += dw[i];
   }
 }
 
@@ -378,44 +448,25 @@ __global__ void k_fuse_weights(const float* w0, const float* w1, const float* w2
                                float* wn, int wc) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= wc) return;
-  const float* w[3] = {w0, w1, w2};
-  if (method == 1) {
-    for (int i = 0; i < nin; ++i) wn[i * wc + ch] = 1.f;
-    return;
-  }
-  if (method == 2) {      // 'attn': softmax over the inputs (efficientdet_keras.py:84-88)
-    float m = w[0][ch], e[3], s = 0.f;
-    for (int i = 1; i < nin; ++i) m = fmaxf(m, w[i][ch]);
-    for (int i = 0; i < nin; ++i) { e[i] = expf(w[i][ch] - m); s += e[i]; }
-    for (int i = 0; i < nin; ++i) wn[i * wc + ch] = e[i] / s;
-    return;
-  }
-  float r[3], s = 0.f;
-  for (int i = 0; i < nin; ++i) { r[i] = fmaxf(w[i][ch], 0.f); s += r[i]; }
-  for (int i = 0; i < nin; ++i) wn[i * wc + ch] = r[i] / (s + 0.0001f);
+  const float* wp[3] = {w0, w1, w2};
+  float w[3] = {0.f, 0.f, 0.f}, r[3];
+  if (method != 1)
+    for (int i = 0; i < nin; ++i) w[i] = wp[i][ch];
+  normalise_weights(w, nin, method, r);
+  for (int i = 0; i < nin; ++i) wn[i * wc + ch] = r[i];
 }
 
 __global__ void k_fuse_weights_bwd(const float* w0, const float* w1, const float* w2, int nin, int method,
                                    const float* dwn, float* dw0, float* dw1, float* dw2, int wc) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= wc || method == 1) return;
-  const float* w[3] = {w0, w1, w2};
-  float* dw[3] = {dw0, dw1, dw2};
-  if (method == 2) {      // softmax backward: dw_i = p_i * (dwn_i - sum_j dwn_j p_j)
-    float m = w[0][ch], p[3], s = 0.f, dot = 0.f;
-    for (int i = 1; i < nin; ++i) m = fmaxf(m, w[i][ch]);
-    for (int i = 0; i < nin; ++i) { p[i] = expf(w[i][ch] - m); s += p[i]; }
-    for (int i = 0; i < nin; ++i) { p[i] /= s; dot += dwn[i * wc + ch] * p[i]; }
-    for (int i = 0; i < nin; ++i) dw[i][ch] += p[i] * (dwn[i * wc + ch] - dot);
-    return;
-  }
-  float r[3], s = 0.0001f, dot = 0.f;
-  for (int i = 0; i < nin; ++i) { r[i] = fmaxf(w[i][ch], 0.f); s += r[i]; }
-  for (int i = 0; i < nin; ++i) dot += dwn[i * wc + ch] * r[i];
-  for (int i = 0; i < nin; ++i) {
-    const float dr = dwn[i * wc + ch] / s - dot / (s * s);
-    if (w[i][ch] > 0.f) dw[i][ch] += dr;
-  }
+  const float* wp[3] = {w0, w1, w2};
+  float* dwp[3] = {dw0, dw1, dw2};
+  float w[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f}, dw[3];
+  for (int i = 0; i < nin; ++i) { w[i] = wp[i][ch]; d[i] = dwn[i * wc + ch]; }
+  normalise_weights_bwd(w, nin, method, d, dw);
+  for (int i = 0; i < nin; ++i)
+    if (method == 2 || w[i] > 0.f) dwp[i][ch] += dw[i];
 }
 
 // grid of a grid-stride elementwise kernel: one thread per item up to ONE ROUND of what the chip holds of this kernel
@@ -485,11 +536,21 @@ extern "C" int edet_fuse_weights_bwd(const float* w0, const float* w1, const flo
 }
 
 extern "C" int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
-                             const int* modes, int nin, const float* wn, int wc, int act,
-                             void* out, int oh, int ow, int ldo, int dtype, void* stream) {
+                             const int* modes, int nin, float* wn, int wc, int act,
+                             void* out, int oh, int ow, int ldo, const float* const* wraw, int method, int dtype,
+                             void* stream) {
   FuseArgs a;
   if (int rc = fill_args(a, in0, in1, in2, modes, nin, wn, wc, act, oh, ow, ldo)) return rc;
   EDET_CHECK(out, "edet_fuse_fwd: null output");
+  if (wraw && wc == 1) {      // scalar fusion variables: normalised inside the kernel, stored to wn by workgroup 0
+    EDET_CHECK(method >= 0 && method <= 2, "edet_fuse_fwd: bad method %d", method);
+    for (int i = 0; i < nin; ++i) {
+      EDET_CHECK(method == 1 || wraw[i], "edet_fuse_fwd: null fusion variable %d", i);
+      a.wraw[i] = wraw[i];
+    }
+    a.wn_out = wn;
+    a.method = method;
+  }
   const int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8), dtype == EDET_BF16 ? reinterpret_cast<const void*>(&k_fuse<bf16_t, false>) : nullptr);
   if (dtype == EDET_BF16) edet_launch(k_fuse<bf16_t, false>, grid, dim3(THREADS), 0, to_stream(stream), a, (bf16_t*)out, nullptr, nullptr, nullptr, nullptr, nullptr);
   else if (dtype == EDET_F32) edet_launch(k_fuse<float, false>, grid, dim3(THREADS), 0, to_stream(stream), a, (float*)out, nullptr, nullptr, nullptr, nullptr, nullptr);
@@ -502,7 +563,8 @@ extern "C" int edet_fuse_bwd_pre(const edet_tview_t* in0, const edet_tview_t* in
                                  const int* modes, int nin, const float* wn, int wc, int act,
                                  const void* dout, int oh, int ow, int ldo,
                                  void* ds, float* dwn, void* pool_argmax, void* const* gin, const int* gbeta,
-                                 int write_ds, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+                                 int write_ds, void* workspace, size_t workspace_bytes, const float* const* wraw,
+                                 int method, float* const* dwraw, int dtype, void* stream) {
   FuseArgs a;
   if (int rc = fill_args(a, in0, in1, in2, modes, nin, wn, wc, act, oh, ow, ldo)) return rc;
   EDET_CHECK(dout && ds, "edet_fuse_bwd_pre: null pointer");
@@ -519,7 +581,24 @@ extern "C" int edet_fuse_bwd_pre(const edet_tview_t* in0, const edet_tview_t* in
   if (dtype == EDET_BF16) edet_launch(k_fuse<bf16_t, true>, grid, dim3(THREADS), lds, to_stream(stream), a, nullptr, (const bf16_t*)dout, (bf16_t*)ds, dwn, (unsigned char*)pool_argmax, parts);
   else if (dtype == EDET_F32) edet_launch(k_fuse<float, true>, grid, dim3(THREADS), lds, to_stream(stream), a, nullptr, (const float*)dout, (float*)ds, dwn, (unsigned char*)pool_argmax, parts);
   else EDET_CHECK(false, "edet_fuse_bwd_pre: bad dtype %d", dtype);
-  if (parts) edet_launch(k_fuse_dwn_finish, dim3(1), dim3(256), 0, to_stream(stream), (const float*)parts, grid, dwn);
+  if (parts) {
+    FuseWBwd wb;
+    memset(&wb, 0, sizeof(wb));
+    if (wraw && dwraw && method != 1) {       // + the gradient of the raw variables (no edet_fuse_weights_bwd call needed)
+      EDET_CHECK(method == 0 || method == 2, "edet_fuse_bwd_pre: bad method %d", method);
+      for (int i = 0; i < nin; ++i) {
+        EDET_CHECK(wraw[i] && dwraw[i], "edet_fuse_bwd_pre: null fusion variable %d", i);
+        wb.w[i] = wraw[i];
+        wb.dw[i] = dwraw[i];
+      }
+      wb.nin = nin;
+      wb.method = method;
+    }
+    edet_launch(k_fuse_dwn_finish, dim3(1), dim3(256), 0, to_stream(stream), (const float*)parts, grid, dwn, wb);
+  } else {
+    EDET_CHECK(!(wraw && dwraw) || method == 1, "edet_fuse_bwd_pre: the fusion variables' gradient needs wc == 1 and a workspace of %zu bytes",
+               (size_t)grid * 4 * sizeof(float));
+  }
   EDET_LAUNCH_CHECK("edet_fuse_bwd_pre");
   return 0;
 }

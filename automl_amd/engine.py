@@ -275,6 +275,7 @@ class Engine(object):
     self._cmax = cmax
     # batched weight-gradient reductions (see _ws): EDET_DEFER_REDUCE=0 = one reduction launch per layer, as in round 3
     self.defer_reduce = os.environ.get('EDET_DEFER_REDUCE', '1') != '0'
+    self.fuse_wfold = os.environ.get('EDET_FUSE_WFOLD', '1') != '0'
     self._deferring = False
     self._defer_streams = set()
     ws_floats = (64 if self.defer_reduce else 16) * 1024 * 1024      # 256 MiB with deferral (64 MiB: the round-3 scratch)
@@ -910,13 +911,18 @@ class Engine(object):
     wn = self.buf(key + ':wn', (max(4, 3 * wc),), torch.float32)
     method = (2 if wm in ('attn', 'channel_attn') else 0) if wnames else 1
     wp = [ptr(self.param(w)) for w in wnames] + [None] * (3 - len(wnames)) if wnames else [None] * 3
-    call('edet_fuse_weights', wp[0], wp[1], wp[2], nin, method, ptr(wn), wc, self.stream)
+    # scalar fusion variables: normalised inside the fusion kernel, their gradient inside the ordered finish of dwn (no
+    # edet_fuse_weights / edet_fuse_weights_bwd launches: 50 of them per D0 step; EDET_FUSE_WFOLD=0: separate launches)
+    wfold = self.fuse_wfold and wc == 1
+    wraw = (ctypes.c_void_p * 3)(*wp) if wfold else None
+    if not wfold:
+      call('edet_fuse_weights', wp[0], wp[1], wp[2], nin, method, ptr(wn), wc, self.stream)
     tv = [v.tview() for v in inputs]
     tvp = [ctypes.byref(t) for t in tv] + [None] * (3 - nin)
     marr = (ctypes.c_int * 3)(*(list(modes) + [0] * (3 - nin)))
     fbytes = (sum(v.raw.rows for v in inputs) + out.rows) * c * self.esize
     call('edet_fuse_fwd', tvp[0], tvp[1], tvp[2], marr, nin, ptr(wn), wc, act, ptr(out.data), oh, ow, out.ld,
-         self.dtype, self.stream, nbytes=fbytes)
+         wraw, method, self.dtype, self.stream, nbytes=fbytes)
     vout = View(out)
     for v in inputs:
       v.consumers += 1
@@ -941,8 +947,11 @@ class Engine(object):
             gbeta[i] = 1 if v.raw.grad_written else 0
             v.raw.grad_written = True
         write_ds = 1 if any(v.raw.needs_grad and not merged[i] for i, v in enumerate(inputs)) else 0
+        wgrad_folded = wfold and bool(wnames) and method != 1
+        dwraw = (ctypes.c_void_p * 3)(*([ptr(self.grad(w)) for w in wnames] + [None] * (3 - len(wnames)))) if wgrad_folded else None
         call('edet_fuse_bwd_pre', tvp2[0], tvp2[1], tvp2[2], marr, nin, ptr(wn), wc, act, ptr(out.grad), oh, ow,
-             out.ld, ptr(ds), ptr(dwn), ptr(amax), gin, gbeta, write_ds, *self._ws(), self.dtype, self.stream,
+             out.ld, ptr(ds), ptr(dwn), ptr(amax), gin, gbeta, write_ds, *self._ws(),
+             wraw if wgrad_folded else None, method, dwraw, self.dtype, self.stream,
              nbytes=fbytes + out.rows * c * self.esize)
         plane = 0
         for i, v in enumerate(inputs):
@@ -958,7 +967,7 @@ class Engine(object):
                nbytes=(out.rows + v.raw.rows) * c * self.esize,
                tag='%dx%dx%d %s' % (v.raw.h, v.raw.w, c, ('id', 'up2', 'pool')[modes[i]]))
           v.raw.grad_written = True
-        if wnames:
+        if wnames and not wgrad_folded:
           gp = [ptr(self.grad(w)) for w in wnames] + [None] * (3 - len(wnames))
           call('edet_fuse_weights_bwd', wp[0], wp[1], wp[2], nin, method, ptr(dwn), gp[0], gp[1], gp[2],
                wc, self.stream)

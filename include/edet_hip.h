@@ -319,9 +319,12 @@ int edet_se_gate_bwd(const edet_tview_t* in, void* g, const float* dpool,
  * (efficientdet_keras.py:100-113: the same two formulas applied per channel; WSM variables of shape [c]).  */
 int edet_fuse_weights(const float* w0, const float* w1, const float* w2, int nin,
                       int method /*0 fastattn, 1 sum, 2 attn (softmax)*/, float* wn, int wc, void* stream);
+/* wraw (may be NULL): the raw fusion variables {w0, w1, w2} (device scalars) when wc == 1 -- the kernel normalises them
+ * itself with edet_fuse_weights' arithmetic (method as there) and stores the result in wn for the backward calls, so
+ * the edet_fuse_weights launch is not needed; NULL or wc > 1: wn is read as computed by edet_fuse_weights.  */
 int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
-                  const int* modes, int nin, const float* wn, int wc, int act,
-                  void* out, int oh, int ow, int ldo, int dtype, void* stream);
+                  const int* modes, int nin, float* wn, int wc, int act,
+                  void* out, int oh, int ow, int ldo, const float* const* wraw, int method, int dtype, void* stream);
 /* ds = dout * act'(s) (s recomputed) written to `ds`; dwn[i] += sum ds * x_i.
  * gin / gbeta (may be NULL): per input, the gradient buffer of an EDET_RS_IDENTITY input that this call writes itself
  * (gin[i] (+)= wn[i] * ds when gbeta[i]; exactly what edet_fuse_bwd_input gives) -- saves that launch and its read of
@@ -331,12 +334,16 @@ int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, const edet_t
  * per-channel weights: atomic adds.
  * pool_argmax (may be NULL): caller-owned bytes [npool][n][oh][ow][c], one plane per EDET_RS_POOL
  * input in input order; receives the winning tap (ky*3+kx, first maximum of the row-major scan) of
- * every pooled element so that edet_fuse_bwd_input does not have to recompute the 3x3 windows.  */
+ * every pooled element so that edet_fuse_bwd_input does not have to recompute the 3x3 windows.
+ * wraw / dwraw (may be NULL): the raw scalar fusion variables and their gradients {dw0, dw1, dw2}; with both (and
+ * wc == 1, a workspace, method 0 or 2) the ordered finish of dwn also adds the normalisation's backward into dwraw --
+ * edet_fuse_weights_bwd's arithmetic without its launch (an error when the partial-row path is not available).  */
 int edet_fuse_bwd_pre(const edet_tview_t* in0, const edet_tview_t* in1, const edet_tview_t* in2,
                       const int* modes, int nin, const float* wn, int wc, int act,
                       const void* dout, int oh, int ow, int ldo,
                       void* ds, float* dwn, void* pool_argmax, void* const* gin, const int* gbeta, int write_ds,
-                      void* workspace, size_t workspace_bytes, int dtype, void* stream);
+                      void* workspace, size_t workspace_bytes, const float* const* wraw, int method,
+                      float* const* dwraw, int dtype, void* stream);
 /* gradient of one fusion input: gout (+)= wn[i] * resample_i^T(ds).  pool_argmax: this input's
  * plane written by edet_fuse_bwd_pre (EDET_RS_POOL only; NULL -> the windows are recomputed).  */
 int edet_fuse_bwd_input(const edet_tview_t* in, int mode, const float* wn, int wc, int idx,

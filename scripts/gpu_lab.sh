@@ -1,14 +1,15 @@
 # Round-4 lab driver (one gpurun call = one box: batch everything into it).
 # usage: gpu_lab.sh TAG ; the sections are chosen by environment variables:
-#   LAB_PYTEST="-k expr ..."        pytest -m gpu arguments (empty: skipped)
+#   LAB_PYTEST="-k expr ..."        pytest -m gpu arguments (empty: skipped); LAB_PYTEST_K="a or b": a -k expression with spaces
+#   LAB_STEPS=20                    timed steps of every bench run (default 5)
 #   LAB_KERNEL="entry|layers|VAR=a,b;entry|layers|VAR=a,b"   scripts/kernel_lab.py runs
 #   LAB_BENCH="NAME:VAR=val VAR2=val;NAME2:"                bench.py runs (5 steps) with a per-launch table each
 mkdir -p gpurun_out
 T=${1:-lab}
 export TMPDIR=/tmp
 export EDET_SKIP_SLOW=1
-if [ -n "$LAB_PYTEST" ]; then
-  (timeout 1500 python -m pytest tests -m gpu -x -q $LAB_PYTEST 2>&1 | cut -c1-3000 | tail -25) > gpurun_out/${T}_pytest.log
+if [ -n "$LAB_PYTEST$LAB_PYTEST_K" ]; then
+  (timeout 1500 python -m pytest tests -m gpu -x -q $LAB_PYTEST ${LAB_PYTEST_K:+-k "$LAB_PYTEST_K"} 2>&1 | cut -c1-3000 | tail -25) > gpurun_out/${T}_pytest.log
   tail -8 gpurun_out/${T}_pytest.log | cut -c1-1200
 fi
 if [ -n "$LAB_KERNEL" ]; then
@@ -25,7 +26,7 @@ if [ -n "$LAB_BENCH" ]; then
   IFS=';' read -ra RUNS <<< "$LAB_BENCH"
   for v in "${RUNS[@]}"; do
     name=${v%%:*}; envs=${v#*:}
-    (env $envs timeout 600 python bench.py --steps 5 --warmup 2 --no_cpu_baseline --no_other_configs --dump_launches gpurun_out/${T}_${name}_launches.txt 2>&1 | tail -1) > gpurun_out/${T}_${name}_bench.log
+    (env $envs timeout ${LAB_TIMEOUT:-600} python bench.py --steps ${LAB_STEPS:-5} --warmup 2 --no_cpu_baseline --no_other_configs --dump_launches gpurun_out/${T}_${name}_launches.txt 2>&1 | tail -1) > gpurun_out/${T}_${name}_bench.log
     echo "$name: $(python -c "
 import json
 try:

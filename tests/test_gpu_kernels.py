@@ -772,9 +772,24 @@ def test_fuse(dt, case):
   meth = {'fastattn': 0, 'attn': 2}.get(base, 1)
   call('edet_fuse_weights', ptr(wd[0]), ptr(wd[1]), ptr(wd[2]), nin, meth, ptr(wn), wc, gu.stream())
   od = torch.full((n, oh, ow, c), float('nan'), dtype=tdt, device=gu.DEV)
-  call('edet_fuse_fwd', tvp[0], tvp[1], tvp[2], modes, nin, ptr(wn), wc, act, ptr(od), oh, ow, c, edt, gu.stream())
+  call('edet_fuse_fwd', tvp[0], tvp[1], tvp[2], modes, nin, ptr(wn), wc, act, ptr(od), oh, ow, c, None, meth, edt,
+       gu.stream())
   torch.cuda.synchronize()
   gu.check(od, out.detach(), name, 'fuse_fwd %s' % (case,))
+  wraw = (ctypes.c_void_p * 3)(*[ptr(w) for w in wd])
+  if wc == 1:
+    # r04: the raw scalar variables normalised inside the kernel (no edet_fuse_weights launch): the same wn, the same output
+    wn2 = torch.full_like(wn, float('nan'))
+    od2 = torch.full_like(od, float('nan'))
+    _lib.launch_log_start()
+    try:
+      call('edet_fuse_fwd', tvp[0], tvp[1], tvp[2], modes, nin, ptr(wn2), wc, act, ptr(od2), oh, ow, c, wraw, meth, edt,
+           gu.stream())
+    finally:
+      log = _lib.launch_log_stop()
+    torch.cuda.synchronize()
+    assert len(log) == 1, log
+    assert torch.equal(wn2[:nin], wn[:nin]) and torch.equal(od2, od)
   dd = gu.to_dev(dout, tdt)
   ds = torch.empty_like(dd)
   dwn = torch.zeros(max(4, 3 * wc), dtype=torch.float32, device=gu.DEV)
@@ -787,7 +802,7 @@ def test_fuse(dt, case):
     dwn.zero_()
     call('edet_fuse_bwd_pre', tvp[0], tvp[1], tvp[2], modes, nin, ptr(wn), wc, act, ptr(dd), oh, ow, c, ptr(ds),
          ptr(dwn), ptr(amax) if npool else None, None, None, 1, ptr(wsp) if use_ws else None,
-         wsp.numel() * 4 if use_ws else 0, edt, gu.stream())
+         wsp.numel() * 4 if use_ws else 0, None, meth, None, edt, gu.stream())
     torch.cuda.synchronize()
     dwn_runs.append(dwn.clone())
   if wc == 1:
@@ -811,7 +826,7 @@ def test_fuse(dt, case):
     if merged:
       ds.fill_(float('nan'))
       call('edet_fuse_bwd_pre', tvp[0], tvp[1], tvp[2], modes, nin, ptr(wn), wc, act, ptr(dd), oh, ow, c, ptr(ds),
-           ptr(dwn.clone()), ptr(amax) if npool else None, gin, gbeta, 0, None, 0, edt, gu.stream())
+           ptr(dwn.clone()), ptr(amax) if npool else None, gin, gbeta, 0, None, 0, None, meth, None, edt, gu.stream())
       torch.cuda.synchronize()
       for i in merged:
         assert torch.equal(merged[i][..., :c], wants[i][..., :c]), 'merged identity gradient %d (beta %d)' % (i, beta)
@@ -838,6 +853,23 @@ def test_fuse(dt, case):
     for i in range(nin):
       gu.check(dws[i], wq[i].grad, 'f32', 'fuse dW%d' % i, rtol=2e-2 if name == 'bf16' else 2e-3,
                atol=2e-2 if name == 'bf16' else 1e-3, scale_by_max=False)
+    if wc == 1:
+      # r04: the same gradient from the ordered finish of dwn inside edet_fuse_bwd_pre (no edet_fuse_weights_bwd launch)
+      dws2 = [torch.zeros(1, dtype=torch.float32, device=gu.DEV) for _ in range(3)]
+      dwraw = (ctypes.c_void_p * 3)(*[ptr(t) for t in dws2])
+      dwn2 = torch.zeros_like(dwn)
+      _lib.launch_log_start()
+      try:
+        call('edet_fuse_bwd_pre', tvp[0], tvp[1], tvp[2], modes, nin, ptr(wn), wc, act, ptr(dd), oh, ow, c, ptr(ds),
+             ptr(dwn2), ptr(amax) if npool else None, None, None, 1, ptr(wsp), wsp.numel() * 4, wraw, meth, dwraw, edt,
+             gu.stream())
+      finally:
+        log = _lib.launch_log_stop()
+      torch.cuda.synchronize()
+      assert len(log) == 2, log
+      assert torch.equal(dwn2, dwn_runs[1])
+      for i in range(nin):
+        assert torch.equal(dws2[i], dws[i]), ('folded fusion-variable gradient', i, dws2[i], dws[i])
 
 
 # ------------------------------------------------------------------------------------ losses
