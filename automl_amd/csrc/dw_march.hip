@@ -1081,6 +1081,16 @@ int dwm_try_fwd(const edet_tview_t* in, const float* weight, int k, int s, void*
   return 1;
 }
 
+// channels per thread of the 3x3 stride-2 gradient kernels: 4 on the large maps, 2 (deeper load FIFO, more waves) up to
+// 80 x 80 input pixels -- r04 lab, D0 640x640 batch 128, data + weight gradient: 320x320x96 2.55 (4) / 2.77 ms (2),
+// 80x80x240 0.529 (4) / 0.460 ms (2).  By the map, not the batch (the parity runs launch what the batch-128 step launches).
+// EDET_DWM_S2_CPT="<dgrad><wgrad>" (e.g. "24") overrides (lab switch).
+static int s2_cpt(int which, int hw) {
+  const char* e = getenv("EDET_DWM_S2_CPT");
+  if (!e || strlen(e) < 2) return hw > 80 * 80 ? 4 : 2;
+  return e[which] == '2' ? 2 : 4;
+}
+
 int dwm_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, float* dweight, void* workspace,
                   size_t workspace_bytes, hipStream_t st) {
   using namespace dwm;
@@ -1106,6 +1116,7 @@ int dwm_try_wgrad(const edet_tview_t* in, const edet_gview_t* dy, int k, int s, 
     else { if (oact) edet_launch(k_wgrad_lx<K_, S_, CPT_, false, true>, grid, block, lds + ring, st, a); else edet_launch(k_wgrad_lx<K_, S_, CPT_, false, false>, grid, block, lds + ring, st, a); }             \
   } while (0)
   if (k == 3 && s == 1) DWM_WG(3, 1, 4);
+  else if (k == 3 && s == 2 && s2_cpt(1, in->h * in->w) == 2) DWM_WG(3, 2, 2);
   else if (k == 3 && s == 2) DWM_WG(3, 2, 4);
   else if (k == 5 && s == 1) DWM_WG(5, 1, 2);
   else if (k == 5 && s == 2) DWM_WG(5, 2, 2);
@@ -1138,6 +1149,7 @@ int dwm_try_dgrad(const edet_gview_t* dy, const float* weight, int k, int s, con
     else { if (oact) edet_launch(k_dgrad_lx<K_, S_, CPT_, false, true>, grid, block, lds + ring, st, a); else edet_launch(k_dgrad_lx<K_, S_, CPT_, false, false>, grid, block, lds + ring, st, a); }             \
   } while (0)
   if (k == 3 && s == 1) DWM_DG(3, 1, 4);
+  else if (k == 3 && s == 2 && s2_cpt(0, in->h * in->w) == 2) DWM_DG(3, 2, 2);
   else if (k == 3 && s == 2) DWM_DG(3, 2, 4);
   else if (k == 5 && s == 1) DWM_DG(5, 1, 2);
   else if (k == 5 && s == 2) DWM_DG(5, 2, 2);
