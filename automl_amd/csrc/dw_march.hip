@@ -1070,7 +1070,15 @@ int dwm_try_fwd(const edet_tview_t* in, const float* weight, int k, int s, void*
     if (oact) edet_launch(k_fwd_lx<K_, S_, CPT_, true>, dim3(a.P * a.ngroups), dim3(THREADS), lds0 + ring, st, a); \
     else edet_launch(k_fwd_lx<K_, S_, CPT_, false>, dim3(a.P * a.ngroups), dim3(THREADS), lds0 + ring, st, a); \
   } while (0)
-  if (k == 3 && s == 1) DWM_FWD(3, 1, 4);
+  // 3x3: four channels per thread on the large maps, two (six rows of loads in flight, more waves) from 40 x 40 OUTPUT
+  // pixels down -- r04 lab, D0 640x640 batch 128: 40x40x64 0.0340 (4) / 0.0278 ms (2), 40x40x480 0.162 / 0.140, 80x80x240
+  // stride 2 0.166 / 0.142, 20x20x1152 0.097 / 0.089, but 80x80x64 0.057 / 0.068 and 320x320x32 0.43 / 0.56.  By the map,
+  // not the batch.  EDET_DWM_FWD_CPT=4|2 overrides (lab switch).
+  const char* fc = getenv("EDET_DWM_FWD_CPT");
+  const bool c2 = (fc && fc[0]) ? fc[0] == '2' : a.oh * a.ow <= 40 * 40;
+  if (k == 3 && s == 1 && c2) DWM_FWD(3, 1, 2);
+  else if (k == 3 && s == 2 && c2) DWM_FWD(3, 2, 2);
+  else if (k == 3 && s == 1) DWM_FWD(3, 1, 4);
   else if (k == 3 && s == 2) DWM_FWD(3, 2, 4);
   else if (k == 5 && s == 1) DWM_FWD(5, 1, 2);
   else if (k == 5 && s == 2) DWM_FWD(5, 2, 2);
