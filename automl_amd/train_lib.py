@@ -148,13 +148,33 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
     self.use_dist = use_dist or process_group is not None
     self._lr_fn = None
     self.iterations = 0
-    self._moving_normalizer = None      # positives_momentum > 0: python float (host normalizer) or 0-d device tensor
+    # positives_momentum > 0: the moving loss normalizer (train_lib.py:519-531).  A 0-d fp32 DEVICE tensor once the
+    # engine exists (updated in place by both the graph and the eager step, no host synchronisation); a python float
+    # only before that (a state restored into a net that has not stepped yet) or when the caller supplies the
+    # normalizer of a step as a host float (labels['normalizer'])
+    self._moving_normalizer = None
+
+  def get_optimizer_state(self):
+    """Optimizer slots, iteration count and -- with positives_momentum > 0 -- the moving loss normalizer.  (The reference
+    creates that variable inside the loss call, train_lib.py:521-527, untracked by its checkpoints: a resumed reference
+    run restarts the average at 0 and divides the first losses by ~(1 - m) * N.  Carrying it in the state avoids that
+    spike; a state without the key restores to the reference's behaviour.)"""
+    state = super().get_optimizer_state()
+    if self._moving_normalizer is not None:
+      state['moving_normalizer'] = float(self._moving_normalizer)
+    return state
 
   def set_optimizer_state(self, state):
     """Optimizer slots + iteration count; the count also drives the learning-rate schedule and the dynamic EMA decay
     of the next train_step (optimizer.iterations in the reference, train_lib.py:37-173,193-197)."""
     super().set_optimizer_state(state)
     self.iterations = int(state['iterations'])
+    if 'moving_normalizer' in state:
+      value = float(state['moving_normalizer'])
+      if torch.is_tensor(self._moving_normalizer):
+        self._moving_normalizer.fill_(value)
+      else:
+        self._moving_normalizer = value
 
   @staticmethod
   def _check_training_options(c):
@@ -285,6 +305,8 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
     positives_momentum > 0, the mean over the replicas for positives_momentum < 0, the value itself otherwise."""
     m = self._positives_momentum()
     if m > 0:
+      if torch.is_tensor(self._moving_normalizer):      # one representation: the device scalar, once it exists
+        return float(moving_normalizer_update(self._moving_normalizer, float(value), m))
       self._moving_normalizer = moving_normalizer_update(
           0.0 if self._moving_normalizer is None else float(self._moving_normalizer), value, m)
       return self._moving_normalizer
@@ -338,9 +360,13 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
     eng.forward(self._to_device_images(images, eng), training=True)
     dlabels = self._labels_to_device(labels, eng)
     if self._positives_momentum() != 0:
-      # the eager path hands the engine a host normalizer: the moving average / replica mean is formed here
-      base = dlabels['normalizer'] if 'normalizer' in dlabels else float(dlabels['mean_num_positives'].sum().item()) + 1.0
-      dlabels['normalizer'] = self._host_normalizer(base)
+      if 'normalizer' in dlabels:
+        # the caller supplied this step's sum(mean_num_positives) + 1 as a host float: moving average / replica mean on the host
+        dlabels['normalizer'] = self._host_normalizer(dlabels['normalizer'])
+      else:
+        # on the device, as the captured step does it (no .item(): the eager step does not wait for the host either)
+        self._device_normalizer(eng, dlabels['mean_num_positives'])
+        dlabels['normalizer'] = 'device'
     eng.loss_backward(dlabels)
     decay = None
     if self.config.moving_average_decay:

@@ -312,6 +312,46 @@ def test_train_step_bf16_tracks_the_oracle():
   assert cos >= 0.9, cos
 
 
+def test_moving_normalizer_eager_graph_and_restored_state_agree():
+  """config.positives_momentum > 0 (tf2/train_lib.py:519-531).  The eager step forms the moving loss normalizer on the
+  device like the captured step (no .item() per step, one representation), so three eager steps and three
+  graph steps from the same start give the same normalizer and variables; and a run resumed from get_optimizer_state()
+  continues the average instead of restarting it at 0 (its next step equals the uninterrupted run's)."""
+  config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  config.override('positives_momentum=0.9')
+  size, batch = 128, 2
+  vals = perturbed_params(config, 11)
+  rng = np.random.default_rng(5)
+  images = rng.standard_normal((batch, size, size, 3)).astype(np.float32)
+  labels = make_labels(config, batch, size, 9)
+
+  def run(use_graph, steps, state=None, start=None):
+    net = train_lib.EfficientDetNetTrain(config=config, dtype='bf16', params=start if start is not None else vals,
+                                         steps_per_epoch=10, global_batch_size=64, use_graph=use_graph)
+    eng = net._ensure_engine(batch, size, size)
+    if state is not None:
+      net.set_optimizer_state(state)
+    for _ in range(steps):
+      net.train_step((images, labels))
+    torch.cuda.synchronize()
+    return net, eng
+
+  eager, e_eng = run(False, 3)
+  graph, g_eng = run(True, 3)
+  assert torch.is_tensor(eager._moving_normalizer) and torch.is_tensor(graph._moving_normalizer)
+  n_pos = float(torch.as_tensor(labels['mean_num_positives']).sum()) + 1.0
+  want = n_pos * (1 - 0.9 ** 3)      # (1 - m) * sum_k m^(t-k) x for a constant x
+  assert abs(float(eager._moving_normalizer) - want) <= 1e-4 * want
+  assert float(eager._moving_normalizer) == float(graph._moving_normalizer)
+  assert torch.allclose(e_eng.params_flat, g_eng.params_flat, rtol=0, atol=1e-6)
+  # resume after two steps: the third step of the resumed run is the uninterrupted run's third step
+  two, t_eng = run(False, 2)
+  state = two.get_optimizer_state()
+  assert abs(state['moving_normalizer'] - n_pos * (1 - 0.9 ** 2)) <= 1e-4 * n_pos
+  resumed, r_eng = run(False, 1, state=state, start=two.get_weights())
+  assert torch.equal(r_eng.params_flat, e_eng.params_flat)
+
+
 def test_frozen_variables_survive_a_restored_optimizer_state():
   """the fine-tune flow builds the model with config.var_freeze_expr and THEN restores an optimizer state
   saved by an un-frozen run -- non-zero momentum and EMA shadows over the frozen ranges.  The reference keeps frozen

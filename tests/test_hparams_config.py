@@ -135,6 +135,37 @@ def test_positives_momentum_is_the_references_moving_normalizer():
   # off by default: the value itself
   net0 = train_lib.EfficientDetNetTrain(config=hparams_config.get_efficientdet_config('efficientdet-d0'))
   assert net0._host_normalizer(101.0) == 101.0 and net0._moving_normalizer is None
+  # one representation once the device scalar exists: a host-supplied normalizer updates THAT tensor (a net that ran graph
+  # steps and is then handed a host float continues the same average), and the state of the average travels with the
+  # optimizer state (the reference's variable is untracked: a resumed run would restart it at 0)
+  net2 = train_lib.EfficientDetNetTrain(config=config)
+  net2._moving_normalizer = torch.zeros((), dtype=torch.float32)
+  got2 = [net2._host_normalizer(x) for x in xs]
+  np.testing.assert_allclose(got2, want, rtol=1e-6)
+  assert torch.is_tensor(net2._moving_normalizer) and abs(float(net2._moving_normalizer) - want[-1]) < 1e-3
+
+  class _Arena(object):      # (the optimizer slots need a GPU engine; the normalizer part of the state does not)
+    def get_optimizer_state(self):
+      return {'iterations': 7}
+
+    def set_optimizer_state(self, state):
+      self.restored = dict(state)
+
+  class _Engine(object):
+    arena = _Arena()
+  net2.engine = _Engine()
+  state = net2.get_optimizer_state()
+  assert abs(state['moving_normalizer'] - want[-1]) < 1e-3 and state['iterations'] == 7
+  net3 = train_lib.EfficientDetNetTrain(config=config)
+  net3.engine = _Engine()
+  net3.set_optimizer_state(state)
+  assert net3.iterations == 7 and abs(net3._moving_normalizer - want[-1]) < 1e-3      # a float until the engine steps
+  nxt = net3._host_normalizer(50.0)
+  assert abs(nxt - (want[-1] * m + 50.0 * (1 - m))) < 1e-3
+  net2.set_optimizer_state({'iterations': 9, 'moving_normalizer': 12.5})             # into the existing device scalar
+  assert torch.is_tensor(net2._moving_normalizer) and float(net2._moving_normalizer) == 12.5
+  net0.engine = _Engine()
+  assert 'moving_normalizer' not in net0.get_optimizer_state()
 
 
 def test_var_freeze_expr_in_the_arena_and_in_the_oracle():
