@@ -25,11 +25,9 @@ class EfficientDetNet(object):
     config = config or hparams_config.get_efficientdet_config(model_name)
     if 'object_detection' not in config.heads or len(config.heads) != 1:
       raise ValueError('No valid head found: {}'.format(config.heads))
-    if getattr(config, 'survival_prob', None):
-      # efficientdet_keras.py:434-436 / :612-614: stochastic depth with residual connections inside the class / box
-      # towers; no d0..d7x configuration sets it (the backbone's own survival_prob 0.8 is independent of this key)
-      raise ValueError('config.survival_prob=%r (stochastic depth in the class/box towers) is not built' %
-                       config.survival_prob)
+    # (config.survival_prob -- efficientdet_keras.py:434-436 / :612-614: residual connections with stochastic depth inside
+    # the class / box towers; no d0..d7x configuration sets it, the backbone's own survival_prob 0.8 is independent of this
+    # key -- is built since r04: Engine._head_level)
     self.config = config
     self.name = name
     self._dtype, self._device, self._seed = dtype, device, seed

@@ -1136,12 +1136,21 @@ class Engine(object):
     c = self.config
     wf = c.fpn_num_filters
     x = feat
+    sp = getattr(c, 'survival_prob', None)
     for i in range(c.box_class_repeats):
       s = '%s/%s-%d' % (net, prefix, i)
       key = '%s:l%d' % (s, level)
       d = self.dw(key + ':dw', x, s + '/depthwise_kernel', 3, 1)
-      x = self.pw(key + ':pw', d, s + '/pointwise_kernel', wf, bias=s + '/bias',
+      y = self.pw(key + ':pw', d, s + '/pointwise_kernel', wf, bias=s + '/bias',
                   bn='%s/%s-%d-bn-%d' % (net, prefix, i, level), act=self.act)
+      if sp:
+        # config.survival_prob (efficientdet_keras.py:434-436, 612-614): from the second tower layer on
+        # image = drop_connect(act(bn(conv(image)))) + image -- a residual connection in inference too, a per-image
+        # floor(p + u) / p scale on the branch in training (utils.py:329-344; own draws per layer, level and tower).  The
+        # residual operand is a stored tensor, so the first layer's activated output is materialised as well.
+        x = self.bn_res(key + ':out', y, x if i > 0 else None, survival_prob=sp if i > 0 else None)
+      else:
+        x = y
     s = '%s/%s-predict' % (net, prefix)
     key = '%s:l%d' % (s, level)
     if net == 'box_net' and self.logits_f32 and not self.training and self.dtype == EDET_BF16:

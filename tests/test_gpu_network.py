@@ -163,10 +163,12 @@ def test_training_forward_matches_oracle_bf16_layer_by_layer(case):
 
 FREEZE_CASE = ('efficientdet-d0', 'var_freeze_expr=(efficientnet|fpn_cells|resample_p6)', 128, 2)   # finetune the heads
 SMOOTH_CASE = ('efficientdet-d0', 'label_smoothing=0.1', 128, 2)     # FocalLoss(label_smoothing), train_lib.py:400-402
+# residual connections + stochastic depth inside the class / box towers (efficientdet_keras.py:434-436, 612-614)
+TOWER_SD_CASE = ('efficientdet-d0', 'survival_prob=0.8', 128, 4)
 
 
 @pytest.mark.parametrize('case', CASES[:2] + [('efficientdet-d1', '', 192, 2), CASES[3], ('efficientdet-d7x', '', 384, 2), CASES[4],
-                                               CASES[5], CASES[6], FREEZE_CASE, SMOOTH_CASE],
+                                               CASES[5], CASES[6], FREEZE_CASE, SMOOTH_CASE, TOWER_SD_CASE],
                          ids=lambda c: '%s[%s]@%d' % (c[0], c[1], c[2]))
 def test_train_step_matches_oracle_fp32(case):
   """loss values, clipped gradients of every variable, and the updated variables after one step."""
@@ -189,6 +191,11 @@ def test_train_step_matches_oracle_fp32(case):
   if 'd1' in model:
     scales = torch.stack(list(oracle.drop_scale.values()))
     assert scales.shape[0] == 16 and float(scales.max()) > 1.0, scales     # 1/p for the surviving images
+  if 'survival_prob' in override:
+    # two towers x five levels x (box_class_repeats - 1) residual layers, each with its own draws
+    assert len(oracle.drop_scale) == 2 * 5 * (config.box_class_repeats - 1), sorted(oracle.drop_scale)
+    scales = torch.stack(list(oracle.drop_scale.values()))
+    assert float(scales.max()) > 1.0 and float(scales.min()) == 0.0, scales     # some images dropped, some kept
   tl = {k: torch.from_numpy(v) for k, v in labels.items()}
   lr, decay = 0.02, 0.9
   ref_vals, ref_grads = orc.train_step(oracle, torch.from_numpy(images), tl, {}, lr, decay)
@@ -310,6 +317,30 @@ def test_train_step_bf16_tracks_the_oracle():
   cos = num / (np.sqrt(den_a * den_b) + 1e-30)
   print('bf16 gradient cosine vs the fp32 oracle: %.5f' % cos)
   assert cos >= 0.9, cos
+
+
+def test_tower_residuals_in_the_inference_forward():
+  """config.survival_prob also changes the INFERENCE network: from the second tower layer on the layer's output is added
+  to its input (drop_connect is the identity outside training, efficientdet_keras.py:434-436)."""
+  config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  config.override('survival_prob=0.8')
+  vals = perturbed_params(config, 3)
+  rng = np.random.default_rng(17)
+  images = rng.standard_normal((2, 128, 128, 3)).astype(np.float32)
+  net = efficientdet_net.EfficientDetNet(config=config, dtype='f32', params=vals)
+  cls, box = net(torch.from_numpy(images), training=False)
+  torch.cuda.synchronize()
+  oracle = orc.Oracle(config=config, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
+  with torch.no_grad():
+    cls_ref, box_ref = oracle.forward(torch.from_numpy(images), False)
+    config2 = hparams_config.get_efficientdet_config('efficientdet-d0')
+    plain = orc.Oracle(config=config2, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
+    cls_plain, _ = plain.forward(torch.from_numpy(images), False)
+  assert not net.engine.drop_masks
+  for c, cr, b, br in zip(cls, cls_ref, box, box_ref):
+    assert rel_err(c, cr) <= TOL_F32 and rel_err(b, br) <= TOL_F32, (rel_err(c, cr), rel_err(b, br))
+  # (and it IS another network than the one without the residuals: well above the parity tolerance on every level)
+  assert min(rel_err(cr, cp) for cr, cp in zip(cls_ref, cls_plain)) > 3 * TOL_F32
 
 
 def test_moving_normalizer_eager_graph_and_restored_state_agree():
