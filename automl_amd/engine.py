@@ -1042,6 +1042,12 @@ class Engine(object):
       f = feats[-1]
       th, tw = (f.raw.h + 1) // 2, (f.raw.w + 1) // 2
       s = 'resample_p%d' % level
+      if f.raw.c != wf and getattr(c, 'conv_after_downsample', False):
+        # ResampleFeatureMap with conv_after_downsample (efficientdet_keras.py:316-324): the 1x1 convolution (+ BN) runs on
+        # the POOLED map -- a quarter of the rows -- instead of before the pool
+        pooled = self.fuse(s + ':pool', [f], [RS_POOL], [], th, tw, act=ACT_NONE)
+        feats.append(self.pw(s, pooled, s + '/conv2d/kernel', wf, bias=s + '/conv2d/bias', bn=s + '/bn'))
+        continue
       if f.raw.c != wf:
         f = self.pw(s, f, s + '/conv2d/kernel', wf, bias=s + '/conv2d/bias', bn=s + '/bn')
       feats.append(self.fuse(s + ':pool', [f], [RS_POOL], [], th, tw, act=ACT_NONE))
@@ -1101,6 +1107,9 @@ class Engine(object):
       for i, off in enumerate(node['inputs_offsets']):
         f = feats[off]
         if f.raw.c != wf:
+          if getattr(c, 'conv_after_downsample', False) and f.raw.h > th and f.raw.w > tw:
+            # (no BiFPN of fpn_configs.py feeds a node a wider AND larger map; the extra levels P6.. are handled above)
+            raise ValueError('conv_after_downsample inside a BiFPN node is not built')
           rs = '%s/resample_%d_%d_%d' % (scope, i, off, len(feats))
           f = self.pw(rs, f, rs + '/conv2d/kernel', wf, bias=rs + '/conv2d/bias', bn=rs + '/bn')
         fh, fw = f.raw.h, f.raw.w

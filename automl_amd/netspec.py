@@ -38,8 +38,7 @@ class NetSpec(object):
     if c.act_type not in codes:
       raise ValueError('Unsupported act_type {}'.format(c.act_type))
     self.act_code = codes[c.act_type]
-    if not c.separable_conv or c.conv_bn_act_pattern or c.conv_after_downsample or \
-        not c.apply_bn_for_resampling:
+    if not c.separable_conv or c.conv_bn_act_pattern or not c.apply_bn_for_resampling:
       raise ValueError('only the default separable_conv / conv-bn ordering of the d0..d7x configs is built')
     self.stem_filters, self.blocks = eb.backbone_blocks(
         c.backbone_name, c.backbone_config.blocks if c.backbone_config is not None else None)
