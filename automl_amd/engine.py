@@ -621,7 +621,7 @@ class Engine(object):
     return epi, fused
 
   # ------------------------------------------------------------------ layers
-  def pw(self, key, vin, wname, cout, bias=None, bn=None, act=ACT_NONE, ld=None, f32out=False):
+  def pw(self, key, vin, wname, cout, bias=None, bn=None, act=ACT_NONE, ld=None, f32out=False, bias_grad=False):
     """1x1 conv (+bias) [-> BN -> act as a view].  f32out (inference, bf16 storage): the output is stored as fp32 --
     the class / box logits, whose bf16 rounding alone is 3e-3 of their range (Engine.logits_f32)."""
     r = vin.raw
@@ -646,7 +646,24 @@ class Engine(object):
     vin.consumers += 1
     if self.training:
       self.tape.append(lambda: self._pw_bwd(vin, vout, wname, w, ldn, bias is None))
+      if bias_grad and bias and bnl is None:
+        self.tape.append(lambda: self._bias_grad(vout, bias))      # (replayed BEFORE _pw_bwd: the gradient is complete by then)
     return vout
+
+  def _bias_grad(self, vout, bias):
+    """d(bias) += column sums of the output gradient, for a biased convolution with NO BatchNorm behind it that is not a
+    predict layer (those get theirs from the loss kernels; behind a BatchNorm the gradient is analytically zero): the
+    resample convolutions under apply_bn_for_resampling=False.  The BatchNorm-backward pair with mean 0 / rstd 1 / gamma 1:
+    its dbeta is exactly that sum."""
+    r = vout.raw
+    ones = self.buf('ones:c:%d' % r.c, (r.c,), torch.float32)
+    ones.fill_(1.0)
+    zeros = self.zbuf('zeros:c:%d' % r.c, (r.c,))
+    scr = self.buf('biasgrad:scr:%d' % r.c, (3, r.c), torch.float32)
+    call('edet_bn_bwd_reduce', ptr(r.grad), ptr(r.data), r.rows, r.c, r.ld, ptr(zeros), ptr(ones), ptr(self.partials),
+         ctypes.byref(self._nparts), self.dtype, self.stream)
+    call('edet_bn_bwd_finalize', ptr(self.partials), self._nparts.value, r.c, float(r.rows), ptr(ones), ptr(zeros),
+         ptr(ones), None, ptr(self.grad(bias)), None, ptr(scr[0]), ptr(scr[1]), ptr(scr[2]), self.stream)
 
   def _pw_bwd(self, vin, vout, wname, w, ldn, no_bias=False):
     g = self._gview(vout)
@@ -1046,10 +1063,10 @@ class Engine(object):
         # ResampleFeatureMap with conv_after_downsample (efficientdet_keras.py:316-324): the 1x1 convolution (+ BN) runs on
         # the POOLED map -- a quarter of the rows -- instead of before the pool
         pooled = self.fuse(s + ':pool', [f], [RS_POOL], [], th, tw, act=ACT_NONE)
-        feats.append(self.pw(s, pooled, s + '/conv2d/kernel', wf, bias=s + '/conv2d/bias', bn=s + '/bn'))
+        feats.append(self.pw(s, pooled, s + '/conv2d/kernel', wf, bias=s + '/conv2d/bias', bn=(s + '/bn') if c.apply_bn_for_resampling else None, bias_grad=True))
         continue
       if f.raw.c != wf:
-        f = self.pw(s, f, s + '/conv2d/kernel', wf, bias=s + '/conv2d/bias', bn=s + '/bn')
+        f = self.pw(s, f, s + '/conv2d/kernel', wf, bias=s + '/conv2d/bias', bn=(s + '/bn') if c.apply_bn_for_resampling else None, bias_grad=True)
       feats.append(self.fuse(s + ':pool', [f], [RS_POOL], [], th, tw, act=ACT_NONE))
     # ---- BiFPN
     for rep in range(c.fpn_cell_repeats):
@@ -1111,7 +1128,7 @@ class Engine(object):
             # (no BiFPN of fpn_configs.py feeds a node a wider AND larger map; the extra levels P6.. are handled above)
             raise ValueError('conv_after_downsample inside a BiFPN node is not built')
           rs = '%s/resample_%d_%d_%d' % (scope, i, off, len(feats))
-          f = self.pw(rs, f, rs + '/conv2d/kernel', wf, bias=rs + '/conv2d/bias', bn=rs + '/bn')
+          f = self.pw(rs, f, rs + '/conv2d/kernel', wf, bias=rs + '/conv2d/bias', bn=(rs + '/bn') if c.apply_bn_for_resampling else None, bias_grad=True)
         fh, fw = f.raw.h, f.raw.w
         if fh > th and fw > tw:
           if (fh - 1) // th + 1 != 2 or (fw - 1) // tw + 1 != 2:

@@ -38,7 +38,7 @@ class NetSpec(object):
     if c.act_type not in codes:
       raise ValueError('Unsupported act_type {}'.format(c.act_type))
     self.act_code = codes[c.act_type]
-    if not c.separable_conv or c.conv_bn_act_pattern or not c.apply_bn_for_resampling:
+    if not c.separable_conv or c.conv_bn_act_pattern:
       raise ValueError('only the default separable_conv / conv-bn ordering of the d0..d7x configs is built')
     self.stem_filters, self.blocks = eb.backbone_blocks(
         c.backbone_name, c.backbone_config.blocks if c.backbone_config is not None else None)
@@ -103,7 +103,8 @@ class NetSpec(object):
         s = 'resample_p%d' % level
         self._add(s + '/conv2d/kernel', (1, 1, level_ch[-1], wf), 'glorot')
         self._add(s + '/conv2d/bias', (wf,), 'zeros')
-        self._bn(s + '/bn', wf)
+        if c.apply_bn_for_resampling:      # ResampleFeatureMap creates its BatchNorm only then (efficientdet_keras.py:290-296)
+          self._bn(s + '/bn', wf)
       level_ch.append(wf)
     self.level_channels = level_ch
     num_levels = c.max_level - c.min_level + 1
@@ -116,7 +117,8 @@ class NetSpec(object):
             rs = '%s/resample_%d_%d_%d' % (s, i, off, len(ch))
             self._add(rs + '/conv2d/kernel', (1, 1, ch[off], wf), 'glorot')
             self._add(rs + '/conv2d/bias', (wf,), 'zeros')
-            self._bn(rs + '/bn', wf)
+            if c.apply_bn_for_resampling:
+              self._bn(rs + '/bn', wf)
         if self.fpn.weight_method != 'sum':
           # one scalar per input, or one weight per channel for the channel_* methods
           # (efficientdet_keras.py:123-127,142-151)

@@ -167,10 +167,11 @@ SMOOTH_CASE = ('efficientdet-d0', 'label_smoothing=0.1', 128, 2)     # FocalLoss
 TOWER_SD_CASE = ('efficientdet-d0', 'survival_prob=0.8', 128, 4)
 # ResampleFeatureMap with the 1x1 convolution after the pool (efficientdet_keras.py:316-324): P6 from the pooled C5
 CONV_AFTER_CASE = ('efficientdet-d0', 'conv_after_downsample=True', 128, 2)
+NO_RS_BN_CASE = ('efficientdet-d0', 'apply_bn_for_resampling=False', 128, 2)      # the resample convolutions without BatchNorm
 
 
 @pytest.mark.parametrize('case', CASES[:2] + [('efficientdet-d1', '', 192, 2), CASES[3], ('efficientdet-d7x', '', 384, 2), CASES[4],
-                                               CASES[5], CASES[6], FREEZE_CASE, SMOOTH_CASE, TOWER_SD_CASE, CONV_AFTER_CASE],
+                                               CASES[5], CASES[6], FREEZE_CASE, SMOOTH_CASE, TOWER_SD_CASE, CONV_AFTER_CASE, NO_RS_BN_CASE],
                          ids=lambda c: '%s[%s]@%d' % (c[0], c[1], c[2]))
 def test_train_step_matches_oracle_fp32(case):
   """loss values, clipped gradients of every variable, and the updated variables after one step."""
