@@ -228,6 +228,20 @@ __device__ __forceinline__ void grad_load(const edet_gview_t& g, const GradCoef&
   }
 }
 
+// ---------------------------------------------------------------- ordered (run-to-run identical) sums
+// Sum of v[] over the lanes of a wave that share lane % group (group: a power of two <= 64), by an xor butterfly:
+// a fixed tree, so the same bits on every run; afterwards every lane of a class holds the class total.  All 64 lanes
+// must be active at the call.  Used by the fp32 / generic kernels instead of LDS atomics; the waves of a workgroup then
+// add their totals into LDS one wave after the other (wave order), and workgroups hand partial rows to
+// edet_reduce_partials -- no floating-point atomics anywhere on the way.
+template <int NV>
+__device__ __forceinline__ void wave_group_sum(float (&v)[NV], int group) {
+  for (int off = group; off < 64; off <<= 1) {
+#pragma unroll
+    for (int e = 0; e < NV; ++e) v[e] += __shfl_xor(v[e], off, 64);
+  }
+}
+
 // TF 'SAME' geometry
 __host__ __device__ inline int same_out(int in, int s) { return (in + s - 1) / s; }
 __host__ __device__ inline int same_pad_before(int in, int k, int s) {

@@ -30,8 +30,8 @@ struct ConvArgs {
 constexpr int DTHREADS = 256;
 
 // thread -> (pixel p = tid / ncv, channel quad cv = tid % ncv); workgroup = DTHREADS / ncv pixels per step,
-// marching over the pixels of its slice; per-channel sums of the rounded stored values are reduced through
-// LDS atomics into one partial row per workgroup.
+// marching over the pixels of its slice; per-channel sums of the rounded stored values are added through LDS, pixel
+// lane after pixel lane, into one partial row per workgroup.
 template <typename T>
 __global__ __launch_bounds__(DTHREADS) void k_conv_direct(const ConvArgs a) {
   extern __shared__ float red[];      // [2][cout]
@@ -87,15 +87,19 @@ __global__ __launch_bounds__(DTHREADS) void k_conv_direct(const ConvArgs a) {
     }
   }
   if (want_stats) {
-    if (pl < ppw) {
+    // the ppw pixel lanes of a channel quad add their sums one after the other (a fixed order, no LDS atomics: the same
+    // partial row on every run)
+    for (int pv = 0; pv < ppw; ++pv) {
+      if (pl == pv) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (co + e < a.cout) {
-          atomicAdd(&red[co + e], s1[e]);
-          atomicAdd(&red[a.cout + co + e], s2[e]);
-        }
+        for (int e = 0; e < 4; ++e)
+          if (co + e < a.cout) {
+            red[co + e] += s1[e];
+            red[a.cout + co + e] += s2[e];
+          }
+      }
+      __syncthreads();
     }
-    __syncthreads();
     for (int i = threadIdx.x; i < 2 * a.cout; i += DTHREADS)
       a.stat_partials[(size_t)blockIdx.x * 2 * a.cout + i] = red[i];
   }

@@ -28,6 +28,7 @@ struct DwArgs {
   float* stat_partials;
   edet_bwd_epi_t epi;  // dgrad
   float* dweight;      // wgrad
+  float* ws;           // wgrad with P > 1 workgroup slots: partial rows [P][K*K][C]
 };
 
 __device__ __forceinline__ void decode_tile(const DwArgs& a, int sp, int& n, int& ty0, int& tx0) {
@@ -132,15 +133,21 @@ __global__ __launch_bounds__(THREADS) void k_dw_fwd(const DwArgs a) {
     }
   }
   if (want_stats) {
+    // the THREADS / nquad threads of a channel quad: xor butterfly inside the wave, then the waves one after the other
+    // (a fixed order, no LDS atomics: the same partial row on every run)
+    wave_group_sum(s1, nquad);
+    wave_group_sum(s2, nquad);
     __syncthreads();
-    if (q_ok) {
+    for (int wv = 0; wv < THREADS / 64; ++wv) {
+      if ((tid >> 6) == wv && (tid & 63) < nquad && q_ok) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        atomicAdd(&red[quad * 4 + e], s1[e]);
-        atomicAdd(&red[a.cc + quad * 4 + e], s2[e]);
+        for (int e = 0; e < 4; ++e) {
+          red[quad * 4 + e] += s1[e];
+          red[a.cc + quad * 4 + e] += s2[e];
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
     for (int i = tid; i < 2 * a.cc; i += THREADS) {
       const int which = i / a.cc, cl = i - which * a.cc;
       if (c0 + cl < C) a.stat_partials[((size_t)p * 2 + which) * C + c0 + cl] = red[i];
@@ -270,15 +277,21 @@ __global__ __launch_bounds__(THREADS) void k_dw_bwd_data(const DwArgs a) {
     }
   }
   if (want_stats) {
+    // the THREADS / nquad threads of a channel quad: xor butterfly inside the wave, then the waves one after the other
+    // (a fixed order, no LDS atomics: the same partial row on every run)
+    wave_group_sum(s1, nquad);
+    wave_group_sum(s2, nquad);
     __syncthreads();
-    if (q_ok) {
+    for (int wv = 0; wv < THREADS / 64; ++wv) {
+      if ((tid >> 6) == wv && (tid & 63) < nquad && q_ok) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        atomicAdd(&red[quad * 4 + e], s1[e]);
-        atomicAdd(&red[a.cc + quad * 4 + e], s2[e]);
+        for (int e = 0; e < 4; ++e) {
+          red[quad * 4 + e] += s1[e];
+          red[a.cc + quad * 4 + e] += s2[e];
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
     for (int i = tid; i < 2 * a.cc; i += THREADS) {
       const int which = i / a.cc, cl = i - which * a.cc;
       if (c0 + cl < C) a.epi.stat_partials[((size_t)p * 2 + which) * C + c0 + cl] = red[i];
@@ -380,17 +393,27 @@ __global__ __launch_bounds__(THREADS) void k_dw_bwd_weight(const DwArgs a) {
       }
     }
   }
+  // the threads of a channel quad: xor butterfly inside the wave, the waves one after the other, then ONE writer per
+  // element -- this workgroup slot's partial row in the workspace (edet_reduce_partials adds the rows in order) or, with
+  // a single slot, dW itself.  No atomics: the same gradient on every run.
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) wave_group_sum(wacc[t], nquad);
   __syncthreads();
-  if (q_ok) {
+  for (int wv = 0; wv < THREADS / 64; ++wv) {
+    if ((tid >> 6) == wv && (tid & 63) < nquad && q_ok) {
 #pragma unroll
-    for (int t = 0; t < K * K; ++t)
+      for (int t = 0; t < K * K; ++t)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(&red[t * a.cc + quad * 4 + e], wacc[t][e]);
+        for (int e = 0; e < 4; ++e) red[t * a.cc + quad * 4 + e] += wacc[t][e];
+    }
+    __syncthreads();
   }
-  __syncthreads();
   for (int i = tid; i < K * K * a.cc; i += THREADS) {
     const int t = i / a.cc, cl = i - t * a.cc;
-    if (c0 + cl < C) atomicAdd(&a.dweight[(size_t)t * C + c0 + cl], red[i]);
+    if (c0 + cl < C) {
+      if (a.ws) a.ws[((size_t)p * K * K + t) * C + c0 + cl] = red[i];
+      else a.dweight[(size_t)t * C + c0 + cl] += red[i];
+    }
   }
 }
 
@@ -445,7 +468,8 @@ int dispatch(int which, int k, int s, const DwArgs& a, size_t ldsb, hipStream_t 
   return 0;
 }
 
-int run(int which, int k, int s, DwArgs& a, int dtype, void* stream, int* nparts_out) {
+int run(int which, int k, int s, DwArgs& a, int dtype, void* stream, int* nparts_out, void* workspace = nullptr,
+        size_t workspace_bytes = 0) {
   const edet_tview_t& in = a.in;
   EDET_CHECK(in.c % 8 == 0 && in.ld % 8 == 0, "depthwise conv: c (%d) and ld (%d) must be multiples of 8", in.c, in.ld);
   a.oh = same_out(in.h, s);
@@ -455,10 +479,22 @@ int run(int which, int k, int s, DwArgs& a, int dtype, void* stream, int* nparts
   const bool over_input = which == DW_BWD_DATA;
   const size_t ldsb = plan(a, which, k, s, in.n, over_input ? in.h : a.oh, over_input ? in.w : a.ow, in.c);
   EDET_CHECK(ldsb <= 64 * 1024, "depthwise conv: LDS plan too large (%zu bytes)", ldsb);
+  if (which == DW_BWD_WEIGHT) {
+    // the workgroup slots hand their partial sums over through the workspace; without one (or with one too small for
+    // two rows) a single slot per channel chunk adds into dW directly -- slower, the same fixed summation order
+    const size_t row_bytes = (size_t)k * k * in.c * sizeof(float);
+    const size_t ws_rows = workspace ? workspace_bytes / row_bytes : 0;
+    if ((size_t)a.P > ws_rows) a.P = ws_rows >= 2 ? (int)ws_rows : 1;
+    a.ws = a.P > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
+  }
   if (nparts_out) *nparts_out = a.P;
-  if (dtype == EDET_BF16) return dispatch<bf16_t>(which, k, s, a, ldsb, to_stream(stream));
-  if (dtype == EDET_F32) return dispatch<float>(which, k, s, a, ldsb, to_stream(stream));
-  EDET_CHECK(false, "depthwise conv: bad dtype %d", dtype);
+  int rc;
+  if (dtype == EDET_BF16) rc = dispatch<bf16_t>(which, k, s, a, ldsb, to_stream(stream));
+  else if (dtype == EDET_F32) rc = dispatch<float>(which, k, s, a, ldsb, to_stream(stream));
+  else EDET_CHECK(false, "depthwise conv: bad dtype %d", dtype);
+  if (rc == 0 && which == DW_BWD_WEIGHT && a.ws &&
+      edet_reduce_partials(a.ws, a.P, (int64_t)k * k * in.c, a.dweight, to_stream(stream)) != 0) return -2;
+  return rc;
 }
 
 }  // namespace
@@ -519,7 +555,7 @@ extern "C" int edet_dw_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy
     const int rc = dwm_try_wgrad(in, dy, k, stride, dweight, workspace, workspace_bytes, to_stream(stream));
     if (rc != 0) return rc < 0 ? rc : 0;
   }
-  return run(DW_BWD_WEIGHT, k, stride, a, dtype, stream, nullptr);
+  return run(DW_BWD_WEIGHT, k, stride, a, dtype, stream, nullptr, workspace, workspace_bytes);
 }
 
 // Data gradient and weight gradient of one depthwise layer.  Stride 1, bf16: one fused kernel (dw_march.hip,

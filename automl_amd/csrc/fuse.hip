@@ -134,7 +134,11 @@ __device__ __forceinline__ void sample_input(const FuseArgs& a, int i, const Vie
   }
 }
 
-template <typename T, bool BWD>
+// PCDW (backward, one fusion weight per channel, dwn wanted): thread = (8-channel chunk, pixel slice) for the whole
+// kernel, so its dwn sums stay in registers; the slices are added through LDS in slice order and the workgroup's sums go
+// to its partial row (edet_reduce_partials adds the rows in order) or, for a single workgroup, into dwn -- no atomics,
+// the same gradient on every run.
+template <typename T, bool BWD, bool PCDW = false>
 __global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restrict__ out,
                                                  const T* __restrict__ dout, T* __restrict__ ds,
                                                  float* dwn, unsigned char* __restrict__ pool_argmax,
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restric
   const int nvec = a.c / 8;
   const int64_t total = (int64_t)a.n * a.oh * a.ow * nvec;
   const bool per_ch = a.wc > 1;                      // channel_attn / channel_fastattn: one weight per channel
-  extern __shared__ float redc[];                    // per_ch && BWD: [3][c] dwn sums of this workgroup
+  extern __shared__ float redc[];                    // PCDW: [slices][nin][c] dwn sums of this workgroup's pixel slices
   float wn[3] = {0.f, 0.f, 0.f};
   if (!BWD && !per_ch && a.wn_out) {
     float w[3] = {0.f, 0.f, 0.f};
@@ -154,12 +158,19 @@ __global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restric
     for (int i = 0; i < a.nin; ++i) wn[i] = a.wn[i];
   }
   float dw_acc[3] = {0.f, 0.f, 0.f};
-  if (BWD && per_ch && dwn) {
-    for (int i = threadIdx.x; i < 3 * a.c; i += THREADS) redc[i] = 0.f;
-    __syncthreads();
+  float dwc[PCDW ? 3 : 1][8];
+  int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, qstride = (int64_t)gridDim.x * blockDim.x;
+  const int slices = PCDW ? THREADS / nvec : 1;      // (host: c <= 8 * THREADS)
+  if (PCDW) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dwc[PCDW ? i : 0][e] = 0.f;
+    const int chunk = threadIdx.x % nvec, slice = threadIdx.x / nvec;
+    q0 = slice < slices ? ((int64_t)blockIdx.x * slices + slice) * nvec + chunk : total;
+    qstride = (int64_t)gridDim.x * slices * nvec;
   }
-  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
-       q += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t q = q0; q < total; q += qstride) {
     const int c0 = (int)(q % nvec) * 8;
     int64_t pix = q / nvec;
     const int ox = (int)(pix % a.ow);
@@ -243,9 +254,9 @@ __global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restric
       }
       for (int i = 0; i < a.nin; ++i) {
         if (per_ch) {
-          if (dwn) {
+          if (PCDW) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(&redc[i * a.c + c0 + e], d[e] * xi[i][e]);
+            for (int e = 0; e < 8; ++e) dwc[PCDW ? i : 0][e] = fmaf(d[e], xi[i][e], dwc[PCDW ? i : 0][e]);
           }
         } else {
 #pragma unroll
@@ -254,13 +265,24 @@ __global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restric
       }
     }
   }
-  if (BWD && dwn && per_ch) {
+  if (PCDW) {
+    const int chunk = threadIdx.x % nvec, slice = threadIdx.x / nvec;
+    if (slice < slices) {
+      for (int i = 0; i < a.nin; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) redc[((size_t)slice * a.nin + i) * a.c + chunk * 8 + e] = dwc[PCDW ? i : 0][e];
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < a.nin * a.c; i += THREADS) atomicAdd(&dwn[i], redc[i]);   // dwn [3][wc], wc == c
-  } else if (BWD && dwn) {
+    for (int i = threadIdx.x; i < a.nin * a.c; i += THREADS) {   // dwn [nin][wc], wc == c
+      float t = 0.f;
+      for (int sl = 0; sl < slices; ++sl) t += redc[(size_t)sl * a.nin * a.c + i];
+      if (dwn_parts) dwn_parts[(size_t)blockIdx.x * a.nin * a.c + i] = t;
+      else dwn[i] += t;
+    }
+  } else if (BWD && dwn && !per_ch) {
     // scalar fusion weights: wave shuffles, then the waves in order (r04: no LDS atomics); with a partial buffer the
     // workgroup's three sums go to its row there and k_fuse_dwn_finish adds the rows in order -- the same gradient on
-    // every run -- without one they are added into dwn with global atomics as before
+    // every run -- without one the kernel is launched as ONE workgroup, which adds its sums into dwn
     __shared__ float red[THREADS / 64][4];
     for (int i = 0; i < a.nin; ++i) {
       float v = dw_acc[i];
@@ -274,7 +296,7 @@ __global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restric
       if (threadIdx.x < a.nin)
         for (int w = 0; w < THREADS / 64; ++w) t += red[w][threadIdx.x];
       if (dwn_parts) dwn_parts[(size_t)blockIdx.x * 4 + threadIdx.x] = t;
-      else if (threadIdx.x < a.nin) atomicAdd(&dwn[threadIdx.x], t);
+      else if (threadIdx.x < a.nin) dwn[threadIdx.x] += t;       // (no partial buffer: launched as ONE workgroup)
     }
   }
 }
@@ -574,10 +596,23 @@ extern "C" int edet_fuse_bwd_pre(const edet_tview_t* in0, const edet_tview_t* in
     a.gbeta[i] = (gin && gbeta) ? gbeta[i] : 0;
     EDET_CHECK(!a.gin[i] || modes[i] == EDET_RS_IDENTITY, "edet_fuse_bwd_pre: gin[%d] given for a resampled input", i);
   }
-  const size_t lds = wc > 1 ? (size_t)3 * a.c * sizeof(float) : 0;
-  const int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8), dtype == EDET_BF16 ? reinterpret_cast<const void*>(&k_fuse<bf16_t, true>) : nullptr, lds);
-  // scalar fusion weights: ordered partial rows [grid][4] through the workspace (else: atomic adds into dwn)
-  float* parts = (dwn && wc == 1 && workspace && workspace_bytes >= (size_t)grid * 4 * sizeof(float)) ? reinterpret_cast<float*>(workspace) : nullptr;
+  const bool pcdw = wc > 1 && dwn;
+  EDET_CHECK(!pcdw || a.c <= 8 * THREADS, "edet_fuse_bwd_pre: per-channel fusion weights need c <= %d", 8 * THREADS);
+  const size_t lds = pcdw ? (size_t)(THREADS / (a.c / 8)) * nin * a.c * sizeof(float) : 0;
+  int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8), dtype == EDET_BF16 ? (pcdw ? reinterpret_cast<const void*>(&k_fuse<bf16_t, true, true>) : reinterpret_cast<const void*>(&k_fuse<bf16_t, true>)) : nullptr, lds);
+  // ordered partial rows through the workspace -- [grid][4] for scalar fusion weights, [grid][nin * c] for per-channel ones;
+  // without a workspace that holds them ONE workgroup adds its sums into dwn (no atomics either way)
+  const size_t row = pcdw ? (size_t)nin * a.c : 4;
+  float* parts = (dwn && workspace && workspace_bytes >= (size_t)grid * row * sizeof(float)) ? reinterpret_cast<float*>(workspace) : nullptr;
+  if (dwn && !parts) grid = 1;
+  if (pcdw) {
+    if (dtype == EDET_BF16) edet_launch(k_fuse<bf16_t, true, true>, grid, dim3(THREADS), lds, to_stream(stream), a, nullptr, (const bf16_t*)dout, (bf16_t*)ds, dwn, (unsigned char*)pool_argmax, parts);
+    else if (dtype == EDET_F32) edet_launch(k_fuse<float, true, true>, grid, dim3(THREADS), lds, to_stream(stream), a, nullptr, (const float*)dout, (float*)ds, dwn, (unsigned char*)pool_argmax, parts);
+    else EDET_CHECK(false, "edet_fuse_bwd_pre: bad dtype %d", dtype);
+    EDET_LAUNCH_CHECK("edet_fuse_bwd_pre");
+    if (parts && edet_reduce_partials(parts, grid, (int64_t)nin * a.c, dwn, to_stream(stream)) != 0) return -2;
+    return 0;
+  }
   if (dtype == EDET_BF16) edet_launch(k_fuse<bf16_t, true>, grid, dim3(THREADS), lds, to_stream(stream), a, nullptr, (const bf16_t*)dout, (bf16_t*)ds, dwn, (unsigned char*)pool_argmax, parts);
   else if (dtype == EDET_F32) edet_launch(k_fuse<float, true>, grid, dim3(THREADS), lds, to_stream(stream), a, nullptr, (const float*)dout, (float*)ds, dwn, (unsigned char*)pool_argmax, parts);
   else EDET_CHECK(false, "edet_fuse_bwd_pre: bad dtype %d", dtype);

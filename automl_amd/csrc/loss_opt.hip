@@ -31,7 +31,7 @@ inline RowMap row_map_ld(int ld) {
 // Tail of the two loss kernels: the workgroup's loss sum and its per-channel bias-gradient sums.  r04: combined in a fixed
 // order (wave shuffles, waves in order, row-lanes in order through LDS -- no LDS atomics); with a partial buffer the
 // workgroup writes its row [nch | 1] there and edet_reduce_partials2 adds the rows in order (the same loss and bias gradient on
-// every run), without one it adds into the destinations with global atomics as before.
+// every run); without one the kernel is launched as ONE workgroup, which adds into the destinations itself -- no atomics.
 // LDS: scr[THREADS * 8] floats (dynamic).
 __device__ __forceinline__ void loss_tail(float loss_acc, const float (&db)[8], bool ok, int nch, const RowMap& m, float* scr,
                                           float* part, float* sum_dst, float* dbias) {
@@ -49,13 +49,13 @@ __device__ __forceinline__ void loss_tail(float loss_acc, const float (&db)[8], 
   if (tid == 0) {
     float t = 0.f;
     for (int w = 0; w < THREADS / 64; ++w) t += wsum[w];
-    if (row) row[nch] = t; else atomicAdd(sum_dst, t);
+    if (row) row[nch] = t; else *sum_dst += t;          // (no partial buffer: the kernel runs as ONE workgroup)
   }
   if (dbias || row) {
     for (int i = tid; i < nch; i += THREADS) {
       float t = 0.f;
       for (int r = 0; r < m.rpp; ++r) t += scr[r * width + i];
-      if (row) row[i] = t; else atomicAdd(&dbias[i], t);
+      if (row) row[i] = t; else dbias[i] += t;
     }
   }
 }
@@ -432,9 +432,10 @@ extern "C" int edet_focal_loss_smooth(const void* logits, int ld, const int32_t*
     if (g > cap) g = cap;
   }
   if (g < 1) g = 1;
-  // ordered partial rows [g][1 + nch] when the workspace holds them (else: global atomics)
+  // ordered partial rows [g][1 + nch] when the workspace holds them (else: one workgroup)
   const int nch_ = num_anchors * num_classes;
   float* part = (workspace && workspace_bytes >= (size_t)g * (1 + nch_) * sizeof(float)) ? reinterpret_cast<float*>(workspace) : nullptr;
+  if (!part) g = 1;
 #define FOCAL_LAUNCH(T, G)                                                                            \
   edet_launch(k_focal<T, G>, dim3((int)g), dim3(THREADS), lds, to_stream(stream), (const T*)logits, ld, cls_targets, positions, \
       num_anchors, num_classes, alpha, gamma, inv_normalizer, norm_scale_dev, (T*)dlogits, dbias, sums, part, m)
@@ -481,6 +482,7 @@ extern "C" int edet_box_loss(const void* box_out, int ld, const float* box_targe
   if (g < 1) g = 1;
   const size_t lds = (size_t)THREADS * 8 * sizeof(float);
   float* part = (workspace && workspace_bytes >= (size_t)g * (1 + nch) * sizeof(float)) ? reinterpret_cast<float*>(workspace) : nullptr;
+  if (!part) g = 1;
   if (dtype == EDET_BF16)
     edet_launch(k_box<bf16_t>, dim3((int)g), dim3(THREADS), lds, to_stream(stream), (const bf16_t*)box_out, ld, box_targets, positions, nch, delta, inv_normalizer, grad_scale, norm_scale_dev, (bf16_t*)dbox, dbias, sums, part, m);
   else if (dtype == EDET_F32)

@@ -124,43 +124,22 @@ __global__ __launch_bounds__(THREADS) void k_gemm(const GemmArgs a) {
   T* Bs = As + BM * LDA;
   float* Cs = reinterpret_cast<float*>(smem);
   float* red = reinterpret_cast<float*>(smem + C::TILE_BYTES);  // [2][Jp] stat sums
-  float* gs = red + 2 * a.Jp;                                   // [2][Jp] dgate sums (bwd + gate)
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const bool want_stats = a.stat_partials != nullptr;
   const bool want_gate = BWD && a.epi.dgate != nullptr;
 
   for (int i = tid; i < 2 * a.Jp; i += THREADS) red[i] = 0.f;
-  if (want_gate)
-    for (int i = tid; i < 2 * a.Jp; i += THREADS) gs[i] = 0.f;
   __syncthreads();
 
   const int ntn = (a.J + BN - 1) / BN;
   const int ntm = (a.M + BM - 1) / BM;
   const int mt0 = blockIdx.x * a.tiles_per_wg;
   const int mt1 = min(ntm, mt0 + a.tiles_per_wg);
-  int cur_img = -1;
 
   const T* Bm = reinterpret_cast<const T*>(a.Bm);
 
   for (int mt = mt0; mt < mt1; ++mt) {
-    if (want_gate) {
-      const int first_img = (int)(((int64_t)mt * BM) / a.hw);
-      if (first_img != cur_img) {
-        if (cur_img >= 0) {
-          __syncthreads();
-          for (int i = tid; i < 2 * a.Jp; i += THREADS) {
-            const int slot = i / a.Jp, col = i - slot * a.Jp;
-            const float v = gs[i];
-            if (v != 0.f && col < a.J && cur_img + slot < a.tv.n)
-              atomicAdd(&a.epi.dgate[(size_t)(cur_img + slot) * a.J + col], v);
-            gs[i] = 0.f;
-          }
-          __syncthreads();
-        }
-        cur_img = first_img;
-      }
-    }
     // per-thread A staging geometry (fixed for the whole m-tile)
     int a_row[A_TASKS], a_kc[A_TASKS], a_img[A_TASKS];
     int64_t a_m[A_TASKS];
@@ -266,10 +245,9 @@ __global__ __launch_bounds__(THREADS) void k_gemm(const GemmArgs a) {
       const int cc = (tid % CH) * 8;
       const int j = nt * BN + cc;
       const bool col_ok = j < a.J;
-      float s1[8], s2[8], gp[8];
+      float s1[8], s2[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s1[e] = s2[e] = gp[e] = 0.f;
-      int my_img = -1;
+      for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
       float bias8[8], sc8[8], sh8[8], mean8[8], rstd8[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -285,19 +263,6 @@ __global__ __launch_bounds__(THREADS) void k_gemm(const GemmArgs a) {
           }
         }
       }
-      auto flush_gate = [&]() {
-        if (my_img < 0) return;
-        const int slot = my_img - cur_img;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          if (j + e < a.J && gp[e] != 0.f) {
-            if (slot >= 0 && slot < 2) atomicAdd(&gs[slot * a.Jp + j + e], gp[e]);
-            else atomicAdd(&a.epi.dgate[(size_t)my_img * a.J + j + e], gp[e]);
-          }
-          gp[e] = 0.f;
-        }
-      };
-
       for (int half = 0; half < 2; ++half) {
         if ((wave >> 1) == half) {
           const int wr = (wave & 1) * 32;
@@ -329,19 +294,14 @@ __global__ __launch_bounds__(THREADS) void k_gemm(const GemmArgs a) {
             } else {
               const size_t off = (size_t)m * a.tv.ld + j;
               float x[8];
-              const bool need_x = a.tv.act != EDET_ACT_NONE || want_gate || want_stats;
+              const bool need_x = (a.tv.act != EDET_ACT_NONE && !want_gate) || want_stats;
               if (need_x) load8<T>(reinterpret_cast<const T*>(a.tv.data) + off, x);
               float g[8];
               if (want_gate) {
-                const int img = (int)(m / a.hw);
-                if (img != my_img) { flush_gate(); my_img = img; }
+                // SE-gated input: the gradient of the gated VALUE is stored as it is (edet_se_gate_bwd takes it from
+                // there); the gate's own gradient sums come from k_gate_sums after this kernel, in a fixed order
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                  const float z = fmaf(x[e], sc8[e], sh8[e]);
-                  const float av = act_apply_(a.tv.act, z);
-                  gp[e] += v[e] * av;
-                  g[e] = v[e];
-                }
+                for (int e = 0; e < 8; ++e) g[e] = v[e];
               } else if (a.tv.act != EDET_ACT_NONE) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) g[e] = v[e] * act_grad_(a.tv.act, fmaf(x[e], sc8[e], sh8[e]));
@@ -371,33 +331,74 @@ __global__ __launch_bounds__(THREADS) void k_gemm(const GemmArgs a) {
         }
         __syncthreads();
       }
-      if (col_ok && want_stats) {
+      if (want_stats) {
+        // the THREADS / CH threads of a column chunk: xor butterfly inside the wave, then the waves one after the other
+        // (fixed order, no LDS atomics: the same partial row on every run)
+        wave_group_sum(s1, CH);
+        wave_group_sum(s2, CH);
+        for (int wv = 0; wv < THREADS / 64; ++wv) {
+          if (wave == wv && lane < CH && col_ok) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          if (j + e < a.J) {
-            atomicAdd(&red[j + e], s1[e]);
-            atomicAdd(&red[a.Jp + j + e], s2[e]);
+            for (int e = 0; e < 8; ++e) {
+              if (j + e < a.J) {
+                red[j + e] += s1[e];
+                red[a.Jp + j + e] += s2[e];
+              }
+            }
           }
+          __syncthreads();
         }
       }
-      if (want_gate && col_ok) flush_gate();
     }  // nt
   }    // mt
 
   __syncthreads();
-  if (want_gate && cur_img >= 0) {
-    for (int i = tid; i < 2 * a.Jp; i += THREADS) {
-      const int slot = i / a.Jp, col = i - slot * a.Jp;
-      const float v = gs[i];
-      if (v != 0.f && col < a.J && cur_img + slot < a.tv.n)
-        atomicAdd(&a.epi.dgate[(size_t)(cur_img + slot) * a.J + col], v);
-    }
-  }
   if (want_stats) {
     float* dst = a.stat_partials + (size_t)blockIdx.x * 2 * a.J;
     for (int i = tid; i < 2 * a.J; i += THREADS) {
       const int which = i / a.J, col = i - which * a.J;
       dst[i] = red[which * a.Jp + col];
+    }
+  }
+}
+
+// dgate[img][col] += sum over the pixels of the image of d(view)[m][col] * act(bn(x[m][col])) for an SE-gated input
+// view, from the gradient k_gemm has just stored.  Workgroup = (image, 64 columns); thread = (8-column chunk, one of 32
+// pixel slices); the slices are combined by wave_group_sum and then in wave order -- one writer per element, a fixed
+// order: the same bits on every run (the in-kernel version added its sums with LDS / global atomics).
+template <typename T>
+__global__ __launch_bounds__(THREADS) void k_gate_sums(const GemmArgs a) {
+  __shared__ float part[THREADS / 64][64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nchunk = (a.J + 63) / 64;
+  const int img = blockIdx.x / nchunk, j = (blockIdx.x % nchunk) * 64 + (tid & 7) * 8;
+  const int slice = tid >> 3;
+  float gp[8], sc8[8], sh8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { gp[e] = 0.f; sc8[e] = 1.f; sh8[e] = 0.f; }
+  if (j < a.J) {
+    if (a.tv.scale) { loadf8(a.tv.scale + j, sc8); loadf8(a.tv.shift + j, sh8); }     // (Jp-padded rows: c % 8 == 0)
+    for (int r = slice; r < a.hw; r += THREADS / 8) {
+      const size_t off = ((size_t)img * a.hw + r) * a.tv.ld + j;
+      float x[8], v[8];
+      load8<T>(reinterpret_cast<const T*>(a.tv.data) + off, x);
+      load8<T>(reinterpret_cast<const T*>(a.epi.gout) + off, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gp[e] = fmaf(v[e], act_apply_(a.tv.act, fmaf(x[e], sc8[e], sh8[e])), gp[e]);
+    }
+  }
+  wave_group_sum(gp, 8);
+  if (lane < 8) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[wave][lane * 8 + e] = gp[e];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int col = (blockIdx.x % nchunk) * 64 + tid;
+    if (col < a.J) {
+      float t = part[0][tid];
+      for (int w = 1; w < THREADS / 64; ++w) t += part[w][tid];
+      a.epi.dgate[(size_t)img * a.J + col] += t;
     }
   }
 }
@@ -409,7 +410,9 @@ int launch_gemm(GemmArgs& a, int* nparts_out, hipStream_t st) {
   const int grid = cdiv(ntm, a.tiles_per_wg);
   a.Jp = (a.J + 7) / 8 * 8;
   const bool gate = BWD && a.epi.dgate != nullptr;
-  const size_t extra = (size_t)(gate ? 4 : 2) * a.Jp * sizeof(float);
+  EDET_CHECK(!(gate && a.epi.beta), "edet_pw_bwd_data: the gate gradient of an SE-gated input needs beta == 0 (its sums are "
+             "taken from the stored gradient)");
+  const size_t extra = (size_t)2 * a.Jp * sizeof(float);
   if (nparts_out) *nparts_out = grid;
   if (a.J <= 32) {
     edet_launch(k_gemm<T, 2, BWD>, dim3(grid), dim3(THREADS), GemmCfg<T, 2>::TILE_BYTES + extra, st, a);
@@ -419,6 +422,10 @@ int launch_gemm(GemmArgs& a, int* nparts_out, hipStream_t st) {
     edet_launch(k_gemm<T, 8, BWD>, dim3(grid), dim3(THREADS), GemmCfg<T, 8>::TILE_BYTES + extra, st, a);
   }
   EDET_LAUNCH_CHECK(BWD ? "edet_pw_bwd_data" : "edet_pw_fwd");
+  if (gate) {
+    edet_launch(k_gate_sums<T>, dim3(a.tv.n * cdiv(a.J, 64)), dim3(THREADS), 0, st, a);
+    EDET_LAUNCH_CHECK("edet_pw_bwd_data (gate sums)");
+  }
   return 0;
 }
 
@@ -435,6 +442,7 @@ struct WgradArgs {
   int rows_per_wg;
   float* dw;        // [K][N] fp32
   int N;            // = gv.c (row length of dw)
+  float* ws;        // row splits > 1: partial sums [split][K][N], added in split order by edet_reduce_partials
 };
 
 template <typename T> struct WgCfg;
@@ -586,7 +594,9 @@ __global__ __launch_bounds__(THREADS) void k_wgrad(const WgradArgs a) {
       if (i < a.CU && j < a.CV) {
         const int k = u_grad ? j : i;
         const int n = u_grad ? i : j;
-        atomicAdd(&a.dw[(size_t)k * a.N + n], acc[nj][r]);
+        // one writer per element: this split's partial row, or (a single split) dW itself -- no atomics
+        if (a.ws) a.ws[((size_t)split * a.tv.c + k) * a.N + n] = acc[nj][r];
+        else a.dw[(size_t)k * a.N + n] += acc[nj][r];
       }
     }
   }
@@ -610,7 +620,7 @@ void launch_wgrad_nj(const WgradArgs& a, int grid, hipStream_t st) {
 }
 
 template <typename T>
-int launch_wgrad(WgradArgs& a, hipStream_t st) {
+int launch_wgrad(WgradArgs& a, void* workspace, size_t workspace_bytes, hipStream_t st) {
   const int K = a.tv.c, N = a.gv.c;
   a.N = N;
   a.u_is_grad = N >= K ? 1 : 0;
@@ -620,12 +630,18 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
   const int nti = cdiv(a.CU, 64);
   // ~1024 workgroups; each at least 512 rows
   int split = 1024 / nti;
+  // the row splits hand their partial sums over through the workspace (ordered reduction, the same bits on every run);
+  // without one a single split adds into dW directly
+  const size_t row_bytes = (size_t)K * N * sizeof(float);
+  const int ws_rows = workspace ? (int)(workspace_bytes / row_bytes < 4096 ? workspace_bytes / row_bytes : 4096) : 0;
+  if (split > ws_rows) split = ws_rows;
   if (split < 1) split = 1;
   int64_t rows = cdiv(a.M, split);
   if (rows < 512) rows = 512;
   rows = (rows + 63) / 64 * 64;
   a.rows_per_wg = (int)rows;
   split = cdiv(a.M, rows);
+  a.ws = split > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
   const int grid = nti * split;
   if (a.CV <= 64) launch_wgrad_nj<T, 4>(a, grid, st);
   else if (a.CV <= 128) launch_wgrad_nj<T, 8>(a, grid, st);
@@ -633,6 +649,7 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
   else if (a.CV <= 320) launch_wgrad_nj<T, 20>(a, grid, st);
   else launch_wgrad_nj<T, 40>(a, grid, st);
   EDET_LAUNCH_CHECK("edet_pw_bwd_weight");
+  if (a.ws && edet_reduce_partials(a.ws, split, (int64_t)K * N, a.dw, st) != 0) return -2;
   return 0;
 }
 
@@ -778,9 +795,9 @@ extern "C" int edet_pw_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy
     if (rc == 0 && !big_first && impl == PW_AUTO && (int64_t)in->c * dy->c >= 4096)
       rc = pwb_try_wgrad(in, dy, dweight, workspace, workspace_bytes, to_stream(stream));
     if (rc != 0) return rc < 0 ? rc : 0;
-    return launch_wgrad<bf16_t>(a, to_stream(stream));
+    return launch_wgrad<bf16_t>(a, workspace, workspace_bytes, to_stream(stream));
   }
-  if (dtype == EDET_F32) return launch_wgrad<float>(a, to_stream(stream));
+  if (dtype == EDET_F32) return launch_wgrad<float>(a, workspace, workspace_bytes, to_stream(stream));
   EDET_CHECK(false, "edet_pw_bwd_weight: bad dtype %d", dtype);
 }
 

@@ -680,6 +680,9 @@ int pwt_try_bwd(const edet_gview_t* dy, const void* w, int ldw, const edet_tview
 #undef PWT_GO
   if (rc <= 0) return rc;
   EDET_LAUNCH_CHECK("edet_pw_bwd(tile)");
+  // INVARIANT (deferred reductions): only [a.ws, a.ws + S*K*N) -- the dW partial rows -- outlives this call; the engine
+  // hands the NEXT call the workspace behind that range (edet_reduce_deferred_end).  gate_ws / the dump scratch lie
+  // beyond it and are consumed by k_gate_finish, launched right here on the same stream: nothing else may read them later.
   if (edet_reduce_partials(a.ws, a.S, (int64_t)K * N, dweight, st) != 0) return -2;
   if (gated && epi->dgate) {
     edet_launch(k_gate_finish, dim3((in->n * K + 255) / 256), dim3(256), 0, st, a.gate_ws, in->n, K, a.spi, a.sps,

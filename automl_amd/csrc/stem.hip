@@ -21,7 +21,7 @@ struct StemArgs {
   float* stat_partials;
   edet_gview_t gy;
   float* dweight;
-  float* ws;        // weight gradient: per-workgroup partials [P][27 * cout] (NULL: atomic adds into dweight)
+  float* ws;        // weight gradient: per-workgroup partials [P][27 * cout] (NULL: one workgroup, which adds into dweight)
   int tiles_y, tiles_x, nsp, P;
 };
 
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(THREADS) void k_stem_bwd_weight_mfma(const StemArgs
   for (int q = tid; q < 27 * cout; q += THREADS) {
     const int k = q / cout, ch = q - k * cout;
     if (a.ws) a.ws[(size_t)blockIdx.x * 27 * cout + q] = red[k * 64 + ch];
-    else atomicAdd(&a.dweight[q], red[k * 64 + ch]);
+    else a.dweight[q] += red[k * 64 + ch];        // (no workspace: launched as ONE workgroup, see stem_launch)
   }
 }
 
@@ -375,14 +375,20 @@ __global__ __launch_bounds__(THREADS) void k_stem_fwd(const StemArgs a) {
     }
   }
   if (want_stats) {
+    // wave shuffles, then the waves one after the other (a fixed order, no LDS atomics: the same partial row on every run)
 #pragma unroll
     for (int c = 0; c < CO; ++c) {
-      float u = s1[c], v = s2[c];
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) { u += __shfl_down(u, off, 64); v += __shfl_down(v, off, 64); }
-      if ((tid & 63) == 0) { atomicAdd(&red[c], u); atomicAdd(&red[CO + c], v); }
+      for (int off = 32; off > 0; off >>= 1) { s1[c] += __shfl_down(s1[c], off, 64); s2[c] += __shfl_down(s2[c], off, 64); }
     }
     __syncthreads();
+    for (int wv = 0; wv < THREADS / 64; ++wv) {
+      if (tid == wv * 64) {
+#pragma unroll
+        for (int c = 0; c < CO; ++c) { red[c] += s1[c]; red[CO + c] += s2[c]; }
+      }
+      __syncthreads();
+    }
     for (int i = tid; i < 2 * CO; i += THREADS)
       a.stat_partials[(size_t)blockIdx.x * 2 * CO + i] = red[i];
   }
@@ -392,7 +398,8 @@ __global__ __launch_bounds__(THREADS) void k_stem_fwd(const StemArgs a) {
 // Thread = (pixel slice s, window position ky*3+kx, channel quad q): per pixel it reads the 3 input channels
 // of its window position (LDS broadcast across the quads) and one float4 of dy, and does 12 FMAs into
 // register accumulators -- 1/3 LDS instruction per FMA (the tap-major version needed 5/4).  The slices are
-// combined through LDS, so a workgroup issues one atomic per weight.
+// combined through LDS one after the other and the workgroup's sums go to its partial row of the workspace
+// (edet_reduce_partials adds the rows in order) or, for a single workgroup, into dW: no atomics, the same bits on every run.
 template <typename T, int CV>
 __global__ __launch_bounds__(THREADS) void k_stem_bwd_weight(const StemArgs a) {
   constexpr int CO = CV * 8;
@@ -459,14 +466,19 @@ __global__ __launch_bounds__(THREADS) void k_stem_bwd_weight(const StemArgs a) {
   float* red = dyt;                           // [27][CO]
   for (int i = tid; i < 27 * CO; i += THREADS) red[i] = 0.f;
   __syncthreads();
-  if (active) {
+  for (int sv = 0; sv < S; ++sv) {
+    if (active && sl == sv) {
 #pragma unroll
-    for (int ci = 0; ci < 3; ++ci)
+      for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(&red[(kk * 3 + ci) * CO + q * 4 + e], acc[ci][e]);
+        for (int e = 0; e < 4; ++e) red[(kk * 3 + ci) * CO + q * 4 + e] += acc[ci][e];
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  for (int i = tid; i < 27 * CO; i += THREADS) atomicAdd(&a.dweight[i], red[i]);
+  for (int i = tid; i < 27 * CO; i += THREADS) {
+    if (a.ws) a.ws[(size_t)blockIdx.x * 27 * CO + i] = red[i];
+    else a.dweight[i] += red[i];
+  }
 }
 
 template <typename T>
@@ -518,6 +530,7 @@ int stem_launch(bool fwd, StemArgs& a, hipStream_t st) {
     a.tiles_x = cdiv(a.ow, MPX);
     a.nsp = a.n * a.tiles_y * a.tiles_x;
     a.P = a.nsp < EDET_MAX_PARTS ? a.nsp : EDET_MAX_PARTS;
+    if (!a.ws) a.P = 1;
     EDET_CHECK(a.cout <= 64, "stem: cout %d unsupported (need <= 64)", a.cout);
     if (a.cout <= 32) edet_launch(k_stem_bwd_weight_mfma<1>, dim3(a.P), dim3(THREADS), 0, st, a);
     else edet_launch(k_stem_bwd_weight_mfma<2>, dim3(a.P), dim3(THREADS), 0, st, a);
@@ -540,6 +553,7 @@ int stem_launch(bool fwd, StemArgs& a, hipStream_t st) {
   a.tiles_x = cdiv(a.ow, TW);
   a.nsp = a.n * a.tiles_y * a.tiles_x;
   a.P = a.nsp < EDET_MAX_PARTS ? a.nsp : EDET_MAX_PARTS;
+  if (!fwd && !a.ws) a.P = 1;       // no workspace for the partial rows: one workgroup adds into dW directly
   const dim3 grid(a.P), block(THREADS);
 #define STEM_CASE(CV)                                                   \
   case CV:                                                              \
@@ -556,6 +570,7 @@ int stem_launch(bool fwd, StemArgs& a, hipStream_t st) {
   }
 #undef STEM_CASE
   EDET_LAUNCH_CHECK("edet_stem");
+  if (!fwd && a.ws && edet_reduce_partials(a.ws, a.P, (int64_t)27 * a.cout, a.dweight, st) != 0) return -2;
   return 0;
 }
 
@@ -595,8 +610,8 @@ extern "C" int edet_stem_bwd_weight(const void* images, int n, int h, int w,
   a.img = images; a.n = n; a.h = h; a.w = w; a.cout = dy->c; a.gy = *dy; a.dweight = dweight;
   stem_geometry(a);
   EDET_CHECK(a.oh == dy->h && a.ow == dy->w, "edet_stem_bwd_weight: dy geometry mismatch");
-  // bf16: ordered partial sums through the workspace when it holds EDET_MAX_PARTS of them
-  if (dtype == EDET_BF16 && workspace && workspace_bytes >= (size_t)EDET_MAX_PARTS * 27 * dy->c * sizeof(float))
+  // ordered partial sums through the workspace when it holds EDET_MAX_PARTS of them (else: one workgroup, no partials)
+  if (workspace && workspace_bytes >= (size_t)EDET_MAX_PARTS * 27 * dy->c * sizeof(float))
     a.ws = reinterpret_cast<float*>(workspace);
   if (dtype == EDET_BF16) return stem_launch<bf16_t>(false, a, to_stream(stream));
   if (dtype == EDET_F32) return stem_launch<float>(false, a, to_stream(stream));

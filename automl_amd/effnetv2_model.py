@@ -167,9 +167,10 @@ class V2Engine(engine_lib.Engine):
 
       def stem_bwd():
         g = self._gview(v0)
-        call('edet_stem_bwd_weight', ptr(images), n, h, w, ctypes.byref(g), ptr(self.grad(wstem)), ptr(self.workspace),
-             self.workspace.numel() * 4, self.dtype,
+        # behind the partial sums that earlier layers left for the deferred reductions (Engine._ws / _ws_mark)
+        call('edet_stem_bwd_weight', ptr(images), n, h, w, ctypes.byref(g), ptr(self.grad(wstem)), *self._ws(), self.dtype,
              self.stream, nbytes=(n * h * w * 3 + y0.rows * y0.c) * self.esize)
+        self._ws_mark()
       self.tape.append(stem_bwd)
     if training or spec.blocks[0].has_residual or spec.blocks[0].conv_type == 1:
       # the dense convolutions (and a first block that adds its input back) read a STORED tensor: the stem
@@ -235,8 +236,8 @@ class V2Engine(engine_lib.Engine):
       g = _lib.GView(ptr(dl.data), None, None, None, None, n, 1, 1, ncls, dl.ld)
       wname = name + '/head/dense/kernel'
       _, _, wcopy, ldn = self._pw_copies(wname, c, ncls)
-      call('edet_pw_bwd_weight', ctypes.byref(tv), ctypes.byref(g), ptr(self.grad(wname)), ptr(self.workspace),
-           self.workspace.numel() * 4, self.dtype, self.stream)
+      call('edet_pw_bwd_weight', ctypes.byref(tv), ctypes.byref(g), ptr(self.grad(wname)), *self._ws(), self.dtype, self.stream)
+      self._ws_mark()
       self.grad(name + '/head/dense/bias').add_(dl.data.reshape(n, -1)[:, :ncls].float().sum(0))
       dpv = self.buf('head:dpooled', (n, 1, 1, pv.ld), self.tdtype)
       epi = _lib.BwdEpi(ptr(dpv), 0, None, None, None, None)

@@ -656,8 +656,11 @@ class Engine(object):
     resample convolutions under apply_bn_for_resampling=False.  The BatchNorm-backward pair with mean 0 / rstd 1 / gamma 1:
     its dbeta is exactly that sum."""
     r = vout.raw
+    assert r.grad is not None and r.grad_written, 'bias gradient of %s before its output gradient is complete' % bias
+    fresh = ('ones:c:%d' % r.c) not in self._bufs
     ones = self.buf('ones:c:%d' % r.c, (r.c,), torch.float32)
-    ones.fill_(1.0)
+    if fresh:
+      ones.fill_(1.0)          # (once, at creation: not a launch of every replayed step)
     zeros = self.zbuf('zeros:c:%d' % r.c, (r.c,))
     scr = self.buf('biasgrad:scr:%d' % r.c, (3, r.c), torch.float32)
     call('edet_bn_bwd_reduce', ptr(r.grad), ptr(r.data), r.rows, r.c, r.ld, ptr(zeros), ptr(ones), ptr(self.partials),
@@ -1204,6 +1207,11 @@ class Engine(object):
       for i in range(c.box_class_repeats):
         self._pw_copies('%s/%s-%d/pointwise_kernel' % (net, prefix, i), c.fpn_num_filters, c.fpn_num_filters)
       self._pw_copies('%s/%s-predict/pointwise_kernel' % (net, prefix), c.fpn_num_filters, out_ch)
+    if self.logits_f32 and not self.training and self.dtype == EDET_BF16:
+      # ... and the fp32 copies of the box-predict kernel (_head_level's fp32 island): the chain that casts them first would
+      # otherwise do so on ITS stream while the other chain reads the same buffer with no event in between
+      with self._fp32_island():
+        self._pw_copies('box_net/box-predict/pointwise_kernel', c.fpn_num_filters, box_ch)
     main_tape = self.tape
     tapes = {}
 

@@ -153,6 +153,9 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
     # only before that (a state restored into a net that has not stepped yet) or when the caller supplies the
     # normalizer of a step as a host float (labels['normalizer'])
     self._moving_normalizer = None
+    # a list: every graph-mode data-parallel step appends (start, end) events recorded on the step's stream around the
+    # gradient all-reduce (between the two captured graphs) -- its duration as the device sees it; None = off
+    self.collective_timer = None
 
   def get_optimizer_state(self):
     """Optimizer slots, iteration count and -- with positives_momentum > 0 -- the moving loss normalizer.  (The reference
@@ -175,6 +178,10 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
         self._moving_normalizer.fill_(value)
       else:
         self._moving_normalizer = value
+    elif torch.is_tensor(self._moving_normalizer):
+      self._moving_normalizer.zero_()     # a state without the key: the reference's behaviour, the average restarts at 0
+    else:
+      self._moving_normalizer = None
 
   @staticmethod
   def _check_training_options(c):
@@ -284,7 +291,15 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
       eng.refresh_drop_masks()      # stochastic-depth draws live in static buffers the graph reads
       ga.replay()
       if gb is not None:
+        timer = self.collective_timer
+        if timer is not None:           # bench.py / the world-size-1 rehearsal: the collective's own duration
+          e0 = torch.cuda.Event(enable_timing=True)
+          e0.record()
         reduce_fn(eng.grads_flat)
+        if timer is not None:
+          e1 = torch.cuda.Event(enable_timing=True)
+          e1.record()
+          timer.append((e0, e1))
         gb.replay()
       eng.arena.version += 1        # what optimizer_apply does on the host when it is not replayed
       eng.arena.step_count += 1

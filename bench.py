@@ -395,14 +395,24 @@ def main():
   if dist is not None:
     dist.barrier()
   torch.cuda.synchronize()
+  if use_dist and args.graph:
+    net.collective_timer = []          # HIP events around every gradient all-reduce of the timed region
   t0 = time.perf_counter()
+  enqueue_s = []
   for _ in range(args.steps):
+    t_step = time.perf_counter()
     step()
+    enqueue_s.append(time.perf_counter() - t_step)
   host_enqueue = time.perf_counter() - t0      # host time to enqueue K steps (launches are asynchronous)
   torch.cuda.synchronize()
+  local_elapsed = time.perf_counter() - t0     # this rank's own K steps (before the closing barrier)
   if dist is not None:
     dist.barrier()
   elapsed = time.perf_counter() - t0
+  allreduce_ms = None
+  if net.collective_timer:
+    allreduce_ms = [a.elapsed_time(b) for a, b in net.collective_timer]
+  net.collective_timer = None
   eager_ms_per_step = None
   if args.graph:
     net.use_graph = False
@@ -416,10 +426,14 @@ def main():
   prof = _lib.profiler.summary()
   _lib.profiler = None
   ranks_seen = 1
+  rank_ms = [local_elapsed / args.steps * 1e3] * 2      # slowest / fastest rank's own ms per step
   if dist is not None:
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    t = torch.tensor([local_elapsed, -local_elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    rank_ms = [float(t[0].item()) / args.steps * 1e3, -float(t[1].item()) / args.steps * 1e3]
     ones = torch.ones(1, dtype=torch.float32, device=device)
     dist.all_reduce(ones, op=dist.ReduceOp.SUM)          # through the same RCCL communicator as the gradients
     ranks_seen = int(ones.item())
@@ -450,7 +464,16 @@ def main():
                    'loss': losses.get('loss'), 'param_crc32': param_crc,
                    'collectives': (dist.get_backend() if dist is not None else None),
                    'launch': 'hipGraph replay of the captured step' if args.graph else 'eager',
+                   # host time per enqueued step over the K back-to-back steps: from the second step on the graph launch
+                   # waits for room in the device queue, so this tracks the DEVICE time; the first step of the region
+                   # (empty queue after the synchronize) and the fastest one are what the host itself needs
                    'host_enqueue_ms_per_step': host_enqueue / args.steps * 1e3,
+                   'host_enqueue_ms_first_step': enqueue_s[0] * 1e3, 'host_enqueue_ms_min': min(enqueue_s) * 1e3,
+                   # first contact with a multi-GPU node: the spread of the ranks' own times and the collective itself
+                   'per_rank_ms_per_step': {'max': rank_ms[0], 'min': rank_ms[1]},
+                   'allreduce_ms_per_step': ({'mean': sum(allreduce_ms) / len(allreduce_ms), 'max': max(allreduce_ms),
+                                              'bytes': int(eng.grads_flat.numel()) * 4}
+                                             if allreduce_ms else None),
                    'eager_ms_per_step': eager_ms_per_step},
         'roofline': {
             'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -153,7 +153,9 @@ int edet_stem_fwd(const void* images, int n, int h, int w, const float* weight,
                   int dtype, void* stream);
 /* dweight [3,3,3,cout] fp32 is accumulated into.  workspace: caller-owned device scratch for the per-workgroup
  * partial sums (27 * cout floats each, at most EDET_MAX_PARTS of them), added in a fixed order -- the same
- * gradient on every run; may be NULL, then the partials are combined with atomic adds.  */
+ * gradient on every run; may be NULL (or smaller than EDET_MAX_PARTS rows), then ONE workgroup computes the whole sum
+ * and adds it into dweight itself (slow, still the same bits on every run: the library has no floating-point atomics
+ * on this path in either storage type).  */
 int edet_stem_bwd_weight(const void* images, int n, int h, int w,
                          const edet_gview_t* dy, float* dweight, void* workspace, size_t workspace_bytes,
                          int dtype, void* stream);
@@ -177,8 +179,8 @@ int edet_pw_bwd_data(const edet_gview_t* dy, const void* w, int ldw,
                      int dtype, void* stream);
 /* dweight[cin][cout] (fp32, HWIO of a 1x1 kernel) += in^T dy.
  * workspace: caller-owned device scratch (fp32 partial sums [splits][cin][cout], deterministic
- * two-pass reduction); may be NULL, then partials are combined with atomic adds.  64 MiB covers
- * every EfficientDet-D0..D7x layer at full speed.  */
+ * two-pass reduction); may be NULL -- the fp32 / generic kernel then runs a single row split that adds into dweight
+ * itself (slow, no atomics, the same bits on every run).  64 MiB covers every EfficientDet-D0..D7x layer at full speed.  */
 int edet_pw_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy, float* dweight,
                        void* workspace, size_t workspace_bytes, int dtype, void* stream);
 /* both gradients of one layer in one call (TF's Conv2DBackpropInput + Conv2DBackpropFilter under the reference's
@@ -330,8 +332,9 @@ int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, const edet_t
  * (gin[i] (+)= wn[i] * ds when gbeta[i]; exactly what edet_fuse_bwd_input gives) -- saves that launch and its read of
  * ds; write_ds = 0 when no other input needs the stored ds.
  * workspace (may be NULL): caller-owned scratch for the per-workgroup partial sums of the scalar fusion weights
- * (16 bytes per workgroup: 64 KiB is enough), added in a fixed order -- the same dwn on every run; NULL or
- * per-channel weights: atomic adds.
+ * (16 bytes per workgroup: 64 KiB is enough; per-channel weights: nin * c floats per workgroup), added in a fixed order
+ * -- the same dwn on every run; NULL or too small: the kernel runs as ONE workgroup that adds its sums into dwn itself
+ * (slow, no atomics).
  * pool_argmax (may be NULL): caller-owned bytes [npool][n][oh][ow][c], one plane per EDET_RS_POOL
  * input in input order; receives the winning tap (ky*3+kx, first maximum of the row-major scan) of
  * every pooled element so that edet_fuse_bwd_input does not have to recompute the 3x3 windows.
@@ -364,7 +367,7 @@ int edet_fuse_weights_bwd(const float* w0, const float* w1, const float* w2, int
  * (sum(mean_num_positives) + 1, train_lib.py:517).
  * workspace: caller-owned device scratch for the per-workgroup partial rows (loss sum + bias gradient), added in a
  * fixed order -- the same loss and bias gradient on every run; (a few thousand rows of 1 + channels floats: 8 MiB
- * covers every EfficientDet head); NULL or too small: the partials are combined with atomic adds.  */
+ * covers every EfficientDet head); NULL or too small: the kernel runs as ONE workgroup (slow, no atomics).  */
 int edet_focal_loss(const void* logits, int ld, const int32_t* cls_targets,
                     int64_t positions, int num_anchors, int num_classes,
                     float alpha, float gamma, float inv_normalizer, const float* norm_scale_dev,

@@ -465,6 +465,33 @@ def test_model_backward_matches_oracle_fp32(model_name, size, over):
   assert not bad, 'gradient mismatch in %d/%d tensors, worst %s' % (len(bad), len(params), bad[:8])
 
 
+@pytest.mark.gpu
+def test_model_backward_bf16_deferred_reductions_equal_immediate_ones():
+  """bf16 storage (EffNetV2Model's default): the weight-gradient partial sums of a layer wait in the workspace for
+  the batched reduction (Engine._ws / _ws_mark), so every later call -- the stem's weight gradient is the last one --
+  has to work BEHIND them.  The same backward pass with one reduction launch per layer (EDET_DEFER_REDUCE=0 semantics,
+  nothing waits in the workspace) must give the same gradients bit for bit: same partial sums, same order."""
+  model_name, size, over, batch = 'efficientnetv2-b0', 64, 'num_classes=24,survival_prob=0,dropout_rate=0', 4
+  spec = effnetv2_model.V2Spec(effnetv2_configs.model_config(model_name, over))
+  vals = _perturbed(spec, 9)
+  rng = np.random.default_rng(13)
+  images = torch.from_numpy(rng.standard_normal((batch, size, size, 3)).astype(np.float32))
+  dlog = torch.from_numpy(rng.standard_normal((batch, 24)).astype(np.float32))
+  got = {}
+  for defer in (True, False):
+    net = effnetv2_model.EffNetV2Model(model_name, over, dtype='bf16', params=vals)
+    eng = net._ensure_engine(batch, size, size)
+    eng.defer_reduce = defer
+    net(images, training=True)
+    got[defer] = net.backward(dlog)
+    torch.cuda.synchronize()
+  assert set(got[True]) == set(got[False])
+  differ = [k for k in got[True] if not np.array_equal(np.asarray(got[True][k]), np.asarray(got[False][k]))]
+  assert not differ, 'deferred and immediate weight-gradient reductions differ in %d tensors: %s' % (len(differ), differ[:6])
+  stem = np.asarray(got[True][spec.name + '/stem/conv2d/kernel'])
+  assert np.isfinite(stem).all() and float(np.abs(stem).max()) > 0
+
+
 V2_GRAPH_CASES = [   # fixtures of tests/golden/make_golden_graph_v2.py: (file, model)
     ('reference_graph_v2_b0.npz', 'efficientnetv2-b0'),
     ('reference_graph_v2_s.npz', 'efficientnetv2-s'),

@@ -294,6 +294,29 @@ def test_pw_bwd(dt, shape, mode, gbn, monkeypatch):
       test_pw_bwd_data(dt, shape, mode, gbn, 'auto', one_call=True)
 
 
+@pytest.mark.parametrize('shape', [(4, 33, 31, 16, 96), (2, 9, 7, 24, 40), (3, 13, 11, 144, 24), (2, 5, 5, 64, 810),
+                                   (1, 20, 20, 1152, 192)])
+@pytest.mark.parametrize('mode', ['plain_beta', 'bn_swish_stats', 'gate'])
+def test_pw_bwd_fp32_is_bit_reproducible(shape, mode):
+  """r05: the fp32 / generic pointwise kernels (pw_gemm.hip) hold no floating-point atomics any more -- BatchNorm-backward
+  sums by wave butterflies and wave order, the SE gate sums by k_gate_sums (one writer per element), dW through ordered
+  partial rows -- so the same call gives every output BIT FOR BIT, tiles that straddle images and ragged maps included."""
+  f32 = gu.DTYPES[0]
+  assert f32[0] == 'f32'
+  _lib.launch_log_start()
+  try:
+    first = pw_bwd_case(f32, shape, mode, True, 'auto', one_call=True, conv_y=False)
+  finally:
+    log = _lib.launch_log_stop()
+  assert any('k_gemm<float' in k for k in log) and any('k_wgrad<float' in k for k in log), sorted(log)
+  if mode == 'gate':
+    assert any('k_gate_sums<float' in k for k in log), sorted(log)
+  second = pw_bwd_case(f32, shape, mode, True, 'auto', one_call=True, conv_y=False)
+  for key, t in first.items():
+    if t is not None:
+      assert torch.equal(t, second[key]), 'run-to-run difference in %s' % key
+
+
 # r04: the one-pass TILED backward (pw_tile_bwd.hip).  Shapes for every (KT, NT) instantiation: K <= 64 / K in several
 # 128-channel slices with a ragged last slice, N <= 64 / <= 128, N % 8 != 0, maps whose pixel count is not a multiple of
 # the 64-row step (the gated steps are image-aligned), images that straddle row splits, more than 8 splits.
@@ -544,8 +567,8 @@ def test_stem(dt, shape):
       torch.cuda.synchronize()
       gu.check(dwd, wq.grad, name, 'stem_bwd_weight %s' % (shape,), rtol=wtol, atol=wtol)
       runs.append(dwd)
-  if name == 'bf16':      # with the workspace: ordered partial sums, the same bits on every run
-    assert torch.equal(runs[0], runs[1])
+  # ordered partial sums with the workspace, ONE workgroup without it: the same bits on every run, both storage types (r05)
+  assert torch.equal(runs[0], runs[1]) and torch.equal(runs[2], runs[3])
 
 
 # ------------------------------------------------------------------------------------ BatchNorm

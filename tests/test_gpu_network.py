@@ -166,22 +166,50 @@ SMOOTH_CASE = ('efficientdet-d0', 'label_smoothing=0.1', 128, 2)     # FocalLoss
 # residual connections + stochastic depth inside the class / box towers (efficientdet_keras.py:434-436, 612-614)
 TOWER_SD_CASE = ('efficientdet-d0', 'survival_prob=0.8', 128, 4)
 # ResampleFeatureMap with the 1x1 convolution after the pool (efficientdet_keras.py:316-324): P6 from the pooled C5
-CONV_AFTER_CASE = ('efficientdet-d0', 'conv_after_downsample=True', 128, 2)
+# (four images: with two, pool(C5) -- 4 x 4 at 128 px, 320 channels, in front of the whole backbone's gradient -- holds two
+# windows whose top-2 candidates are 3.5e-6 apart, and the ORACLE'S OWN gradients flip by up to 70 % of a tensor under a 1e-7
+# scaling of its input: the round-4 red gate.  tests/test_train_step_conditioning.py now measures every case of this list.)
+CONV_AFTER_CASE = ('efficientdet-d0', 'conv_after_downsample=True', 128, 4)
 NO_RS_BN_CASE = ('efficientdet-d0', 'apply_bn_for_resampling=False', 128, 2)      # the resample convolutions without BatchNorm
 
 
-@pytest.mark.parametrize('case', CASES[:2] + [('efficientdet-d1', '', 192, 2), CASES[3], ('efficientdet-d7x', '', 384, 2), CASES[4],
-                                               CASES[5], CASES[6], FREEZE_CASE, SMOOTH_CASE, TOWER_SD_CASE, CONV_AFTER_CASE, NO_RS_BN_CASE],
-                         ids=lambda c: '%s[%s]@%d' % (c[0], c[1], c[2]))
-def test_train_step_matches_oracle_fp32(case):
-  """loss values, clipped gradients of every variable, and the updated variables after one step."""
+TRAIN_STEP_CASES = CASES[:2] + [('efficientdet-d1', '', 192, 2), CASES[3], ('efficientdet-d7x', '', 384, 2), CASES[4],
+                                CASES[5], CASES[6], FREEZE_CASE, SMOOTH_CASE, TOWER_SD_CASE, CONV_AFTER_CASE, NO_RS_BN_CASE]
+TRAIN_STEP_SEEDS = (5, 23, 29)        # variables, images, labels
+# Per-tensor gradient errors are taken relative to max(|g|_max of the tensor, GRAD_FLOOR * the largest |g| of the step).
+# 1e-3 (tests/test_oracle_conditioning.py uses the same): the tensors below it are the ones whose gradient is ZERO in exact
+# arithmetic -- a bias or BatchNorm beta in front of another BatchNorm (tower and BiFPN convolution biases, the projection
+# beta of block 0) -- where the oracle holds nothing but its own cancellation residue (~2e-7 of the largest gradient, moving
+# by 40 % under a one-ulp input change); against an absolute bar of 1e-5 of the largest gradient they are still checked.
+GRAD_FLOOR = 1e-3
+
+
+def train_step_problem(case):
+  """(config, variables, images, labels) of one test_train_step_matches_oracle_fp32 case -- shared with the CPU-side
+  conditioning guard (tests/test_train_step_conditioning.py), which runs the oracle alone on the same problem."""
   model, override, size, batch = case
   config = hparams_config.get_efficientdet_config(model)
   config.override(override)
-  vals = perturbed_params(config, 5)
-  rng = np.random.default_rng(23)
+  vals = perturbed_params(config, TRAIN_STEP_SEEDS[0])
+  rng = np.random.default_rng(TRAIN_STEP_SEEDS[1])
   images = rng.standard_normal((batch, size, size, 3)).astype(np.float32)
-  labels = make_labels(config, batch, size, 29)
+  labels = make_labels(config, batch, size, TRAIN_STEP_SEEDS[2])
+  return config, vals, images, labels
+
+
+def train_step_case_is_ill_conditioned(case):
+  """The two documented carve-outs (measured by the conditioning guard, which asserts that they ARE ill conditioned):
+  d7x at a CPU-tractable size and the activations with a kink."""
+  return 'd7x' in case[0] or 'act_type=relu' in case[1]
+
+
+@pytest.mark.parametrize('case', TRAIN_STEP_CASES, ids=lambda c: '%s[%s]@%d' % (c[0], c[1], c[2]))
+def test_train_step_matches_oracle_fp32(case):
+  """loss values, clipped gradients of every variable, and the updated variables after one step.  Every case of the list
+  is measured by tests/test_train_step_conditioning.py (CPU, oracle only): the well-conditioned ones move by less than a
+  third of the tolerance used here when the input is scaled by 1 +- 1e-7."""
+  model, override, size, batch = case
+  config, vals, images, labels = train_step_problem(case)
   net = train_lib.EfficientDetNetTrain(config=config, dtype='f32', params=vals)
   eng = net._ensure_engine(batch, size, size)
   eng.forward(net._to_device_images(torch.from_numpy(images), eng), training=True)
@@ -228,7 +256,7 @@ def test_train_step_matches_oracle_fp32(case):
       wsm_ref.append(float(g.reshape(-1)[0]))
       continue
     err = float((mine - g).abs().max())
-    scale = max(float(g.abs().max()), 1e-4 * gmax)
+    scale = max(float(g.abs().max()), GRAD_FLOOR * gmax)
     if not err <= 1e-2 * scale:
       bad.append((name, err / scale))
   bad.sort(key=lambda t: -t[1])
@@ -241,7 +269,7 @@ def test_train_step_matches_oracle_fp32(case):
   # gradient on a few anchors, so one flip can move a per-channel sum by percents (the set of affected tensors changes
   # from run to run: 12 ... 320 of 493); the smooth activations (swish, hswish away from +-3) do not have this
   kink = 'act_type=relu' in override
-  ill_conditioned = 'd7x' in model or kink
+  ill_conditioned = train_step_case_is_ill_conditioned(case)
   if ill_conditioned:
     # d7x at a CPU-tractable image size holds 2x2 pixels at level 8: 8 BiFPN cells and 5-deep heads normalise
     # by batch statistics of 8 samples.  The ORACLE'S OWN gradients move by up to 13 % of a tensor's max (862
@@ -257,13 +285,11 @@ def test_train_step_matches_oracle_fp32(case):
         len(bad), len(ref_grads), bad[:2], cos))
     assert cos >= 0.995 and all(e <= 0.5 for _, e in bad), (cos, bad[:5])
   else:
-    # every tensor within 1e-2 of its max -- up to the conditioning of the map itself: the oracle's own per-tensor
-    # gradients move by up to 1e-2 under a 1e-7 scaling of its input (tests/test_oracle_conditioning.py), and the
-    # device's fp32 atomics (SE / loss sums) realise such perturbations: now and then ONE small tensor lands at
-    # 1.1e-2 ... 1.7e-2 (r02h: a fusion scalar pair; r02x: an SE bias).  At most 1 % of the tensors may exceed 1e-2,
-    # none 5e-2.
-    assert len(bad) <= max(1, len(ref_grads) // 100) and all(e <= 5e-2 for _, e in bad), \
-        'gradient mismatch in %d/%d tensors, worst: %s' % (len(bad), len(ref_grads), bad[:12])
+    # EVERY tensor within 1e-2 of its max.  (Rounds 2-4 allowed 1 % of the tensors to miss it: the fp32 kernels then
+    # added their sums with atomics, in a different order on every run.  Round 5: no floating-point atomics are left on
+    # this path -- the same bits on every run, test_train_step_is_bit_reproducible[f32] -- and the conditioning guard
+    # bounds what the oracle's own rounding can move: < 3e-3.  No allowance.)
+    assert not bad, 'gradient mismatch in %d/%d tensors, worst: %s' % (len(bad), len(ref_grads), bad[:12])
   new = eng.get_params()
   if 'var_freeze_expr' in override:
     # tf2/train_lib.py:478-491: the frozen variables are out of the L2 term, the clip norms (both compared above through
@@ -421,22 +447,32 @@ def test_frozen_variables_survive_a_restored_optimizer_state():
   assert not torch.equal(before[0][a:b], eng.params_flat[a:b])        # the heads did train
 
 
-@pytest.mark.parametrize('model,size,batch', [('efficientdet-d0', 640, 8), ('efficientdet-d1', 256, 3)])
-def test_train_step_is_bit_reproducible(model, size, batch):
+@pytest.mark.parametrize('model,size,batch,dtype', [
+    ('efficientdet-d0', 640, 8, 'bf16'), ('efficientdet-d1', 256, 3, 'bf16'),
+    # r05: the fp32 engine (the one every end-to-end gradient parity test runs) -- its generic kernels (pw_gemm.hip,
+    # dwconv.hip, the fp32 stem, the per-channel fusion backward, the dense convolution) combine their sums in a fixed order too
+    ('efficientdet-d0', 256, 3, 'f32'), ('efficientdet-d1', 192, 3, 'f32'),
+    ('efficientdet-d0[fpn_weight_method=channel_fastattn]', 128, 2, 'f32'),
+    ('efficientdet-d0[fpn_weight_method=channel_fastattn]', 256, 2, 'bf16')])
+def test_train_step_is_bit_reproducible(model, size, batch, dtype):
   """r04: the bf16 training step has no floating-point atomics left on its path (BatchNorm partial rows, SE pooling / FC /
   gate gradients, loss sums and bias gradients, fusion-weight gradients, stem / depthwise / pointwise weight gradients
   are all combined in a fixed order), so the same step run twice -- two engines built from the same variables, the same
   batch, the same stochastic-depth draws -- gives the gradient arena, the updated variables, the EMA shadows and the
-  BatchNorm moving statistics BIT FOR BIT.  d0 at the benchmark's 640 x 640 (batch 8) and d1 (stochastic depth).  The
-  one exception is documented: the reported L2 loss VALUE is still summed with atomics (it feeds nothing)."""
+  BatchNorm moving statistics BIT FOR BIT, and every reported loss value.  d0 at the benchmark's 640 x 640 (batch 8), d1
+  (stochastic depth), the per-channel fusion method; r05: both storage types."""
+  override = ''
+  if '[' in model:
+    model, override = model[:-1].split('[')
   config = hparams_config.get_efficientdet_config(model)
+  config.override(override)
   vals = perturbed_params(config, 11)
   rng = np.random.default_rng(97)
   images = torch.from_numpy(rng.standard_normal((batch, size, size, 3)).astype(np.float32))
   labels = make_labels(config, batch, size, 101)
   runs = []
   for _ in range(2):
-    net = train_lib.EfficientDetNetTrain(config=config, dtype='bf16', params=vals, seed=5)
+    net = train_lib.EfficientDetNetTrain(config=config, dtype=dtype, params=vals, seed=5)
     eng = net._ensure_engine(batch, size, size)
     for _step in range(2):
       eng.refresh_drop_masks()
@@ -452,7 +488,7 @@ def test_train_step_is_bit_reproducible(model, size, batch):
   assert torch.equal(g0, g1), 'gradient arena differs between two runs: %d elements' % int((g0 != g1).sum())
   assert torch.equal(p0, p1) and torch.equal(e0, e1), 'updated variables / EMA shadows differ between two runs'
   assert torch.equal(s0, s1), 'BatchNorm moving statistics differ between two runs'
-  for k in ('cls_loss', 'box_loss', 'gradient_norm'):
+  for k in ('cls_loss', 'box_loss', 'gradient_norm', 'reg_l2_loss', 'loss'):
     assert l0[k] == l1[k], (k, l0[k], l1[k])
 
 
@@ -712,3 +748,12 @@ def test_rccl_path_on_the_device_at_world_size_one(tmp_path):
   assert plain['config']['collectives'] is None
   assert rccl['config']['param_crc32'] == plain['config']['param_crc32'], (plain['config'], rccl['config'])
   assert rccl['config']['loss'] == plain['config']['loss']
+  # first-contact fields for the multi-GPU scaling run (r05): every rank's own time and the collective's duration
+  ar = rccl['config']['allreduce_ms_per_step']
+  assert ar and ar['bytes'] >= 4 * 3_880_067 and 0 < ar['mean'] <= ar['max'] < rccl['ms_per_step'], (ar, rccl['ms_per_step'])
+  assert plain['config']['allreduce_ms_per_step'] is None
+  for line in (plain, rccl):
+    c = line['config']
+    assert 0 < c['per_rank_ms_per_step']['min'] <= c['per_rank_ms_per_step']['max'] <= 1.001 * line['ms_per_step'], c
+    assert 0 < c['host_enqueue_ms_min'] <= c['host_enqueue_ms_first_step'], c
+    assert c['host_enqueue_ms_min'] <= c['host_enqueue_ms_per_step'] * 1.001, c
