@@ -610,7 +610,8 @@ extern "C" int edet_fuse_bwd_pre(const edet_tview_t* in0, const edet_tview_t* in
     else if (dtype == EDET_F32) edet_launch(k_fuse<float, true, true>, grid, dim3(THREADS), lds, to_stream(stream), a, nullptr, (const float*)dout, (float*)ds, dwn, (unsigned char*)pool_argmax, parts);
     else EDET_CHECK(false, "edet_fuse_bwd_pre: bad dtype %d", dtype);
     EDET_LAUNCH_CHECK("edet_fuse_bwd_pre");
-    if (parts && edet_reduce_partials(parts, grid, (int64_t)nin * a.c, dwn, to_stream(stream)) != 0) return -2;
+    // (edet_reduce_partials2: launched NOW, never recorded for a deferred batch -- edet_fuse_weights_bwd reads dwn next)
+    if (parts && edet_reduce_partials2(parts, grid, (int64_t)nin * a.c, dwn, (int64_t)nin * a.c, nullptr, to_stream(stream)) != 0) return -2;
     return 0;
   }
   if (dtype == EDET_BF16) edet_launch(k_fuse<bf16_t, true>, grid, dim3(THREADS), lds, to_stream(stream), a, nullptr, (const bf16_t*)dout, (bf16_t*)ds, dwn, (unsigned char*)pool_argmax, parts);
