@@ -138,11 +138,12 @@ __device__ __forceinline__ void sample_input(const FuseArgs& a, int i, const Vie
 // kernel, so its dwn sums stay in registers; the slices are added through LDS in slice order and the workgroup's sums go
 // to its partial row (edet_reduce_partials adds the rows in order) or, for a single workgroup, into dwn -- no atomics,
 // the same gradient on every run.
-template <typename T, bool BWD, bool PCDW = false>
-__global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restrict__ out,
-                                                 const T* __restrict__ dout, T* __restrict__ ds,
-                                                 float* dwn, unsigned char* __restrict__ pool_argmax,
-                                                 float* dwn_parts = nullptr) {
+// (one body, two kernel symbols: k_fuse<T, BWD> keeps its name and signature -- the committed kernel statistics and the
+// coverage test of tests/test_gpu_bench_shapes.py name it -- and k_fuse_pc<T> is the PCDW backward)
+template <typename T, bool BWD, bool PCDW>
+__device__ __forceinline__ void fuse_body(const FuseArgs& a, T* __restrict__ out, const T* __restrict__ dout,
+                                          T* __restrict__ ds, float* dwn, unsigned char* __restrict__ pool_argmax,
+                                          float* dwn_parts) {
   const int nvec = a.c / 8;
   const int64_t total = (int64_t)a.n * a.oh * a.ow * nvec;
   const bool per_ch = a.wc > 1;                      // channel_attn / channel_fastattn: one weight per channel
@@ -299,6 +300,21 @@ __global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restric
       else if (threadIdx.x < a.nin) dwn[threadIdx.x] += t;       // (no partial buffer: launched as ONE workgroup)
     }
   }
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(THREADS) void k_fuse(const FuseArgs a, T* __restrict__ out,
+                                                 const T* __restrict__ dout, T* __restrict__ ds,
+                                                 float* dwn, unsigned char* __restrict__ pool_argmax,
+                                                 float* dwn_parts = nullptr) {
+  fuse_body<T, BWD, false>(a, out, dout, ds, dwn, pool_argmax, dwn_parts);
+}
+template <typename T>
+__global__ __launch_bounds__(THREADS) void k_fuse_pc(const FuseArgs a, T* __restrict__ out,
+                                                    const T* __restrict__ dout, T* __restrict__ ds,
+                                                    float* dwn, unsigned char* __restrict__ pool_argmax,
+                                                    float* dwn_parts) {
+  fuse_body<T, true, true>(a, out, dout, ds, dwn, pool_argmax, dwn_parts);
 }
 
 // dwn[i] += the workgroup rows of k_fuse<.., true>, in row order (i < 3); with the raw variables (r04) also their
@@ -599,15 +615,15 @@ extern "C" int edet_fuse_bwd_pre(const edet_tview_t* in0, const edet_tview_t* in
   const bool pcdw = wc > 1 && dwn;
   EDET_CHECK(!pcdw || a.c <= 8 * THREADS, "edet_fuse_bwd_pre: per-channel fusion weights need c <= %d", 8 * THREADS);
   const size_t lds = pcdw ? (size_t)(THREADS / (a.c / 8)) * nin * a.c * sizeof(float) : 0;
-  int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8), dtype == EDET_BF16 ? (pcdw ? reinterpret_cast<const void*>(&k_fuse<bf16_t, true, true>) : reinterpret_cast<const void*>(&k_fuse<bf16_t, true>)) : nullptr, lds);
+  int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8), dtype == EDET_BF16 ? (pcdw ? reinterpret_cast<const void*>(&k_fuse_pc<bf16_t>) : reinterpret_cast<const void*>(&k_fuse<bf16_t, true>)) : nullptr, lds);
   // ordered partial rows through the workspace -- [grid][4] for scalar fusion weights, [grid][nin * c] for per-channel ones;
   // without a workspace that holds them ONE workgroup adds its sums into dwn (no atomics either way)
   const size_t row = pcdw ? (size_t)nin * a.c : 4;
   float* parts = (dwn && workspace && workspace_bytes >= (size_t)grid * row * sizeof(float)) ? reinterpret_cast<float*>(workspace) : nullptr;
   if (dwn && !parts) grid = 1;
   if (pcdw) {
-    if (dtype == EDET_BF16) edet_launch(k_fuse<bf16_t, true, true>, grid, dim3(THREADS), lds, to_stream(stream), a, nullptr, (const bf16_t*)dout, (bf16_t*)ds, dwn, (unsigned char*)pool_argmax, parts);
-    else if (dtype == EDET_F32) edet_launch(k_fuse<float, true, true>, grid, dim3(THREADS), lds, to_stream(stream), a, nullptr, (const float*)dout, (float*)ds, dwn, (unsigned char*)pool_argmax, parts);
+    if (dtype == EDET_BF16) edet_launch(k_fuse_pc<bf16_t>, grid, dim3(THREADS), lds, to_stream(stream), a, nullptr, (const bf16_t*)dout, (bf16_t*)ds, dwn, (unsigned char*)pool_argmax, parts);
+    else if (dtype == EDET_F32) edet_launch(k_fuse_pc<float>, grid, dim3(THREADS), lds, to_stream(stream), a, nullptr, (const float*)dout, (float*)ds, dwn, (unsigned char*)pool_argmax, parts);
     else EDET_CHECK(false, "edet_fuse_bwd_pre: bad dtype %d", dtype);
     EDET_LAUNCH_CHECK("edet_fuse_bwd_pre");
     // (edet_reduce_partials2: launched NOW, never recorded for a deferred batch -- edet_fuse_weights_bwd reads dwn next)

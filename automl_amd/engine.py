@@ -290,6 +290,7 @@ class Engine(object):
     # 3 and 4 compete: 71.7 -> 75.1 ms, r02g); every weight-gradient kernel deferred to the side stream (nothing on
     # the data-gradient chain waits for them: 68.3 -> 69.7 ms, r02n).
     self.small_level_stream = True
+    self.side_move = os.environ.get('EDET_SIDE_MOVE', '')      # '' | 'class' | 'box': see _heads_two_chains
     self._side_pending = False
     self.bns = {}
     self._cast_plan = None
@@ -1214,23 +1215,31 @@ class Engine(object):
         self._pw_copies('box_net/box-predict/pointwise_kernel', c.fpn_num_filters, box_ch)
     main_tape = self.tape
     tapes = {}
+    # which chain runs which (level, tower): the big levels on the main chain, the small ones on the side chain;
+    # Engine.side_move ('class' / 'box', lab switch EDET_SIDE_MOVE) hands that tower of the FIRST small level to the main
+    # chain (the timeline of the replayed step shows the main queue waiting for the side stream at both joins)
+    towers = (('class_net', 'class', cls_ch), ('box_net', 'box', box_ch))
+    work = {'main': [], 'side': []}
+    for li in range(len(feats)):
+      for tw in towers:
+        on_main = li < nbig or (li == nbig and self.side_move == tw[1])
+        work['main' if on_main else 'side'].append((li, tw))
 
-    def chain(which, lis):
+    def chain(which):
       def job():
         self.tape = []
-        out = []
-        for li in lis:
-          level = c.min_level + li
-          out.append((self._head_level(feats[li], level, 'class_net', 'class', cls_ch),
-                      self._head_level(feats[li], level, 'box_net', 'box', box_ch)))
+        out = {}
+        for li, (net, prefix, out_ch) in work[which]:
+          out[li, net] = self._head_level(feats[li], c.min_level + li, net, prefix, out_ch)
         tapes[which] = self.tape
         return out
       return job
     try:
-      big, small = self._fork_join(chain('main', range(nbig)), chain('side', range(nbig, len(feats))))
+      done, side_done = self._fork_join(chain('main'), chain('side'))
     finally:
       self.tape = main_tape
-    outs = big + small
+    done.update(side_done)
+    outs = [(done[li, 'class_net'], done[li, 'box_net']) for li in range(len(feats))]
     if self.training:
       def bwd():
         def replay(which):

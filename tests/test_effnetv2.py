@@ -469,8 +469,11 @@ def test_model_backward_matches_oracle_fp32(model_name, size, over):
 def test_model_backward_bf16_deferred_reductions_equal_immediate_ones():
   """bf16 storage (EffNetV2Model's default): the weight-gradient partial sums of a layer wait in the workspace for
   the batched reduction (Engine._ws / _ws_mark), so every later call -- the stem's weight gradient is the last one --
-  has to work BEHIND them.  The same backward pass with one reduction launch per layer (EDET_DEFER_REDUCE=0 semantics,
-  nothing waits in the workspace) must give the same gradients bit for bit: same partial sums, same order."""
+  has to work BEHIND them (V2Engine.stem_bwd handed the stem kernel the workspace BASE, on top of the first
+  recorded layer's partial rows).  The same backward pass with one reduction launch per layer (EDET_DEFER_REDUCE=0
+  semantics, nothing waits in the workspace) must give the same gradients up to the summation order of the partial rows
+  (the batched kernel adds them in another fixed order than the immediate one: <= 1e-4 of a tensor's largest element, where
+  an overwritten partial row is an error of order one), and each mode is bit-reproducible on its own."""
   model_name, size, over, batch = 'efficientnetv2-b0', 64, 'num_classes=24,survival_prob=0,dropout_rate=0', 4
   spec = effnetv2_model.V2Spec(effnetv2_configs.model_config(model_name, over))
   vals = _perturbed(spec, 9)
@@ -478,17 +481,24 @@ def test_model_backward_bf16_deferred_reductions_equal_immediate_ones():
   images = torch.from_numpy(rng.standard_normal((batch, size, size, 3)).astype(np.float32))
   dlog = torch.from_numpy(rng.standard_normal((batch, 24)).astype(np.float32))
   got = {}
-  for defer in (True, False):
+  for defer in (True, False, 'again'):
     net = effnetv2_model.EffNetV2Model(model_name, over, dtype='bf16', params=vals)
     eng = net._ensure_engine(batch, size, size)
-    eng.defer_reduce = defer
+    eng.defer_reduce = bool(defer)
     net(images, training=True)
-    got[defer] = net.backward(dlog)
+    got[defer] = {k: np.asarray(v).copy() for k, v in net.backward(dlog).items()}
     torch.cuda.synchronize()
   assert set(got[True]) == set(got[False])
-  differ = [k for k in got[True] if not np.array_equal(np.asarray(got[True][k]), np.asarray(got[False][k]))]
-  assert not differ, 'deferred and immediate weight-gradient reductions differ in %d tensors: %s' % (len(differ), differ[:6])
-  stem = np.asarray(got[True][spec.name + '/stem/conv2d/kernel'])
+  worst = []
+  for k, a in got[True].items():
+    b = got[False][k]
+    scale = max(float(np.abs(b).max()), 1e-12)
+    worst.append((float(np.abs(a - b).max()) / scale, k))
+    assert np.array_equal(a, got['again'][k]), 'the deferred mode is not bit-reproducible in %s' % k
+  worst.sort(reverse=True)
+  print('deferred vs immediate reductions, worst tensors: %s' % worst[:4])
+  assert worst[0][0] <= 1e-4, 'deferred and immediate weight-gradient reductions differ: %s' % worst[:6]
+  stem = got[True][spec.name + '/stem/conv2d/kernel']
   assert np.isfinite(stem).all() and float(np.abs(stem).max()) > 0
 
 
