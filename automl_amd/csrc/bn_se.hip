@@ -36,15 +36,36 @@ inline int persistent_grid(int64_t rows, int rpp, int max_wg) {
 }
 
 // ------------------------------------------------------------------ forward statistics finalize
-// Column sums of the [nparts][2][c] partial rows: one workgroup per 32 channels, 32 row slices per
-// channel (4 independent loads in flight per thread), fp64 accumulation, LDS tree at the end.
-constexpr int FIN_CH = 32, FIN_SL = 32;   // 1024-lane workgroups: 32 rows of partials per step
+// Column sums of the [nparts][2][c] partial rows: one 1024-lane workgroup per FIN_CH channels, FIN_SL row slices per
+// channel (8 rows = 16 independent loads in flight per thread), fp64 accumulation, the slices added in order at the end.
+// r05 lab switches (compile time, the kernel symbols stay the same): EDET_FIN_SL = row slices per channel of the
+// 1024-lane workgroup (32: 32 channels x 32 slices; 64: 16 channels x 64 slices -- half the rows per thread, twice the
+// workgroups), EDET_FIN_DEEP = 1: a first tier with 16 rows (32 loads) in flight per thread.
+#ifndef EDET_FIN_SL
+#define EDET_FIN_SL 64      // r05d, same box, 30 steps: 32 -> 50.99 / 50.87 ms, 64 -> 50.71 ms, 64 + DEEP 50.97, 32 + DEEP 51.81
+#endif
+#ifndef EDET_FIN_DEEP
+#define EDET_FIN_DEEP 0
+#endif
+constexpr int FIN_SL = EDET_FIN_SL, FIN_CH = 1024 / FIN_SL;   // 1024-lane workgroups: FIN_SL rows of partials per step
 
 __device__ __forceinline__ void partial_colsum(const float* __restrict__ partials, int nparts, int c, int ch,
                                                int slice, double& s, double& s2) {
   double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
   if (ch < c) {
     int p = slice;
+#if EDET_FIN_DEEP
+    for (; p + 15 * FIN_SL < nparts; p += 16 * FIN_SL) {      // sixteen rows in flight, same order of additions
+      float u[16], v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        u[i] = partials[((size_t)(p + i * FIN_SL) * 2) * c + ch];
+        v[i] = partials[((size_t)(p + i * FIN_SL) * 2 + 1) * c + ch];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) { a0 += (double)u[i]; b0 += (double)v[i]; a1 += (double)u[i + 1]; b1 += (double)v[i + 1]; }
+    }
+#endif
     // eight rows (16 loads) in flight per thread first -- the kernel is a chain of L2 latencies, ~10 us of step time per
     // launch and 216 launches per EfficientDet-D0 step -- added in exactly the order of the two-row loop below (same bits)
     for (; p + 7 * FIN_SL < nparts; p += 8 * FIN_SL) {

@@ -90,6 +90,9 @@ typedef struct edet_gview {
  *   act          : g = d * act'(z),  z = data*scale+shift
  *   gate         : store D = d (the gated gradient) and accumulate
  *                  dgate[n,c] += sum_hw D * act(z); edet_se_gate_bwd finishes.
+ *                  (beta must be 0 with a gate: the fp32 / generic kernel takes
+ *                  the gate sums from the gradient it has just stored, in a
+ *                  fixed order -- no atomics; an SE output has one consumer.)
  *   beta != 0    : g += previous contents of gout.
  *   stat_partials: per-workgroup partial sums of (g, g*xhat), xhat =
  *                  (data-mean)*rstd, row p at stat_partials[p*2*c .. ]; the
