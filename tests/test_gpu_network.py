@@ -310,12 +310,16 @@ def _seg_index(eng, name):
   return int((eng.seg_offsets.cpu() == off).nonzero()[0][0])
 
 
-def test_train_step_bf16_tracks_the_oracle():
+@pytest.mark.parametrize('override', ['', 'conv_after_downsample=True', 'apply_bn_for_resampling=False'])
+def test_train_step_bf16_tracks_the_oracle(override):
   """bf16 storage, one full step of d0 at 384 px, end to end against the fp32 oracle: loss values to 2e-2 and the
   direction of the whole clipped gradient (cosine >= 0.9).  Per-tensor agreement is not defined end to end in bf16
   training mode (tests/test_oracle_conditioning.py); tests/test_gpu_bench_shapes.py checks every stored gradient and
-  every variable's gradient of the 640x640 step layer by layer."""
+  every variable's gradient of the 640x640 step layer by layer.  r05: also with the two resampling options
+  of round 4 -- the 1x1 convolution after the pool, and resample convolutions without BatchNorm, whose bias gradients go
+  through the BatchNorm-backward reduce (Engine._bias_grad) -- in the storage type and on the two-stream path the benchmark uses."""
   config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  config.override(override)
   size, batch = 384, 2
   vals = perturbed_params(config, 7)
   rng = np.random.default_rng(31)
@@ -346,6 +350,29 @@ def test_train_step_bf16_tracks_the_oracle():
   cos = num / (np.sqrt(den_a * den_b) + 1e-30)
   print('bf16 gradient cosine vs the fp32 oracle: %.5f' % cos)
   assert cos >= 0.9, cos
+
+
+def test_first_inference_forward_after_a_variable_change_equals_the_second():
+  """the fp32 compute copies of the box-predict kernel (the fp32 island of the bf16 inference forward) are cast
+  BEFORE the two head chains fork -- otherwise the chain that casts them first does so on its own stream while the other
+  chain reads the same buffer with no event in between.  The first forward after construction, and the first one after the
+  variables changed, must give exactly what the next forward (copies already made) gives."""
+  config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  vals = perturbed_params(config, 3)
+  rng = np.random.default_rng(71)
+  images = torch.from_numpy(rng.standard_normal((2, 256, 256, 3)).astype(np.float32))
+  net = efficientdet_net.EfficientDetNet(config=config, dtype='bf16', params=vals)
+
+  def outputs():
+    cls, box = net(images, training=False)
+    torch.cuda.synchronize()
+    return [t.clone() for t in cls + box]
+  for round_ in range(2):
+    first, second = outputs(), outputs()
+    for a, b in zip(first, second):
+      assert torch.equal(a, b), 'first and second forward differ (round %d)' % round_
+    moved = {k: (v * np.float32(1.01)).astype(np.float32) for k, v in vals.items() if k.endswith('pointwise_kernel')}
+    net.engine.set_params(moved)
 
 
 def test_tower_residuals_in_the_inference_forward():
