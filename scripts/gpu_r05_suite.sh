@@ -1,4 +1,4 @@
-# Round-5 lab: the whole GPU suite over N worker processes (pytest-xdist; the driver's own run is serial), every failure
+# Round-5 lab (NOT to be repeated: four processes on one GPU ran 3x slower than the serial suite, LABNOTES.md): the whole GPU suite over N worker processes (pytest-xdist), every failure
 # listed (no -x), then a short bench line.  usage (via gpurun): bash scripts/gpu_r05_suite.sh TAG [workers]
 mkdir -p gpurun_out
 T=${1:-r05suite}
