@@ -290,7 +290,6 @@ class Engine(object):
     # 3 and 4 compete: 71.7 -> 75.1 ms, r02g); every weight-gradient kernel deferred to the side stream (nothing on
     # the data-gradient chain waits for them: 68.3 -> 69.7 ms, r02n).
     self.small_level_stream = True
-    self.side_move = os.environ.get('EDET_SIDE_MOVE', '')      # '' | 'class' | 'box': see _heads_two_chains
     self._side_pending = False
     self.bns = {}
     self._cast_plan = None
@@ -309,7 +308,7 @@ class Engine(object):
     self._f32_island = False
     self.fuse_merge_identity = os.environ.get('EDET_FUSE_MERGE', '1') != '0'   # BiFPN backward: see Engine.fuse
     self.overlap_s2_wgrad = os.environ.get('EDET_S2_OVERLAP', '0') == '1'
-    self.fused_dw_bwd = True     # one edet_dw_bwd call per stride-1 layer
+    self.fused_dw_bwd = True     # one edet_dw_bwd call per layer (bf16: ONE kernel for both gradients, any stride)
     self.fused_pw_bwd = True     # one edet_pw_bwd call per pointwise layer whose input needs a gradient
     # cross-replica BatchNorm (utils.SyncBatchNormalization / TpuBatchNormalization, utils.py:166-241):
     # (all_reduce_fn, world_size) or None.  Set by train_lib when sync_bn=True.
@@ -771,7 +770,7 @@ class Engine(object):
     g = self._gview(vout)
     nb = (vin.raw.rows + vout.raw.rows) * vin.raw.c * self.esize
     tag = '%dx%dx%d k%ds%d' % (vin.raw.h, vin.raw.w, vin.raw.c, k, stride)
-    if vin.raw.needs_grad and stride == 1 and self.fused_dw_bwd:
+    if vin.raw.needs_grad and self.fused_dw_bwd:
       epi, fused = self._epi(vin)
       call('edet_dw_bwd', ctypes.byref(g), ptr(self.param(wname)), k, stride, ctypes.byref(vin.tview()),
            ctypes.byref(epi), ctypes.byref(self._nparts), ptr(self.grad(wname)), *self._ws(), self.dtype, self.stream, nbytes=2 * nb, tag=tag)
@@ -1215,14 +1214,14 @@ class Engine(object):
         self._pw_copies('box_net/box-predict/pointwise_kernel', c.fpn_num_filters, box_ch)
     main_tape = self.tape
     tapes = {}
-    # which chain runs which (level, tower): the big levels on the main chain, the small ones on the side chain;
-    # Engine.side_move ('class' / 'box', lab switch EDET_SIDE_MOVE) hands that tower of the FIRST small level to the main
-    # chain (the timeline of the replayed step shows the main queue waiting for the side stream at both joins)
+    # which chain runs which (level, tower): the big levels on the main chain, the small ones on the side chain.  Both
+    # towers of a level stay on ONE chain: they accumulate into the same feature gradient, and only stream order
+    # orders the beta = 0 writer before the beta = 1 one (r05 lab: splitting a level lost 0.5 ms anyway)
     towers = (('class_net', 'class', cls_ch), ('box_net', 'box', box_ch))
     work = {'main': [], 'side': []}
     for li in range(len(feats)):
       for tw in towers:
-        on_main = li < nbig or (li == nbig and self.side_move == tw[1])
+        on_main = li < nbig
         work['main' if on_main else 'side'].append((li, tw))
 
     def chain(which):

@@ -39,7 +39,7 @@ ENTRY_KERNELS = {
     'edet_dw_bwd_data': ['dwm::k_dgrad', 'k_dw_bwd_data'],
     'edet_dw_bwd_weight': ['dwm::k_wgrad', 'k_dw_bwd_weight'],
     'edet_dw_fwd': ['dwm::k_fwd', 'k_dw_fwd'],
-    'edet_dw_bwd': ['dwm::k_bwd_fused'],
+    'edet_dw_bwd': ['dwm::k_bwd_one', 'dwm::k_bwd_fused'],
     'edet_pw_bwd_weight': ['pws::k_pw_wgrad', 'pwb::k_big_wgrad', 'k_wgrad<unsigned short'],
     'edet_pw_bwd_data': ['pws::k_pw_dgrad', 'pwb::k_big_gemm<true', 'k_gemm<unsigned short, 8, true', 'k_gemm<unsigned short, 4, true', 'k_gemm<unsigned short, 2, true'],
     'edet_pw_bwd': ['pwt::k_pw_bwd_tile', 'pwt::k_gate_finish', 'pws::k_pw_bwd_fused', 'pws::k_noy_apply', 'pws::k_pw_wgrad', 'pwb::k_big_wgrad', 'k_wgrad<unsigned short', 'pws::k_pw_dgrad',
