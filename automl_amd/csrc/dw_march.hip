@@ -232,159 +232,7 @@ template <int S, int CPT> struct PfDepth {
 
 __host__ __device__ constexpr int gcd_(int x, int y) { return y == 0 ? x : gcd_(y, x % y); }
 
-template <int K, int S, int CPT, bool OACT>
-__global__ __launch_bounds__(THREADS) void k_fwd_lx(const Args a) {
-  constexpr int NSL = (K + S - 1) / S;   // output rows in flight
-  constexpr int U0 = S * NSL;            // row steps after which the window slots repeat
-  // The FIFO of rows in flight is a ring of NF register sets addressed by static indices: no set is ever copied into
-  // its neighbour (r03q: the shift fm[i] = fm[i+1] at every step survived unrolling as NF moves per array and U0 steps,
-  // about as many VALU instructions as the 3x3 multiply-adds).  The row loop is unrolled over lcm(U0, NF) steps, so NF
-  // is chosen as a divisor or a small multiple of U0 near the depth the lab found best (6 rows at stride 1, 4 at 2).
-  constexpr int PF = U0 == 3 ? 5 : (U0 == 5 ? 4 : (U0 == 4 ? 3 : (U0 == 6 ? 5 : PfDepth<S, CPT>::fwd)));
-  constexpr int NF = PF + 1;
-  constexpr int U = U0 * NF / gcd_(U0, NF);   // static unroll of the row loop
-  constexpr int HALO = K - S;            // window columns beyond TX * S
-  extern __shared__ float red[];
-  const int C = a.in.c, H = a.in.h, W = a.in.w;
-  const Lane l = lane_setup<CPT>(a, C);
-  const int width = a.nch * CPT;
-  const int WIN = a.TX * S + HALO;
-  float* ring = red + red_floats(a.nch, CPT);          // [2][WIN][width]
-  const bool in_tile = l.px < a.TX;                    // thread owns window columns
-  const bf16_t* IN = reinterpret_cast<const bf16_t*>(a.in.data);
-  float w[K * K][CPT], sc[CPT], sh[CPT];
-  float st[2][CPT];
-#pragma unroll
-  for (int e = 0; e < CPT; ++e) { sc[e] = 1.f; sh[e] = 0.f; st[0][e] = st[1][e] = 0.f; }
-#pragma unroll
-  for (int t = 0; t < K * K; ++t)
-#pragma unroll
-    for (int e = 0; e < CPT; ++e) w[t][e] = l.active ? a.w[(size_t)t * C + l.c + e] : 0.f;
-  if (l.active && a.in.scale) { loadf<CPT>(a.in.scale + l.c, sc); loadf<CPT>(a.in.shift + l.c, sh); }
-  const bool want_stats = a.stat_partials != nullptr;
-
-  for (int tile = l.tile0; tile < l.tend; tile += l.tstep) {
-    const int per_img = a.tiles_y * a.tiles_x;
-    const int n = tile / per_img, rr = tile - n * per_img;
-    const int ty = rr / a.tiles_x, tx = rr - ty * a.tiles_x;
-    const int oy0 = ty * a.TY, oy1 = min(a.oh, oy0 + a.TY);
-    const int ox = tx * a.TX + l.px;
-    const bool xok = l.active && ox < a.ow;
-    const int wc0 = tx * a.TX * S - a.pad_l;           // input column of window column 0
-    bool mok[S];
-#pragma unroll
-    for (int j = 0; j < S; ++j) {
-      const int ix = wc0 + l.px * S + j;
-      mok[j] = l.active && ix >= 0 && ix < W;
-    }
-    const int ixh = wc0 + a.TX * S + l.px;
-    const bool hown = HALO > 0 && l.px < HALO && in_tile;
-    const bool hok = hown && l.c < C && ixh >= 0 && ixh < W;
-    const bf16_t* ibase = IN + ((int64_t)n * H * W * a.in.ld + l.c);
-    bf16_t* obase = a.out + ((size_t)n * a.oh * a.ow + ox) * a.ldo + l.c;
-    float acc[NSL][CPT];
-#pragma unroll
-    for (int s = 0; s < NSL; ++s)
-#pragma unroll
-      for (int e = 0; e < CPT; ++e) acc[s][e] = 0.f;
-
-    const int t0 = (oy0 * S / U0) * U0, t_last = (oy1 - 1) * S + K - 1;   // t = input row + pad_t
-    Raw<CPT> fm[NF][S], fh[NF];                             // ring: step tt consumes set tt % NF, fills (tt + PF) % NF
-#pragma unroll
-    for (int i = 0; i <= PF; ++i) {
-      fh[i] = raw_zero<CPT>();
-#pragma unroll
-      for (int j = 0; j < S; ++j) fm[i][j] = raw_zero<CPT>();
-    }
-    // Every load of a step is issued on every step, at an in-range address (row, column and channel clamped): what
-    // lies outside the image / the channel range is zeroed where the row is consumed (mok / hok below).  A load under
-    // a branch turns every wait on the FIFO into a wait for ALL loads in flight -- the newest row included, i.e. the
-    // whole HBM latency once per row step (r03o: the waits of these kernels were all vmcnt(0)).
-    int64_t coff[S], hoff;
-#pragma unroll
-    for (int j = 0; j < S; ++j) coff[j] = (int64_t)min(max(wc0 + l.px * S + j, 0), W - 1) * a.in.ld;
-    hoff = hown ? (int64_t)min(max(ixh, 0), W - 1) * a.in.ld : coff[0];
-    const bf16_t* ibase_c = IN + ((int64_t)n * H * W * a.in.ld + (l.c < C ? l.c : 0));
-    auto load_row = [&](int t, Raw<CPT> (&dst)[S], Raw<CPT>& hdst) {
-      const bf16_t* rp = ibase_c + (int64_t)min(max(t - a.pad_t, 0), H - 1) * W * a.in.ld;
-#pragma unroll
-      for (int j = 0; j < S; ++j) dst[j] = raw_load<CPT>(rp + coff[j]);
-      if (HALO > 0) hdst = raw_load<CPT>(rp + hoff);
-    };
-#pragma unroll
-    for (int i = 0; i < PF; ++i) load_row(t0 + i, fm[i], fh[i]);
-    for (int tb = t0; tb <= t_last; tb += U) {
-#pragma unroll
-      for (int tt = 0; tt < U; ++tt) {
-        const int t = tb + tt;
-        load_row(t + PF, fm[(tt + PF) % NF], fh[(tt + PF) % NF]);      // PF input rows in flight per thread
-        const int r = t - a.pad_t;
-        const bool row_ok = t <= t_last && r >= 0 && r < H;   // uniform over the workgroup
-        float* buf = ring + (t & 1) * WIN * width;
-        if (row_ok && in_tile) {
-#pragma unroll
-          for (int j = 0; j < S; ++j) {
-            float x[CPT];
-            raw_unpack<CPT>(fm[tt % NF][j], x);
-            view_act<CPT, OACT>(a.in, sc, sh, x);
-            if (!mok[j]) {
-#pragma unroll
-              for (int e = 0; e < CPT; ++e) x[e] = 0.f;   // 'SAME' padding is zero in the activated domain
-            }
-            lds_put<CPT>(buf + (l.px * S + j) * width + l.chunk * CPT, x);
-          }
-          if (hown) {
-            float x[CPT];
-            raw_unpack<CPT>(fh[tt % NF], x);
-            view_act<CPT, OACT>(a.in, sc, sh, x);
-            if (!hok) {
-#pragma unroll
-              for (int e = 0; e < CPT; ++e) x[e] = 0.f;
-            }
-            lds_put<CPT>(buf + (a.TX * S + l.px) * width + l.chunk * CPT, x);
-          }
-        }
-        __syncthreads();
-        if (row_ok && in_tile) {
-#pragma unroll
-          for (int kx = 0; kx < K; ++kx) {
-            float x[CPT];
-            lds_get<CPT>(buf + (l.px * S + kx) * width + l.chunk * CPT, x);
-#pragma unroll
-            for (int ky = 0; ky < K; ++ky) {
-              if ((tt - ky) % S == 0) {                    // static: this input row feeds output (t - ky) / S
-                const int sl = slot_of((tt - ky) / S, NSL);
-#pragma unroll
-                for (int e = 0; e < CPT; ++e) acc[sl][e] = fmaf(w[ky * K + kx][e], x[e], acc[sl][e]);
-              }
-            }
-          }
-        }
-        if ((tt - (K - 1)) % S == 0) {                     // static: output row (t - K + 1) / S is complete
-          const int sl = slot_of((tt - (K - 1)) / S, NSL);
-          const int oy = (t - (K - 1)) / S;
-          if (t <= t_last && t >= K - 1 && oy >= oy0 && oy < oy1 && xok) {
-            store_bf<CPT>(obase + (size_t)oy * a.ow * a.ldo, acc[sl]);
-            if (want_stats) {
-#pragma unroll
-              for (int e = 0; e < CPT; ++e) {
-                const float v = bf2f(f2bf(acc[sl][e]));
-                st[0][e] += v;
-                st[1][e] = fmaf(v, v, st[1][e]);
-              }
-            }
-          }
-#pragma unroll
-          for (int e = 0; e < CPT; ++e) acc[sl][e] = 0.f;
-        }
-      }
-    }
-    __syncthreads();      // the next tile's first row reuses the ring slot of this tile's last rows
-  }
-  if (want_stats) block_channel_sums<CPT, 2>(a, l, C, st, a.stat_partials, red);
-}
-
-// weight gradient with the activated input row exchanged through LDS (see k_fwd_lx); dy is the thread's own
+// weight gradient with the activated input row exchanged through LDS (see k_fwd_v2); dy is the thread's own
 // column, so its BatchNorm backward was already applied once per element.
 template <int K, int S, int CPT, bool GBN, bool OACT>
 __global__ __launch_bounds__(THREADS) void k_wgrad_lx(const Args a) {
@@ -965,7 +813,7 @@ __global__ __launch_bounds__(THREADS, (CPT * K >= 10 || S == 2) ? 2 : 3) void k_
         for (int i = 0; i < NV; ++i) { dacc[s][u][i] = zero2; xt[s][u][i] = zero2; dsw[s][u][i] = one2; xw[s][u].u[i] = 0; }
 
     RawV<NV> fz[NF], fy[GBN ? NF : 1], fhz[NF], fhy[GBN ? NF : 1], fx[NF][S][S];
-    // every load of a step is issued on every step at an in-range address (see k_fwd_lx)
+    // every load of a step is issued on every step at an in-range address (see k_fwd_v2)
     auto load_step = [&](int oy, RawV<NV>& z, RawV<NV>& y, RawV<NV>& hz, RawV<NV>& hy, RawV<NV> (&x)[S][S]) {
       const uint32_t zr = (uint32_t)min(max(oy, 0), a.oh - 1) * grow_b;
       z = ldg<NV>(z_img, goff, zr);
@@ -1135,11 +983,16 @@ __global__ __launch_bounds__(THREADS, (CPT * K >= 10 || S == 2) ? 2 : 3) void k_
 }
 
 // =====================================================================================================
-// Forward, round 6: k_fwd_lx rewritten with the instruction economy of k_bwd_one (the r05 counters show the forward
+// Forward, round 6: the round-2..5 kernel (k_fwd_lx) rewritten with the instruction economy of k_bwd_one (the r05 counters show the forward
 // kernels 29-37 % issue-stalled at four waves per SIMD): raw buffer loads (uniform row offset + a per-thread byte
 // offset that is constant over a tile), 2-vectors of adjacent channels, the uniform row conditions as ranges of the
 // step index, all K neighbour reads of a step in front of its multiply-adds.  Same march: thread = output column x
 // CPT channels over the input rows t = r + pad_t of its tile, ceil(K / S) output rows in flight.
+// Every load of a step is issued on every step, at an in-range address (row, column and channel clamped): what lies
+// outside the image / the channel range is zeroed where the row is consumed.  A load under a branch turns every wait
+// on the FIFO into a wait for ALL loads in flight -- the newest row included, i.e. the whole HBM latency once per row
+// step (r03o: the waits of the first kernels were all vmcnt(0)).  The FIFO of rows in flight is a ring of NF register
+// sets addressed by static indices (the row loop is unrolled over lcm(U0, NF) steps): no set is ever copied.
 template <int K, int S, int CPT, int ACTM>
 __global__ __launch_bounds__(THREADS, (K == 3 && CPT == 2) ? 6 : 4) void k_fwd_v2(const Args a) {
   constexpr int NV = CPT / 2;
@@ -1367,20 +1220,6 @@ inline void plan(Args& a, int C, int n, int space_w, int space_h, int max_p, int
   xcd_map(a);
 }
 
-// lab switch EDET_DWM_ROUNDS=r: persistent workgroups = r x what the chip holds of THIS kernel at once (occupancy query)
-inline void replan_rounds(Args& a, const void* fn, size_t lds, int max_p) {
-  const char* e = getenv("EDET_DWM_ROUNDS");
-  if (!e || !e[0]) return;
-  const int slots = edet_resident_wgs(fn, THREADS, lds);
-  if (slots <= 0) return;
-  int P = (int)(atof(e) * slots) / a.ngroups;
-  if (P < 1) P = 1;
-  if (P > max_p) P = max_p;
-  if (P > a.ntiles) P = a.ntiles;
-  a.P = P;
-  xcd_map(a);
-}
-
 }  // namespace dwm
 
 // return 1 = handled, 0 = not applicable (caller falls back), < 0 = error
@@ -1390,30 +1229,18 @@ int dwm_try_fwd(const edet_tview_t* in, const float* weight, int k, int s, void*
   if (in->gate || in->c % 8 != 0) return 0;
   Args a;
   memset(&a, 0, sizeof(a));
-  const bool oact = in->act > EDET_ACT_SWISH;      // relu / relu6 / hswish: the OACT instantiations
   a.in = *in; a.w = weight; a.out = reinterpret_cast<bf16_t*>(out); a.ldo = ldo; a.stat_partials = stat_partials;
   a.oh = same_out(in->h, s); a.ow = same_out(in->w, s);
   a.pad_t = same_pad_before(in->h, k, s); a.pad_l = same_pad_before(in->w, k, s);
-#define DWM_FWD(K_, S_, CPT_)                                                             \
-  do {                                                                                    \
-    plan<CPT_>(a, in->c, in->n, a.ow, a.oh, EDET_MAX_PARTS, K_);                          \
-    const size_t lds0 = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                  \
-    const size_t ring = (size_t)2 * (a.TX * S_ + K_ - S_) * a.nch * CPT_ * sizeof(float); \
-    replan_rounds(a, reinterpret_cast<const void*>(&k_fwd_lx<K_, S_, CPT_, false>), lds0 + ring, EDET_MAX_PARTS); \
-    if (oact) edet_launch(k_fwd_lx<K_, S_, CPT_, true>, dim3(a.P * a.ngroups), dim3(THREADS), lds0 + ring, st, a); \
-    else edet_launch(k_fwd_lx<K_, S_, CPT_, false>, dim3(a.P * a.ngroups), dim3(THREADS), lds0 + ring, st, a); \
-  } while (0)
+  // the kernel's 32-bit offsets inside one image
+  if ((int64_t)in->h * in->w * in->ld * 2 >= 0x7fffffffLL || (int64_t)a.oh * a.ow * ldo * 2 >= 0x7fffffffLL) return 0;
   // 3x3: four channels per thread on the large maps, two (six rows of loads in flight, more waves) from 40 x 40 OUTPUT
   // pixels down -- r04 lab, D0 640x640 batch 128: 40x40x64 0.0340 (4) / 0.0278 ms (2), 40x40x480 0.162 / 0.140, 80x80x240
   // stride 2 0.166 / 0.142, 20x20x1152 0.097 / 0.089, but 80x80x64 0.057 / 0.068 and 320x320x32 0.43 / 0.56.  By the map,
   // not the batch.  EDET_DWM_FWD_CPT=4|2 overrides (lab switch).
   const char* fc = getenv("EDET_DWM_FWD_CPT");
   const bool c2 = (fc && fc[0]) ? fc[0] == '2' : a.oh * a.ow <= 40 * 40;
-  const char* v2_env = getenv("EDET_DWM_FWD2");          // lab switch: 0 = the round-5 kernel (k_fwd_lx)
-  const bool v2 = !(v2_env && v2_env[0] == '0') && (int64_t)in->h * in->w * in->ld * 2 < 0x7fffffffLL &&
-                  (int64_t)a.oh * a.ow * ldo * 2 < 0x7fffffffLL;
-  if (v2) {
-    const int actm = in->act == EDET_ACT_NONE ? 0 : (in->act == EDET_ACT_SWISH ? 1 : 2);
+  const int actm = in->act == EDET_ACT_NONE ? 0 : (in->act == EDET_ACT_SWISH ? 1 : 2);
 #define DWM_FWD2(K_, S_, CPT_)                                                            \
   do {                                                                                    \
     plan<CPT_>(a, in->c, in->n, a.ow, a.oh, EDET_MAX_PARTS, K_);                          \
@@ -1424,26 +1251,14 @@ int dwm_try_fwd(const edet_tview_t* in, const float* weight, int k, int s, void*
     else if (actm == 1) edet_launch(k_fwd_v2<K_, S_, CPT_, 1>, grid, block, lds0 + ring, st, a); \
     else edet_launch(k_fwd_v2<K_, S_, CPT_, 2>, grid, block, lds0 + ring, st, a);                \
   } while (0)
-    if (k == 3 && s == 1 && c2) DWM_FWD2(3, 1, 2);
-    else if (k == 3 && s == 2 && c2) DWM_FWD2(3, 2, 2);
-    else if (k == 3 && s == 1) DWM_FWD2(3, 1, 4);
-    else if (k == 3 && s == 2) DWM_FWD2(3, 2, 4);
-    else if (k == 5 && s == 1) DWM_FWD2(5, 1, 2);
-    else if (k == 5 && s == 2) DWM_FWD2(5, 2, 2);
-    else return 0;
-#undef DWM_FWD2
-    if (nparts_out) *nparts_out = a.P;
-    EDET_LAUNCH_CHECK("edet_dw_fwd(march v2)");
-    return 1;
-  }
-  if (k == 3 && s == 1 && c2) DWM_FWD(3, 1, 2);
-  else if (k == 3 && s == 2 && c2) DWM_FWD(3, 2, 2);
-  else if (k == 3 && s == 1) DWM_FWD(3, 1, 4);
-  else if (k == 3 && s == 2) DWM_FWD(3, 2, 4);
-  else if (k == 5 && s == 1) DWM_FWD(5, 1, 2);
-  else if (k == 5 && s == 2) DWM_FWD(5, 2, 2);
+  if (k == 3 && s == 1 && c2) DWM_FWD2(3, 1, 2);
+  else if (k == 3 && s == 2 && c2) DWM_FWD2(3, 2, 2);
+  else if (k == 3 && s == 1) DWM_FWD2(3, 1, 4);
+  else if (k == 3 && s == 2) DWM_FWD2(3, 2, 4);
+  else if (k == 5 && s == 1) DWM_FWD2(5, 1, 2);
+  else if (k == 5 && s == 2) DWM_FWD2(5, 2, 2);
   else return 0;
-#undef DWM_FWD
+#undef DWM_FWD2
   if (nparts_out) *nparts_out = a.P;
   EDET_LAUNCH_CHECK("edet_dw_fwd(march)");
   return 1;

@@ -751,6 +751,8 @@ extern "C" int edet_pw_bwd_data(const edet_gview_t* dy, const void* w, int ldw,
              "edet_pw_bwd_data: strides must be multiples of 8");
   EDET_CHECK(!(epi->stat_partials && epi->beta), "edet_pw_bwd_data: fused stats need beta == 0");
   EDET_CHECK(!(epi->dgate && !in->gate), "edet_pw_bwd_data: dgate given but input view has no gate");
+  // (checked here, in front of the dispatch: the same call must not pass or fail by the implementation it lands on)
+  EDET_CHECK(!(in->gate && epi->dgate && epi->beta), "edet_pw_bwd_data: the gate gradient of an SE-gated input needs beta == 0");
   GemmArgs a;
   memset(&a, 0, sizeof(a));
   a.tv = *in; a.gv = *dy;
@@ -818,6 +820,7 @@ extern "C" int edet_pw_bwd(const edet_gview_t* dy, const void* w, int ldw, const
              "edet_pw_bwd: strides must be multiples of 8");
   EDET_CHECK(!(epi->stat_partials && epi->beta), "edet_pw_bwd: fused stats need beta == 0");
   EDET_CHECK(!(epi->dgate && !in->gate), "edet_pw_bwd: dgate given but input view has no gate");
+  EDET_CHECK(!(in->gate && epi->dgate && epi->beta), "edet_pw_bwd: the gate gradient of an SE-gated input needs beta == 0");
   if (dtype == EDET_BF16) {
     const int impl = pw_impl_env();
     if (impl == PW_AUTO || impl == PW_STREAM) {

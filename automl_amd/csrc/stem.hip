@@ -56,6 +56,27 @@ constexpr int MIH = (MROWS - 1) * 2 + 3;     // 5 input rows
 constexpr int MROWP = MIW * 3 + 5;           // 392 elements per LDS row
 constexpr int MZERO = MIH * MROWP;           // index of an always-zero element
 
+constexpr int MCH = MROWP / 8;                // 49 16-byte chunks per LDS row (387 elements used)
+static_assert(MCH * 8 == MROWP && MIH * MCH <= THREADS, "one staging chunk per thread");
+
+// Image staging, fast path (r06): the tile's five input rows as 16-byte chunks, ONE per thread, instead of 1935 two-byte
+// loads (7.6 per thread, 128 bytes per wave instruction) -- legal when a tile row starts on a 16-byte boundary and chunks
+// never straddle the right image edge: pad_l == 0 and w % 8 == 0 (every even size; otherwise the element loop).
+// Chunk `tid` of tile `sp` (zeros outside the image, for sp beyond the last tile and for tid >= 245).
+__device__ __forceinline__ bool stem_fast(const StemArgs& a) { return a.pad_l == 0 && (a.w & 7) == 0; }
+__device__ __forceinline__ uint4 stem_chunk(const StemArgs& a, const bf16_t* img, int sp, int tid) {
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (sp < a.nsp && tid < MIH * MCH) {
+    const int per_img = a.tiles_y * a.tiles_x;
+    const int n = sp / per_img, rr = sp - n * per_img;
+    const int oy0 = (rr / a.tiles_x) * MROWS, ox0 = (rr % a.tiles_x) * MPX;
+    const int gy = oy0 * 2 - a.pad_t + tid / MCH, gx3 = ox0 * 6 + (tid % MCH) * 8;
+    if (gy >= 0 && gy < a.h && gx3 < a.w * 3)
+      v = *reinterpret_cast<const uint4*>(img + (size_t)(n * a.h + gy) * a.w * 3 + gx3);
+  }
+  return v;
+}
+
 template <int NCT>  // channel tiles of 32
 __global__ __launch_bounds__(THREADS) void k_stem_fwd_mfma(const StemArgs a) {
   __shared__ __align__(16) bf16_t tile[MIH * MROWP + 8];
@@ -91,6 +112,8 @@ __global__ __launch_bounds__(THREADS) void k_stem_fwd_mfma(const StemArgs a) {
     for (int t = 0; t < 16; ++t) s1[ct][t] = s2[ct][t] = 0.f;
   for (int i = tid; i < 2 * 64; i += THREADS) red[i] = 0.f;
   if (tid < 8) tile[MZERO + tid] = 0;
+  const bool fast = stem_fast(a);
+  uint4 nxt = fast ? stem_chunk(a, img, blockIdx.x, tid) : make_uint4(0, 0, 0, 0);
 
   const int wr = wave >> 1, wx = (wave & 1) * 32 + j;   // this lane's pixel inside the tile
   for (int sp = blockIdx.x; sp < a.nsp; sp += a.P) {
@@ -99,12 +122,18 @@ __global__ __launch_bounds__(THREADS) void k_stem_fwd_mfma(const StemArgs a) {
     const int oy0 = (rr / a.tiles_x) * MROWS, ox0 = (rr % a.tiles_x) * MPX;
     const int iy0 = oy0 * 2 - a.pad_t, ix3 = (ox0 * 2 - a.pad_l) * 3;
     __syncthreads();
-    for (int q = tid; q < MIH * MIW * 3; q += THREADS) {
-      const int ly = q / (MIW * 3), r = q - ly * (MIW * 3);
-      const int gy = iy0 + ly, gx3 = ix3 + r;
-      bf16_t v = 0;
-      if (gy >= 0 && gy < a.h && gx3 >= 0 && gx3 < a.w * 3) v = img[(size_t)(n * a.h + gy) * a.w * 3 + gx3];
-      tile[ly * MROWP + r] = v;
+    if (fast) {
+      // one 16-byte chunk per thread, loaded while the previous tile was on the matrix cores
+      if (tid < MIH * MCH) *reinterpret_cast<uint4*>(tile + (tid / MCH) * MROWP + (tid % MCH) * 8) = nxt;
+      nxt = stem_chunk(a, img, sp + a.P, tid);
+    } else {
+      for (int q = tid; q < MIH * MIW * 3; q += THREADS) {
+        const int ly = q / (MIW * 3), r = q - ly * (MIW * 3);
+        const int gy = iy0 + ly, gx3 = ix3 + r;
+        bf16_t v = 0;
+        if (gy >= 0 && gy < a.h && gx3 >= 0 && gx3 < a.w * 3) v = img[(size_t)(n * a.h + gy) * a.w * 3 + gx3];
+        tile[ly * MROWP + r] = v;
+      }
     }
     __syncthreads();
     const int base = (2 * wr) * MROWP + wx * 6;
@@ -233,6 +262,8 @@ __global__ __launch_bounds__(THREADS) void k_stem_bwd_weight_mfma(const StemArgs
   if (gbn && c_ok) { loadf8(a.gy.a + sc * 8, ga); loadf8(a.gy.b + sc * 8, gb); loadf8(a.gy.cc + sc * 8, gc); }
   for (int q = tid; q < 27 * 64; q += THREADS) red[q] = 0.f;
   if (tid < 8) tile[MZERO + tid] = 0;
+  const bool fast = stem_fast(a);
+  uint4 nxt = fast ? stem_chunk(a, img, blockIdx.x, tid) : make_uint4(0, 0, 0, 0);
   f32x16 acc[NCT];
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct)
@@ -248,12 +279,18 @@ __global__ __launch_bounds__(THREADS) void k_stem_bwd_weight_mfma(const StemArgs
     const int oy0 = (rr / a.tiles_x) * MROWS, ox0 = (rr % a.tiles_x) * MPX;
     const int iy0 = oy0 * 2 - a.pad_t, ix3 = (ox0 * 2 - a.pad_l) * 3;
     __syncthreads();
-    for (int q = tid; q < MIH * MIW * 3; q += THREADS) {
-      const int ly = q / (MIW * 3), r = q - ly * (MIW * 3);
-      const int gy = iy0 + ly, gx3 = ix3 + r;
-      bf16_t v = 0;
-      if (gy >= 0 && gy < a.h && gx3 >= 0 && gx3 < a.w * 3) v = img[(size_t)(n * a.h + gy) * a.w * 3 + gx3];
-      tile[ly * MROWP + r] = v;
+    if (fast) {
+      // one 16-byte chunk per thread, loaded while the previous tile was on the matrix cores
+      if (tid < MIH * MCH) *reinterpret_cast<uint4*>(tile + (tid / MCH) * MROWP + (tid % MCH) * 8) = nxt;
+      nxt = stem_chunk(a, img, sp + a.P, tid);
+    } else {
+      for (int q = tid; q < MIH * MIW * 3; q += THREADS) {
+        const int ly = q / (MIW * 3), r = q - ly * (MIW * 3);
+        const int gy = iy0 + ly, gx3 = ix3 + r;
+        bf16_t v = 0;
+        if (gy >= 0 && gy < a.h && gx3 >= 0 && gx3 < a.w * 3) v = img[(size_t)(n * a.h + gy) * a.w * 3 + gx3];
+        tile[ly * MROWP + r] = v;
+      }
     }
     // dy rows of this wave's 32 pixels -> its LDS tile (zero outside the image and beyond cout)
     const int oy = oy0 + wr;

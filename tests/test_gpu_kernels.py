@@ -1062,14 +1062,14 @@ def test_tuned_kernels_with_the_other_activations(act, monkeypatch):
   generic = {k: v for k, v in log.items() if any(g in k for g in GENERIC_KERNELS)}
   assert not generic, 'fell back to the generic kernels: %s' % generic
   for family in ('pws::k_pw_fwd', 'pws::k_pw_dgrad', 'pws::k_pw_wgrad', 'pwb::k_big_gemm', 'pwb::k_big_wgrad',
-                 'pwt::k_pw_bwd_tile', 'dwm::k_fwd_lx', 'dwm::k_dgrad_lx', 'dwm::k_wgrad_lx', 'dwm::k_bwd_one'):
+                 'pwt::k_pw_bwd_tile', 'dwm::k_fwd_v2', 'dwm::k_dgrad_lx', 'dwm::k_wgrad_lx', 'dwm::k_bwd_one'):
     assert any(family in k for k in log), (family, sorted(log))
   # ... and every tuned kernel that ran is an OACT instantiation (last template argument)
   # (OACT is the last template argument, except: pwb::k_big_gemm carries it fourth -- in front of F32OUT --, the one-pass
   # tiled kernel fifth -- in front of the slice count; the one-pass depthwise backward has an activation MODE last: 2)
   def oact_of(k):
     targs = [t.strip() for t in k.split('<', 1)[1].rsplit('>(', 1)[0].split(',')]
-    if 'dwm::k_bwd_one' in k:
+    if 'dwm::k_bwd_one' in k or 'dwm::k_fwd_v2' in k:
       return 'true' if targs[-1] == '2' else 'false'
     return targs[3] if 'pwb::k_big_gemm' in k else (targs[4] if 'pwt::k_pw_bwd_tile' in k else targs[-1])
   tuned = [k for k in log if any(ns in k for ns in ('pws::k_', 'pwb::k_', 'pwt::k_pw_bwd', 'dwm::k_')) and 'k_reduce' not in k]
