@@ -94,10 +94,26 @@ __device__ __forceinline__ void partial_colsum(const float* __restrict__ partial
   red[0][slice][cl] = a0 + a1;
   red[1][slice][cl] = b0 + b1;
   __syncthreads();
+  // the slices in two fixed levels (r06: one thread adding all FIN_SL slices was a chain of FIN_SL dependent LDS reads,
+  // ~1 us of a ~6 us kernel that runs 216 times per step): FIN_G leaders add FIN_SL / FIN_G consecutive slices each,
+  // slice 0 adds the leaders in order -- the same tree on every run
+  constexpr int FIN_G = 8, PER = FIN_SL / FIN_G;
+  static_assert(FIN_SL % FIN_G == 0, "slice groups");
+  double u = 0.0, v = 0.0;
+  if (slice < FIN_G) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { u += red[0][slice * PER + i][cl]; v += red[1][slice * PER + i][cl]; }
+  }
+  __syncthreads();                   // every leader has read its slices before any of them overwrites rows 0 .. FIN_G - 1
+  if (slice < FIN_G) {
+    red[0][slice][cl] = u;
+    red[1][slice][cl] = v;
+  }
+  __syncthreads();
   s = 0.0; s2 = 0.0;
   if (slice == 0) {
 #pragma unroll
-    for (int i = 0; i < FIN_SL; ++i) { s += red[0][i][cl]; s2 += red[1][i][cl]; }
+    for (int i = 0; i < FIN_G; ++i) { s += red[0][i][cl]; s2 += red[1][i][cl]; }
   }
 }
 

@@ -1181,7 +1181,7 @@ inline void xcd_map(Args& a) {
 
 // space_w / space_h: extent of the marched tile space (output pixels; for dgrad the q / oy step space)
 template <int CPT>
-inline void plan(Args& a, int C, int n, int space_w, int space_h, int max_p, int k, int slack_h = 0) {
+inline void plan(Args& a, int C, int n, int space_w, int space_h, int max_p, int k, int slack_h = 0, int p_small = 2048) {
   const int nvec = (C + CPT - 1) / CPT;
   // <= 128 contiguous bytes per pixel and workgroup.  (r02t lab: 64- or 32-byte channel groups for the two-channel
   // kernels -- wider column tiles, half the column halo -- are slower: backward 11.04 -> 11.40 / 12.01 ms, forward
@@ -1210,9 +1210,11 @@ inline void plan(Args& a, int C, int n, int space_w, int space_h, int max_p, int
   // depthwise layer shapes of D0 640x640 batch 128): the 3x3 layers on the 160 / 320-row maps want many short-lived
   // workgroups (8192: 320x320x32 fused backward 1.00 -> 0.86 ms, forward 0.61 -> 0.52 ms), every other layer fewer,
   // longer-lived ones (2048: 40x40x480 k5 backward 0.65 -> 0.54, 20x20x1152 k5 0.46 -> 0.38 ms); over the 15 shapes
-  // backward 11.21 -> 10.52 ms, forward 4.84 -> 4.67 ms against round 2's 4096 everywhere.  EDET_DWM_P overrides.
+  // backward 11.21 -> 10.52 ms, forward 4.84 -> 4.67 ms against round 2's 4096 everywhere.  r06l lab, the round-6 kernels:
+  // the forward (four waves per SIMD now) wants 4096 on those layers (3.39 -> 3.34 ms over the 15 shapes, 20x20x1152 k3 0.071
+  // -> 0.064 ms), the one-pass backward keeps 2048 (7.14 / 7.16 / 7.35 ms at default / 2048 / 4096).  EDET_DWM_P overrides.
   const char* p_env = getenv("EDET_DWM_P");
-  int P = ((p_env && p_env[0]) ? atoi(p_env) : ((k == 3 && a.in.h >= 160) ? 8192 : 2048)) / a.ngroups;
+  int P = ((p_env && p_env[0]) ? atoi(p_env) : ((k == 3 && a.in.h >= 160) ? 8192 : p_small)) / a.ngroups;
   if (P < 64) P = 64;
   if (P > max_p) P = max_p;
   if (P > a.ntiles) P = a.ntiles;
@@ -1243,7 +1245,7 @@ int dwm_try_fwd(const edet_tview_t* in, const float* weight, int k, int s, void*
   const int actm = in->act == EDET_ACT_NONE ? 0 : (in->act == EDET_ACT_SWISH ? 1 : 2);
 #define DWM_FWD2(K_, S_, CPT_)                                                            \
   do {                                                                                    \
-    plan<CPT_>(a, in->c, in->n, a.ow, a.oh, EDET_MAX_PARTS, K_);                          \
+    plan<CPT_>(a, in->c, in->n, a.ow, a.oh, EDET_MAX_PARTS, K_, 0, 4096);                 \
     const size_t lds0 = (size_t)red_floats(a.nch, CPT_) * sizeof(float);                  \
     const size_t ring = (size_t)2 * (a.TX * S_ + K_ - S_) * a.nch * CPT_ * sizeof(float); \
     const dim3 grid(a.P * a.ngroups), block(THREADS);                                     \
