@@ -352,7 +352,7 @@ def test_train_step_bf16_tracks_the_oracle(override):
   assert cos >= 0.9, cos
 
 
-TRAJ_STEPS, TRAJ_LOSS_TOL, TRAJ_EMA_COS, TRAJ_UPDATE_COS = 20, 2e-2, 0.999, 0.5
+TRAJ_STEPS, TRAJ_LOSS_TOL, TRAJ_EMA_COS, TRAJ_UPDATE_COS = 20, 1e-2, 0.9999, 0.3
 
 
 def test_bf16_training_tracks_fp32_storage_training_over_twenty_steps():
@@ -365,7 +365,11 @@ def test_bf16_training_tracks_fp32_storage_training_over_twenty_steps():
     * every loss value of every step within TRAJ_LOSS_TOL of the fp32 run's,
     * the EMA shadow variables after the last step: cosine >= TRAJ_EMA_COS over the whole vector,
     * the net update (theta_20 - theta_0, a far stricter quantity: the variables barely move in 20 steps): cosine of the
-      two runs' update vectors >= TRAJ_UPDATE_COS (printed; the bound is the measured value with margin)."""
+      two runs' update vectors >= TRAJ_UPDATE_COS.
+  Measured (r06, one MI355X): worst relative difference over the 20 steps loss 1.2e-3, cls_loss 2e-4, box_loss 3.6e-3; loss
+  366.56 -> 334.61 (fp32 storage) / 366.57 -> 334.68 (bf16); EMA cosine 0.99996; update cosine 0.52 -- the DIRECTION of a
+  bf16 step deep in the network is not the fp32 step's (the ill-conditioning the layer-by-layer tests work around), the
+  loss it reaches is.  The bounds are the measured values with margin (2.8x on the loss, 0.3 on the update cosine)."""
   config = hparams_config.get_efficientdet_config('efficientdet-d0')
   size, batch = 384, 8
   vals = perturbed_params(config, 11)
