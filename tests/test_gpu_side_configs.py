@@ -410,7 +410,7 @@ def test_d7x_1536_batch8_train_step_tracks_the_1_image_step_and_is_covered():
   print('d7x 1536 batch 8 vs 1, gradient of the logits per level: class %s, box %s' % (derr[:nl], derr[nl:]))
   # class logits: a smooth function of logits that agree to a bf16 ulp (measured 7.4e-3).  Box outputs: the Huber
   # gradient saturates at +-delta (0.1) and the zero-bias box outputs of the training-mode network move by tenths of
-  # their range between two runs (BOX_CHAOS_BOUND of tests/test_gpu_bench_shapes.py), so signs flip: printed, not held
+  # their range between two runs (the measured-conditioning bound of tests/test_gpu_bench_shapes.py), so signs flip: printed, not held
   assert max(derr[:nl]) <= 2e-2, 'gradient of the class logits, batch 8 vs 1: %s' % (derr,)
   groups = {'predict': [], 'tower': [], 'fpn': [], 'backbone': []}
   for n in one.grads:
