@@ -242,6 +242,13 @@ __device__ __forceinline__ void wave_group_sum(float (&v)[NV], int group) {
   }
 }
 
+// Internal bit of edet_bwd_epi_t::flags (set by the bf16 dispatch of edet_pw_bwd / edet_pw_bwd_data, never by callers): the
+// SE gate-gradient sums of this data-gradient launch are formed AFTERWARDS from the stored gradient by k_gate_sums (one
+// writer per element, a fixed order) -- the kernel stores d as it is and adds nothing to dgate itself.  r06: the wide
+// two-kernel paths (pw_big.hip, pw_stream.hip) added their sums with floating-point atomics, the last ones of the bf16
+// training step (efficientdet-d7x: 1344 -> 224 / 960 -> 160 at 96 x 96).
+#define EDET_EPI_GATE_SUMS_LATER 0x40000000
+
 // TF 'SAME' geometry
 __host__ __device__ inline int same_out(int in, int s) { return (in + s - 1) / s; }
 __host__ __device__ inline int same_pad_before(int in, int k, int s) {

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
   if (grp >= a.ngrp) return;
   const int j0 = jt * BJ;
   const bool want_stats = a.stat_partials != nullptr;
-  const bool want_gate = BWD && a.epi.dgate != nullptr;
+  const bool want_gate = BWD && a.epi.dgate != nullptr;       // SE-gated input: the gradient of the gated value is stored as it is
+  const bool gate_sums = want_gate && !(a.epi.flags & EDET_EPI_GATE_SUMS_LATER);      // ... and its sums are formed here (atomics)
   const bool swish = !OACT && a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr;
   constexpr bool other = OACT;
   const bool gated = !BWD && a.tv.gate != nullptr;
@@ -466,16 +467,19 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
           unpack8(xr[i], x);
           const size_t off = (size_t)m * a.tv.ld + ej;
           if (want_gate) {
-            if (!single_img) {
-              const int img = m / a.hw;
-              if (img != gp_img) { flush_gate(); gp_img = img; }
+            if (gate_sums) {
+              if (!single_img) {
+                const int img = m / a.hw;
+                if (img != gp_img) { flush_gate(); gp_img = img; }
+              }
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float z = fmaf(x[e], sc[e], sh[e]);
+                gp[e] = fmaf(d[e], other ? act_other_(a.tv.act, z) : (swish ? swishf_(z) : z), gp[e]);
+              }
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float z = fmaf(x[e], sc[e], sh[e]);
-              gp[e] = fmaf(d[e], other ? act_other_(a.tv.act, z) : (swish ? swishf_(z) : z), gp[e]);
-              g[e] = d[e];
-            }
+            for (int e = 0; e < 8; ++e) g[e] = d[e];
           } else if (swish) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) g[e] = d[e] * swish_gradf_(fmaf(x[e], sc[e], sh[e]));
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_big_gemm(const GemmArgs a) {
           }
         }
       }
-      if (want_gate) {
+      if (gate_sums) {
         if (single_img) {
           __syncthreads();
           float* red = reinterpret_cast<float*>(smem);          // [16][BJ]

@@ -763,11 +763,20 @@ extern "C" int edet_pw_bwd_data(const edet_gview_t* dy, const void* w, int ldw,
     const int impl = pw_impl_env();
     const bool big_first = impl == PW_BIG || (impl == PW_AUTO && pw_prefers_big(PW_OP_DGRAD, a.M, in->c, dy->c));
     int rc = 0;
-    if (big_first) rc = pwb_try_dgrad(dy, w, ldw, in, epi, nparts_out, to_stream(stream));
+    // SE-gated input: the tuned kernels store the gradient of the gated value and leave the gate-gradient sums to
+    // k_gate_sums below (one writer per element; r06: their own sums were floating-point atomics, the last of the bf16
+    // training step) -- the generic kernel (launch_gemm) does the same on its own
+    edet_bwd_epi_t e2 = *epi;
+    if (epi->dgate) e2.flags |= EDET_EPI_GATE_SUMS_LATER;
+    if (big_first) rc = pwb_try_dgrad(dy, w, ldw, in, &e2, nparts_out, to_stream(stream));
     if (rc == 0 && impl != PW_TILED && impl != PW_BIG)
-      rc = pws_try_dgrad(dy, w, ldw, in, epi, nparts_out, to_stream(stream));
+      rc = pws_try_dgrad(dy, w, ldw, in, &e2, nparts_out, to_stream(stream));
     if (rc == 0 && !big_first && impl == PW_AUTO && (int64_t)in->c * dy->c >= 4096)
-      rc = pwb_try_dgrad(dy, w, ldw, in, epi, nparts_out, to_stream(stream));
+      rc = pwb_try_dgrad(dy, w, ldw, in, &e2, nparts_out, to_stream(stream));
+    if (rc > 0 && epi->dgate) {
+      edet_launch(k_gate_sums<bf16_t>, dim3(a.tv.n * cdiv(a.J, 64)), dim3(THREADS), 0, to_stream(stream), a);
+      EDET_LAUNCH_CHECK("edet_pw_bwd_data (gate sums)");
+    }
     if (rc != 0) return rc < 0 ? rc : 0;
     return launch_gemm<bf16_t, true>(a, nparts_out, to_stream(stream));
   }

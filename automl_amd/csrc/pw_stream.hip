@@ -430,7 +430,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_pw_dgrad(const BwdArgs a) {
   float* wst = reinterpret_cast<float*>(Ct + TR * a.SC);                // [2][KOpad] stat sums of this wave
   float* wgt = wst + 2 * a.KOpad;                                       // [KOpad] dgate sums of the current image
   const bool want_stats = a.epi.stat_partials != nullptr;
-  const bool want_gate = a.epi.dgate != nullptr;
+  const bool want_gate = a.epi.dgate != nullptr;      // SE-gated input: the gradient of the gated value is stored as it is
+  const bool gate_sums = want_gate && !(a.epi.flags & EDET_EPI_GATE_SUMS_LATER);   // ... and its sums are formed here (atomics)
   const bool swish = !OACT && a.tv.act == EDET_ACT_SWISH, affine = a.tv.scale != nullptr;
   constexpr bool other = OACT;
 
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_pw_dgrad(const BwdArgs a) {
     // dgate bookkeeping: sums in wgt belong to one image; a super-tile that straddles two images goes
     // straight to global atomics
     bool gate_direct = false;
-    if (want_gate) {
+    if (gate_sums) {
       const int img0 = row0 / a.hw, img1 = (row0 + rows_in_st - 1) / a.hw;
       gate_direct = img0 != img1;
       if (gate_img >= 0 && (gate_direct || img0 != gate_img)) {
@@ -572,7 +573,10 @@ __global__ __launch_bounds__(THREADS, 2) void k_pw_dgrad(const BwdArgs a) {
             float x[8], g[8];
             unpack8(xr[p], x);
             const size_t off = (size_t)(trow0 + r) * a.tv.ld + ch0;
-            if (want_gate) {
+            if (want_gate && !gate_sums) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) g[e] = d[e];
+            } else if (want_gate) {
               float gsum[8];
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
@@ -633,7 +637,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_pw_dgrad(const BwdArgs a) {
             }
           }
         }
-        if (want_gate && !gate_direct) {
+        if (gate_sums && !gate_direct) {
 #pragma unroll
           for (int e = 0; e < 8; ++e)
             if (ch0 + e < a.KO) atomicAdd(&wgt[ch0 + e], s1[e]);
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_pw_dgrad(const BwdArgs a) {
     }
   }
   __builtin_amdgcn_wave_barrier();
-  if (want_gate && gate_img >= 0) {
+  if (gate_sums && gate_img >= 0) {
     for (int c = lane; c < a.KO; c += 64) {
       const float v = wgt[c];
       if (v != 0.f) atomicAdd(&a.epi.dgate[(size_t)gate_img * a.KO + c], v);
@@ -1735,6 +1739,8 @@ int pws_try_bwd_fused(const edet_gview_t* dy, const void* w, int ldw, const edet
   const int R = dy->c, KO = in->c;
   if (!workspace || KO % 8 != 0 || dy->ld % 8 != 0 || in->ld % 8 != 0 || R > 160 || KO > 160) return 0;
   if (epi->stat_partials && epi->dgate) return 0;     // one set of running sums per lane: BatchNorm backward OR gate
+  if (in->gate && epi->dgate) return 0;               // r06: this kernel's gate-gradient sums are atomics -- the tiled one-pass kernel
+                                                      // (ordered slots) or the two-kernel path + k_gate_sums take SE-gated inputs
   FusedArgs a;
   memset(&a, 0, sizeof(a));
   a.gv = *dy; a.tv = *in; a.W = reinterpret_cast<const bf16_t*>(w); a.ldw = ldw; a.epi = *epi;

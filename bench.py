@@ -216,6 +216,16 @@ def parity_block(config, size):
   out['training_forward_layer_by_layer'] = {'stored_tensors_checked': len(hook.fwd_err),
                                             'worst_rel_err': max(hook.fwd_err.values()),
                                             'worst_tensor': max(hook.fwd_err, key=hook.fwd_err.get)}
+  # ... and the logits themselves, per pyramid level (the predict layers' stored outputs of that same teacher-forced pass:
+  # the worst tensor above is usually one of these -- a bf16-stored logit carries one rounding of 2^-8 of its range)
+  import re
+  per_level = {'class': {}, 'box': {}}
+  for key, e in hook.fwd_err.items():
+    m = re.search(r'(class|box)-predict\D*?l(\d+)', key)
+    if m:
+      per_level[m.group(1)][int(m.group(2))] = max(e, per_level[m.group(1)].get(int(m.group(2)), 0.0))
+  out['training_forward_logits_vs_emulating_oracle_per_level'] = {
+      k: [v[l] for l in sorted(v)] for k, v in per_level.items() if v}
   return out
 
 

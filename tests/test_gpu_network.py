@@ -542,7 +542,11 @@ def test_frozen_variables_survive_a_restored_optimizer_state():
     # dwconv.hip, the fp32 stem, the per-channel fusion backward, the dense convolution) combine their sums in a fixed order too
     ('efficientdet-d0', 256, 3, 'f32'), ('efficientdet-d1', 192, 3, 'f32'),
     ('efficientdet-d0[fpn_weight_method=channel_fastattn]', 128, 2, 'f32'),
-    ('efficientdet-d0[fpn_weight_method=channel_fastattn]', 256, 2, 'bf16')])
+    ('efficientdet-d0[fpn_weight_method=channel_fastattn]', 256, 2, 'bf16'),
+    # r06: efficientdet-d7x at its own 1536 x 1536 (one image): the wide projections whose maps exceed the one-pass tiled
+    # kernel's envelope (1344 -> 224 and 960 -> 160 at 96 x 96) run the two-kernel backward, whose SE gate-gradient sums
+    # were the last floating-point atomics of the bf16 path
+    ('efficientdet-d7x', 1536, 1, 'bf16')])
 def test_train_step_is_bit_reproducible(model, size, batch, dtype):
   """r04: the bf16 training step has no floating-point atomics left on its path (BatchNorm partial rows, SE pooling / FC /
   gate gradients, loss sums and bias gradients, fusion-weight gradients, stem / depthwise / pointwise weight gradients
