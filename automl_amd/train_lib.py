@@ -7,6 +7,7 @@ across data-parallel replicas (implicit in optimizer.apply_gradients, :683), SGD
 TFA MovingAverage EMA (:176-199).  LR schedules restate :37-173.
 """
 import math
+import os
 
 import torch
 
@@ -146,6 +147,7 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
     self.global_batch_size = global_batch_size
     self.process_group = process_group
     self.use_dist = use_dist or process_group is not None
+    self.one_graph_dp = os.environ.get('EDET_DP_ONE_GRAPH', '0') == '1'      # see _graph_step
     self._lr_fn = None
     self.iterations = 0
     # positives_momentum > 0: the moving loss normalizer (train_lib.py:519-531).  A 0-d fp32 DEVICE tensor once the
@@ -276,15 +278,36 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
         # the capture pass runs optimizer_apply's host bookkeeping once WITHOUT executing anything: keep the counters
         # where they were, the replay below accounts for the step
         counters = (eng.arena.version, eng.arena.step_count)
-        ga = torch.cuda.CUDAGraph()
-        # thread_local: other threads of the process (the RCCL watchdog) may touch the HIP runtime meanwhile
-        with torch.cuda.graph(ga, capture_error_mode='thread_local'):
-          body_a()
-        gb = None
-        if reduce_fn is not None:
-          gb = torch.cuda.CUDAGraph()
-          with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode='thread_local'):
-            body_b()
+        ga = gb = None
+        if reduce_fn is not None and self.one_graph_dp:
+          # The collective captured INSIDE the step's graph (RCCL 2.26 supports stream capture): no host hop between the
+          # two halves.  Opt-in (EDET_DP_ONE_GRAPH=1): exercised on the device at world size 1 only -- no multi-GPU node
+          # was available to any round -- so the default stays the two-graph structure below; if the capture itself
+          # raises, the step falls back to it.
+          try:
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga, capture_error_mode='thread_local'):
+              body_a()
+              reduce_fn(eng.grads_flat)
+              body_b()
+          except Exception as e:      # noqa: BLE001 -- any capture failure: the robust structure
+            import warnings
+            warnings.warn('one-graph data-parallel capture failed (%s); using two graphs around an eager all-reduce' % (e,))
+            ga = None
+            torch.cuda.synchronize()
+          eng.arena.version, eng.arena.step_count = counters
+        if ga is None:
+          ga = torch.cuda.CUDAGraph()
+          # thread_local: other threads of the process (the RCCL watchdog) may touch the HIP runtime meanwhile
+          with torch.cuda.graph(ga, capture_error_mode='thread_local'):
+            body_a()
+          if reduce_fn is not None:
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode='thread_local'):
+              body_b()
+          g['one_graph'] = False
+        else:
+          g['one_graph'] = True
         g['graphs'] = (ga, gb)
         eng.arena.version, eng.arena.step_count = counters
       ga, gb = g['graphs']

@@ -473,7 +473,8 @@ def main():
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'ranks_seen': ranks_seen,
                    'loss': losses.get('loss'), 'param_crc32': param_crc,
                    'collectives': (dist.get_backend() if dist is not None else None),
-                   'launch': 'hipGraph replay of the captured step' if args.graph else 'eager',
+                   'launch': ('hipGraph replay of the captured step' + (
+                       ' (one graph, all-reduce captured inside)' if (net._graph or {}).get('one_graph') else '')) if args.graph else 'eager',
                    # host time per enqueued step over the K back-to-back steps: from the second step on the graph launch
                    # waits for room in the device queue, so this tracks the DEVICE time; the first step of the region
                    # (empty queue after the synchronize) and the fastest one are what the host itself needs

@@ -827,15 +827,20 @@ def test_rccl_path_on_the_device_at_world_size_one(tmp_path):
   common = [os.path.join(root, 'bench.py'), '--gpus', '1', '--batch', '8', '--steps', '3', '--warmup', '3',
             '--image_size', '256', '--no_cpu_baseline', '--no_other_configs']
   lines = {}
-  for name, cmd in (('plain', [sys.executable] + common),
-                    ('rccl', [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
-                              '--master-addr', '127.0.0.1', '--master-port', str(port)] + common + ['--force_dist'])):
+  launcher = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+              '--master-addr', '127.0.0.1', '--master-port', str(port)]
+  for name, cmd in (('plain', [sys.executable] + common), ('rccl', launcher + common + ['--force_dist']),
+                    # r06: the opt-in structure with the all-reduce captured INSIDE the one graph of the step
+                    ('rccl_one_graph', launcher + common + ['--force_dist'])):
+    env['EDET_DP_ONE_GRAPH'] = '1' if name == 'rccl_one_graph' else '0'
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0, (name, r.stdout[-2000:], r.stderr[-3000:])
     out = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(out) == 1, (name, r.stdout[-2000:])
     lines[name] = json.loads(out[0])
-  plain, rccl = lines['plain'], lines['rccl']
+  plain, rccl, one = lines['plain'], lines['rccl'], lines['rccl_one_graph']
+  assert 'one graph' in one['config']['launch'] and 'one graph' not in rccl['config']['launch'], (one['config']['launch'],)
+  assert one['config']['param_crc32'] == plain['config']['param_crc32'] and one['config']['loss'] == plain['config']['loss']
   assert rccl['config']['collectives'] == 'nccl' and rccl['config']['ranks_seen'] == 1 and rccl['n_gpus'] == 1, rccl['config']
   assert rccl['config']['launch'].startswith('hipGraph') and np.isfinite(rccl['config']['loss'])
   assert plain['config']['collectives'] is None
