@@ -557,7 +557,15 @@ int launch(Args& a, int* nparts_out, size_t workspace_bytes, hipStream_t st) {
   // Row splits: one round of resident workgroups (EDET_PWT_ROUNDS rounds), at least EDET_PWT_MINSTEPS steps each,
   // bounded by the statistic partial rows and the workspace.  Every split writes a K x N fp32 partial that
   // edet_reduce_partials reads back.
-  const int slots = (resident > 0 ? resident : 512) * env_int("EDET_PWT_ROUNDS", 1);
+  // Rounds of resident workgroups.  One round everywhere except where K is cut into MANY slices (r06 lab, D0 640x640 batch
+  // 128, EDET_PWT_ROUNDS = 1 / 2 / 3 / 4): 40x40x672->112 (11 slices) 0.355 / 0.299 / 0.259 / 0.274 ms, 20x20x672->192 0.179 /
+  // 0.164 / 0.144 / 0.163, 20x20x1152->192 (18 slices, two column slices) 0.284 / 0.210 / 0.261 / 0.230, 20x20x1152->320
+  // (18 slices, three column slices, one workgroup per CU) 0.608 / 0.496 / 0.454 / 0.390; every layer with <= 8 slices
+  // loses 3-30 % beyond one round.  The slices of a row split re-read the same (dz, y) rows and only share them through
+  // the L2 while they walk in step: nothing synchronises them, and the longer the split the further they drift apart.
+  int rounds = env_int("EDET_PWT_ROUNDS", 0);
+  if (rounds <= 0) rounds = a.nsl >= 16 ? (NSL >= 3 ? 4 : 2) : (a.nsl >= 10 ? 3 : 1);
+  const int slots = (resident > 0 ? resident : 512) * rounds;
   int S = env_int("EDET_PWT_SPLITS", slots / a.nsl);
   const int minsteps = env_int("EDET_PWT_MINSTEPS", 4);
   if (S > a.T / minsteps) S = a.T / minsteps;
