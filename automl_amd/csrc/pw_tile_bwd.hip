@@ -653,12 +653,15 @@ int pwt_try_bwd(const edet_gview_t* dy, const void* w, int ldw, const edet_tview
     // pixels per image
     // (by pixels per image, not rows: the 1-image parity runs then take the same path as the batch-8 step)
     const int hw = in->h * in->w;
-    if (K > 128 && hw > env_int("EDET_PWT_NSL_MAXHW", 8192)) return 0;
+    // r06: with 2-4 rounds of row splits (launch) the sliced kernel also wins on efficientdet-d7x's 96 x 96 projections --
+    // 1344->224 0.92 -> 0.32 ms, 960->160 0.69 -> 0.23 ms per call at batch 8 -- which the round-4 limit of 8192 pixels
+    // left to the two-kernel path
+    if (K > 128 && hw > env_int("EDET_PWT_NSL_MAXHW", 16384)) return 0;
     const bool wide_expand = nsl > 3 && nsl <= 6 && gbn && !xgen && K <= 128 && env_int("EDET_PWT_WIDE", 1);
     // 7 slices (class predict): up to two K slices (efficientdet-d0 .. d2: 64 / 88 / 112 filters) -- every further slice
     // re-reads the 810-column gradient --, and any K on the small maps, where the two-kernel path would run the generic
     // weight gradient (fp32 atomics) and the re-reads cost nothing (maps up to 8192 pixels per image)
-    if (nsl > 3 && !wide_expand && (nsl > 7 || gbn || xgen || (K > 128 && hw > env_int("EDET_PWT_NSL_MAXHW", 8192)))) return 0;
+    if (nsl > 3 && !wide_expand && (nsl > 7 || gbn || xgen || (K > 128 && hw > env_int("EDET_PWT_NSL_MAXHW", 16384)))) return 0;
     // r04d lab (D0 640x640 batch 128): 80x80x40->240 0.437 -> 0.210 ms, 40x40x40->240 0.109 -> 0.055, 20x20x1152->192 0.417 ->
     // 0.284, 20x20x672->192 0.266 -> 0.180; three slices hold one workgroup per compute unit (94 KB of LDS) and LOSE on
     // the gated 20x20x1152->320 (0.571 -> 0.612 ms) -- kept all the same: the two-kernel path adds the SE gate-gradient
