@@ -564,7 +564,9 @@ int launch(Args& a, int* nparts_out, size_t workspace_bytes, hipStream_t st) {
   // loses 3-30 % beyond one round.  The slices of a row split re-read the same (dz, y) rows and only share them through
   // the L2 while they walk in step: nothing synchronises them, and the longer the split the further they drift apart.
   int rounds = env_int("EDET_PWT_ROUNDS", 0);
-  if (rounds <= 0) rounds = a.nsl >= 16 ? (NSL >= 3 ? 4 : 2) : (a.nsl >= 10 ? 3 : 1);
+  // (efficientdet-d7x, 384 -> 384 BiFPN / tower layers: 6 slices, three column slices: 96x96 0.239 / 0.214 / 0.162 / 0.183 ms,
+  // 48x48 0.094 / 0.077 / 0.076 / 0.076)
+  if (rounds <= 0) rounds = NSL >= 3 ? (a.nsl >= 16 ? 4 : (a.nsl >= 4 ? 3 : 1)) : (a.nsl >= 16 ? 2 : (a.nsl >= 10 ? 3 : 1));
   const int slots = (resident > 0 ? resident : 512) * rounds;
   int S = env_int("EDET_PWT_SPLITS", slots / a.nsl);
   const int minsteps = env_int("EDET_PWT_MINSTEPS", 4);
@@ -655,13 +657,13 @@ int pwt_try_bwd(const edet_gview_t* dy, const void* w, int ldw, const edet_tview
     const int hw = in->h * in->w;
     // r06: with 2-4 rounds of row splits (launch) the sliced kernel also wins on efficientdet-d7x's 96 x 96 projections --
     // 1344->224 0.92 -> 0.32 ms, 960->160 0.69 -> 0.23 ms per call at batch 8 -- which the round-4 limit of 8192 pixels
-    // left to the two-kernel path
-    if (K > 128 && hw > env_int("EDET_PWT_NSL_MAXHW", 16384)) return 0;
+    // left to the two-kernel path; and on its 192 x 192 BiFPN layers (384 -> 384: 0.64 -> 0.48 ms)
+    if (K > 128 && hw > env_int("EDET_PWT_NSL_MAXHW", 65536)) return 0;
     const bool wide_expand = nsl > 3 && nsl <= 6 && gbn && !xgen && K <= 128 && env_int("EDET_PWT_WIDE", 1);
     // 7 slices (class predict): up to two K slices (efficientdet-d0 .. d2: 64 / 88 / 112 filters) -- every further slice
     // re-reads the 810-column gradient --, and any K on the small maps, where the two-kernel path would run the generic
     // weight gradient (fp32 atomics) and the re-reads cost nothing (maps up to 8192 pixels per image)
-    if (nsl > 3 && !wide_expand && (nsl > 7 || gbn || xgen || (K > 128 && hw > env_int("EDET_PWT_NSL_MAXHW", 16384)))) return 0;
+    if (nsl > 3 && !wide_expand && (nsl > 7 || gbn || xgen || (K > 128 && hw > env_int("EDET_PWT_NSL_MAXHW", 65536)))) return 0;
     // r04d lab (D0 640x640 batch 128): 80x80x40->240 0.437 -> 0.210 ms, 40x40x40->240 0.109 -> 0.055, 20x20x1152->192 0.417 ->
     // 0.284, 20x20x672->192 0.266 -> 0.180; three slices hold one workgroup per compute unit (94 KB of LDS) and LOSE on
     // the gated 20x20x1152->320 (0.571 -> 0.612 ms) -- kept all the same: the two-kernel path adds the SE gate-gradient

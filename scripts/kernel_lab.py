@@ -110,7 +110,7 @@ def build_case(entry, shape):
       gout = torch.empty(n, h, w, gu.pad8(cin), dtype=tdt, device=dev)
       mean, rstd = vec(cin, -0.2, 0.2), vec(cin)
       dwt = torch.zeros(cin, cout, dtype=torch.float32, device=dev)
-      if cout in (64, 36):      # BiFPN / tower / resample layers: the input is a plain stored tensor, nothing to chain into
+      if cout in (64, 36) or (cin == cout and cin in (88, 112, 160, 224, 288, 384)):      # BiFPN / tower / resample layers (fpn_num_filters of d0 .. d7x): the input is a plain stored tensor, nothing to chain into
         tv = gu.tview(x, cin)
         if cout == 36:
           gv = gu.gview(dz, cout)      # predict layer: no BatchNorm behind it
