@@ -308,6 +308,11 @@ class Engine(object):
     self._f32_island = False
     self.fuse_merge_identity = os.environ.get('EDET_FUSE_MERGE', '1') != '0'   # BiFPN backward: see Engine.fuse
     self.overlap_s2_wgrad = os.environ.get('EDET_S2_OVERLAP', '0') == '1'
+    # bucketed gradient all-reduce overlapped with the backward pass (set_overlap_reduce): None = off
+    self._overlap_reduce = None
+    self._reduce_marks = {}
+    self._comm_stream = None
+    self._bucket_no = 0
     self.fused_dw_bwd = True     # one edet_dw_bwd call per layer (bf16: ONE kernel for both gradients, any stride)
     self.fused_pw_bwd = True     # one edet_pw_bwd call per pointwise layer whose input needs a gradient
     # cross-replica BatchNorm (utils.SyncBatchNormalization / TpuBatchNormalization, utils.py:166-241):
@@ -1050,13 +1055,21 @@ class Engine(object):
       self.tape.append(stem_bwd)
     # ---- MBConv blocks
     reds = []
+    self._reduce_marks = {}
+    bucket_blocks = self._bucket_blocks() if (training and self._overlap_reduce is not None) else ()
     for b in spec.blocks:
+      if b.index in bucket_blocks:
+        # everything the tape holds from here on belongs to variables at or behind this block's first one
+        self._reduce_marks[len(self.tape)] = bucket_blocks[b.index]
       x = self._mbconv(x, b, '%s/blocks_%d' % (bb, b.index))
       if b.index in spec.reductions:
         reds.append(x)
     all_feats = [None] + reds
     feats = list(all_feats[c.min_level:c.max_level + 1])
     wf = c.fpn_num_filters
+    if training and self._overlap_reduce is not None:
+      self._reduce_marks[0] = 0                                     # stem + first blocks: the last bucket
+      self._reduce_marks[len(self.tape)] = self._first_non_backbone_elem()   # BiFPN + heads: the first one
     # ---- extra levels P6.. (efficientdet_keras.py:823-836,900-901)
     for level in range(6, c.max_level + 1):
       f = feats[-1]
@@ -1309,13 +1322,97 @@ class Engine(object):
 
   def backward(self):
     self._defer_begin()          # the weight-gradient sums of this pass: recorded, added in a few batched launches
+    marks = self._reduce_marks if self._overlap_reduce is not None else {}
+    self._bucket_hi = self.n_train_elems
+    self._bucket_no = 0
     try:
-      for fn in reversed(self.tape):
-        fn()
+      for i in range(len(self.tape) - 1, -1, -1):
+        self.tape[i]()
+        if i in marks:
+          self._reduce_bucket(marks[i])
     finally:
       self._defer_end()
     self.tape = []
     self._join_side()
+    if marks:
+      self._finish_buckets()
+
+  # ---- gradient all-reduce overlapped with the backward pass (north_star; legal only without the global-norm clip) ----
+  def set_overlap_reduce(self, reduce_fn, buckets=6):
+    """reduce_fn(flat_slice) = in-place SUM all-reduce.  The reference clips the LOCAL gradient by its GLOBAL norm before
+    apply_gradients reduces it (train_lib.py:675-683), which needs every gradient of the step: with clip_gradients_norm > 0
+    nothing may be reduced before the backward pass has ended.  With clip_gradients_norm = 0 (hparams_config.py:220 allows
+    it) the local gradient of a variable is final as soon as its layer's backward has run, so the arena is reduced in
+    `buckets` contiguous ranges in the order the backward pass completes them -- BiFPN + heads first, then the backbone
+    stages last to first (the arena is laid out in forward order) -- on a communication stream, under the backward
+    kernels of the earlier layers.  The L2 gradient (train_lib.py:486-491) is added per range just before its reduce."""
+    clip = abs(self.config.clip_gradients_norm) if self.config.clip_gradients_norm else 0.0
+    if reduce_fn is not None and clip > 0:
+      raise ValueError('overlapping the gradient all-reduce with the backward pass needs clip_gradients_norm=0: the '
+                       'reference clips the local gradient by its global norm BEFORE the reduce (train_lib.py:675-683)')
+    self._overlap_reduce = reduce_fn
+    self._overlap_buckets = int(buckets)
+    if reduce_fn is not None and self._comm_stream is None:
+      self._comm_stream = torch.cuda.Stream(device=self.device)
+      self._seg_host = [int(o) for o in self.arena.seg_offsets.cpu().tolist()]
+      self._bucket_gn = torch.zeros(64, dtype=torch.float32, device=self.device)
+
+  def _first_non_backbone_elem(self):
+    bb = self.config.backbone_name + '/'
+    return min(self.offsets[n][0] for n in self.seg_names if not n.startswith(bb))
+
+  def _bucket_blocks(self):
+    """{block index: first arena element of the block} for the blocks that open a backbone bucket: walking the blocks
+    from the last one, a bucket is closed once it holds its share of the backbone's elements."""
+    bb = self.config.backbone_name
+    first = {}
+    for b in self.spec.blocks:
+      pre = '%s/blocks_%d/' % (bb, b.index)
+      first[b.index] = min(self.offsets[n][0] for n in self.seg_names if n.startswith(pre))
+    end = self._first_non_backbone_elem()
+    share = end / max(self._overlap_buckets - 1, 1)
+    out, hi = {}, end
+    for idx in sorted(first, reverse=True):
+      if hi - first[idx] >= share and first[idx] > 0:
+        out[idx] = first[idx]
+        hi = first[idx]
+    return out
+
+  def _reduce_bucket(self, lo):
+    """The arena range [lo, previous lo) is final: flush its deferred weight-gradient sums, add the L2 gradient, and hand it
+    to the communication stream."""
+    hi = self._bucket_hi
+    if lo >= hi:
+      return
+    self._defer_end()                 # the partial sums recorded so far -> the arena
+    self._join_side()                 # (first bucket: the side chain's share of the tower gradients)
+    seg = self._seg_host
+    s0, s1 = seg.index(lo), seg.index(hi)
+    c = self.config
+    no = self._bucket_no
+    sq = self.buf('ovl:sq%d' % no, (2 * (s1 - s0) * _lib.OPT_SPLIT,), torch.float32)
+    st = self.stream
+    call('edet_opt_l2_norms', ptr(self.grads_flat), ptr(self.params_flat), self.seg_offsets.data_ptr() + 8 * s0,
+         self.seg_flags.data_ptr() + 4 * s0, s1 - s0, float(c.weight_decay), ptr(sq), st)
+    call('edet_opt_clip_factors', ptr(sq), s1 - s0, 0.0, self.seg_factor.data_ptr() + 4 * s0,
+         self._bucket_gn.data_ptr() + 4 * no, ptr(self.loss_sums[2:]), st)
+    main = torch.cuda.current_stream(self.device)
+    ready = torch.cuda.Event()
+    ready.record(main)
+    self._comm_stream.wait_event(ready)
+    with torch.cuda.stream(self._comm_stream):
+      self._overlap_reduce(self.grads_flat[lo:hi])
+    self._bucket_hi = lo
+    self._bucket_no = no + 1
+    self._defer_begin()
+
+  def _finish_buckets(self):
+    assert self._bucket_hi == 0, self._bucket_hi
+    done = torch.cuda.Event()
+    done.record(self._comm_stream)
+    torch.cuda.current_stream(self.device).wait_event(done)
+    gn = self._bucket_gn[:self._bucket_no]
+    self.gnorm.copy_(torch.sqrt((gn * gn).sum()).reshape(1))      # the local gradient's norm (reported only)
 
   def set_hyper(self, lr, ema_decay=None):
     """Per-step scalars -> device (hyper[0] = learning rate, hyper[1] = EMA decay).  Stream-ordered H2D
@@ -1353,6 +1450,9 @@ class Engine(object):
   def optimizer_step(self, lr, ema_decay=None, all_reduce=None):
     """L2 + clip (local, before the reduce) + [all-reduce SUM] + SGD momentum + EMA."""
     self.set_hyper(lr, ema_decay)
+    if self._overlap_reduce is not None:       # L2 + reduce already done range by range inside backward()
+      self.optimizer_apply(ema_decay is not None, True)
+      return
     self.optimizer_local(all_reduce is not None)
     if all_reduce is not None:
       all_reduce(self.grads_flat)

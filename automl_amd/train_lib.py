@@ -130,7 +130,7 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
   """
 
   def __init__(self, *args, steps_per_epoch=1000, global_batch_size=None, process_group=None,
-               use_dist=False, use_graph=False, sync_bn=False, **kwargs):
+               use_dist=False, use_graph=False, sync_bn=False, overlap_grad_reduce=None, **kwargs):
     """use_graph: capture the whole step (forward, loss, backward, L2/clip, update: ~1600 kernel launches)
     into a hipGraph at the second call for a given batch shape and replay it afterwards; inputs are
     copied into static device buffers (input_buffers() exposes them for in-place filling), learning
@@ -148,6 +148,16 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
     self.process_group = process_group
     self.use_dist = use_dist or process_group is not None
     self.one_graph_dp = os.environ.get('EDET_DP_ONE_GRAPH', '0') == '1'      # see _graph_step
+    # The gradient all-reduce in buckets UNDER the backward pass (Engine.set_overlap_reduce) -- what north_star asks for.
+    # Legal only with clip_gradients_norm = 0: the reference clips the local gradient by its global norm before the reduce
+    # (train_lib.py:675-683), so with the default clip_gradients_norm = 10 the one flat reduce after the backward pass stays.
+    if overlap_grad_reduce is None:
+      overlap_grad_reduce = os.environ.get('EDET_DP_OVERLAP', '0') == '1'
+    self.overlap_grad_reduce = bool(overlap_grad_reduce)
+    if self.overlap_grad_reduce and self.config.clip_gradients_norm:
+      raise ValueError('overlap_grad_reduce needs clip_gradients_norm=0 (the reference clips by the global norm of the '
+                       'local gradient before the reduce, train_lib.py:675-683); got %r' % (self.config.clip_gradients_norm,))
+    self.overlap_buckets = int(os.environ.get('EDET_DP_BUCKETS', '6'))
     self._lr_fn = None
     self.iterations = 0
     # positives_momentum > 0: the moving loss normalizer (train_lib.py:519-531).  A 0-d fp32 DEVICE tensor once the
@@ -255,10 +265,15 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
     glabels = dict(g['labels'])
     glabels['normalizer'] = 'device'
     reduce_fn = make_grad_all_reduce(self.process_group) if self.use_dist else None
+    overlap = self.overlap_grad_reduce and reduce_fn is not None
+    eng.set_overlap_reduce(reduce_fn if overlap else None, self.overlap_buckets)
 
     def body_a():
       eng.forward(g['images'], training=True)
-      eng.loss_backward(glabels)
+      eng.loss_backward(glabels)           # (overlap: the bucketed all-reduce runs inside, on the communication stream)
+      if overlap:
+        eng.optimizer_apply(decay is not None, True)
+        return
       eng.optimizer_local(reduce_fn is not None)
       if reduce_fn is None:
         eng.optimizer_apply(decay is not None, False)
@@ -269,7 +284,7 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
     if g['steps'] == 0:
       # first step eager: allocates every buffer and runs the one-time kernel attribute setup
       body_a()
-      if reduce_fn is not None:
+      if reduce_fn is not None and not overlap:
         reduce_fn(eng.grads_flat)
         body_b()
     else:
@@ -279,7 +294,13 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
         # where they were, the replay below accounts for the step
         counters = (eng.arena.version, eng.arena.step_count)
         ga = gb = None
-        if reduce_fn is not None and self.one_graph_dp:
+        if overlap:
+          # forward, backward with the bucketed collectives on their own stream (a parallel branch of the graph), update
+          ga = torch.cuda.CUDAGraph()
+          with torch.cuda.graph(ga, capture_error_mode='thread_local'):
+            body_a()
+          g['overlap'] = True
+        elif reduce_fn is not None and self.one_graph_dp:
           # The collective captured INSIDE the step's graph (RCCL 2.26 supports stream capture): no host hop between the
           # two halves.  Opt-in (EDET_DP_ONE_GRAPH=1): exercised on the device at world size 1 only -- no multi-GPU node
           # was available to any round -- so the default stays the two-graph structure below; if the capture itself
@@ -301,7 +322,7 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
           # thread_local: other threads of the process (the RCCL watchdog) may touch the HIP runtime meanwhile
           with torch.cuda.graph(ga, capture_error_mode='thread_local'):
             body_a()
-          if reduce_fn is not None:
+          if reduce_fn is not None and not overlap:
             gb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode='thread_local'):
               body_b()
@@ -395,6 +416,8 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
       vals = eng.loss_values()
       vals['learning_rate'] = lr
       return vals
+    reduce_fn = make_grad_all_reduce(self.process_group) if self.use_dist else None
+    eng.set_overlap_reduce(reduce_fn if self.overlap_grad_reduce else None, self.overlap_buckets)
     eng.forward(self._to_device_images(images, eng), training=True)
     dlabels = self._labels_to_device(labels, eng)
     if self._positives_momentum() != 0:
@@ -409,9 +432,6 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
     decay = None
     if self.config.moving_average_decay:
       decay = ema_decay_dynamic(self.config.moving_average_decay, self.iterations)
-    reduce_fn = None
-    if self.use_dist:
-      reduce_fn = make_grad_all_reduce(self.process_group)
     eng.optimizer_step(lr, decay, reduce_fn)
     self.iterations += 1
     if not sync_loss:

@@ -331,6 +331,11 @@ def main():
   ap.add_argument('--force_dist', action='store_true',
                   help='world size 1 through the data-parallel path all the same: RCCL communicator, the gradient '
                        'all-reduce between the two captured graphs (rehearsal of the multi-GPU launch structure on one GPU)')
+  ap.add_argument('--clip_gradients_norm', type=float, default=None,
+                  help='override config.clip_gradients_norm (hparams_config.py:220); 0 = no clipping')
+  ap.add_argument('--overlap_reduce', action='store_true',
+                  help='the gradient all-reduce in buckets under the backward pass (needs --clip_gradients_norm 0: the '
+                       'reference clips by the global norm of the local gradient before the reduce, train_lib.py:675-683)')
   ap.add_argument('--graph', type=int, default=int(os.environ.get('EDET_GRAPH', '1')),
                   help='1: the timed steps replay the step captured as a hipGraph; 0: eager launches')
   args = ap.parse_args()
@@ -362,9 +367,12 @@ def main():
 
   config = hparams_config.get_efficientdet_config(args.model)
   config.override('image_size=%d' % args.image_size)
+  if args.clip_gradients_norm is not None:
+    config.clip_gradients_norm = args.clip_gradients_norm
   net = train_lib.EfficientDetNetTrain(config=config, dtype=args.dtype, device=device, seed=0,
                                        global_batch_size=args.batch * world, use_dist=use_dist,
-                                       steps_per_epoch=1000, use_graph=bool(args.graph))
+                                       steps_per_epoch=1000, use_graph=bool(args.graph),
+                                       overlap_grad_reduce=args.overlap_reduce and use_dist)
   eng = net._ensure_engine(args.batch, args.image_size, args.image_size)
   images, labels = synth_batch(config, args.batch, args.image_size, 3 + rank, device, eng.tdtype)
   norm_host = labels.pop('normalizer')     # graph mode computes the normalizer on the device instead
@@ -457,7 +465,7 @@ def main():
     n_l, ms_l, bytes_l = prof[dominant]
     achieved = bytes_l / (ms_l * 1e-3) / 1e9
     is_headline = args.model == 'efficientdet-d0' and args.image_size == 640 and args.batch == 128 and \
-        args.dtype == 'bf16'
+        args.dtype == 'bf16' and args.clip_gradients_norm is None
     traffic, traffic_src = pmc_traffic(dominant, n_l / args.steps) if is_headline else (None, None)
     out = {
         'metric': 'images/sec %s %dx%d fwd+bwd (whole job; per-GPU = value / n_gpus)' % (
@@ -475,6 +483,10 @@ def main():
                    'collectives': (dist.get_backend() if dist is not None else None),
                    'launch': ('hipGraph replay of the captured step' + (
                        ' (one graph, all-reduce captured inside)' if (net._graph or {}).get('one_graph') else '')) if args.graph else 'eager',
+                   'clip_gradients_norm': config.clip_gradients_norm,
+                   'grad_reduce': (None if dist is None else
+                                   ('%d buckets on a communication stream under the backward pass' % eng._bucket_no)
+                                   if net.overlap_grad_reduce else 'one flat all-reduce after the local clip'),
                    # host time per enqueued step over the K back-to-back steps: from the second step on the graph launch
                    # waits for room in the device queue, so this tracks the DEVICE time; the first step of the region
                    # (empty queue after the synchronize) and the fastest one are what the host itself needs

@@ -147,3 +147,15 @@ def test_negative_positives_momentum_is_the_cross_replica_mean(tmp_path):
     d = torch.load(os.path.join(str(tmp_path), 'norm%d.pt' % r))
     assert abs(float(d['host']) - 25.0) < 1e-6, d
     assert abs(float(d['inv']) - 1.0 / 11.0) < 1e-7, d
+
+
+def test_overlapped_reduce_is_refused_with_the_global_norm_clip():
+  """The bucketed all-reduce under the backward pass is only legal without the global-norm clip (the reference clips the
+  LOCAL gradient by its global norm before apply_gradients reduces it, train_lib.py:675-683)."""
+  config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  assert config.clip_gradients_norm == 10.0
+  with pytest.raises(ValueError, match='clip_gradients_norm=0'):
+    train_lib.EfficientDetNetTrain(config=config, overlap_grad_reduce=True)
+  config.clip_gradients_norm = 0
+  net = train_lib.EfficientDetNetTrain(config=config, overlap_grad_reduce=True)
+  assert net.overlap_grad_reduce

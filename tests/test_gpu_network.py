@@ -792,17 +792,25 @@ def test_bench_spawns_two_ranks_and_reports_them(tmp_path):
   env = dict(os.environ, EDET_BENCH_SAME_DEVICE='1', EDET_BENCH_BACKEND='gloo')
   for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
     env.pop(k, None)
-  for graph in ('1', '0'):
+  crcs = {}
+  # (r06) the last two runs: no clip, flat reduce after the backward pass vs. the bucketed reduce under it (eager: gloo
+  # cannot be captured) -- two real ranks, the SAME updated variables bit for bit
+  for graph, extra in (('1', []), ('0', []), ('0', ['--clip_gradients_norm', '0']),
+                       ('0', ['--clip_gradients_norm', '0', '--overlap_reduce'])):
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--batch', '8', '--steps', '3',
                         '--warmup', '1', '--image_size', '256', '--graph', graph, '--no_cpu_baseline',
-                        '--no_other_configs'], env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+                        '--no_other_configs'] + extra, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0, (graph, r.stdout[-2000:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
+    crcs[graph, tuple(extra)] = (line['config']['param_crc32'], line['config']['grad_reduce'])
     assert line['n_gpus'] == 2 and line['config']['ranks_seen'] == 2 and line['config']['global_batch'] == 16, line['config']
     assert line['steps'] == 3 and line['value'] > 0 and abs(line['value'] - 16 * 3 / (line['ms_per_step'] * 3e-3)) < 1e-6 * line['value']
     assert line['scaling'] == 'weak' and line['config']['parallelism'] == 'dp2' and np.isfinite(line['config']['loss'])
+  flat, ovl = crcs['0', ('--clip_gradients_norm', '0')], crcs['0', ('--clip_gradients_norm', '0', '--overlap_reduce')]
+  assert 'flat' in flat[1] and 'buckets' in ovl[1], (flat, ovl)
+  assert flat[0] == ovl[0], (flat, ovl)
 
 
 def test_rccl_path_on_the_device_at_world_size_one(tmp_path):
@@ -829,9 +837,15 @@ def test_rccl_path_on_the_device_at_world_size_one(tmp_path):
   lines = {}
   launcher = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
               '--master-addr', '127.0.0.1', '--master-port', str(port)]
+  noclip = ['--clip_gradients_norm', '0']
   for name, cmd in (('plain', [sys.executable] + common), ('rccl', launcher + common + ['--force_dist']),
                     # r06: the opt-in structure with the all-reduce captured INSIDE the one graph of the step
-                    ('rccl_one_graph', launcher + common + ['--force_dist'])):
+                    ('rccl_one_graph', launcher + common + ['--force_dist']),
+                    # r06: clip_gradients_norm = 0 -> the all-reduce in buckets on a communication stream UNDER the backward
+                    # pass (captured as a parallel branch of the step's graph); same variables as the plain run without clip
+                    ('plain_noclip', [sys.executable] + common + noclip),
+                    ('rccl_overlap', launcher + common + noclip + ['--force_dist', '--overlap_reduce']),
+                    ('rccl_overlap_eager', launcher + common + noclip + ['--force_dist', '--overlap_reduce', '--graph', '0'])):
     env['EDET_DP_ONE_GRAPH'] = '1' if name == 'rccl_one_graph' else '0'
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0, (name, r.stdout[-2000:], r.stderr[-3000:])
@@ -839,6 +853,11 @@ def test_rccl_path_on_the_device_at_world_size_one(tmp_path):
     assert len(out) == 1, (name, r.stdout[-2000:])
     lines[name] = json.loads(out[0])
   plain, rccl, one = lines['plain'], lines['rccl'], lines['rccl_one_graph']
+  nc, ov, ove = lines['plain_noclip'], lines['rccl_overlap'], lines['rccl_overlap_eager']
+  assert 'buckets' in ov['config']['grad_reduce'] and int(ov['config']['grad_reduce'].split()[0]) >= 4, ov['config']
+  assert ov['config']['param_crc32'] == nc['config']['param_crc32'], (nc['config'], ov['config'])
+  assert ove['config']['param_crc32'] == nc['config']['param_crc32'], (nc['config'], ove['config'])
+  assert abs(ov['config']['loss'] - nc['config']['loss']) <= 1e-5 * abs(nc['config']['loss'])   # (L2 term summed per bucket)
   assert 'one graph' in one['config']['launch'] and 'one graph' not in rccl['config']['launch'], (one['config']['launch'],)
   assert one['config']['param_crc32'] == plain['config']['param_crc32'] and one['config']['loss'] == plain['config']['loss']
   assert rccl['config']['collectives'] == 'nccl' and rccl['config']['ranks_seen'] == 1 and rccl['n_gpus'] == 1, rccl['config']
