@@ -71,6 +71,10 @@ SIGNATURES = {
     'edet_conv_fwd': [PT, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, PI, c_int, c_void_p],
     'edet_conv_bwd_data': [PG, c_void_p, c_int, c_int, c_int, PT, PE, PI, c_int, c_void_p],
     'edet_conv_bwd_weight': [PT, PG, c_int, c_int, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],
+    'edet_mbconv_fused_supported': [PT, c_int, c_int, c_int, c_int],
+    'edet_mbconv_expand_stats': [PT, c_void_p, c_int, c_int, c_void_p, PI, c_int, c_void_p],
+    'edet_mbconv_expand_dw_fwd': [PT, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                  c_int, c_void_p, c_int, c_void_p, PI, c_int, c_void_p],
     'edet_dw_fwd': [PT, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, PI, c_int, c_void_p],
     'edet_dw_bwd_data': [PG, c_void_p, c_int, c_int, PT, PE, PI, c_int, c_void_p],
     'edet_dw_bwd_weight': [PT, PG, c_int, c_int, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p],

@@ -1,0 +1,485 @@
+// Head of an MBConv block in ONE kernel for the bf16 path on gfx950: expansion 1x1 convolution -> BatchNorm ->
+// activation -> depthwise k x k convolution (k in {3,5}, stride in {1,2}, TF 'SAME').
+//
+// Reference: efficientdet/backbone/efficientnet_model.py:378-392 (MBConvBlock.call: x = act(bn0(expand_conv(x)));
+// x = act(bn1(depthwise_conv(x)))), the layers built at :304-327.  The expanded tensor is the widest tensor of the
+// block (6 x the block input): the two-kernel path (edet_pw_fwd, edet_dw_fwd) writes it once and reads it back once.
+// Here the depthwise march (dw_march.hip, k_fwd_v2) gets the rows of the expanded tensor from the matrix cores instead
+// of from HBM: a workgroup owns 48 expanded channels (three 16-row MFMA blocks; every EfficientNet expansion width is
+// a multiple of 48) and a window of 64 input columns (4 waves x 16 pixels), marches down the image, and per input row
+//   * every lane loads ONE 16-byte chunk of the block input (8 of the <= 32 input channels of its pixel -- the B
+//     operand of v_mfma_f32_16x16x32_bf16, straight from global memory, prefetched a few rows ahead), applies the
+//     producer's BatchNorm on load, and the wave multiplies it with three resident 16 x 32 slices of the expansion
+//     kernel: D = W^T X^T, so a lane receives 4 consecutive channels x 3 blocks of ITS pixel;
+//   * the 12 values are rounded to bf16 (what the two-kernel path stores and reads back), optionally stored (training:
+//     the backward pass reads the raw expanded tensor), sent through the expansion BatchNorm + activation and parked
+//     in a two-row fp32 LDS ring;
+//   * after one barrier the same threads, now as (output pixel, channel chunk), read the K neighbours of the row back
+//     and accumulate the depthwise taps into ceil(K / S) output rows held in registers, exactly as k_fwd_v2 does.
+// The window overlaps its right neighbour by K - S columns (and a row tile its lower neighbour by K - S rows): 1.5-6 %
+// of the expansion is computed twice, nothing is exchanged between workgroups.
+//
+// In training the statistics of the expansion's BatchNorm must exist before the depthwise convolution can run:
+// k_exp_stats makes them in a first pass over the block input only (same MFMA, same rounding, nothing stored);
+// inference needs no such pass and never stores the expanded tensor at all.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace mbf {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t brsrc_t;
+
+constexpr int THREADS = 256;
+constexpr int GC = 48;      // expanded channels per workgroup
+constexpr int GCP = 52;     // floats per pixel in the LDS ring (48 + 4: the 8 lanes of a ds_write_b128 group on 32 banks)
+constexpr int WINC = 64;    // window columns per workgroup (4 waves x 16 pixels)
+
+__device__ __forceinline__ brsrc_t make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__host__ __device__ constexpr int gcd_(int x, int y) { return y == 0 ? x : gcd_(y, x % y); }
+__host__ __device__ constexpr int fdiv_(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+__host__ __device__ constexpr int slot_of(int rel, int n) { return ((rel % n) + n) % n; }
+struct URange {
+  int lo; uint32_t span;
+  __device__ __forceinline__ void set(int l, int h) { lo = l; span = h > l ? (uint32_t)(h - l) : 0u; }
+  __device__ __forceinline__ bool has(int v) const { return (uint32_t)(v - lo) < span; }
+};
+
+template <int K, int S> struct Geo {
+  static constexpr int TXV = (WINC - K) / S + 1;       // output columns whose taps lie inside the window
+  static constexpr int NSL = (K + S - 1) / S;          // output rows in flight
+  static constexpr int U0 = S * NSL;
+  static constexpr int CPT = K == 3 ? 6 : 2;           // channels per tap thread (K*K*CPT/2 weight register pairs)
+  static constexpr int NCH = GC / CPT;
+  static constexpr int SLOTS = THREADS / NCH;          // output pixels handled side by side
+  static constexpr int NPX = (TXV + SLOTS - 1) / SLOTS;
+  static constexpr int NF = U0 == 3 ? 6 : (U0 == 4 ? 8 : (U0 == 5 ? 5 : 6));   // rows of block-input loads in flight + 1
+};
+
+struct Args {
+  edet_tview_t in;            // block input [n][H][W][cin]: affine view (the producer's BatchNorm) or a stored tensor
+  const bf16_t* wt; int ldw;  // expansion kernel, transposed: [cexp][ldw], input channel contiguous
+  int cexp;
+  const float* esc; const float* esh; int act;   // expansion BatchNorm (scale, shift), activation code
+  bf16_t* e_out; int lde;     // raw expanded tensor (training) or NULL
+  const float* dww;           // depthwise kernel [K][K][cexp] fp32
+  bf16_t* out; int ldo;
+  float* stat_partials;       // [P][2][cexp] of the depthwise output (training) or NULL
+  int oh, ow, pad_t, pad_l;
+  int ngroups, TY, tiles_x, tiles_y, ntiles, P;
+  long long M;                // k_exp_stats: pixels
+};
+
+__device__ __forceinline__ bf16x8 zero_frag() { return __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u)); }
+
+// the lane's B-operand chunk: 8 input channels of its pixel, the producer's BatchNorm applied, rounded to bf16
+__device__ __forceinline__ bf16x8 b_operand(const u32x4 raw, bool affine, const float (&sc)[8], const float (&sh)[8]) {
+  if (!affine) return __builtin_bit_cast(bf16x8, raw);
+  float x[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    x[2 * i] = __uint_as_float(raw[i] << 16);
+    x[2 * i + 1] = __uint_as_float(raw[i] & 0xffff0000u);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], sc[e], sh[e]);
+  u32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = pack2bf(x[2 * i], x[2 * i + 1]);
+  return __builtin_bit_cast(bf16x8, o);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// statistics of the expansion output (sum, sum of squares of the bf16-rounded values per channel) without storing it
+__global__ __launch_bounds__(THREADS) void k_exp_stats(const Args a) {
+  __shared__ float red[4][2][GC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, q = lane >> 4;
+  const int g = blockIdx.x % a.ngroups, p = blockIdx.x / a.ngroups;
+  const int cin = a.in.c, cg0 = g * GC;
+  const bool kq = 8 * q < cin;
+  const bool affine = a.in.scale != nullptr;
+  bf16x8 afr[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+    afr[j] = kq ? *reinterpret_cast<const bf16x8*>(a.wt + (size_t)(cg0 + 16 * j + px) * a.ldw + 8 * q) : zero_frag();
+  float isc[8], ish[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { isc[e] = 1.f; ish[e] = 0.f; }
+  if (affine && kq) { loadf8(a.in.scale + 8 * q, isc); loadf8(a.in.shift + 8 * q, ish); }
+  f32x4 s1[3], s2[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { s1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[j] = s1[j]; }
+  const bf16_t* X = reinterpret_cast<const bf16_t*>(a.in.data);
+  const long long M = a.M, nchunks = (M + 15) / 16;
+  const long long stride = (long long)a.P * 4;
+  constexpr int UN = 4;
+  for (long long c0 = (long long)p * 4 + wave; c0 < nchunks; c0 += stride * UN) {
+    u32x4 raw[UN];
+    bool ok[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long long row = (c0 + u * stride) * 16 + px;
+      ok[u] = row < M && kq;
+      const long long rc = row < M ? row : M - 1;
+      raw[u] = *reinterpret_cast<const u32x4*>(X + rc * a.in.ld + (kq ? 8 * q : 0));
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const bf16x8 b = ok[u] ? b_operand(raw[u], affine, isc, ish) : zero_frag();
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[j], b, z4, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = bf2f(f2bf(acc[r]));
+          s1[j][r] += e;
+          s2[j][r] = fmaf(e, e, s2[j][r]);
+        }
+      }
+    }
+  }
+  // the 16 pixel lanes of a channel: xor butterfly (a fixed tree), then the waves in wave order
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s1[j][r] += __shfl_xor(s1[j][r], off, 64);
+        s2[j][r] += __shfl_xor(s2[j][r], off, 64);
+      }
+  }
+  if (px == 0) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        red[wave][0][16 * j + 4 * q + r] = s1[j][r];
+        red[wave][1][16 * j + 4 * q + r] = s2[j][r];
+      }
+  }
+  __syncthreads();
+  if (tid < 2 * GC) {
+    const int r = tid / GC, c = tid % GC;
+    const float t = ((red[0][r][c] + red[1][r][c]) + red[2][r][c]) + red[3][r][c];
+    a.stat_partials[((size_t)p * 2 + r) * a.cexp + cg0 + c] = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// ACTM: 1 swish, 2 relu / relu6 / hswish / mish / srelu
+template <int K, int S, int ACTM, bool STORE_E>
+__global__ __launch_bounds__(THREADS, 2) void k_exp_dw_fwd(const Args a) {
+  using G = Geo<K, S>;
+  constexpr int CPT = G::CPT, NV = CPT / 2, NSL = G::NSL, U0 = G::U0, NF = G::NF, PF = NF - 1;
+  constexpr int U = U0 * NF / gcd_(U0, NF);
+  constexpr int NPX = G::NPX, TXV = G::TXV, NCH = G::NCH, SLOTS = G::SLOTS;
+  extern __shared__ float ring[];      // [2][WINC][GCP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, q = lane >> 4;
+  const int H = a.in.h, W = a.in.w, cin = a.in.c;
+  // block b runs on XCD b % 8: the channel groups of a tile slot back to back on one XCD (they read the same block-input
+  // lines and write parts of the same output lines), every XCD walking a contiguous range of tiles (dw_march.hip, r06)
+  const int x8 = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int g = jb % a.ngroups, ph = jb / a.ngroups;
+  const int t8 = (a.ntiles + 7) / 8;
+  const int tile0 = x8 * t8 + ph, tstep = a.P / 8, tend = min(a.ntiles, (x8 + 1) * t8);
+  const int pslot = ph * 8 + x8;
+  const int cg0 = g * GC;
+  // ---- expansion-phase constants
+  const bool kq = 8 * q < cin;
+  const bool affine = a.in.scale != nullptr;
+  bf16x8 afr[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+    afr[j] = kq ? *reinterpret_cast<const bf16x8*>(a.wt + (size_t)(cg0 + 16 * j + px) * a.ldw + 8 * q) : zero_frag();
+  float isc[8], ish[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { isc[e] = 1.f; ish[e] = 0.f; }
+  if (affine && kq) { loadf8(a.in.scale + 8 * q, isc); loadf8(a.in.shift + 8 * q, ish); }
+  f32x4 esc[3], esh[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    esc[j] = *reinterpret_cast<const f32x4*>(a.esc + cg0 + 16 * j + 4 * q);
+    esh[j] = *reinterpret_cast<const f32x4*>(a.esh + cg0 + 16 * j + 4 * q);
+  }
+  const int wcol = wave * 16 + px;
+  // ---- tap-phase constants
+  const int chunk = tid % NCH, slot = tid / NCH;
+  const bool tact = tid < SLOTS * NCH;
+  const int ct = cg0 + chunk * CPT;
+  f2 w[K * K][NV], st[2][NV];
+  const f2 zero2 = {0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < K * K; ++t)
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      w[t][i] = tact ? *reinterpret_cast<const f2*>(a.dww + (size_t)t * a.cexp + ct + 2 * i) : zero2;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) st[0][i] = st[1][i] = zero2;
+  const bool want_stats = a.stat_partials != nullptr;
+  const uint32_t irow_b = (uint32_t)W * a.in.ld * 2, orow_b = (uint32_t)a.ow * a.ldo * 2;
+  const uint32_t erow_b = STORE_E ? (uint32_t)W * a.lde * 2 : 0u;
+  const char* IN = reinterpret_cast<const char*>(a.in.data);
+  char* OUT = reinterpret_cast<char*>(a.out);
+  char* EO = reinterpret_cast<char*>(a.e_out);
+
+  for (int tile = tile0; tile < tend; tile += tstep) {
+    const int per_img = a.tiles_y * a.tiles_x;
+    const int n = tile / per_img, rr = tile - n * per_img;
+    const int ty = rr / a.tiles_x, tx = rr - ty * a.tiles_x;
+    const int oy0 = ty * a.TY, oy1 = min(a.oh, oy0 + a.TY);
+    const int wc0 = tx * TXV * S - a.pad_l;            // input column of window column 0
+    const int ix = wc0 + wcol;
+    const bool colok = ix >= 0 && ix < W;
+    const uint32_t xoff = (uint32_t)min(max(ix, 0), W - 1) * (uint32_t)(a.in.ld * 2) + (kq ? 16u * q : 0u);
+    // a window column is STORED by the tile that owns it: the first TXV * S columns, the whole window in the last tile
+    const bool ecol = STORE_E && colok && (wcol < TXV * S || tx == a.tiles_x - 1);
+    const uint32_t eoff = STORE_E ? (uint32_t)min(max(ix, 0), W - 1) * (uint32_t)(a.lde * 2) + (uint32_t)(cg0 + 4 * q) * 2u : 0u;
+    bool pok[NPX];
+    uint32_t ooff[NPX], lrd[NPX];
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      const int oxl = slot + i * SLOTS, ox = tx * TXV + oxl;
+      pok[i] = tact && oxl < TXV && ox < a.ow;
+      ooff[i] = (uint32_t)min(ox, a.ow - 1) * (uint32_t)(a.ldo * 2) + (uint32_t)ct * 2u;
+      lrd[i] = (uint32_t)(min(oxl, TXV - 1) * S * GCP + chunk * CPT);
+    }
+    const brsrc_t in_img = make_rsrc(IN + (size_t)n * H * irow_b);
+    const brsrc_t out_img = make_rsrc(OUT + (size_t)n * a.oh * orow_b);
+    const brsrc_t e_img = make_rsrc(STORE_E ? EO + (size_t)n * H * erow_b : OUT);
+    // steps t = input row + pad_t; the input row exists for pad_t <= t < H + pad_t; output row oy completes at oy S + K - 1
+    const int t0 = oy0 * S, t_last = (oy1 - 1) * S + K - 1;
+    URange row_rng, out_rng, erow_rng;
+    row_rng.set(max(t0, a.pad_t), min(t_last + 1, H + a.pad_t));
+    out_rng.set(t0 + K - 1, t_last + 1);
+    erow_rng.set(max(t0, a.pad_t), min(ty == a.tiles_y - 1 ? t_last + 1 : oy1 * S, H + a.pad_t));
+    f2 acc[NSL][NPX][NV];
+#pragma unroll
+    for (int s2 = 0; s2 < NSL; ++s2)
+#pragma unroll
+      for (int i = 0; i < NPX; ++i)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[s2][i][v] = zero2;
+    u32x4 fx[NF];
+    auto load_row = [&](int t) -> u32x4 {
+      const uint32_t ro = (uint32_t)min(max(t - a.pad_t, 0), H - 1) * irow_b;
+      return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(in_img, xoff, ro, 0));
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) fx[i] = load_row(t0 + i);
+    for (int tb = t0; tb <= t_last; tb += U) {
+#pragma unroll
+      for (int tt = 0; tt < U; ++tt) {
+        const int t = tb + tt;
+        fx[(tt + PF) % NF] = load_row(t + PF);
+        const bool row_ok = row_rng.has(t);          // uniform
+        float* buf = ring + (t & 1) * WINC * GCP;
+        if (row_ok) {
+          const bf16x8 b = kq ? b_operand(fx[tt % NF], affine, isc, ish) : zero_frag();
+          const bool est = ecol && erow_rng.has(t);
+          const uint32_t ero = STORE_E ? (uint32_t)(t - a.pad_t) * erow_b : 0u;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[j], b, z4, 0, 0, 0);
+            u32x2 u;
+            u[0] = pack2bf(e[0], e[1]);
+            u[1] = pack2bf(e[2], e[3]);
+            if (STORE_E && est) __builtin_amdgcn_raw_buffer_store_b64(u, e_img, eoff + 32u * j, ero, 0);
+            float y[4];
+            y[0] = __uint_as_float(u[0] << 16); y[1] = __uint_as_float(u[0] & 0xffff0000u);
+            y[2] = __uint_as_float(u[1] << 16); y[3] = __uint_as_float(u[1] & 0xffff0000u);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float z = fmaf(y[r], esc[j][r], esh[j][r]);
+              const float v = ACTM == 1 ? z * sigmoidf_(z) : act_other_(a.act, z);
+              y[r] = colok ? v : 0.f;                  // 'SAME' padding is zero in the activated domain
+            }
+            *reinterpret_cast<float4*>(buf + wcol * GCP + 16 * j + 4 * q) = make_float4(y[0], y[1], y[2], y[3]);
+          }
+        }
+        __syncthreads();
+        if (row_ok && tact) {
+#pragma unroll
+          for (int i = 0; i < NPX; ++i) {
+            f2 x[K][NV];
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+              for (int v = 0; v < NV; ++v) x[kx][v] = *reinterpret_cast<const f2*>(buf + lrd[i] + kx * GCP + 2 * v);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+#pragma unroll
+              for (int ky = 0; ky < K; ++ky) {
+                if (((tt - ky) % S + S) % S == 0) {          // static: this input row feeds output row (t - ky) / S
+                  const int sl = slot_of(fdiv_(tt - ky, S), NSL);
+#pragma unroll
+                  for (int v = 0; v < NV; ++v) acc[sl][i][v] = w[ky * K + kx][v] * x[kx][v] + acc[sl][i][v];
+                }
+              }
+            }
+          }
+        }
+        if (((tt - (K - 1)) % S + S) % S == 0) {           // static: output row (t - K + 1) / S is complete
+          const int sl = slot_of(fdiv_(tt - (K - 1), S), NSL);
+          if (out_rng.has(t)) {
+            const uint32_t oro = (uint32_t)((t - (K - 1)) / S) * orow_b;
+#pragma unroll
+            for (int i = 0; i < NPX; ++i) {
+              if (pok[i]) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                  const uint32_t o = pack2bf(acc[sl][i][v].x, acc[sl][i][v].y);
+                  __builtin_amdgcn_raw_buffer_store_b32(o, out_img, ooff[i] + 4u * v, oro, 0);
+                  if (want_stats) {
+                    f2 r2;
+                    r2.x = __uint_as_float(o << 16); r2.y = __uint_as_float(o & 0xffff0000u);
+                    st[0][v] += r2;
+                    st[1][v] = r2 * r2 + st[1][v];
+                  }
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < NPX; ++i)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[sl][i][v] = zero2;
+        }
+      }
+    }
+    __syncthreads();      // the next tile's first row reuses the ring slot of this tile's last rows
+  }
+  if (want_stats) {
+    // per-thread channel sums -> one partial row per tile slot: thread-major in LDS, then the SLOTS pixel slots of a
+    // channel in slot order (no atomics: the same sums on every run)
+    float* red = ring;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      __syncthreads();
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        red[tid * CPT + 2 * v] = tact ? st[r][v].x : 0.f;
+        red[tid * CPT + 2 * v + 1] = tact ? st[r][v].y : 0.f;
+      }
+      __syncthreads();
+      if (tid < GC) {
+        const int ch = tid / CPT, e = tid % CPT;
+        float t = 0.f;
+        for (int s = 0; s < SLOTS; ++s) t += red[(s * NCH + ch) * CPT + e];
+        a.stat_partials[((size_t)pslot * 2 + r) * a.cexp + cg0 + tid] = t;
+      }
+    }
+  }
+}
+
+inline bool supported(const edet_tview_t* in, int cexp, int k, int s, int dtype) {
+  if (dtype != EDET_BF16 || !in) return false;
+  if (in->gate || in->act != EDET_ACT_NONE) return false;
+  if (in->c % 8 != 0 || in->c > 32 || in->ld != in->c) return false;
+  if (cexp % GC != 0) return false;
+  if ((k != 3 && k != 5) || (s != 1 && s != 2)) return false;
+  if ((int64_t)in->h * in->w * cexp * 2 >= 0x7fffffffLL) return false;      // 32-bit offsets inside one image
+  return true;
+}
+
+}  // namespace mbf
+
+/* 1 = the fused MBConv head kernels apply to this layer, 0 = use edet_pw_fwd + edet_dw_fwd */
+extern "C" int edet_mbconv_fused_supported(const edet_tview_t* in, int cexp, int k, int stride, int dtype) {
+  return mbf::supported(in, cexp, k, stride, dtype) ? 1 : 0;
+}
+
+extern "C" int edet_mbconv_expand_stats(const edet_tview_t* in, const void* wt, int ldw, int cexp,
+                                        float* stat_partials, int* nparts_out, int dtype, void* stream) {
+  using namespace mbf;
+  EDET_CHECK(in && wt && stat_partials && nparts_out, "edet_mbconv_expand_stats: null argument");
+  EDET_CHECK(supported(in, cexp, 3, 1, dtype), "edet_mbconv_expand_stats: unsupported layer (bf16, <= 32 input channels, "
+             "expanded channels %% 48 == 0, plain affine input view)");
+  EDET_CHECK(ldw >= in->c && ldw % 8 == 0, "edet_mbconv_expand_stats: bad kernel stride");
+  Args a;
+  memset(&a, 0, sizeof(a));
+  a.in = *in; a.wt = reinterpret_cast<const bf16_t*>(wt); a.ldw = ldw; a.cexp = cexp; a.stat_partials = stat_partials;
+  a.ngroups = cexp / GC;
+  a.M = (long long)in->n * in->h * in->w;
+  const long long nchunks = (a.M + 15) / 16;
+  long long P = (nchunks + 4 * 4 - 1) / (4 * 4);      // >= 4 chunks of 16 pixels per wave
+  if (P > 512) P = 512;
+  if (P < 1) P = 1;
+  a.P = (int)P;
+  edet_launch(k_exp_stats, dim3(a.P * a.ngroups), dim3(THREADS), 0, to_stream(stream), a);
+  EDET_LAUNCH_CHECK("edet_mbconv_expand_stats");
+  *nparts_out = a.P;
+  return 0;
+}
+
+extern "C" int edet_mbconv_expand_dw_fwd(const edet_tview_t* in, const void* wt, int ldw, int cexp,
+                                         const float* exp_scale, const float* exp_shift, int act,
+                                         void* expanded_out, int lde, const float* dw_weight, int k, int stride,
+                                         void* out, int ldo, float* stat_partials, int* nparts_out, int dtype,
+                                         void* stream) {
+  using namespace mbf;
+  EDET_CHECK(in && wt && exp_scale && exp_shift && dw_weight && out, "edet_mbconv_expand_dw_fwd: null argument");
+  EDET_CHECK(supported(in, cexp, k, stride, dtype), "edet_mbconv_expand_dw_fwd: unsupported layer (bf16, <= 32 input "
+             "channels, expanded channels %% 48 == 0, k in {3,5}, stride in {1,2}, plain affine input view)");
+  EDET_CHECK(act >= EDET_ACT_SWISH && act <= EDET_ACT_LAST, "edet_mbconv_expand_dw_fwd: the expansion has an activation");
+  EDET_CHECK(ldw >= in->c && ldw % 8 == 0 && ldo >= cexp && ldo % 2 == 0 && (!expanded_out || (lde >= cexp && lde % 4 == 0)),
+             "edet_mbconv_expand_dw_fwd: bad strides");
+  EDET_CHECK(!stat_partials || nparts_out, "edet_mbconv_expand_dw_fwd: nparts_out is needed with stat_partials");
+  Args a;
+  memset(&a, 0, sizeof(a));
+  a.in = *in; a.wt = reinterpret_cast<const bf16_t*>(wt); a.ldw = ldw; a.cexp = cexp;
+  a.esc = exp_scale; a.esh = exp_shift; a.act = act;
+  a.e_out = reinterpret_cast<bf16_t*>(expanded_out); a.lde = lde;
+  a.dww = dw_weight; a.out = reinterpret_cast<bf16_t*>(out); a.ldo = ldo; a.stat_partials = stat_partials;
+  a.oh = same_out(in->h, stride); a.ow = same_out(in->w, stride);
+  a.pad_t = same_pad_before(in->h, k, stride); a.pad_l = same_pad_before(in->w, k, stride);
+  EDET_CHECK((int64_t)a.oh * a.ow * ldo * 2 < 0x7fffffffLL && (int64_t)in->h * in->w * (lde > 0 ? lde : 1) * 2 < 0x7fffffffLL,
+             "edet_mbconv_expand_dw_fwd: image too large for 32-bit offsets");
+  a.ngroups = cexp / GC;
+  const int txv = (WINC - k) / stride + 1;
+  {
+    const int cap = a.oh >= 160 ? 80 : 40;
+    const int nt = (a.oh + cap - 1) / cap;
+    a.TY = (a.oh + nt - 1) / nt;
+  }
+  a.tiles_x = (a.ow + txv - 1) / txv;
+  a.tiles_y = (a.oh + a.TY - 1) / a.TY;
+  a.ntiles = in->n * a.tiles_x * a.tiles_y;
+  {
+    // tile slots (= statistic partial rows, <= EDET_MAX_PARTS): a whole number of rounds over the tiles of every XCD
+    const char* p_env = getenv("EDET_MBF_P");      // lab switch
+    const int pmax = (p_env && p_env[0]) ? atoi(p_env) : EDET_MAX_PARTS;
+    const int t8 = (a.ntiles + 7) / 8;
+    const int rounds = (t8 + pmax / 8 - 1) / (pmax / 8);
+    a.P = 8 * ((t8 + rounds - 1) / rounds);
+  }
+  const size_t lds = (size_t)2 * WINC * GCP * sizeof(float);
+  const dim3 grid(a.P * a.ngroups), block(THREADS);
+  hipStream_t st = to_stream(stream);
+  const bool se = expanded_out != nullptr;
+  const bool sw = act == EDET_ACT_SWISH;
+#define MBF_GO(K_, S_)                                                                          \
+  do {                                                                                          \
+    if (sw) { if (se) edet_launch(k_exp_dw_fwd<K_, S_, 1, true>, grid, block, lds, st, a);      \
+              else edet_launch(k_exp_dw_fwd<K_, S_, 1, false>, grid, block, lds, st, a); }      \
+    else { if (se) edet_launch(k_exp_dw_fwd<K_, S_, 2, true>, grid, block, lds, st, a);         \
+           else edet_launch(k_exp_dw_fwd<K_, S_, 2, false>, grid, block, lds, st, a); }         \
+  } while (0)
+  if (k == 3 && stride == 1) MBF_GO(3, 1);
+  else if (k == 3 && stride == 2) MBF_GO(3, 2);
+  else if (k == 5 && stride == 1) MBF_GO(5, 1);
+  else MBF_GO(5, 2);
+#undef MBF_GO
+  EDET_LAUNCH_CHECK("edet_mbconv_expand_dw_fwd");
+  if (nparts_out) *nparts_out = a.P;
+  return 0;
+}

@@ -313,6 +313,10 @@ class Engine(object):
     self._reduce_marks = {}
     self._comm_stream = None
     self._bucket_no = 0
+    # head of an MBConv block (expansion -> BatchNorm -> activation -> depthwise) in one kernel where the library has one
+    # (mbconv_fused.hip: bf16, <= 32 block-input channels): the expanded tensor is not read back by the depthwise
+    # convolution -- and never stored at all in inference.  EDET_MBCONV_FUSED=0: the two-kernel path (lab switch)
+    self.fused_mbconv_head = os.environ.get('EDET_MBCONV_FUSED', '1') != '0'
     self.fused_dw_bwd = True     # one edet_dw_bwd call per layer (bf16: ONE kernel for both gradients, any stride)
     self.fused_pw_bwd = True     # one edet_pw_bwd call per pointwise layer whose input needs a gradient
     # cross-replica BatchNorm (utils.SyncBatchNormalization / TpuBatchNormalization, utils.py:166-241):
@@ -1110,14 +1114,21 @@ class Engine(object):
     conv_names = ['conv2d', 'conv2d_1']
     bi = ci = 0
     x = xin
-    if b.expand_ratio != 1:
-      x = self.pw(scope + ':exp', x, '%s/%s/kernel' % (scope, conv_names[ci]), cexp,
-                  bn='%s/%s' % (scope, bn_names[bi]), act=self.act)
+    if b.expand_ratio != 1 and self._mbconv_head_fusable(x, cexp, b.kernel_size, b.stride):
+      x = self.mbconv_head(scope, x, '%s/%s/kernel' % (scope, conv_names[ci]), cexp, '%s/%s' % (scope, bn_names[bi]),
+                           scope + '/depthwise_conv2d/depthwise_kernel', b.kernel_size, b.stride,
+                           '%s/%s' % (scope, bn_names[bi + 1]))
       ci += 1
+      bi += 2
+    else:
+      if b.expand_ratio != 1:
+        x = self.pw(scope + ':exp', x, '%s/%s/kernel' % (scope, conv_names[ci]), cexp,
+                    bn='%s/%s' % (scope, bn_names[bi]), act=self.act)
+        ci += 1
+        bi += 1
+      x = self.dw(scope + ':dw', x, scope + '/depthwise_conv2d/depthwise_kernel', b.kernel_size, b.stride,
+                  bn='%s/%s' % (scope, bn_names[bi]), act=self.act)
       bi += 1
-    x = self.dw(scope + ':dw', x, scope + '/depthwise_conv2d/depthwise_kernel', b.kernel_size, b.stride,
-                bn='%s/%s' % (scope, bn_names[bi]), act=self.act)
-    bi += 1
     if b.se_filters:
       x = self.se(scope + ':se', x, scope, b.se_filters)
     y = self.pw(scope + ':proj', x, '%s/%s/kernel' % (scope, conv_names[ci]), b.output_filters,
@@ -1125,6 +1136,46 @@ class Engine(object):
     sps = getattr(self.spec, 'survival_probs', None)
     return self.bn_res(scope + ':out', y, xin if b.has_residual else None,
                        survival_prob=sps[b.index] if sps else None)
+
+  def _mbconv_head_fusable(self, vin, cexp, k, stride):
+    if not self.fused_mbconv_head or self.dtype != EDET_BF16 or self.act == ACT_NONE:
+      return False
+    return _lib.load().edet_mbconv_fused_supported(ctypes.byref(vin.tview()), cexp, k, stride, self.dtype) == 1
+
+  def mbconv_head(self, scope, vin, wexp, cexp, bn_exp, wdw, k, stride, bn_dw):
+    """x = act(bn0(expand_conv(x))); x = act(bn1(depthwise_conv(x))) (efficientnet_model.py:378-392) through
+    edet_mbconv_expand_dw_fwd.  Training: the expansion's batch statistics first (edet_mbconv_expand_stats, the block
+    input only), the raw expanded tensor stored for the backward pass, whose tape entries are those of the two-kernel
+    path (Engine.pw, Engine.dw).  Inference: the expanded tensor is never stored."""
+    r = vin.raw
+    cin = r.c
+    wt, ldk, w, ldn = self._pw_copies(wexp, cin, cexp)
+    bne, bnd = self.get_bn(bn_exp, cexp), self.get_bn(bn_dw, cexp)
+    oh, _, _ = utils.same_padding(r.h, k, stride)
+    ow, _, _ = utils.same_padding(r.w, k, stride)
+    tv = vin.tview()
+    tag = '%dx%dx%d->%d k%ds%d' % (r.h, r.w, cin, cexp, k, stride)
+    e_raw = None
+    if self.training:
+      e_raw = Raw(self, scope + ':exp', r.n, r.h, r.w, cexp)
+      call('edet_mbconv_expand_stats', ctypes.byref(tv), ptr(wt), ldk, cexp, ptr(self.partials),
+           ctypes.byref(self._nparts), self.dtype, self.stream, nbytes=r.rows * cin * self.esize, tag=tag)
+    self._bn_forward(bne, r.rows, self._nparts.value)
+    out = Raw(self, scope + ':dw', r.n, oh, ow, cexp)
+    stats = ptr(self.partials) if self.training else None
+    call('edet_mbconv_expand_dw_fwd', ctypes.byref(tv), ptr(wt), ldk, cexp, ptr(bne.scale), ptr(bne.shift), self.act,
+         ptr(e_raw.data) if e_raw is not None else None, e_raw.ld if e_raw is not None else 0,
+         ptr(self.param(wdw)), k, stride, ptr(out.data), out.ld, stats, ctypes.byref(self._nparts), self.dtype, self.stream,
+         nbytes=(r.rows * cin + (r.rows * cexp if e_raw is not None else 0) + out.rows * cexp) * self.esize, tag=tag)
+    self._bn_forward(bnd, out.rows, self._nparts.value)
+    vout = View(out, bnd, self.act)
+    vin.consumers += 1
+    if self.training:
+      ve = View(e_raw, bne, self.act)
+      ve.consumers = 1
+      self.tape.append(lambda: self._pw_bwd(vin, ve, wexp, w, ldn, True))
+      self.tape.append(lambda: self._dw_bwd(ve, vout, wdw, k, stride))
+    return vout
 
   def _fpn_cell(self, feats, cell_scope):
     c = self.config

@@ -216,6 +216,31 @@ int edet_conv_bwd_data(const edet_gview_t* dy, const void* w_t, int ldw, int k, 
 int edet_conv_bwd_weight(const edet_tview_t* in, const edet_gview_t* dy, int k, int stride,
                          float* dweight, void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
+/* ---- head of an MBConv block in one kernel (bf16 storage) ----------------------------------
+ * efficientnet_model.py:378-392: x = act(bn0(expand_conv(x))); x = act(bn1(depthwise_conv(x))) -- the layers of
+ * :304-327.  The expanded tensor (6 x the block input) is produced by the matrix cores INSIDE the depthwise march
+ * instead of being written by edet_pw_fwd and read back by edet_dw_fwd (automl_amd/csrc/mbconv_fused.hip).
+ *   in           : the block input as an affine view (the producer's BatchNorm on load, or a stored tensor): no
+ *                  activation, no gate, c <= 32 channels (c % 8 == 0).
+ *   w_t          : the expansion kernel as edet_pw_fwd takes it -- compute copy [cexp][ldw], input channel contiguous;
+ *                  cexp % 48 == 0 (every EfficientNet expansion width is).
+ *   exp_scale/exp_shift : the expansion's BatchNorm as edet_bn_finalize / edet_bn_eval wrote it; act: its activation.
+ *   expanded_out : NULL (inference: the expanded tensor is never stored) or the raw expanded tensor [n,h,w,lde], which
+ *                  the training backward pass reads (edet_dw_bwd, edet_pw_bwd) exactly as if edet_pw_fwd had stored it.
+ *   out / stat_partials / nparts_out : as edet_dw_fwd.
+ * Training needs the batch statistics of the expansion before the depthwise convolution can run:
+ * edet_mbconv_expand_stats makes the partial rows (same matrix-core products, same bf16 rounding, nothing stored) that
+ * edet_bn_finalize turns into exp_scale / exp_shift.  edet_mbconv_fused_supported: 1 = these two entry points apply to
+ * the layer, 0 = the caller runs edet_pw_fwd + edet_dw_fwd.  */
+int edet_mbconv_fused_supported(const edet_tview_t* in, int cexp, int k, int stride, int dtype);
+int edet_mbconv_expand_stats(const edet_tview_t* in, const void* w_t, int ldw, int cexp,
+                             float* stat_partials, int* nparts_out, int dtype, void* stream);
+int edet_mbconv_expand_dw_fwd(const edet_tview_t* in, const void* w_t, int ldw, int cexp,
+                              const float* exp_scale, const float* exp_shift, int act,
+                              void* expanded_out, int lde, const float* dw_weight, int k, int stride,
+                              void* out, int ldo, float* stat_partials, int* nparts_out, int dtype,
+                              void* stream);
+
 /* ---- depthwise convolution k in {3,5}, stride in {1,2}, TF 'SAME' ----------
  * DepthwiseConv2D call sites: efficientnet_model.py:320-327 and the depthwise
  * half of SeparableConv2D.  weight fp32 [k,k,c] (HWIO with multiplier 1).  */
