@@ -33,10 +33,14 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t brsrc_t;
 
-constexpr int THREADS = 256;
-constexpr int GC = 48;      // expanded channels per workgroup
-constexpr int GCP = 52;     // floats per pixel in the LDS ring (48 + 4: the 8 lanes of a ds_write_b128 group on 32 banks)
-constexpr int WINC = 64;    // window columns per workgroup (4 waves x 16 pixels)
+constexpr int THREADS = 256; // k_exp_stats
+constexpr int GC = 48;      // expanded channels per wave: three 16-row MFMA blocks
+// Every global store of the march is issued on every step, by every lane: what must not be written goes to this offset,
+// beyond the descriptor's num_records (2^31 - 1), where the hardware drops it.  A store under a branch -- even a uniform
+// one -- makes the compiler's count of the memory operations in flight unknowable, and every wait on the block-input
+// FIFO then becomes a wait for (nearly) ALL of them, the stores of the expanded row included (r06 lab: s_waitcnt vmcnt(1)
+// in front of every store and MFMA; the training kernel took the inference kernel's time PLUS the time of its stores).
+constexpr uint32_t OOB = 0x80000000u;
 
 __device__ __forceinline__ brsrc_t make_rsrc(const void* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
@@ -50,17 +54,6 @@ struct URange {
   __device__ __forceinline__ bool has(int v) const { return (uint32_t)(v - lo) < span; }
 };
 
-template <int K, int S> struct Geo {
-  static constexpr int TXV = (WINC - K) / S + 1;       // output columns whose taps lie inside the window
-  static constexpr int NSL = (K + S - 1) / S;          // output rows in flight
-  static constexpr int U0 = S * NSL;
-  static constexpr int CPT = K == 3 ? 6 : 2;           // channels per tap thread (K*K*CPT/2 weight register pairs)
-  static constexpr int NCH = GC / CPT;
-  static constexpr int SLOTS = THREADS / NCH;          // output pixels handled side by side
-  static constexpr int NPX = (TXV + SLOTS - 1) / SLOTS;
-  static constexpr int NF = U0 == 3 ? 6 : (U0 == 4 ? 8 : (U0 == 5 ? 5 : 6));   // rows of block-input loads in flight + 1
-};
-
 struct Args {
   edet_tview_t in;            // block input [n][H][W][cin]: affine view (the producer's BatchNorm) or a stored tensor
   const bf16_t* wt; int ldw;  // expansion kernel, transposed: [cexp][ldw], input channel contiguous
@@ -72,13 +65,15 @@ struct Args {
   float* stat_partials;       // [P][2][cexp] of the depthwise output (training) or NULL
   int oh, ow, pad_t, pad_l;
   int ngroups, TY, tiles_x, tiles_y, ntiles, P;
+  int ngb;                    // channel blocks (workgroups) per tile slot: cexp / (48 NGR)
   long long M;                // k_exp_stats: pixels
+  int dbg;                    // lab switch EDET_MBF_DBG (1: the stores of the expanded tensor are dropped)
 };
 
 __device__ __forceinline__ bf16x8 zero_frag() { return __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u)); }
 
 // the lane's B-operand chunk: 8 input channels of its pixel, the producer's BatchNorm applied, rounded to bf16
-__device__ __forceinline__ bf16x8 b_operand(const u32x4 raw, bool affine, const float (&sc)[8], const float (&sh)[8]) {
+__device__ __forceinline__ bf16x8 b_operand(const u32x4 raw, bool affine, const float* sc, const float* sh) {
   if (!affine) return __builtin_bit_cast(bf16x8, raw);
   float x[8];
 #pragma unroll
@@ -96,32 +91,42 @@ __device__ __forceinline__ bf16x8 b_operand(const u32x4 raw, bool affine, const 
 
 // ------------------------------------------------------------------------------------------------------------------
 // statistics of the expansion output (sum, sum of squares of the bf16-rounded values per channel) without storing it
-__global__ __launch_bounds__(THREADS) void k_exp_stats(const Args a) {
-  __shared__ float red[4][2][GC];
+template <int NG>      // channel groups per workgroup: the block input is loaded and transformed once for all of them
+__global__ __launch_bounds__(THREADS, 2) void k_exp_stats(const Args a) {
+  __shared__ float red[4][2][NG * GC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, q = lane >> 4;
-  const int g = blockIdx.x % a.ngroups, p = blockIdx.x / a.ngroups;
-  const int cin = a.in.c, cg0 = g * GC;
+  const int p = blockIdx.x;
+  const int cin = a.in.c;
   const bool kq = 8 * q < cin;
   const bool affine = a.in.scale != nullptr;
-  bf16x8 afr[3];
+  bf16x8 afr[NG][3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
-    afr[j] = kq ? *reinterpret_cast<const bf16x8*>(a.wt + (size_t)(cg0 + 16 * j + px) * a.ldw + 8 * q) : zero_frag();
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      afr[g][j] = kq ? *reinterpret_cast<const bf16x8*>(a.wt + (size_t)(g * GC + 16 * j + px) * a.ldw + 8 * q) : zero_frag();
   float isc[8], ish[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { isc[e] = 1.f; ish[e] = 0.f; }
   if (affine && kq) { loadf8(a.in.scale + 8 * q, isc); loadf8(a.in.shift + 8 * q, ish); }
-  f32x4 s1[3], s2[3];
+  // Two 16-pixel chunks at a time: v_cvt_pk_bf16_f32 packs the SAME channel of the two chunks' pixels, and one
+  // v_dot2c_f32_bf16 each adds the pair (against (1, 1)) and its squares to the channel's sums: 1.5 VALU instructions
+  // per element instead of 2.5 with packed fp32 math (r06 lab: the pass is VALU-bound, 0.25 ms for 0.42 GB read)
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+  float s1[NG][3][4], s2[NG][3][4];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) { s1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[j] = s1[j]; }
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1[g][j][r] = 0.f; s2[g][j][r] = 0.f; }
+  const bf2_t ones = __builtin_bit_cast(bf2_t, 0x3f803f80u);
   const bf16_t* X = reinterpret_cast<const bf16_t*>(a.in.data);
   const long long M = a.M, nchunks = (M + 15) / 16;
   const long long stride = (long long)a.P * 4;
-  constexpr int UN = 4;
-  for (long long c0 = (long long)p * 4 + wave; c0 < nchunks; c0 += stride * UN) {
-    u32x4 raw[UN];
-    bool ok[UN];
+  constexpr int UN = NG >= 3 ? 2 : 4;
+  auto fetch = [&](long long c0, u32x4 (&raw)[UN], bool (&ok)[UN]) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const long long row = (c0 + u * stride) * 16 + px;
@@ -129,99 +134,156 @@ __global__ __launch_bounds__(THREADS) void k_exp_stats(const Args a) {
       const long long rc = row < M ? row : M - 1;
       raw[u] = *reinterpret_cast<const u32x4*>(X + rc * a.in.ld + (kq ? 8 * q : 0));
     }
+  };
+  u32x4 raw[UN], nxt[UN];
+  bool ok[UN], nok[UN];
+  long long c0 = (long long)p * 4 + wave;
+  if (c0 < nchunks) fetch(c0, raw, ok);
+  for (; c0 < nchunks; c0 += stride * UN) {
+    const long long c1 = c0 + stride * UN;
+    fetch(c1 < nchunks ? c1 : c0, nxt, nok);          // the next round's loads under this round's arithmetic
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const bf16x8 b = ok[u] ? b_operand(raw[u], affine, isc, ish) : zero_frag();
+    for (int u = 0; u < UN; u += 2) {
+      const bf16x8 b0 = ok[u] ? b_operand(raw[u], affine, isc, ish) : zero_frag();
+      const bf16x8 b1 = ok[u + 1] ? b_operand(raw[u + 1], affine, isc, ish) : zero_frag();
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[j], b, z4, 0, 0, 0);
+      for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = bf2f(f2bf(acc[r]));
-          s1[j][r] += e;
-          s2[j][r] = fmaf(e, e, s2[j][r]);
+        for (int j = 0; j < 3; ++j) {
+          const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+          const f32x4 e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[g][j], b0, z4, 0, 0, 0);
+          const f32x4 e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[g][j], b1, z4, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bf2_t pr = __builtin_bit_cast(bf2_t, pack2bf(e0[r], e1[r]));
+            s1[g][j][r] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, s1[g][j][r], false);
+            s2[g][j][r] = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, s2[g][j][r], false);
+          }
         }
-      }
     }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) { raw[u] = nxt[u]; ok[u] = nok[u]; }
   }
   // the 16 pixel lanes of a channel: xor butterfly (a fixed tree), then the waves in wave order
 #pragma unroll
-  for (int off = 1; off < 16; off <<= 1) {
+  for (int g = 0; g < NG; ++g)
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s1[j][r] += __shfl_xor(s1[j][r], off, 64);
-        s2[j][r] += __shfl_xor(s2[j][r], off, 64);
-      }
-  }
-  if (px == 0) {
+      for (int h = 0; h < 2; ++h) {
+        float v[4] = {s1[g][j][2 * h], s1[g][j][2 * h + 1], s2[g][j][2 * h], s2[g][j][2 * h + 1]};
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+        for (int off = 1; off < 16; off <<= 1)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        red[wave][0][16 * j + 4 * q + r] = s1[j][r];
-        red[wave][1][16 * j + 4 * q + r] = s2[j][r];
+          for (int i = 0; i < 4; ++i) v[i] += __shfl_xor(v[i], off, 64);
+        if (px == 0) {
+          const int c = g * GC + 16 * j + 4 * q + 2 * h;
+          red[wave][0][c] = v[0]; red[wave][0][c + 1] = v[1];
+          red[wave][1][c] = v[2]; red[wave][1][c + 1] = v[3];
+        }
       }
-  }
   __syncthreads();
-  if (tid < 2 * GC) {
-    const int r = tid / GC, c = tid % GC;
+  for (int i = tid; i < 2 * NG * GC; i += THREADS) {
+    const int r = i / (NG * GC), c = i % (NG * GC);
     const float t = ((red[0][r][c] + red[1][r][c]) + red[2][r][c]) + red[3][r][c];
-    a.stat_partials[((size_t)p * 2 + r) * a.cexp + cg0 + c] = t;
+    a.stat_partials[((size_t)p * 2 + r) * a.cexp + c] = t;
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Workgroup shape: NGR channel groups of 48 x NPH sixteen-pixel window parts = NGR * NPH waves.  A workgroup owns ALL
+// expanded channels of its window, so the raw expanded row it stores (training) is contiguous in memory: 32 pixels x
+// 192 / 288 bytes.  (r06 lab, 320x320x16->96: with the two channel groups of a pixel in two workgroups -- 96-byte
+// pieces, two writers per 128-byte line -- the stores cost 0.44 ms of a 1.41 ms kernel; one group alone, contiguous
+// rows: 0.07 ms for half the bytes; a plain fill writes the 2.5 GB in 0.37 ms.)
+template <int NGR_, int NPH_> struct Shape {
+  static constexpr int NGR = NGR_, NPH = NPH_;
+  static constexpr int NW = NGR * NPH, NT = 64 * NW;
+  static constexpr int WINC = 16 * NPH;       // window columns
+  static constexpr int GCW = GC * NGR;        // channels of the workgroup (= cexp)
+  static constexpr int GCP = GCW + 4;         // floats per pixel in the ring: the 8 lanes of a ds_write_b128 group on 32 banks
+  static constexpr int ESTG = GCW * 2 + 8;    // bytes per pixel of the staged raw row: the 16 lanes of a ds_write_b64 group on 32 banks
+  static constexpr int ECH = GCW * 2 / 16;    // 16-byte chunks per pixel
+  static constexpr int TABF = 2 * GCW + 64;   // floats of the coefficient tables behind the ring
+  static constexpr int NIT = (WINC * ECH + NT - 1) / NT;     // staged chunks per thread and row
+};
+template <int K, int S, typename SH> struct Geo {
+  static constexpr int TXV = (SH::WINC - K) / S + 1;    // output columns whose taps lie inside the window
+  static constexpr int NSL = (K + S - 1) / S;           // output rows in flight
+  static constexpr int U0 = S * NSL;
+  static constexpr int CPT = K == 3 ? 4 : 2;            // channels per tap thread (K*K*CPT/2 weight register pairs)
+  static constexpr int NCH = SH::GCW / CPT;
+  static constexpr int SLOTS = SH::NT / NCH;            // output pixels handled side by side
+  static constexpr int NPX = (TXV + SLOTS - 1) / SLOTS;
+  static constexpr int NF = U0;                         // rows of block-input loads in flight + 1 (16 bytes per lane and row)
+};
+
 // ACTM: 1 swish, 2 relu / relu6 / hswish / mish / srelu
-template <int K, int S, int ACTM, bool STORE_E>
-__global__ __launch_bounds__(THREADS, 2) void k_exp_dw_fwd(const Args a) {
-  using G = Geo<K, S>;
+// (Three waves per SIMD: at four, the 3x3 stride-2 instantiations fit 128 VGPRs only with 1-7 spilled registers, and the
+// six-wave one then stored wrong values in the first row of a tile -- zeros in two of a lane's four MFMA results, r06
+// scripts/mbf_debug.py; no instantiation may spill: tests/test_abi.py checks the build's resource report.)
+template <int K, int S, int ACTM, bool STORE_E, typename SH>
+__global__ __launch_bounds__(SH::NT, 3) void k_exp_dw_fwd(const Args a) {
+  using G = Geo<K, S, SH>;
   constexpr int CPT = G::CPT, NV = CPT / 2, NSL = G::NSL, U0 = G::U0, NF = G::NF, PF = NF - 1;
   constexpr int U = U0 * NF / gcd_(U0, NF);
   constexpr int NPX = G::NPX, TXV = G::TXV, NCH = G::NCH, SLOTS = G::SLOTS;
+  constexpr int NT = SH::NT, WINC = SH::WINC, GCW = SH::GCW, GCP = SH::GCP, ESTG = SH::ESTG, ECH = SH::ECH, NIT = SH::NIT;
   extern __shared__ float ring[];      // [2][WINC][GCP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, q = lane >> 4;
+  const int gw = wave % SH::NGR, pw = wave / SH::NGR;      // the wave's channel group and window part
   const int H = a.in.h, W = a.in.w, cin = a.in.c;
-  // block b runs on XCD b % 8: the channel groups of a tile slot back to back on one XCD (they read the same block-input
-  // lines and write parts of the same output lines), every XCD walking a contiguous range of tiles (dw_march.hip, r06)
+  // block b runs on XCD b % 8: every XCD walks a contiguous range of tiles (neighbouring windows and row tiles share
+  // block-input lines in that XCD's L2; dw_march.hip, r06)
+  // (a.ngb > 1: the workgroup owns GCW of the cexp channels; the channel blocks of a tile slot sit back to back on one XCD)
   const int x8 = blockIdx.x & 7, jb = blockIdx.x >> 3;
-  const int g = jb % a.ngroups, ph = jb / a.ngroups;
+  const int gblk = jb % a.ngb, ph = jb / a.ngb;
+  const int cb = gblk * GCW;           // first channel of the workgroup
   const int t8 = (a.ntiles + 7) / 8;
   const int tile0 = x8 * t8 + ph, tstep = a.P / 8, tend = min(a.ntiles, (x8 + 1) * t8);
   const int pslot = ph * 8 + x8;
-  const int cg0 = g * GC;
+  const int cg0 = gw * GC;
   // ---- expansion-phase constants
   const bool kq = 8 * q < cin;
   const bool affine = a.in.scale != nullptr;
   bf16x8 afr[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j)
-    afr[j] = kq ? *reinterpret_cast<const bf16x8*>(a.wt + (size_t)(cg0 + 16 * j + px) * a.ldw + 8 * q) : zero_frag();
-  float isc[8], ish[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { isc[e] = 1.f; ish[e] = 0.f; }
-  if (affine && kq) { loadf8(a.in.scale + 8 * q, isc); loadf8(a.in.shift + 8 * q, ish); }
-  f32x4 esc[3], esh[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    esc[j] = *reinterpret_cast<const f32x4*>(a.esc + cg0 + 16 * j + 4 * q);
-    esh[j] = *reinterpret_cast<const f32x4*>(a.esh + cg0 + 16 * j + 4 * q);
+    afr[j] = kq ? *reinterpret_cast<const bf16x8*>(a.wt + (size_t)(cb + cg0 + 16 * j + px) * a.ldw + 8 * q) : zero_frag();
+  // coefficient tables in LDS (behind the ring): expansion BatchNorm of the workgroup's channels, the producer's
+  // BatchNorm of the <= 32 block-input channels -- 40 VGPRs that buy another wave per SIMD
+  float* tab = ring + 2 * WINC * GCP;      // [0,GCW) esc  [GCW,2 GCW) esh  then 32 isc, 32 ish
+  // training: the raw bf16 row of the expanded tensor is staged here ([2][WINC][ESTG bytes]) and leaves as 16-byte
+  // stores of whole pixels (r06 lab: 8-byte stores straight from the MFMA layout doubled the kernel's time)
+  unsigned char* stage = reinterpret_cast<unsigned char*>(tab + SH::TABF);
+  for (int i = tid; i < GCW; i += NT) { tab[i] = a.esc[cb + i]; tab[GCW + i] = a.esh[cb + i]; }
+  if (tid < 32) {
+    tab[2 * GCW + tid] = (affine && tid < cin) ? a.in.scale[tid] : 1.f;
+    tab[2 * GCW + 32 + tid] = (affine && tid < cin) ? a.in.shift[tid] : 0.f;
   }
-  const int wcol = wave * 16 + px;
+  __syncthreads();
+  const float* t_esc = tab + cg0 + 4 * q;
+  const float* t_isc = tab + 2 * GCW + (kq ? 8 * q : 0);
+  const int wcol = pw * 16 + px;
+  // store phase: thread -> up to NIT (pixel, 16-byte chunk) pairs of the staged row
+  int spx[NIT], spart[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int id = tid + NT * it;
+    spx[it] = min(id / ECH, WINC - 1); spart[it] = id % ECH;      // (ids beyond the row: a valid LDS address, never stored)
+  }
   // ---- tap-phase constants
   const int chunk = tid % NCH, slot = tid / NCH;
   const bool tact = tid < SLOTS * NCH;
-  const int ct = cg0 + chunk * CPT;
+  const int ct = chunk * CPT;
   f2 w[K * K][NV], st[2][NV];
   const f2 zero2 = {0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < K * K; ++t)
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-      w[t][i] = tact ? *reinterpret_cast<const f2*>(a.dww + (size_t)t * a.cexp + ct + 2 * i) : zero2;
+      w[t][i] = tact ? *reinterpret_cast<const f2*>(a.dww + (size_t)t * a.cexp + cb + ct + 2 * i) : zero2;
 #pragma unroll
   for (int i = 0; i < NV; ++i) st[0][i] = st[1][i] = zero2;
   const bool want_stats = a.stat_partials != nullptr;
@@ -241,16 +303,22 @@ __global__ __launch_bounds__(THREADS, 2) void k_exp_dw_fwd(const Args a) {
     const bool colok = ix >= 0 && ix < W;
     const uint32_t xoff = (uint32_t)min(max(ix, 0), W - 1) * (uint32_t)(a.in.ld * 2) + (kq ? 16u * q : 0u);
     // a window column is STORED by the tile that owns it: the first TXV * S columns, the whole window in the last tile
-    const bool ecol = STORE_E && colok && (wcol < TXV * S || tx == a.tiles_x - 1);
-    const uint32_t eoff = STORE_E ? (uint32_t)min(max(ix, 0), W - 1) * (uint32_t)(a.lde * 2) + (uint32_t)(cg0 + 4 * q) * 2u : 0u;
+    uint32_t eoff[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int ixs = wc0 + spx[it];
+      const bool eok = STORE_E && a.dbg != 1 && tid + NT * it < WINC * ECH && ixs >= 0 && ixs < W &&
+                       (spx[it] < TXV * S || tx == a.tiles_x - 1);
+      eoff[it] = eok ? (uint32_t)ixs * (uint32_t)(a.lde * 2) + (uint32_t)(cb * 2 + 16 * spart[it]) : OOB;
+    }
     bool pok[NPX];
     uint32_t ooff[NPX], lrd[NPX];
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
       const int oxl = slot + i * SLOTS, ox = tx * TXV + oxl;
       pok[i] = tact && oxl < TXV && ox < a.ow;
-      ooff[i] = (uint32_t)min(ox, a.ow - 1) * (uint32_t)(a.ldo * 2) + (uint32_t)ct * 2u;
-      lrd[i] = (uint32_t)(min(oxl, TXV - 1) * S * GCP + chunk * CPT);
+      ooff[i] = pok[i] ? (uint32_t)ox * (uint32_t)(a.ldo * 2) + (uint32_t)(cb + ct) * 2u : OOB;
+      lrd[i] = (uint32_t)(min(oxl, TXV - 1) * S * GCP + ct);
     }
     const brsrc_t in_img = make_rsrc(IN + (size_t)n * H * irow_b);
     const brsrc_t out_img = make_rsrc(OUT + (size_t)n * a.oh * orow_b);
@@ -275,7 +343,11 @@ __global__ __launch_bounds__(THREADS, 2) void k_exp_dw_fwd(const Args a) {
     };
 #pragma unroll
     for (int i = 0; i < PF; ++i) fx[i] = load_row(t0 + i);
-    for (int tb = t0; tb <= t_last; tb += U) {
+    // U steps, statically unrolled.  The first round is peeled (called once in front of the loop): the compiler's count of
+    // memory operations in flight at the loop head is the minimum over the entry edge and the back edge, and with the
+    // prologue (PF loads, no stores) as the entry edge every round's first wait on the FIFO became vmcnt(1) -- a drain
+    // of all stores and of the rows loaded ahead, once per round (r06, ISA of the first version)
+    auto round = [&](const int tb) __attribute__((always_inline)) {
 #pragma unroll
       for (int tt = 0; tt < U; ++tt) {
         const int t = tb + tt;
@@ -283,9 +355,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_exp_dw_fwd(const Args a) {
         const bool row_ok = row_rng.has(t);          // uniform
         float* buf = ring + (t & 1) * WINC * GCP;
         if (row_ok) {
-          const bf16x8 b = kq ? b_operand(fx[tt % NF], affine, isc, ish) : zero_frag();
-          const bool est = ecol && erow_rng.has(t);
-          const uint32_t ero = STORE_E ? (uint32_t)(t - a.pad_t) * erow_b : 0u;
+          const bf16x8 b = kq ? b_operand(fx[tt % NF], affine, t_isc, t_isc + 32) : zero_frag();
+          unsigned char* sbuf = stage + (t & 1) * WINC * ESTG + wcol * ESTG + cg0 * 2 + 8 * q;
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -293,28 +364,48 @@ __global__ __launch_bounds__(THREADS, 2) void k_exp_dw_fwd(const Args a) {
             u32x2 u;
             u[0] = pack2bf(e[0], e[1]);
             u[1] = pack2bf(e[2], e[3]);
-            if (STORE_E && est) __builtin_amdgcn_raw_buffer_store_b64(u, e_img, eoff + 32u * j, ero, 0);
+            if (STORE_E) *reinterpret_cast<u32x2*>(sbuf + 32 * j) = u;
             float y[4];
             y[0] = __uint_as_float(u[0] << 16); y[1] = __uint_as_float(u[0] & 0xffff0000u);
             y[2] = __uint_as_float(u[1] << 16); y[3] = __uint_as_float(u[1] & 0xffff0000u);
+            const f32x4 sc4 = *reinterpret_cast<const f32x4*>(t_esc + 16 * j);
+            const f32x4 sh4 = *reinterpret_cast<const f32x4*>(t_esc + GCW + 16 * j);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float z = fmaf(y[r], esc[j][r], esh[j][r]);
+              const float z = fmaf(y[r], sc4[r], sh4[r]);
               const float v = ACTM == 1 ? z * sigmoidf_(z) : act_other_(a.act, z);
               y[r] = colok ? v : 0.f;                  // 'SAME' padding is zero in the activated domain
             }
-            *reinterpret_cast<float4*>(buf + wcol * GCP + 16 * j + 4 * q) = make_float4(y[0], y[1], y[2], y[3]);
+            *reinterpret_cast<float4*>(buf + wcol * GCP + cg0 + 16 * j + 4 * q) = make_float4(y[0], y[1], y[2], y[3]);
           }
         }
         __syncthreads();
+        if (STORE_E) {
+          const bool est = erow_rng.has(t);       // uniform; erow_rng lies inside row_rng
+          const uint32_t ero = est ? (uint32_t)(t - a.pad_t) * erow_b : 0u;
+          const unsigned char* sb = stage + (t & 1) * WINC * ESTG;
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(sb + spx[it] * ESTG + 16 * spart[it]);
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(sb + spx[it] * ESTG + 16 * spart[it] + 8);
+            u32x4 v; v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+            __builtin_amdgcn_raw_buffer_store_b128(v, e_img, est ? eoff[it] : OOB, ero, 0);
+          }
+        }
         if (row_ok && tact) {
 #pragma unroll
           for (int i = 0; i < NPX; ++i) {
             f2 x[K][NV];
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx)
+            for (int kx = 0; kx < K; ++kx) {
+              if (NV == 2) {
+                const float4 t4 = *reinterpret_cast<const float4*>(buf + lrd[i] + kx * GCP);
+                x[kx][0] = f2{t4.x, t4.y}; x[kx][NV - 1] = f2{t4.z, t4.w};
+              } else {
 #pragma unroll
-              for (int v = 0; v < NV; ++v) x[kx][v] = *reinterpret_cast<const f2*>(buf + lrd[i] + kx * GCP + 2 * v);
+                for (int v = 0; v < NV; ++v) x[kx][v] = *reinterpret_cast<const f2*>(buf + lrd[i] + kx * GCP + 2 * v);
+              }
+            }
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) {
 #pragma unroll
@@ -330,21 +421,31 @@ __global__ __launch_bounds__(THREADS, 2) void k_exp_dw_fwd(const Args a) {
         }
         if (((tt - (K - 1)) % S + S) % S == 0) {           // static: output row (t - K + 1) / S is complete
           const int sl = slot_of(fdiv_(tt - (K - 1), S), NSL);
-          if (out_rng.has(t)) {
-            const uint32_t oro = (uint32_t)((t - (K - 1)) / S) * orow_b;
+          {
+            const bool oyok = out_rng.has(t);      // uniform
+            const uint32_t oro = oyok ? (uint32_t)((t - (K - 1)) / S) * orow_b : 0u;
 #pragma unroll
             for (int i = 0; i < NPX; ++i) {
-              if (pok[i]) {
+              const bool valid = oyok && pok[i];
+              uint32_t o[NV];
+#pragma unroll
+              for (int v = 0; v < NV; ++v) o[v] = pack2bf(acc[sl][i][v].x, acc[sl][i][v].y);
+              const uint32_t oo = oyok ? ooff[i] : OOB;
+              if (NV == 2) {
+                u32x2 o2; o2[0] = o[0]; o2[1] = o[NV - 1];
+                __builtin_amdgcn_raw_buffer_store_b64(o2, out_img, oo, oro, 0);
+              } else {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) __builtin_amdgcn_raw_buffer_store_b32(o[v], out_img, oo + 4u * v, oro, 0);
+              }
+              if (want_stats) {
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
-                  const uint32_t o = pack2bf(acc[sl][i][v].x, acc[sl][i][v].y);
-                  __builtin_amdgcn_raw_buffer_store_b32(o, out_img, ooff[i] + 4u * v, oro, 0);
-                  if (want_stats) {
-                    f2 r2;
-                    r2.x = __uint_as_float(o << 16); r2.y = __uint_as_float(o & 0xffff0000u);
-                    st[0][v] += r2;
-                    st[1][v] = r2 * r2 + st[1][v];
-                  }
+                  const uint32_t ov = valid ? o[v] : 0u;
+                  f2 r2;
+                  r2.x = __uint_as_float(ov << 16); r2.y = __uint_as_float(ov & 0xffff0000u);
+                  st[0][v] += r2;
+                  st[1][v] = r2 * r2 + st[1][v];
                 }
               }
             }
@@ -355,7 +456,9 @@ __global__ __launch_bounds__(THREADS, 2) void k_exp_dw_fwd(const Args a) {
             for (int v = 0; v < NV; ++v) acc[sl][i][v] = zero2;
         }
       }
-    }
+    };
+    round(t0);
+    for (int tb = t0 + U; tb <= t_last; tb += U) round(tb);
     __syncthreads();      // the next tile's first row reuses the ring slot of this tile's last rows
   }
   if (want_stats) {
@@ -371,22 +474,40 @@ __global__ __launch_bounds__(THREADS, 2) void k_exp_dw_fwd(const Args a) {
         red[tid * CPT + 2 * v + 1] = tact ? st[r][v].y : 0.f;
       }
       __syncthreads();
-      if (tid < GC) {
-        const int ch = tid / CPT, e = tid % CPT;
+      for (int c = tid; c < GCW; c += NT) {
+        const int ch = c / CPT, e = c % CPT;
         float t = 0.f;
         for (int s = 0; s < SLOTS; ++s) t += red[(s * NCH + ch) * CPT + e];
-        a.stat_partials[((size_t)pslot * 2 + r) * a.cexp + cg0 + tid] = t;
+        a.stat_partials[((size_t)pslot * 2 + r) * a.cexp + cb + c] = t;
       }
     }
   }
+}
+
+// Tile slots (= workgroups = statistic partial rows, <= EDET_MAX_PARTS): at most ONE round of resident workgroups (r06
+// lab, 160x160x24->144: 768 six-wave workgroups on a chip that holds 512 ran a second, half-empty round: +30 %), and a
+// whole number of tiles per slot on every XCD.  EDET_MBF_P overrides the cap (lab switch).
+inline void pick_slots(Args& a, const void* fn, int threads, size_t lds) {
+  const char* p_env = getenv("EDET_MBF_P");
+  int pmax = EDET_MAX_PARTS;
+  if (p_env && p_env[0]) pmax = atoi(p_env);
+  else {
+    const int res = edet_resident_wgs(fn, threads, lds);
+    if (res / a.ngb >= 8 && res / a.ngb < pmax) pmax = res / a.ngb;
+  }
+  if (pmax < 8) pmax = 8;
+  const int t8 = (a.ntiles + 7) / 8;
+  const int rounds = (t8 + pmax / 8 - 1) / (pmax / 8);
+  a.P = 8 * ((t8 + rounds - 1) / rounds);
 }
 
 inline bool supported(const edet_tview_t* in, int cexp, int k, int s, int dtype) {
   if (dtype != EDET_BF16 || !in) return false;
   if (in->gate || in->act != EDET_ACT_NONE) return false;
   if (in->c % 8 != 0 || in->c > 32 || in->ld != in->c) return false;
-  if (cexp % GC != 0) return false;
-  if ((k != 3 && k != 5) || (s != 1 && s != 2)) return false;
+  if (cexp % GC != 0 || cexp > 3 * GC) return false;      // a workgroup owns every expanded channel: up to three groups of 48
+  // (k, stride) of the MBConv stages whose block input has <= 32 channels: 3x3 stride 1 / 2, 5x5 stride 2
+  if (!((k == 3 && (s == 1 || s == 2)) || (k == 5 && s == 2))) return false;
   if ((int64_t)in->h * in->w * cexp * 2 >= 0x7fffffffLL) return false;      // 32-bit offsets inside one image
   return true;
 }
@@ -412,10 +533,15 @@ extern "C" int edet_mbconv_expand_stats(const edet_tview_t* in, const void* wt, 
   a.M = (long long)in->n * in->h * in->w;
   const long long nchunks = (a.M + 15) / 16;
   long long P = (nchunks + 4 * 4 - 1) / (4 * 4);      // >= 4 chunks of 16 pixels per wave
-  if (P > 512) P = 512;
+  if (P > 1024) P = 1024;
   if (P < 1) P = 1;
   a.P = (int)P;
-  edet_launch(k_exp_stats, dim3(a.P * a.ngroups), dim3(THREADS), 0, to_stream(stream), a);
+  const dim3 grid(a.P), block(THREADS);
+  switch (a.ngroups) {
+    case 1: edet_launch(k_exp_stats<1>, grid, block, 0, to_stream(stream), a); break;
+    case 2: edet_launch(k_exp_stats<2>, grid, block, 0, to_stream(stream), a); break;
+    default: edet_launch(k_exp_stats<3>, grid, block, 0, to_stream(stream), a); break;
+  }
   EDET_LAUNCH_CHECK("edet_mbconv_expand_stats");
   *nparts_out = a.P;
   return 0;
@@ -445,7 +571,19 @@ extern "C" int edet_mbconv_expand_dw_fwd(const edet_tview_t* in, const void* wt,
   EDET_CHECK((int64_t)a.oh * a.ow * ldo * 2 < 0x7fffffffLL && (int64_t)in->h * in->w * (lde > 0 ? lde : 1) * 2 < 0x7fffffffLL,
              "edet_mbconv_expand_dw_fwd: image too large for 32-bit offsets");
   a.ngroups = cexp / GC;
-  const int txv = (WINC - k) / stride + 1;
+  const bool se = expanded_out != nullptr;
+  // Workgroup shape.  Two channel groups (cexp = 96) in training: ONE four-wave workgroup owns both groups of a 32-column
+  // window and stores whole pixels of the expanded row (r06 lab 320x320x16->96: 1.30 -> 1.06 ms against two workgroups
+  // that each write 96 of a pixel's 192 bytes).  Otherwise four-wave workgroups of 48 channels over a 64-column window:
+  // fewest recomputed halo columns, no barrier across more than four waves (160x160x24->144, six-wave whole-pixel shape
+  // against three workgroups per window: training 0.78 / 0.56 vs 0.64 / 0.54 ms for k3s1 / k5s2, inference 0.60 / 0.50 vs
+  // 0.46 / 0.31).  EDET_MBF_SHAPE=1|2 forces the per-group / whole-pixel shape (lab switch).
+  const char* sh_env = getenv("EDET_MBF_SHAPE");
+  const bool whole = (sh_env && sh_env[0]) ? sh_env[0] == '2' : (se && a.ngroups == 2);
+  const int ngr = (whole && a.ngroups > 1) ? a.ngroups : 1;
+  a.ngb = a.ngroups / ngr;
+  const int winc = ngr == 1 ? 64 : 32;      // Shape<1,4>, Shape<2,2>, Shape<3,2>
+  const int txv = (winc - k) / stride + 1;
   {
     const int cap = a.oh >= 160 ? 80 : 40;
     const int nt = (a.oh + cap - 1) / cap;
@@ -454,31 +592,36 @@ extern "C" int edet_mbconv_expand_dw_fwd(const edet_tview_t* in, const void* wt,
   a.tiles_x = (a.ow + txv - 1) / txv;
   a.tiles_y = (a.oh + a.TY - 1) / a.TY;
   a.ntiles = in->n * a.tiles_x * a.tiles_y;
-  {
-    // tile slots (= statistic partial rows, <= EDET_MAX_PARTS): a whole number of rounds over the tiles of every XCD
-    const char* p_env = getenv("EDET_MBF_P");      // lab switch
-    const int pmax = (p_env && p_env[0]) ? atoi(p_env) : EDET_MAX_PARTS;
-    const int t8 = (a.ntiles + 7) / 8;
-    const int rounds = (t8 + pmax / 8 - 1) / (pmax / 8);
-    a.P = 8 * ((t8 + rounds - 1) / rounds);
-  }
-  const size_t lds = (size_t)2 * WINC * GCP * sizeof(float);
-  const dim3 grid(a.P * a.ngroups), block(THREADS);
+  { const char* d = getenv("EDET_MBF_DBG"); a.dbg = (d && d[0]) ? atoi(d) : 0; }
   hipStream_t st = to_stream(stream);
-  const bool se = expanded_out != nullptr;
   const bool sw = act == EDET_ACT_SWISH;
-#define MBF_GO(K_, S_)                                                                          \
+#define MBF_GO2(K_, S_, SH_)                                                                    \
   do {                                                                                          \
-    if (sw) { if (se) edet_launch(k_exp_dw_fwd<K_, S_, 1, true>, grid, block, lds, st, a);      \
-              else edet_launch(k_exp_dw_fwd<K_, S_, 1, false>, grid, block, lds, st, a); }      \
-    else { if (se) edet_launch(k_exp_dw_fwd<K_, S_, 2, true>, grid, block, lds, st, a);         \
-           else edet_launch(k_exp_dw_fwd<K_, S_, 2, false>, grid, block, lds, st, a); }         \
+    const size_t lds = (size_t)(2 * SH_::WINC * SH_::GCP + SH_::TABF) * sizeof(float) +         \
+                       (se ? (size_t)2 * SH_::WINC * SH_::ESTG : 0);                            \
+    pick_slots(a, reinterpret_cast<const void*>(sw ? (se ? k_exp_dw_fwd<K_, S_, 1, true, SH_> : k_exp_dw_fwd<K_, S_, 1, false, SH_>) \
+                                                      : (se ? k_exp_dw_fwd<K_, S_, 2, true, SH_> : k_exp_dw_fwd<K_, S_, 2, false, SH_>)), \
+               SH_::NT, lds);                                                                   \
+    const dim3 grid(a.P * a.ngb), block(SH_::NT);                                               \
+    if (sw) { if (se) edet_launch(k_exp_dw_fwd<K_, S_, 1, true, SH_>, grid, block, lds, st, a); \
+              else edet_launch(k_exp_dw_fwd<K_, S_, 1, false, SH_>, grid, block, lds, st, a); } \
+    else { if (se) edet_launch(k_exp_dw_fwd<K_, S_, 2, true, SH_>, grid, block, lds, st, a);    \
+           else edet_launch(k_exp_dw_fwd<K_, S_, 2, false, SH_>, grid, block, lds, st, a); }    \
+  } while (0)
+  typedef Shape<1, 4> Sh1;
+  typedef Shape<2, 2> Sh2;
+  typedef Shape<3, 2> Sh3;
+#define MBF_GO(K_, S_)                                  \
+  do {                                                  \
+    if (ngr == 1) MBF_GO2(K_, S_, Sh1);                 \
+    else if (ngr == 2) MBF_GO2(K_, S_, Sh2);            \
+    else MBF_GO2(K_, S_, Sh3);                          \
   } while (0)
   if (k == 3 && stride == 1) MBF_GO(3, 1);
   else if (k == 3 && stride == 2) MBF_GO(3, 2);
-  else if (k == 5 && stride == 1) MBF_GO(5, 1);
   else MBF_GO(5, 2);
 #undef MBF_GO
+#undef MBF_GO2
   EDET_LAUNCH_CHECK("edet_mbconv_expand_dw_fwd");
   if (nparts_out) *nparts_out = a.P;
   return 0;

@@ -63,3 +63,25 @@ def test_engine_refuses_to_run_without_gpu():
   net = efficientdet_net.EfficientDetNet('efficientdet-d0')
   with pytest.raises(_lib.EdetError):
     net(torch.zeros(1, 64, 64, 3))
+
+
+def test_fused_mbconv_kernels_do_not_spill_registers():
+  """automl_amd/csrc/mbconv_fused.hip: no instantiation of the fused MBConv head may spill vector registers (r06: the
+  six-wave 3x3 stride-2 instantiation, built for four waves per SIMD with 7 spilled VGPRs, stored wrong values in the
+  first row of a tile on the device).  hipcc cross-compiles without a GPU; the resource report is the compiler's."""
+  import os
+  import re
+  import subprocess
+  import tempfile
+  from automl_amd import build
+  src = os.path.join(build.CSRC, 'mbconv_fused.hip')
+  with tempfile.TemporaryDirectory() as tmp:
+    r = subprocess.run([build.HIPCC] + build.FLAGS + ['-c', src, '-o', os.path.join(tmp, 'm.o'),
+                        '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0, r.stderr[-2000:]
+  names = re.findall(r'Function Name: (\S+)', r.stderr)
+  spills = [int(v) for v in re.findall(r'VGPRs Spill: (\d+)', r.stderr)]
+  scratch = [int(v) for v in re.findall(r'ScratchSize \[bytes/lane\]: (\d+)', r.stderr)]
+  assert len(names) == len(spills) == len(scratch) and len(names) >= 30, (len(names), len(spills))
+  bad = [(n, s, c) for n, s, c in zip(names, spills, scratch) if 'k_exp_dw_fwd' in n and (s or c)]
+  assert not bad, bad

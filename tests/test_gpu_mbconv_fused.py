@@ -22,8 +22,9 @@ BF = ('bf16', _lib.EDET_BF16, torch.bfloat16)
 
 # (n, h, w, cin, cexp): ragged maps, several column windows (w > 62 / 31 outputs), several row tiles (oh > 40), the
 # channel counts of the layers the engine fuses (16 -> 96, 24 -> 144) and the envelope's corners (8, 32 input channels)
-SHAPES = [(2, 9, 11, 16, 96), (1, 70, 67, 24, 144), (2, 33, 130, 16, 48), (1, 20, 20, 32, 192), (3, 5, 5, 8, 48),
-          (1, 170, 9, 24, 144), (2, 64, 64, 16, 96), (1, 63, 125, 24, 96)]
+SHAPES = [(2, 9, 11, 16, 96), (1, 70, 67, 24, 144), (2, 33, 130, 16, 48), (1, 20, 20, 32, 144), (3, 5, 5, 8, 48),
+          (1, 170, 9, 24, 144), (2, 64, 64, 16, 96), (1, 63, 125, 24, 96), (2, 31, 40, 32, 96)]
+KS = [(3, 1), (3, 2), (5, 2)]       # the (kernel, stride) pairs of the MBConv stages with <= 32 block-input channels
 
 
 def _bf(t):
@@ -86,7 +87,7 @@ def test_expand_stats(shape, affine):
 
 
 @pytest.mark.parametrize('shape', SHAPES)
-@pytest.mark.parametrize('ks', [(3, 1), (3, 2), (5, 1), (5, 2)])
+@pytest.mark.parametrize('ks', KS)
 @pytest.mark.parametrize('mode', ['train_affine', 'train_plain', 'infer_affine'])
 def test_expand_dw_fwd(shape, ks, mode, act=ACT_SWISH):
   n, h, w, cin, cexp = shape
@@ -126,8 +127,28 @@ def test_expand_dw_fwd(shape, ks, mode, act=ACT_SWISH):
 @pytest.mark.parametrize('act', [ACT_RELU6, ACT_HSWISH])
 def test_expand_dw_fwd_other_activations(act):
   """relu6 / hswish (the lite models, utils.activation_fn utils.py:36-53): the ACTM = 2 instantiations."""
-  for ks in ((3, 2), (5, 1)):
+  for ks in ((3, 2), (5, 2)):
     test_expand_dw_fwd((2, 33, 70, 16, 96), ks, 'train_affine', act)
+
+
+def test_layers_outside_the_envelope_are_refused():
+  """edet_mbconv_fused_supported says 0 and the entry points fail with a message (the engine then runs edet_pw_fwd +
+  edet_dw_fwd): more than 32 block-input channels, an expansion width that is not 1..3 groups of 48, 5x5 stride 1."""
+  lib = _lib.load()
+  for (cin, cexp, k, s) in ((40, 240, 3, 1), (32, 192, 3, 1), (16, 64, 3, 2), (24, 144, 5, 1)):
+    xd = torch.zeros((1, 8, 8, cin), dtype=torch.bfloat16, device=gu.DEV)
+    tv = gu.tview(xd, cin, None, None, None, ACT_NONE)
+    assert lib.edet_mbconv_fused_supported(ctypes.byref(tv), cexp, k, s, _lib.EDET_BF16) == 0, (cin, cexp, k, s)
+    wt = torch.zeros(cexp, cin, dtype=torch.bfloat16, device=gu.DEV)
+    sc = torch.ones(cexp, dtype=torch.float32, device=gu.DEV)
+    dww = torch.zeros((k, k, cexp), dtype=torch.float32, device=gu.DEV)
+    out = torch.zeros((1, 8, 8, cexp), dtype=torch.bfloat16, device=gu.DEV)
+    with pytest.raises(_lib.EdetError, match='unsupported layer'):
+      call('edet_mbconv_expand_dw_fwd', ctypes.byref(tv), ptr(wt), cin, cexp, ptr(sc), ptr(sc), ACT_SWISH, None, 0,
+           ptr(dww), k, s, ptr(out), cexp, None, None, _lib.EDET_BF16, gu.stream())
+  xd = torch.zeros((1, 8, 8, 16), dtype=torch.float32, device=gu.DEV)
+  tv = gu.tview(xd, 16, None, None, None, ACT_NONE)
+  assert lib.edet_mbconv_fused_supported(ctypes.byref(tv), 96, 3, 2, _lib.EDET_F32) == 0      # fp32 storage: the two-kernel path
 
 
 def test_fused_equals_the_two_kernel_path_bit_for_bit_in_storage():
