@@ -280,6 +280,36 @@ def other_configs():
   eng._bufs.clear()
   del net, eng, images, labels
   torch.cuda.empty_cache()
+  # the inference forward of the headline network (north_star: "inference/training path"; inference BatchNorm, the MBConv
+  # heads of the 320x320 / 160x160 maps never store their expanded tensor: csrc/mbconv_fused.hip), hipGraph replay
+  from automl_amd import efficientdet_net
+  config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  config.override('image_size=640')
+  inet = efficientdet_net.EfficientDetNet(config=config, dtype='bf16', seed=0)
+  eng = inet._ensure_engine(128, 640, 640)
+  images = torch.from_numpy(np.random.default_rng(2).standard_normal((128, 640, 640, 3)).astype(np.float32))
+  images = images.to('cuda:0', torch.bfloat16).contiguous()
+  for _ in range(3):
+    eng.forward(images, training=False)
+  torch.cuda.synchronize()
+  g = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(g):
+    eng.forward(images, training=False)
+  g.replay()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(20):
+    g.replay()
+  torch.cuda.synchronize()
+  dt = (time.perf_counter() - t0) / 20
+  out['efficientdet-d0 640x640 batch 128 bf16 inference forward (network only, fp32 logits)'] = {
+      'images_per_sec': 128 / dt, 'ms_per_step': dt * 1e3, 'steps': 20,
+      'fused_mbconv_heads': bool(eng.fused_mbconv_head)}
+  inet.engine = None
+  inet._engines.clear()
+  eng._bufs.clear()
+  del inet, eng, g, images
+  torch.cuda.empty_cache()
   # the headline workload in the storage precision that meets the north_star's 1e-3 logit tolerance end to end (fp32
   # activations / gradients, the validation kernels: 16x16x4 fp32 MFMA pointwise, generic depthwise) -- what the
   # tolerance costs next to the bf16 line
