@@ -317,6 +317,7 @@ class Engine(object):
     # (mbconv_fused.hip: bf16, <= 32 block-input channels): the expanded tensor is not read back by the depthwise
     # convolution -- and never stored at all in inference.  EDET_MBCONV_FUSED=0: the two-kernel path (lab switch)
     self.fused_mbconv_head = os.environ.get('EDET_MBCONV_FUSED', '1') != '0'
+    self.fused_heads = set()     # block scopes whose head ran fused in the last forward pass (inference: no ':exp' tensor)
     self.fused_dw_bwd = True     # one edet_dw_bwd call per layer (bf16: ONE kernel for both gradients, any stride)
     self.fused_pw_bwd = True     # one edet_pw_bwd call per pointwise layer whose input needs a gradient
     # cross-replica BatchNorm (utils.SyncBatchNormalization / TpuBatchNormalization, utils.py:166-241):
@@ -1009,6 +1010,7 @@ class Engine(object):
     self.training = training
     self.update_moving = update_moving
     self.tape = []
+    self.fused_heads = set()
     # compute copies of the kernels and the inference BatchNorm vectors are rebuilt only when a variable
     # changed since they were made (every training step; in inference only after set_params)
     if self._cast_dirty or not hasattr(self, '_cast_done'):
@@ -1149,6 +1151,7 @@ class Engine(object):
     path (Engine.pw, Engine.dw).  Inference: the expanded tensor is never stored."""
     r = vin.raw
     cin = r.c
+    self.fused_heads.add(scope)
     wt, ldk, w, ldn = self._pw_copies(wexp, cin, cexp)
     bne, bnd = self.get_bn(bn_exp, cexp), self.get_bn(bn_dw, cexp)
     oh, _, _ = utils.same_padding(r.h, k, stride)

@@ -315,7 +315,10 @@ def test_model_forward_bf16_layer_by_layer(model_name, size, training):
   nblocks = len(net.spec.blocks)
   print('%s@%d training=%s bf16 teacher-forced: %d tensors, worst %s; tail %s' % (
       model_name, size, training, len(hook.fwd_err), hook.worst(hook.fwd_err), _fmt(tail)))
-  assert len(hook.fwd_err) >= 2 * nblocks + 2 and not hook.missing, (len(hook.fwd_err), hook.missing[:8])
+  # r06: an MBConv head that ran fused in INFERENCE (csrc/mbconv_fused.hip: <= 32 block-input channels) never stores its
+  # expanded tensor -- its depthwise output is then checked against the oracle's value from the block INPUT the device stored
+  unstored = {s + ':exp' for s in net.engine.fused_heads} if not training else set()
+  assert len(hook.fwd_err) >= 2 * nblocks + 2 and set(hook.missing) <= unstored, (len(hook.fwd_err), hook.missing[:8])
   assert max(hook.fwd_err.values()) <= TOL_LAYER, hook.worst(hook.fwd_err, 6)
   assert max(tail.values()) <= TOL_LAYER, tail
 

@@ -161,7 +161,8 @@ def test_v2s_224_batch2_forward_layer_by_layer():
   with torch.no_grad():
     want = o.forward(images, False)
   print('v2-s 224 B=2 teacher-forced: %d tensors, worst %s' % (len(hook.fwd_err), hook.worst(hook.fwd_err)))
-  assert len(hook.fwd_err) >= 100 and not hook.missing, (len(hook.fwd_err), hook.missing[:8])
+  unstored = {s + ':exp' for s in net.engine.fused_heads}      # (inference, fused MBConv heads: none in V2-S, cin >= 48)
+  assert len(hook.fwd_err) >= 100 and set(hook.missing) <= unstored, (len(hook.fwd_err), hook.missing[:8])
   assert max(hook.fwd_err.values()) <= TOL_LAYER, hook.worst(hook.fwd_err, 6)
   tail = {nm: rel_err(got[nm], want[nm]) for nm in ('pooled_features', 'head')}
   assert tuple(got['head'].shape) == (N_IMG, 1000) and max(tail.values()) <= TOL_LAYER, tail
