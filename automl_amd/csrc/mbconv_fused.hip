@@ -322,7 +322,7 @@ __global__ __launch_bounds__(SH::NT, 3) void k_exp_dw_fwd(const Args a) {
     }
     const brsrc_t in_img = make_rsrc(IN + (size_t)n * H * irow_b);
     const brsrc_t out_img = make_rsrc(OUT + (size_t)n * a.oh * orow_b);
-    const brsrc_t e_img = make_rsrc(STORE_E ? EO + (size_t)n * H * erow_b : OUT);
+    char* e_base = STORE_E ? EO + (size_t)n * H * erow_b : OUT;
     // steps t = input row + pad_t; the input row exists for pad_t <= t < H + pad_t; output row oy completes at oy S + K - 1
     const int t0 = oy0 * S, t_last = (oy1 - 1) * S + K - 1;
     URange row_rng, out_rng, erow_rng;
@@ -364,7 +364,9 @@ __global__ __launch_bounds__(SH::NT, 3) void k_exp_dw_fwd(const Args a) {
             u32x2 u;
             u[0] = pack2bf(e[0], e[1]);
             u[1] = pack2bf(e[2], e[3]);
-            if (STORE_E) *reinterpret_cast<u32x2*>(sbuf + 32 * j) = u;
+            if (STORE_E) {
+              *reinterpret_cast<u32x2*>(sbuf + 32 * j) = u;
+            }
             float y[4];
             y[0] = __uint_as_float(u[0] << 16); y[1] = __uint_as_float(u[0] & 0xffff0000u);
             y[2] = __uint_as_float(u[1] << 16); y[3] = __uint_as_float(u[1] & 0xffff0000u);
@@ -382,14 +384,22 @@ __global__ __launch_bounds__(SH::NT, 3) void k_exp_dw_fwd(const Args a) {
         __syncthreads();
         if (STORE_E) {
           const bool est = erow_rng.has(t);       // uniform; erow_rng lies inside row_rng
-          const uint32_t ero = est ? (uint32_t)(t - a.pad_t) * erow_b : 0u;
+          char* e_row = e_base + (est ? (size_t)(t - a.pad_t) * erow_b : 0);
           const unsigned char* sb = stage + (t & 1) * WINC * ESTG;
 #pragma unroll
           for (int it = 0; it < NIT; ++it) {
             const u32x2 lo = *reinterpret_cast<const u32x2*>(sb + spx[it] * ESTG + 16 * spart[it]);
             const u32x2 hi = *reinterpret_cast<const u32x2*>(sb + spx[it] * ESTG + 16 * spart[it] + 8);
+            // A GLOBAL 16-byte store under the lane's own condition (exec mask, no branch: the block is one instruction),
+            // not a buffer store.  buffer_store_dwordx4 -- which the backend also makes out of two adjacent 8-byte buffer
+            // stores -- fetches its data registers late: the compiler put a VALU write of the store's FIRST data register
+            // (v_cndmask of the next store's offset) two instructions behind the store, and on the device lanes 12-15 of
+            // every 16-lane row then stored the new value as their first dword: wrong first channels of a chunk in the
+            // expanded tensor, on some rows of the batch-128 run only, the depthwise output untouched (r06,
+            // scripts/mbf_debug2.py; LLVM guards this store-data hazard only for MUBUF stores WITHOUT a register soffset).
+            // Two separated 8-byte buffer stores are correct but cost 12-20 % of the kernel.
             u32x4 v; v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
-            __builtin_amdgcn_raw_buffer_store_b128(v, e_img, est ? eoff[it] : OOB, ero, 0);
+            if (est && eoff[it] != OOB) *reinterpret_cast<u32x4*>(e_row + eoff[it]) = v;
           }
         }
         if (row_ok && tact) {

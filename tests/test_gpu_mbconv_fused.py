@@ -182,3 +182,44 @@ def test_fused_equals_the_two_kernel_path_bit_for_bit_in_storage():
   assert flips <= 1e-3 * e0.numel(), flips
   assert float((e0 - e1).abs().max()) <= 2.0 ** -7 * float(e0.abs().max())
   gu.check(o0, o1, 'bf16', 'fused vs two-kernel depthwise output')
+
+
+@pytest.mark.parametrize('layer', [(320, 16, 96, 3, 2), (160, 24, 144, 3, 1), (160, 24, 144, 5, 2)],
+                         ids=lambda l: '%dx%dx%d->%d_k%ds%d' % (l[0], l[0], l[1], l[2], l[3], l[4]))
+def test_batch_128_equals_64_copies_of_the_two_image_run(layer):
+  """The three layers the engine fuses at EfficientDet-D0 640x640 batch 128 (several tiles per workgroup, every XCD
+  walking its own tile range): 64 copies of two images must give 64 copies of the two-image result BIT FOR BIT --
+  the stored expanded tensor and the depthwise output.  (r06: with the expanded row leaving through buffer_store_dwordx4
+  the first dword of some chunks was wrong at this size only; the two-image result itself is oracle-checked above.)"""
+  hw, cin, cexp, k, s = layer
+  n = 128
+  rng = np.random.default_rng(gu.seed_of(layer))
+  x2 = gu.rnd(rng, (2, hw, hw, cin), torch.bfloat16)
+  wk = gu.rnd(rng, (cin, cexp), torch.bfloat16, 1.0 / np.sqrt(cin))
+  isc = torch.from_numpy((1 + 0.3 * rng.standard_normal(cin)).astype(np.float32))
+  ish = torch.from_numpy((0.3 * rng.standard_normal(cin)).astype(np.float32))
+  escd = gu.fdev(torch.from_numpy((1 + 0.3 * rng.standard_normal(cexp)).astype(np.float32)))
+  eshd = gu.fdev(torch.from_numpy((0.3 * rng.standard_normal(cexp)).astype(np.float32)))
+  dwwd = gu.fdev(torch.from_numpy((rng.standard_normal((k, k, cexp)) / k).astype(np.float32)))
+  oh = (hw + s - 1) // s
+  res = {}
+  for nn in (2, n):
+    x = x2 if nn == 2 else x2.repeat(nn // 2, 1, 1, 1)
+    xd, wt, ldk, tv = _device_inputs(x, isc, ish, wk, cin, cexp)
+    out = torch.full((nn, oh, oh, cexp), float('nan'), dtype=torch.bfloat16, device=gu.DEV)
+    eout = torch.full((nn, hw, hw, cexp), float('nan'), dtype=torch.bfloat16, device=gu.DEV)
+    parts, npart = partial_buf(cexp), NP(0)
+    call('edet_mbconv_expand_dw_fwd', ctypes.byref(tv), ptr(wt), ldk, cexp, ptr(escd), ptr(eshd), ACT_SWISH,
+         ptr(eout), cexp, ptr(dwwd), k, s, ptr(out), cexp, ptr(parts), ctypes.byref(npart), _lib.EDET_BF16, gu.stream())
+    torch.cuda.synchronize()
+    res[nn] = (eout, out, gu.sum_partials(parts, npart.value, cexp))
+  e2, o2, (s1_2, s2_2) = res[2]
+  e, o, (s1, s2) = res[n]
+  assert bool(torch.isfinite(e2.float()).all()) and bool(torch.isfinite(o2.float()).all())
+  e = e.view((n // 2, 2) + tuple(e2.shape[1:]))
+  o = o.view((n // 2, 2) + tuple(o2.shape[1:]))
+  for kk in range(n // 2):
+    assert torch.equal(e[kk].view(torch.int16), e2.view(torch.int16)), ('expanded tensor, image pair', kk)
+    assert torch.equal(o[kk].view(torch.int16), o2.view(torch.int16)), ('depthwise output, image pair', kk)
+  gu.check(s1, s1_2 * (n // 2), 'bf16', 'statistics sum', rtol=1e-4, atol=1e-2, scale_by_max=False)
+  gu.check(s2, s2_2 * (n // 2), 'bf16', 'statistics sumsq', rtol=1e-4)
