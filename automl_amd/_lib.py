@@ -120,6 +120,10 @@ SIGNATURES = {
     'edet_opt_scale': [c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     'edet_opt_sgd_ema': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                          c_float, c_void_p],
+    'edet_zero': [c_void_p, ctypes.c_size_t, c_void_p],
+    'edet_cast_to_f32': [c_void_p, c_void_p, c_int64, c_int, c_void_p],
+    'edet_axpy_clear': [c_void_p, c_void_p, c_int64, c_int, c_void_p],
+    'edet_loss_normalizer': [c_void_p, c_int, c_void_p, c_void_p],
     'edet_pre_nms': [c_void_p, c_void_p, PI, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                      c_void_p, c_void_p],
     'edet_pre_nms_topk_workspace_bytes': [c_int, c_int, ctypes.POINTER(ctypes.c_size_t)],
@@ -202,11 +206,14 @@ class Profiler(object):
 
 
 profiler = None
+recorder = None      # automl_amd.plan.Recorder while a step plan is being recorded: sees every call before it is made
 
 
 def call(name, *args, nbytes=0, tag=''):
   """Calls lib.<name>(*args); raises EdetError with edet_last_error() on failure."""
   lib = load()
+  if recorder is not None:
+    recorder.on_call(name, args)
   p = profiler
   if p is not None and (p.names is None or name in p.names):
     import torch

@@ -526,3 +526,72 @@ extern "C" int edet_opt_sgd_ema(float* params, float* grads, float* velocity, fl
   EDET_LAUNCH_CHECK("edet_opt_sgd_ema");
   return 0;
 }
+
+// ---- step plumbing that used to be torch calls (round 6: every launch of a step goes through this ABI, so that a step
+// can be recorded and replayed by a host without a Python interpreter: net_runtime.cpp) ---------------------------------
+namespace {
+__global__ __launch_bounds__(THREADS) void k_axpy_clear(float* __restrict__ dst, float* __restrict__ src, int64_t n, int clear) {
+  const int64_t stride = (int64_t)gridDim.x * THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += stride) {
+    dst[i] += src[i];
+    if (clear) src[i] = 0.f;
+  }
+}
+// inv_out[0] = 1 / (sum_i mean_num_positives[i] + 1): one wave, lanes in a fixed order (the counts are integers: exact)
+__global__ __launch_bounds__(64) void k_loss_normalizer(const float* __restrict__ mnp, int n, float* __restrict__ inv_out) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) s += mnp[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) inv_out[0] = 1.0f / (s + 1.0f);
+}
+}  // namespace
+
+namespace {
+__global__ __launch_bounds__(THREADS) void k_widen_bf16(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += stride)
+    dst[i] = __uint_as_float((uint32_t)src[i] << 16);
+}
+}  // namespace
+
+extern "C" int edet_cast_to_f32(const void* src, float* dst, int64_t count, int src_dtype, void* stream) {
+  EDET_CHECK(src && dst, "edet_cast_to_f32: null pointer");
+  if (count <= 0) return 0;
+  if (src_dtype == EDET_F32) {
+    const hipError_t e = hipMemcpyAsync(dst, src, (size_t)count * 4, hipMemcpyDeviceToDevice, to_stream(stream));
+    EDET_CHECK(e == hipSuccess, "edet_cast_to_f32: hipMemcpyAsync: %s", hipGetErrorString(e));
+    return 0;
+  }
+  EDET_CHECK(src_dtype == EDET_BF16, "edet_cast_to_f32: bad dtype %d", src_dtype);
+  int64_t grid = (count + THREADS - 1) / THREADS;
+  if (grid > 4096) grid = 4096;
+  edet_launch(k_widen_bf16, dim3((unsigned)grid), dim3(THREADS), 0, to_stream(stream), (const bf16_t*)src, dst, count);
+  EDET_LAUNCH_CHECK("edet_cast_to_f32");
+  return 0;
+}
+
+extern "C" int edet_zero(void* dst, size_t bytes, void* stream) {
+  EDET_CHECK(dst || bytes == 0, "edet_zero: null pointer");
+  if (bytes == 0) return 0;
+  const hipError_t e = hipMemsetAsync(dst, 0, bytes, to_stream(stream));
+  EDET_CHECK(e == hipSuccess, "edet_zero: hipMemsetAsync: %s", hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int edet_axpy_clear(float* dst, float* src, int64_t n, int clear_src, void* stream) {
+  EDET_CHECK(dst && src && n >= 0, "edet_axpy_clear: bad arguments");
+  if (n == 0) return 0;
+  int64_t grid = (n + THREADS - 1) / THREADS;
+  if (grid > 2048) grid = 2048;
+  edet_launch(k_axpy_clear, dim3((unsigned)grid), dim3(THREADS), 0, to_stream(stream), dst, src, n, clear_src);
+  EDET_LAUNCH_CHECK("edet_axpy_clear");
+  return 0;
+}
+
+extern "C" int edet_loss_normalizer(const float* mean_num_positives, int n, float* inv_out, void* stream) {
+  EDET_CHECK(mean_num_positives && inv_out && n > 0, "edet_loss_normalizer: bad arguments");
+  edet_launch(k_loss_normalizer, dim3(1), dim3(64), 0, to_stream(stream), mean_num_positives, n, inv_out);
+  EDET_LAUNCH_CHECK("edet_loss_normalizer");
+  return 0;
+}

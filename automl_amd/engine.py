@@ -404,28 +404,34 @@ class Engine(object):
     the current stream waits for afterwards (legal inside a stream capture: the side stream joins it)."""
     side = self._side_branch()
     main = torch.cuda.current_stream(self.device)
+    rec = _lib.recorder          # a step plan being recorded (automl_amd/plan.py) sees the fork and the join as events
     fork = torch.cuda.Event()
     fork.record(main)
     side.stream.wait_event(fork)
+    if rec is not None:
+      rec.stream_wait(side.stream.cuda_stream, rec.event_record(main.cuda_stream))
     try:
       self._branch = side
       with torch.cuda.stream(side.stream):
         b = side_job()
         done = torch.cuda.Event()
         done.record(side.stream)
+        rec_done = rec.event_record(side.stream.cuda_stream) if rec is not None else None
       self._branch = self._main
       a = main_job()
     finally:
       self._branch = self._main
     main.wait_event(done)
+    if rec is not None:
+      rec.stream_wait(main.cuda_stream, rec_done)
     return a, b
 
   def _join_side(self):
     """Adds (and clears) the side chain's gradient arena; called once at the end of the backward pass, after the join."""
     if self._side_pending:
       lo, hi = self._side_range
-      self.grads_flat[lo:hi].add_(self._side_grads[lo:hi])
-      self._side_grads[lo:hi].zero_()
+      call('edet_axpy_clear', self.grads_flat.data_ptr() + 4 * lo, self._side_grads.data_ptr() + 4 * lo, hi - lo, 1,
+           self.stream)
       self._side_pending = False
 
   def buf(self, key, shape, dtype):
@@ -533,7 +539,8 @@ class Engine(object):
     """fp32 copy of a stored tensor, same view (BatchNorm / activation are applied on load by the fp32 kernels)."""
     r = v.raw
     out = Raw(self, key, r.n, r.h, r.w, r.c, r.ld, needs_grad=False, dtype=torch.float32)
-    out.data.copy_(r.data)
+    call('edet_cast_to_f32', ptr(r.data), ptr(out.data), r.data.numel(), EDET_BF16 if r.data.dtype == torch.bfloat16 else EDET_F32,
+         self.stream)
     return View(out, v.bn, v.act, v.gate)
 
   def _cast_all(self):
@@ -1023,9 +1030,9 @@ class Engine(object):
     for bn in self.bns.values():
       bn.bwd_ready = False
     for t in self._zero_list:      # atomic accumulation targets (SE pooled sums, ...) start every pass at zero
-      t.zero_()
+      call('edet_zero', ptr(t), t.numel() * 4, self.stream)
     if training:
-      self.grads_flat.zero_()
+      call('edet_zero', ptr(self.grads_flat), self.grads_flat.numel() * 4, self.stream)
 
   def forward(self, images, training=False, update_moving=True):
     """images: device tensor [B,H,W,3] in the engine dtype. Returns (cls_views, box_views)."""
@@ -1476,7 +1483,10 @@ class Engine(object):
 
   def set_normalizer(self, mean_num_positives):
     """hyper[2] = 1 / (sum(mean_num_positives) + 1) computed on the device (train_lib.py:517), no host sync."""
-    torch.reciprocal(mean_num_positives.reshape(-1).float().sum() + 1.0, out=self.hyper[2])
+    m = mean_num_positives.reshape(-1)
+    if m.dtype != torch.float32 or not m.is_contiguous():
+      m = m.float().contiguous()
+    call('edet_loss_normalizer', ptr(m), m.numel(), self.hyper.data_ptr() + 8, self.stream)
 
   def optimizer_local(self, scale_for_reduce):
     """L2 (train_lib.py:486-491) + per-tensor and global-norm clip factors of the LOCAL gradient (:675-682);

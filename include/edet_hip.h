@@ -444,6 +444,20 @@ int edet_opt_sgd_ema(float* params, float* grads, float* velocity, float* ema,
                      const int64_t* seg_offsets, const float* seg_factor, const int32_t* seg_flags, int nseg,
                      const float* hyper_dev, float momentum, void* stream);
 
+/* ---- step plumbing (round 6): the few operations of a step that are not layers, so that EVERY launch of a step goes
+ * through this ABI and a step can be recorded and replayed without the Python interpreter (include/edet_net.h).
+ * edet_zero: the start-of-step clears of the accumulation targets and the gradient arena (Engine._begin).
+ * edet_axpy_clear: dst += src, then src = 0 when clear_src -- the side chain's gradient arena joined into the main one
+ *   (Engine._join_side).
+ * edet_loss_normalizer: inv_out[0] = 1 / (sum(mean_num_positives[0..n)) + 1), the per-step loss normalizer of
+ *   tf2/train_lib.py:517-534 (positives_momentum = 0) kept on the device.  */
+int edet_zero(void* dst, size_t bytes, void* stream);
+/* dst[i] = (float)src[i]: the fp32 copy of a stored tensor in front of a layer that runs in fp32 inside a bf16 network (the
+ * box-predict island of the inference pass, Engine._to_f32); exact (bf16 -> fp32 widens) */
+int edet_cast_to_f32(const void* src, float* dst, int64_t count, int src_dtype, void* stream);
+int edet_axpy_clear(float* dst, float* src, int64_t n, int clear_src, void* stream);
+int edet_loss_normalizer(const float* mean_num_positives, int n, float* inv_out, void* stream);
+
 /* ---- detection post-processing -------------------------------
  * tf2/postprocess.py: merge_class_box_level_outputs :67-79, topk_class_boxes :82-117, pre_nms :120-157, nms :160-206,
  * clip_boxes :61-64, postprocess_global :375-406, per_class_nms :409-467; nms_np.py: hard_nms :84-120, soft_nms

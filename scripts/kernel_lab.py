@@ -85,6 +85,8 @@ def build_case(entry, shape):
     x = rand(n, h, w, gu.pad8(cin))
     gate = (torch.rand(n, cin, device=dev, generator=gen) * 0.8 + 0.2).float()
     tv = gu.tview(x, cin, vec(cin), vec(cin, -0.3, 0.3), gate if cin >= 96 and cin > cout else None, _lib.ACT_SWISH)
+    if os.environ.get('EDET_LAB_PLAIN') == '1':      # a stored tensor as it is (BiFPN / tower layers)
+      tv = gu.tview(x, cin)
     nbytes = n * h * w * (cin + cout) * 2
     if entry == 'pw_fwd':
       wt = rand(cout, gu.pad8(cin)) * (1.0 / np.sqrt(cin))
@@ -172,7 +174,11 @@ def main():
   ap.add_argument('--rounds', type=int, default=3, help='rotated measurement passes per layer (minimum reported)')
   ap.add_argument('--ab', default='', help='VAR=v1,v2,...: time every layer under each value of one environment switch')
   ap.add_argument('--list', action='store_true')
+  ap.add_argument('--lib', default='', help='another build of the library to load instead of automl_amd/libedet_hip.so')
   args = ap.parse_args()
+  if args.lib:
+    from automl_amd import _lib as _l
+    _l.LIB_PATH = os.path.abspath(args.lib)
   table = PW_LAYERS if args.entry.startswith('pw') else DW_LAYERS
   if args.list:
     for row in PW_LAYERS + DW_LAYERS:
