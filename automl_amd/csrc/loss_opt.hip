@@ -518,6 +518,48 @@ extern "C" int edet_opt_scale(float* grads, const int64_t* seg_offsets, const fl
   return 0;
 }
 
+namespace {
+// tf.keras.optimizers.Adam (ResourceApplyAdam): m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); w -= alpha m / (sqrt(v) + eps)
+// with alpha = lr sqrt(1 - b2^t) / (1 - b1^t) formed by the host for this step (hyper[0]); TFA MovingAverage on top
+__device__ __forceinline__ void adam1(float g, float& m, float& u, float& w, float& em, float alpha, float b1, float b2,
+                                      float eps, float decay, bool has_ema) {
+  m += (g - m) * (1.f - b1);
+  u += (g * g - u) * (1.f - b2);
+  w -= (m * alpha) / (sqrtf(u) + eps);
+  if (has_ema) em -= (1.f - decay) * (em - w);
+}
+
+__global__ __launch_bounds__(THREADS) void k_adam_ema(float* params, const float* grads, float* m1, float* m2, float* ema,
+                                                     const int64_t* seg_off, const float* seg_factor,
+                                                     const int32_t* seg_flags, const float* hyper, float b1, float b2, float eps) {
+  const int s = blockIdx.x;
+  int64_t b, e;
+  if (!slice_range(seg_off, s, blockIdx.y, b, e)) return;
+  if (seg_flags && (seg_flags[s] & EDET_SEG_FROZEN)) return;      // not in the optimizer's variable list
+  const float f = seg_factor ? seg_factor[s] : 1.f;
+  const float alpha = hyper[0], decay = hyper[1];
+  const bool has_ema = ema != nullptr;
+  for (int64_t i = b + threadIdx.x; i < e; i += THREADS) {
+    float m = m1[i], u = m2[i], w = params[i], em = has_ema ? ema[i] : 0.f;
+    adam1(grads[i] * f, m, u, w, em, alpha, b1, b2, eps, decay, has_ema);
+    m1[i] = m;
+    m2[i] = u;
+    params[i] = w;
+    if (has_ema) ema[i] = em;
+  }
+}
+}  // namespace
+
+extern "C" int edet_opt_adam_ema(float* params, const float* grads, float* m, float* v, float* ema,
+                                 const int64_t* seg_offsets, const float* seg_factor, const int32_t* seg_flags, int nseg,
+                                 const float* hyper_dev, float beta1, float beta2, float epsilon, void* stream) {
+  EDET_CHECK(params && grads && m && v && seg_offsets && hyper_dev && nseg > 0, "edet_opt_adam_ema: bad arguments");
+  edet_launch(k_adam_ema, dim3(nseg, OPT_SPLIT), dim3(THREADS), 0, to_stream(stream), params, grads, m, v, ema, seg_offsets,
+              seg_factor, seg_flags, hyper_dev, beta1, beta2, epsilon);
+  EDET_LAUNCH_CHECK("edet_opt_adam_ema");
+  return 0;
+}
+
 extern "C" int edet_opt_sgd_ema(float* params, float* grads, float* velocity, float* ema,
                                 const int64_t* seg_offsets, const float* seg_factor, const int32_t* seg_flags, int nseg,
                                 const float* hyper_dev, float momentum, void* stream) {

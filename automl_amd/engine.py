@@ -223,14 +223,26 @@ class ParamArena(object):
       self._slice(self.ema, None, name).copy_(t)
 
   def get_optimizer_state(self):
-    """Host copy of the optimizer slots: momentum, EMA shadows, iteration count."""
-    return {'velocity': self.velocity.cpu().numpy().copy(), 'ema': self.ema.cpu().numpy().copy(),
-            'iterations': self.step_count}
+    """Host copy of the optimizer slots: momentum (Adam: first moment), EMA shadows, iteration count; Adam's second moment
+    when that optimizer has run."""
+    state = {'velocity': self.velocity.cpu().numpy().copy(), 'ema': self.ema.cpu().numpy().copy(),
+             'iterations': self.step_count}
+    if getattr(self, 'adam_v', None) is not None:
+      state['adam_v'] = self.adam_v.cpu().numpy().copy()
+    return state
 
   def set_optimizer_state(self, state):
     self.velocity.copy_(torch.as_tensor(state['velocity']))
     self.ema.copy_(torch.as_tensor(state['ema']))
+    if 'adam_v' in state:
+      self.second_moment().copy_(torch.as_tensor(state['adam_v']))
     self.step_count = int(state['iterations'])
+
+  def second_moment(self):
+    """Adam's v slot, allocated on first use (the SGD configurations never pay for it)."""
+    if getattr(self, 'adam_v', None) is None:
+      self.adam_v = torch.zeros_like(self.velocity)
+    return self.adam_v
 
 
 class Branch(object):
@@ -246,6 +258,7 @@ class Branch(object):
 
 class Engine(object):
   """Builds buffers for (config, batch, image size, dtype) and runs forward / backward / update."""
+  ADAM_BETA2, ADAM_EPSILON = 0.999, 1e-7      # tf.keras.optimizers.Adam defaults
 
   def __init__(self, config, batch_size, image_size=None, dtype='bf16', device='cuda:0', seed=0,
                params=None, spec=None, stochastic_depth=True, arena=None):
@@ -325,6 +338,10 @@ class Engine(object):
     self.sync_bn = None
     self.bn_bessel = True        # Keras fused BatchNorm: Bessel-corrected batch variance into moving_variance
     self.drop_masks = {}      # block scope -> (mask [n,c] fp32 = floor(p + u_n) / p, survival probability p)
+    # optimizer = 'adam' (train_lib.py:183-186): Keras defaults for what the reference does not set
+    self.adam = str(getattr(config, 'optimizer', 'sgd')).lower() == 'adam'
+    if self.adam:
+      self.arena.second_moment()
     self._rng = torch.Generator(device=self.device)
     self._rng.manual_seed(1000003 * seed + 17)
 
@@ -1479,6 +1496,11 @@ class Engine(object):
     """Per-step scalars -> device (hyper[0] = learning rate, hyper[1] = EMA decay).  Stream-ordered H2D
     copy from pageable memory (staged synchronously by the runtime, so the host values may change at once);
     kept OUTSIDE the captured step."""
+    if self.adam:
+      # tf.keras Adam's bias-corrected rate of THIS step (t = iterations + 1), ResourceApplyAdam's alpha
+      t = self.arena.step_count + 1
+      b1 = float(self.config.momentum)
+      lr = lr * math.sqrt(1.0 - self.ADAM_BETA2 ** t) / (1.0 - b1 ** t)
     self.hyper[:2].copy_(torch.tensor([lr, ema_decay or 0.0], dtype=torch.float32), non_blocking=True)
 
   def set_normalizer(self, mean_num_positives):
@@ -1503,7 +1525,15 @@ class Engine(object):
       call('edet_opt_scale', ptr(self.grads_flat), ptr(self.seg_offsets), ptr(self.seg_factor), self.nseg, st)
 
   def optimizer_apply(self, use_ema, already_scaled):
-    """SGD momentum + EMA (train_lib.py:176-199) with lr / decay from self.hyper (set_hyper)."""
+    """SGD momentum (or Adam) + EMA (train_lib.py:176-199) with lr / decay from self.hyper (set_hyper)."""
+    if self.adam:
+      call('edet_opt_adam_ema', ptr(self.params_flat), ptr(self.grads_flat), ptr(self.velocity), ptr(self.arena.second_moment()),
+           ptr(self.ema) if use_ema else None, ptr(self.seg_offsets), None if already_scaled else ptr(self.seg_factor),
+           ptr(self.seg_flags), self.nseg, ptr(self.hyper), float(self.config.momentum), self.ADAM_BETA2, self.ADAM_EPSILON,
+           self.stream)
+      self.arena.version += 1
+      self.arena.step_count += 1
+      return
     call('edet_opt_sgd_ema', ptr(self.params_flat), ptr(self.grads_flat), ptr(self.velocity),
          ptr(self.ema) if use_ema else None, ptr(self.seg_offsets),
          None if already_scaled else ptr(self.seg_factor), ptr(self.seg_flags), self.nseg, ptr(self.hyper),

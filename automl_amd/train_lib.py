@@ -202,8 +202,8 @@ class EfficientDetNetTrain(efficientdet_net.EfficientDetNet):
     unsupported = []
     if getattr(c, 'iou_loss_type', None):
       unsupported.append('iou_loss_type=%r (BoxIouLoss, train_lib.py:440-466)' % c.iou_loss_type)
-    if str(getattr(c, 'optimizer', 'sgd')).lower() != 'sgd':
-      unsupported.append('optimizer=%r (only SGD momentum, train_lib.py:183-185)' % c.optimizer)
+    if str(getattr(c, 'optimizer', 'sgd')).lower() not in ('sgd', 'adam'):
+      unsupported.append("optimizer=%r (the reference has 'sgd' and 'adam', train_lib.py:180-188)" % c.optimizer)
     if unsupported:
       raise ValueError('training options that are not built: ' + '; '.join(unsupported))
 

@@ -443,6 +443,12 @@ int edet_opt_scale(float* grads, const int64_t* seg_offsets, const float* seg_fa
 int edet_opt_sgd_ema(float* params, float* grads, float* velocity, float* ema,
                      const int64_t* seg_offsets, const float* seg_factor, const int32_t* seg_flags, int nseg,
                      const float* hyper_dev, float momentum, void* stream);
+/* optimizer = 'adam' (train_lib.py:183-186: tf.keras.optimizers.Adam(learning_rate, beta_1=momentum), beta_2 0.999,
+ * epsilon 1e-7): m, v = the two slot arenas; hyper_dev[0] = alpha_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) of THIS step
+ * (formed by the host: Engine.set_hyper), hyper_dev[1] = EMA decay; clip factors, frozen segments and the EMA as above */
+int edet_opt_adam_ema(float* params, const float* grads, float* m, float* v, float* ema,
+                      const int64_t* seg_offsets, const float* seg_factor, const int32_t* seg_flags, int nseg,
+                      const float* hyper_dev, float beta1, float beta2, float epsilon, void* stream);
 
 /* ---- step plumbing (round 6): the few operations of a step that are not layers, so that EVERY launch of a step goes
  * through this ABI and a step can be recorded and replayed without the Python interpreter (include/edet_net.h).

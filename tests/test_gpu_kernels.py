@@ -1024,6 +1024,50 @@ def test_optimizer():
   gu.check(gd2, g2, 'f32', 'scaled grads', rtol=1e-5, atol=1e-6)
 
 
+def test_optimizer_adam():
+  """edet_opt_adam_ema against tf.keras.optimizers.Adam's update (ResourceApplyAdam) in numpy float32: unaligned and
+  multi-slice segments, per-segment clip factors, a frozen segment, the EMA on top; two steps (t = 1, 2)."""
+  rng = np.random.default_rng(13)
+  sizes = [7, 64, 1, 1000, 33, 4096, 40003]
+  flags = [1, 0, 0, 1, _lib.SEG_FROZEN, 0, 1]
+  offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+  tot = int(offs[-1])
+  p = rng.standard_normal(tot).astype(np.float32)
+  m = np.zeros(tot, np.float32)
+  u = np.zeros(tot, np.float32)
+  ema = p.copy()
+  fac = rng.uniform(0.2, 1.0, len(sizes)).astype(np.float32)
+  b1, b2, eps, lr, decay = np.float32(0.9), np.float32(0.999), np.float32(1e-7), 0.01, np.float32(0.95)
+  pd, md, ud, ed = (torch.from_numpy(t.copy()).to(gu.DEV) for t in (p, m, u, ema))
+  od = torch.from_numpy(offs).to(gu.DEV)
+  fd = torch.tensor(flags, dtype=torch.int32, device=gu.DEV)
+  facd = torch.from_numpy(fac).to(gu.DEV)
+  for t in (1, 2):
+    g = (rng.standard_normal(tot) * 3).astype(np.float32)
+    alpha = np.float32(lr * np.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t))
+    hyper = torch.tensor([float(alpha), float(decay)], dtype=torch.float32, device=gu.DEV)
+    gd = torch.from_numpy(g).to(gu.DEV)
+    call('edet_opt_adam_ema', ptr(pd), ptr(gd), ptr(md), ptr(ud), ptr(ed), ptr(od), ptr(facd), ptr(fd), len(sizes), ptr(hyper),
+         float(b1), float(b2), float(eps), gu.stream())
+    torch.cuda.synchronize()
+    for i in range(len(sizes)):
+      sl = slice(int(offs[i]), int(offs[i + 1]))
+      if flags[i] == _lib.SEG_FROZEN:
+        continue
+      gs = g[sl] * fac[i]
+      m[sl] = m[sl] + (gs - m[sl]) * (np.float32(1) - b1)
+      u[sl] = u[sl] + (gs * gs - u[sl]) * (np.float32(1) - b2)
+      p[sl] = p[sl] - (m[sl] * alpha) / (np.sqrt(u[sl]) + eps)
+      ema[sl] = ema[sl] - (np.float32(1) - decay) * (ema[sl] - p[sl])
+    gu.check(md, torch.from_numpy(m), 'f32', 'adam m, step %d' % t, rtol=1e-5, atol=1e-6)
+    gu.check(ud, torch.from_numpy(u), 'f32', 'adam v, step %d' % t, rtol=1e-5, atol=1e-7)
+    gu.check(pd, torch.from_numpy(p), 'f32', 'adam params, step %d' % t, rtol=1e-5, atol=2e-6)
+    gu.check(ed, torch.from_numpy(ema), 'f32', 'ema, step %d' % t, rtol=1e-5, atol=2e-6)
+  sl = slice(int(offs[4]), int(offs[5]))      # the frozen segment: value, both slots and the shadow bit for bit
+  assert torch.equal(md[sl].cpu(), torch.zeros(33)) and torch.equal(ud[sl].cpu(), torch.zeros(33))
+  assert np.array_equal(pd[sl].cpu().numpy(), p[sl]) and np.array_equal(ed[sl].cpu().numpy(), ema[sl])
+
+
 # ------------------------------------------------------------------------------------ relu / relu6 / hswish
 GENERIC_KERNELS = ('k_gemm<', 'k_wgrad<', 'k_dw_fwd<', 'k_dw_bwd_data<', 'k_dw_bwd_weight<')
 

@@ -585,6 +585,71 @@ def test_train_step_is_bit_reproducible(model, size, batch, dtype):
     assert l0[k] == l1[k], (k, l0[k], l1[k])
 
 
+def test_adam_steps_match_oracle_fp32():
+  """optimizer='adam' (tf2/train_lib.py:183-186: tf.keras.optimizers.Adam(learning_rate, beta_1=momentum)): two training steps
+  of d0 in fp32 storage against the oracle's Adam.  The first and second moments are linear / quadratic in the clipped
+  gradient and are compared like it (1e-2 of each tensor's largest element); the variables move by +-alpha wherever the
+  gradient is resolved (Adam normalises the step), so they are compared where |m| >= 1e-2 of the tensor's largest |m| --
+  on the elements whose gradient is analytically zero (a bias in front of a BatchNorm) the SIGN of rounding noise decides
+  a full-size step on either side."""
+  case = ('efficientdet-d0', 'optimizer=adam', 128, 2)
+  model, override, size, batch = case
+  config, vals, images, labels = train_step_problem(case)
+  assert config.optimizer == 'adam'
+  net = train_lib.EfficientDetNetTrain(config=config, dtype='f32', params=vals)
+  eng = net._ensure_engine(batch, size, size)
+  assert eng.adam
+  oracle = orc.Oracle(config=config, params={k: torch.from_numpy(v.copy()) for k, v in vals.items()})
+  with torch.no_grad():
+    oracle.forward(torch.from_numpy(images), False)
+  tl = {k: torch.from_numpy(v) for k, v in labels.items()}
+  opt = {}
+  lr, decay = 0.003, 0.9
+  for step in range(2):
+    ref_vals, _ = orc.train_step(oracle, torch.from_numpy(images), tl, opt, lr, decay)
+    eng.forward(net._to_device_images(torch.from_numpy(images), eng), training=True)
+    eng.loss_backward(net._labels_to_device(labels, eng))
+    eng.optimizer_step(lr, decay)
+    torch.cuda.synchronize()
+    got = eng.loss_values()
+    for k in ('cls_loss', 'box_loss'):
+      assert abs(got[k] - ref_vals[k]) <= 5e-3 * abs(ref_vals[k]) + 1e-5, (step, k, got[k], ref_vals[k])
+    state = eng.arena.get_optimizer_state()
+    assert state['iterations'] == step + 1 and 'adam_v' in state
+    P = oracle.params()
+    worst = {'m': 0.0, 'v': 0.0, 'w': 0.0}
+    floor = 1e-3 * max(float(opt[k]['v'].abs().max()) for k in opt if k != '__iterations__')
+    for name in oracle.trainable_names():
+      off, n = eng.offsets[name][:2]
+      m_ref, u_ref = opt[name]['v'].reshape(-1).numpy(), opt[name]['u'].reshape(-1).numpy()
+      m_got, u_got = state['velocity'][off:off + n], state['adam_v'][off:off + n]
+      ym = max(float(np.abs(m_ref).max()), floor)
+      worst['m'] = max(worst['m'], float(np.abs(m_got - m_ref).max()) / ym)
+      worst['v'] = max(worst['v'], float(np.abs(u_got - u_ref).max()) / max(float(u_ref.max()), floor * floor))
+      w_ref = P[name].detach().reshape(-1).numpy()
+      w_got = eng.param(name).detach().cpu().reshape(-1).numpy()
+      resolved = np.abs(m_ref) >= 1e-2 * ym
+      if resolved.any():
+        worst['w'] = max(worst['w'], float(np.abs(w_got - w_ref)[resolved].max()) / ((step + 1) * lr))
+    assert worst['m'] <= 1e-2 and worst['v'] <= 2e-2, (step, worst)
+    assert worst['w'] <= 5e-2, (step, worst)       # a fraction of the step size alpha ~ lr on the resolved elements
+    # the second step (t = 2: both moments non-zero, another bias correction) starts from the ORACLE's state on both sides:
+    # on the unresolved elements the two sides have just taken full-size steps of opposite sign
+    eng.set_params({k: v.detach().numpy() for k, v in P.items() if k in eng.offsets})
+    for name in oracle.trainable_names():
+      off, n = eng.offsets[name][:2]
+      state['velocity'][off:off + n] = opt[name]['v'].reshape(-1).numpy()
+      state['adam_v'][off:off + n] = opt[name]['u'].reshape(-1).numpy()
+      state['ema'][off:off + n] = opt[name]['ema'].reshape(-1).numpy()
+    eng.arena.set_optimizer_state(state)
+    state = eng.arena.get_optimizer_state()
+  # the slots travel with the optimizer state
+  net2 = train_lib.EfficientDetNetTrain(config=config, dtype='f32', params=vals)
+  eng2 = net2._ensure_engine(batch, size, size)
+  eng2.arena.set_optimizer_state(state)
+  assert torch.equal(eng2.arena.adam_v, eng.arena.adam_v) and eng2.arena.step_count == 2
+
+
 def test_two_steps_decrease_loss_and_are_deterministic_in_shape():
   """EfficientDetNetTrain.train_step end to end twice (API level), d0 at 128."""
   config = hparams_config.get_efficientdet_config('efficientdet-d0')

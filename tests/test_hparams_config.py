@@ -96,11 +96,14 @@ def test_unbuilt_options_raise_instead_of_being_ignored():
   fail loudly (constructing the host objects needs no GPU)."""
   import pytest
   from automl_amd import efficientdet_net, train_lib
-  for override in ('iou_loss_type=ciou', 'optimizer=adam'):
+  for override in ('iou_loss_type=ciou', 'optimizer=rmsprop'):
     config = hparams_config.get_efficientdet_config('efficientdet-d0')
     config.override(override)
     with pytest.raises(ValueError, match='not built'):
       train_lib.EfficientDetNetTrain(config=config)
+  config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  config.override('optimizer=adam')         # tf.keras.optimizers.Adam(lr, beta_1=momentum): built in r06 (edet_opt_adam_ema)
+  train_lib.EfficientDetNetTrain(config=config)
   config = hparams_config.get_efficientdet_config('efficientdet-d0')
   config.override('survival_prob=0.8')      # stochastic depth in the towers: built since r04 (Engine._head_level)
   efficientdet_net.EfficientDetNet(config=config)
