@@ -25,6 +25,7 @@ cpn $G/${T}_timeline.txt $P/${T}_timeline_b128.txt
 cpn $G/${T}_pytest_gpu.log $P/${T}_pytest_gpu.log
 cpn $G/${T}_bench_v2s.json $P/${T}_bench_v2s_224_b256.json
 cpn $G/${T}_bench_d7x.json $P/${T}_bench_d7x_1536_b8.json
+cpn $G/${T}_plan_bench.json $P/${T}_plan_bench.json
 cpn $G/${T}_labeling.json $P/${T}_labeling.json
 cpn $G/${T}_postprocess_bench_b128.jsonl $P/${T}_postprocess_bench_b128.jsonl
 [ -s $P/${T}_kernel_stats_b128.csv ] && echo ${T}_kernel_stats_b128.csv > $P/CURRENT && echo "  profiles/CURRENT -> $(cat $P/CURRENT)"
