@@ -329,6 +329,28 @@ def other_configs():
   out['efficientdet-d0 640x640 batch 128 fp32-storage train step (the precision that meets 1e-3 end to end; eager)'] = {
       'images_per_sec': 128 / dt, 'ms_per_step': dt * 1e3, 'steps': 3,
       'hbm_frac': 2 * ALG_MB_PER_IMG * 1e6 * 128 / dt / 1e9 / HBM_PEAK_GBS}     # fp32: twice the bf16 bytes
+  net._graph, net.engine = None, None
+  net._engines.clear()
+  eng._bufs.clear()
+  del net, eng, images, labels
+  torch.cuda.empty_cache()
+  # the headline step WITHOUT the Python engine in the loop: recorded as a step plan, replayed by the library's own host
+  # runtime through the network-level C ABI (include/edet_net.h: edet_train_step; hipGraph replay) -- in a process of its
+  # own (scripts/bench_plan.py), which also checks the variables against the Python host's bit for bit
+  try:
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'scripts', 'bench_plan.py'),
+                        '--steps', '20'], capture_output=True, text=True, timeout=420)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    d = json.loads(lines[-1])
+    out['efficientdet-d0 640x640 batch 128 bf16 train step through the network-level C ABI (edet_train_step: recorded plan, '
+        'C host runtime, hipGraph replay)'] = {
+            'images_per_sec': d['images_per_sec'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'],
+            'variables_bit_equal_to_the_python_host': bool(d['first_step_equals_python_host'] and
+                                                           [v for k, v in d.items() if k.startswith('params_equal')][0]),
+            'plan_file_mb': round(d['plan']['file_bytes'] / 1e6, 1), 'plan_calls_per_step': d['plan']['programs']['train_step']}
+  except Exception as e:      # noqa: BLE001 -- a side measurement must not take the line down
+    out['network-level C ABI replay'] = {'error': str(e)[:200]}
   return out
 
 
