@@ -591,6 +591,43 @@ def test_d0_640_batch128_train_step_tracks_the_tiled_2_image_step():
 BUF_RMS_BOUND = 0.6
 
 
+# ------------------------------------------------------------------ 3b. the step's plumbing entry points (round 6)
+def test_step_plumbing_entry_points():
+  """edet_loss_normalizer (the device-side 1 / (sum(mean_num_positives) + 1) of tf2/train_lib.py:517-534, what bench.py's
+  captured step uses), edet_axpy_clear (the side chain's gradient arena joined into the main one), edet_cast_to_f32 and
+  edet_zero against numpy: exact."""
+  rng = np.random.default_rng(5)
+  for n in (1, 2, 128, 1000):
+    mnp = rng.integers(0, 400, n).astype(np.float32)
+    d = torch.from_numpy(mnp).to(gu.DEV)
+    out = torch.zeros(4, dtype=torch.float32, device=gu.DEV)
+    call('edet_loss_normalizer', ptr(d), n, out.data_ptr() + 8, gu.stream())
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert got[2] == np.float32(1.0) / (np.float32(mnp.sum(dtype=np.float64)) + np.float32(1.0)), (n, got)
+    assert got[0] == 0 and got[1] == 0 and got[3] == 0
+  for n in (1, 777, 100003):
+    a, b = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    da, db = torch.from_numpy(a).to(gu.DEV), torch.from_numpy(b).to(gu.DEV)
+    call('edet_axpy_clear', ptr(da), ptr(db), n, 1, gu.stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(da.cpu().numpy(), a + b) and not db.any()
+    db2 = torch.from_numpy(b).to(gu.DEV)
+    call('edet_axpy_clear', ptr(da), ptr(db2), n, 0, gu.stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(da.cpu().numpy(), (a + b) + b) and np.array_equal(db2.cpu().numpy(), b)
+    h = torch.from_numpy(a).to(gu.DEV).to(torch.bfloat16)
+    f = torch.empty(n, dtype=torch.float32, device=gu.DEV)
+    call('edet_cast_to_f32', ptr(h), ptr(f), n, _lib.EDET_BF16, gu.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(f, h.float())
+    call('edet_cast_to_f32', ptr(da), ptr(f), n, _lib.EDET_F32, gu.stream())
+    call('edet_zero', ptr(da), 4 * (n // 2), gu.stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(f.cpu().numpy(), (a + b) + b)
+    assert not da[:n // 2].any() and np.array_equal(da[n // 2:].cpu().numpy(), ((a + b) + b)[n // 2:])
+
+
 # ------------------------------------------------------------------ 4. coverage of the benchmark's kernel symbols
 def _norm(name):
   return name.replace('void ', '').replace(' ', '')
