@@ -123,6 +123,7 @@ SIGNATURES = {
     'edet_opt_adam_ema': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                           c_float, c_float, c_float, c_void_p],
     'edet_zero': [c_void_p, ctypes.c_size_t, c_void_p],
+    'edet_compact_rows': [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p],
     'edet_cast_to_f32': [c_void_p, c_void_p, c_int64, c_int, c_void_p],
     'edet_axpy_clear': [c_void_p, c_void_p, c_int64, c_int, c_void_p],
     'edet_loss_normalizer': [c_void_p, c_int, c_void_p, c_void_p],

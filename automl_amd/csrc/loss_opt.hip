@@ -613,6 +613,32 @@ extern "C" int edet_cast_to_f32(const void* src, float* dst, int64_t count, int 
   return 0;
 }
 
+namespace {
+// dst[r][0 .. cw) = src[r][0 .. cw) in 4-byte words: a [rows][ld] tensor without its padding columns
+__global__ __launch_bounds__(THREADS) void k_compact_rows(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                         int64_t rows, int cw, int ldw) {
+  const int64_t total = rows * cw, stride = (int64_t)gridDim.x * THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / cw;
+    dst[i] = src[r * ldw + (i - r * cw)];
+  }
+}
+}  // namespace
+
+extern "C" int edet_compact_rows(const void* src, int64_t rows, int c, int ld, void* dst, int elem_bytes, void* stream) {
+  EDET_CHECK(src && dst && rows >= 0 && c > 0 && ld >= c, "edet_compact_rows: bad arguments");
+  EDET_CHECK((elem_bytes == 2 || elem_bytes == 4) && (c * elem_bytes) % 4 == 0 && (ld * elem_bytes) % 4 == 0,
+             "edet_compact_rows: rows must be whole 4-byte words (elem_bytes %d, c %d, ld %d)", elem_bytes, c, ld);
+  if (rows == 0) return 0;
+  const int cw = c * elem_bytes / 4, ldw = ld * elem_bytes / 4;
+  int64_t grid = (rows * cw + THREADS - 1) / THREADS;
+  if (grid > 4096) grid = 4096;
+  edet_launch(k_compact_rows, dim3((unsigned)grid), dim3(THREADS), 0, to_stream(stream), (const uint32_t*)src, (uint32_t*)dst,
+              rows, cw, ldw);
+  EDET_LAUNCH_CHECK("edet_compact_rows");
+  return 0;
+}
+
 extern "C" int edet_zero(void* dst, size_t bytes, void* stream) {
   EDET_CHECK(dst || bytes == 0, "edet_zero: null pointer");
   if (bytes == 0) return 0;

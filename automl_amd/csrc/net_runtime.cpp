@@ -450,6 +450,8 @@ extern "C" int edet_net_use_graph(edet_net_t* net, int on) {
 
 extern "C" int edet_forward(edet_net_t* net, void* stream) { return run_program(net, "forward", stream); }
 
+extern "C" int edet_detect(edet_net_t* net, void* stream) { return run_program(net, "detect", stream); }
+
 extern "C" int edet_train_step(edet_net_t* net, float learning_rate, float ema_decay, void* stream) {
   EDET_CHECK(net, "edet_train_step: null network");
   auto it = net->names.find("hyper");

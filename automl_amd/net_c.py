@@ -20,6 +20,7 @@ NET_SIGNATURES = {
     'edet_copy_to_host': [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t],
     'edet_copy_to_device': [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t],
     'edet_forward': [ctypes.c_void_p, ctypes.c_void_p],
+    'edet_detect': [ctypes.c_void_p, ctypes.c_void_p],
     'edet_train_step': [ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_void_p],
     'edet_dp_init': [ctypes.c_void_p, ALLREDUCE_FN, ctypes.c_void_p],
     'edet_anchors': [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_double,
@@ -112,6 +113,9 @@ class CNet(object):
 
   def forward(self, stream=None):
     _check(self.lib, self.lib.edet_forward(self.h, stream), 'edet_forward')
+
+  def detect(self, stream=None):
+    _check(self.lib, self.lib.edet_detect(self.h, stream), 'edet_detect')
 
   def train_step(self, learning_rate, ema_decay=0.0, stream=None):
     _check(self.lib, self.lib.edet_train_step(self.h, learning_rate, ema_decay, stream), 'edet_train_step')

@@ -132,6 +132,9 @@ class Recorder(object):
         enc.append(('i', int(a)))
       elif t in (_lib.c_float, _lib.c_double):
         enc.append(('f', float(a)))
+      elif t is _lib.c_void_p and (isinstance(a, (ctypes.Array, ctypes.Structure)) or hasattr(a, '_obj')):
+        # a HOST array / out-parameter behind a void* parameter (edet_preprocess_infer's mean, std and scale)
+        enc.append(('b',) + _blob_of(getattr(a, '_obj', a)))
       elif t is _lib.c_void_p:
         if isinstance(a, ctypes.c_void_p):
           a = a.value
@@ -406,12 +409,111 @@ def train_pass(eng, images, dlabels, learning_rate, ema_decay):
   eng.optimizer_apply(bool(ema_decay), True)
 
 
+class _Detect(object):
+  """Buffers and launches of the `detect` program: EfficientDetModel.call with pre_mode='infer', post_mode='global'
+  (efficientdet_keras.py:920-1000) -- edet_preprocess_infer, the network, the level outputs without their padding columns,
+  pre_nms (tf2/postprocess.py:120-157), global NMS + clip + rescale (:375-406).  Every buffer exists BEFORE the recorded
+  pass (the Python host's own path, automl_amd/postprocess.py, allocates its temporaries inside the calls)."""
+
+  def __init__(self, net, eng, images, raw_hw):
+    from automl_amd import anchors as anchors_lib, postprocess, utils
+    c = eng.config
+    self.eng, self.params = eng, c.as_dict()
+    dev = images.device
+    b = int(images.shape[0])
+    rh, rw = int(raw_hw[0]), int(raw_hw[1])
+    self.b, self.rh, self.rw = b, rh, rw
+    self.oh, self.ow = int(images.shape[1]), int(images.shape[2])
+    self.raw = torch.zeros((b, rh, rw, 3), dtype=torch.uint8, device=dev)
+    self.images = torch.empty_like(images)
+    self.mean = (ctypes.c_float * 3)(*[float(v) for v in np.broadcast_to(np.asarray(c.mean_rgb, np.float32).reshape(-1), (3,))])
+    self.std = (ctypes.c_float * 3)(*[float(v) for v in np.broadcast_to(np.asarray(c.stddev_rgb, np.float32).reshape(-1), (3,))])
+    self.scale = ctypes.c_float(0.0)
+    self.tdt = _lib.EDET_BF16 if images.dtype == torch.bfloat16 else _lib.EDET_F32
+    a = anchors_lib.Anchors(c.min_level, c.max_level, c.num_scales, c.aspect_ratios, c.anchor_scale, (self.oh, self.ow))
+    self.anchors = torch.as_tensor(np.asarray(a.boxes, np.float32)).to(dev).contiguous()
+    self.n = int(self.anchors.shape[0])
+    self.na = eng.spec.num_anchors
+    self.k = int(c.nms_configs.get('max_nms_inputs', 0) or 0)
+    kk = self.k if self.k > 0 else self.n
+    self.boxes = torch.empty((b, kk, 4), dtype=torch.float32, device=dev)
+    self.scores = torch.empty((b, kk), dtype=torch.float32, device=dev)
+    self.classes = torch.empty((b, kk), dtype=torch.int32, device=dev)
+    self.ws_topk = None
+    if self.k > 0:
+      need = ctypes.c_size_t(0)
+      _lib.call('edet_pre_nms_topk_workspace_bytes', b, self.k, ctypes.byref(need))
+      self.ws_topk = torch.empty((max(need.value, 8),), dtype=torch.uint8, device=dev)
+    self.cfg = postprocess._tf_nms_cfg(c.nms_configs)
+    self.m = int(self.cfg.max_output_size)
+    need = ctypes.c_size_t(0)
+    _lib.call('edet_nms_workspace_bytes', b, kk, 1, self.m, ctypes.byref(need))
+    self.ws_nms = torch.empty((max(need.value, 8),), dtype=torch.uint8, device=dev)
+    self.out_index = torch.empty((b, self.m), dtype=torch.int32, device=dev)
+    self.out_score = torch.empty((b, self.m), dtype=torch.float32, device=dev)
+    self.valid = torch.empty((b,), dtype=torch.int32, device=dev)
+    self.nms_boxes = torch.empty((b, self.m, 4), dtype=torch.float32, device=dev)
+    self.nms_scores = torch.empty((b, self.m), dtype=torch.float32, device=dev)
+    self.nms_classes = torch.empty((b, self.m), dtype=torch.float32, device=dev)
+    # image_scales of preprocess_infer: one value per image, a function of the two sizes only (the library returns it on
+    # the host); kept on the device as postprocess_global's rescale wants it
+    self.scales = torch.zeros((b,), dtype=torch.float32, device=dev)
+    self.compact = None      # per level (cls, box) without padding columns: made by the first pass (needs the views)
+    self.clip_hw = utils.parse_image_size((self.oh, self.ow))
+
+  def persistent(self):
+    return [self.raw, self.anchors, self.scales]
+
+  def run(self):
+    eng = self.eng
+    st = eng.stream
+    _lib.call('edet_preprocess_infer', self.raw.data_ptr(), 0, self.b, self.rh, self.rw, self.oh, self.ow, self.mean, self.std,
+              self.images.data_ptr(), ctypes.byref(self.scale), self.tdt, st)
+    if not float(self.scales[0]):
+      self.scales.fill_(self.scale.value)      # (before the recorded pass: the warm-up pass does this once)
+    eng.forward(self.images, training=False)
+    views = list(zip(eng.cls_views, eng.box_views))
+    if self.compact is None:
+      self.compact = [tuple(torch.empty((v.raw.n, v.raw.h, v.raw.w, v.raw.c), dtype=v.raw.data.dtype, device=self.raw.device)
+                            for v in pair) for pair in views]
+    dts = {pair[i].raw.data.dtype for pair in views for i in (0, 1)}
+    assert len(dts) == 1, 'class and box outputs of one storage type'
+    dt = dts.pop()
+    for pair, outs in zip(views, self.compact):
+      for v, o in zip(pair, outs):
+        r = v.raw
+        _lib.call('edet_compact_rows', _lib.ptr(r.data), r.n * r.h * r.w, r.c, r.ld, _lib.ptr(o), r.data.element_size(), st)
+    nlev = len(views)
+    cp = (ctypes.c_void_p * nlev)(*[o[0].data_ptr() for o in self.compact])
+    bp = (ctypes.c_void_p * nlev)(*[o[1].data_ptr() for o in self.compact])
+    lp = (ctypes.c_int * nlev)(*[pair[0].raw.h * pair[0].raw.w for pair in views])
+    edt = _lib.EDET_BF16 if dt == torch.bfloat16 else _lib.EDET_F32
+    nc = eng.config.num_classes
+    if self.k > 0:
+      _lib.call('edet_pre_nms_topk', cp, bp, lp, nlev, self.b, self.na, nc, self.anchors.data_ptr(), edt, self.k,
+                self.ws_topk.data_ptr(), self.ws_topk.numel(), self.boxes.data_ptr(), self.scores.data_ptr(),
+                self.classes.data_ptr(), st)
+    else:
+      _lib.call('edet_pre_nms', cp, bp, lp, nlev, self.b, self.na, nc, self.anchors.data_ptr(), edt, self.boxes.data_ptr(),
+                self.scores.data_ptr(), self.classes.data_ptr(), st)
+    kk = int(self.scores.shape[1])
+    _lib.call('edet_nms', self.boxes.data_ptr(), self.scores.data_ptr(), self.classes.data_ptr(), self.b, kk, 1,
+              ctypes.byref(self.cfg), self.ws_nms.data_ptr(), self.ws_nms.numel(), self.out_index.data_ptr(),
+              self.out_score.data_ptr(), self.valid.data_ptr(), st)
+    _lib.call('edet_nms_gather', self.boxes.data_ptr(), self.classes.data_ptr(), self.out_index.data_ptr(),
+              self.out_score.data_ptr(), self.b, kk, self.m, _lib.NMS_PAD_INDEX0, float(self.clip_hw[0]), float(self.clip_hw[1]),
+              self.scales.data_ptr(), self.nms_boxes.data_ptr(), self.nms_scores.data_ptr(), self.nms_classes.data_ptr(), st)
+
+
 def record_network(net, images, labels=None, path='efficientdet.plan', learning_rate=0.01, ema_decay=0.0,
-                   max_init_bytes=32 << 20):
+                   max_init_bytes=32 << 20, detect_raw_hw=None, raw_images=None):
   """Records `forward` (EfficientDetNet.call, inference BatchNorm) and -- with labels -- `train_step` of a network
   (efficientdet_net.EfficientDetNet / train_lib.EfficientDetNetTrain) on device tensors `images` [B,H,W,3] and the label
   dictionary of train_step, and writes the plan.  Returns (summary, expected): `expected` holds what the Python host
   computed in the recorded passes (numpy), for a replay to be compared with.
+
+  detect_raw_hw = (H, W): also records `detect` (EfficientDetModel.call on raw uint8 images of that size: preprocessing,
+  network, global-NMS post-processing; edet_detect); raw_images [B,H,W,3] uint8 are the recorded inputs (default zeros).
 
   The state the plan starts from is the network's state after one un-recorded warm-up pass of each program.
   """
@@ -424,8 +526,15 @@ def record_network(net, images, labels=None, path='efficientdet.plan', learning_
     dl = net._labels_to_device(labels, eng)
     assert 'mean_num_positives' in dl, "the recorded step computes the normalizer on the device: labels['mean_num_positives']"
 
+  det = None
+  if detect_raw_hw is not None:
+    det = _Detect(net, eng, images, detect_raw_hw)
+    if raw_images is not None:
+      det.raw.copy_(torch.as_tensor(raw_images).to(det.raw.device))
   # warm-up: every buffer of both programs exists afterwards
   eng.forward(images, training=False)
+  if det is not None:
+    det.run()
   if dl is not None:
     train_pass(eng, images, dl, learning_rate, ema_decay)
   torch.cuda.synchronize()
@@ -434,6 +543,10 @@ def record_network(net, images, labels=None, path='efficientdet.plan', learning_
                 eng.hyper, images]
   if dl is not None:
     persistent += [t for t in dl.values() if torch.is_tensor(t)]
+  if getattr(eng.arena, 'adam_v', None) is not None:
+    persistent.append(eng.arena.adam_v)
+  if det is not None:
+    persistent += det.persistent()
   rec.snapshot_initial_state(persistent, max_init_bytes)
   expected = {}
   # every program re-makes the compute copies of the variables (and, in inference, the BatchNorm vectors): a replayed step
@@ -464,6 +577,21 @@ def record_network(net, images, labels=None, path='efficientdet.plan', learning_
     names, dev, _, _ = eng._cast_table
     flat = [it for n in names for it in eng._cast_items[n]]
     rec.device_table(dev, [(32 * i + 8 * j, it[j]) for i, it in enumerate(flat) for j in (0, 1)])
+  if det is not None:
+    eng._cast_version = -1
+    rec.begin('detect')
+    det.run()
+    rec.end()
+    torch.cuda.synchronize()
+    for name, t in (('raw_images', det.raw), ('detections.boxes', det.nms_boxes), ('detections.scores', det.nms_scores),
+                    ('detections.classes', det.nms_classes), ('detections.valid_len', det.valid),
+                    ('image_scales', det.scales)):
+      rec.name_buffer(name, t)
+    rec.props.update({'raw_height': det.rh, 'raw_width': det.rw, 'max_output_size': det.m})
+    for k in ('boxes', 'scores', 'classes', 'valid_len'):
+      t = {'boxes': det.nms_boxes, 'scores': det.nms_scores, 'classes': det.nms_classes, 'valid_len': det.valid}[k]
+      expected['detections.' + k] = t.cpu().numpy().copy()
+    rec._keep.append(det)
   if dl is not None:
     eng._cast_version = -1
     rec.begin('train_step')

@@ -458,6 +458,10 @@ int edet_opt_adam_ema(float* params, const float* grads, float* m, float* v, flo
  * edet_loss_normalizer: inv_out[0] = 1 / (sum(mean_num_positives[0..n)) + 1), the per-step loss normalizer of
  *   tf2/train_lib.py:517-534 (positives_momentum = 0) kept on the device.  */
 int edet_zero(void* dst, size_t bytes, void* stream);
+/* dst [rows][c] = the first c elements of every row of src [rows][ld]: the level outputs without their padding columns, as
+ * tf2/postprocess.py's reshape to [B, -1, num_classes] / [B, -1, 4] (:67-79) needs them (what `.contiguous()` did on the
+ * Python host); rows of whole 4-byte words */
+int edet_compact_rows(const void* src, int64_t rows, int c, int ld, void* dst, int elem_bytes, void* stream);
 /* dst[i] = (float)src[i]: the fp32 copy of a stored tensor in front of a layer that runs in fp32 inside a bf16 network (the
  * box-predict island of the inference pass, Engine._to_f32); exact (bf16 -> fp32 widens) */
 int edet_cast_to_f32(const void* src, float* dst, int64_t count, int src_dtype, void* stream);

@@ -63,6 +63,14 @@ int edet_net_use_graph(edet_net_t* net, int on);
  * "cls_outputs_<L>" / "box_outputs_<L>" buffers.  stream: a hipStream_t (NULL = the default stream).  */
 int edet_forward(edet_net_t* net, void* stream);
 
+/* Detection on raw images (efficientdet_keras.EfficientDetModel.call, tf2/efficientdet_keras.py:920-1000, with the reference's
+ * defaults pre_mode='infer', post_mode='global'): "raw_images" uint8 [B, raw_height, raw_width, 3] -> normalise / resize /
+ * pad (:920-951) -> the network -> pre_nms + global NMS + clip + rescale to raw pixels (tf2/postprocess.py:375-406) ->
+ * "detections.boxes" fp32 [B, M, 4] (ymin, xmin, ymax, xmax), "detections.scores" fp32 [B, M], "detections.classes" fp32
+ * [B, M] (1-based), "detections.valid_len" int32 [B]; M = property "max_output_size".  Plans recorded with
+ * record_network(..., detect_raw_hw=(H, W)) hold the program.  */
+int edet_detect(edet_net_t* net, void* stream);
+
 /* One training step over "images" and the target buffers (EfficientDetNetTrain.train_step: forward with batch
  * statistics, focal + Huber loss, backward, L2, per-tensor and global-norm clip, [gradient exchange], SGD momentum + EMA).
  * learning_rate / ema_decay are this step's values of the schedule (train_lib.py:37-173, :193-197; ema_decay 0 = the

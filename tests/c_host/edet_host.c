@@ -63,6 +63,13 @@ int main(int argc, char** argv) {
     snprintf(name, sizeof(name), "box_outputs_%d", (int)l);
     if (dump(net, name, argv[2], "")) return 1;
   }
+  if (edet_net_has_program(net, "detect")) {      /* raw uint8 images -> detections (EfficientDetModel.call) */
+    for (int i = 0; i < 3; ++i) CHECK(edet_detect(net, stream));
+    if (hipStreamSynchronize(stream) != hipSuccess) return 1;
+    const char* det[] = {"detections.boxes", "detections.scores", "detections.classes", "detections.valid_len"};
+    for (int k = 0; k < 4; ++k)
+      if (dump(net, det[k], argv[2], "")) return 1;
+  }
   if (edet_net_has_program(net, "train_step")) {
     for (int s = 0; s < steps; ++s) {
       CHECK(edet_train_step(net, 0.02f, 0.9f, stream));

@@ -16,6 +16,7 @@ from tests.test_gpu_network import make_labels, perturbed_params
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LR, DECAY = 0.02, 0.9
+RAW_HW = (300, 400)      # raw images of the `detect` program (resized into the top-left corner of SIZE x SIZE)
 SIZE = 256      # level 3 is 32 x 32: the heads run as two chains (fork / join events in the plan), levels 4-7 on the side stream
 
 
@@ -30,7 +31,9 @@ def recorded(tmp_path_factory):
   images = torch.from_numpy(rng.standard_normal((2, SIZE, SIZE, 3)).astype(np.float32))
   labels = make_labels(config, 2, SIZE, 101)
   path = str(d / 'd0_256_b2.plan')
-  summary, expected = plan.record_network(net, images, labels, path, learning_rate=LR, ema_decay=DECAY)
+  raw = torch.from_numpy(rng.integers(0, 256, (2,) + RAW_HW + (3,), dtype=np.uint8))
+  summary, expected = plan.record_network(net, images, labels, path, learning_rate=LR, ema_decay=DECAY,
+                                          detect_raw_hw=RAW_HW, raw_images=raw)
   return {'path': path, 'summary': summary, 'expected': expected, 'net': net, 'images': images, 'labels': labels,
           'dir': str(d), 'config': config}
 
@@ -49,9 +52,64 @@ def _logits_equal(cnet, expected, config):
       assert np.array_equal(g, w), '%s: %d bytes differ' % (name, int((g != w).sum()))
 
 
+DET_DTYPES = {'boxes': np.float32, 'scores': np.float32, 'classes': np.float32, 'valid_len': np.int32}
+
+
+def _detections_equal(cnet, expected):
+  for k, dt in DET_DTYPES.items():
+    got = cnet.read('detections.' + k).view(dt)
+    want = expected['detections.' + k].reshape(-1)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), 'detections.%s differs' % k
+  assert int(expected['detections.valid_len'].min()) >= 0
+
+
+def test_detect_program_equals_the_python_model(tmp_path):
+  """An inference-only plan (no training step: the variables never change): the recorded `detect` pass and its replay
+  equal the Python host's own EfficientDetModel path -- preprocess_infer, the network, postprocess_global
+  (efficientdet_keras.py:920-1000) -- bit for bit: boxes in raw-image pixels, scores, classes, valid_len."""
+  from automl_amd import efficientdet_net, postprocess, preprocess
+  config = hparams_config.get_efficientdet_config('efficientdet-d0')
+  config.override('image_size=%d' % SIZE)
+  net = efficientdet_net.EfficientDetNet(config=config, dtype='bf16', params=perturbed_params(config, 11), seed=5)
+  rng = np.random.default_rng(7)
+  raw = torch.from_numpy(rng.integers(0, 256, (2,) + RAW_HW + (3,), dtype=np.uint8))
+  images, scales = preprocess.preprocess_infer(raw, SIZE, config.mean_rgb, config.stddev_rgb, dtype=torch.bfloat16)
+  cls_out, box_out = net(images, training=False)
+  want = postprocess.postprocess_global(config.as_dict(), cls_out, box_out, scales)
+  want = [t.cpu().numpy().copy() for t in want]
+  assert int(want[3].max()) > 0, 'the problem must produce detections'
+  path = str(tmp_path / 'd0_detect.plan')
+  summary, expected = plan.record_network(net, images, None, path, detect_raw_hw=RAW_HW, raw_images=raw)
+  assert set(summary['programs']) == {'forward', 'detect'}
+  for k, w in zip(('boxes', 'scores', 'classes', 'valid_len'), want):
+    assert np.array_equal(expected['detections.' + k].view(np.uint32).reshape(-1), w.view(np.uint32).reshape(-1)), k
+  cnet = net_c.CNet(path)
+  try:
+    assert cnet.prop('raw_height') == RAW_HW[0] and cnet.prop('max_output_size') == 100 and not cnet.has_program('train_step')
+    cnet.use_graph(True)
+    st = torch.cuda.Stream()
+    for _ in range(3):
+      cnet.detect(st.cuda_stream)
+      st.synchronize()
+      _detections_equal(cnet, expected)
+    # other raw images through the same plan: the host writes "raw_images", the replayed graph reads it
+    raw2 = torch.from_numpy(rng.integers(0, 256, (2,) + RAW_HW + (3,), dtype=np.uint8))
+    cnet.write('raw_images', raw2.numpy())
+    cnet.detect(st.cuda_stream)
+    st.synchronize()
+    images2, scales2 = preprocess.preprocess_infer(raw2, SIZE, config.mean_rgb, config.stddev_rgb, dtype=torch.bfloat16)
+    c2, b2 = net(images2, training=False)
+    want2 = postprocess.postprocess_global(config.as_dict(), c2, b2, scales2)
+    for k, w in zip(('boxes', 'scores', 'classes', 'valid_len'), want2):
+      got = cnet.read('detections.' + k).view(np.uint32)
+      assert np.array_equal(got, w.cpu().numpy().view(np.uint32).reshape(-1)), k
+  finally:
+    cnet.close()
+
+
 def test_plan_summary(recorded):
   s = recorded['summary']
-  assert set(s['programs']) == {'forward', 'train_step'}
+  assert set(s['programs']) == {'forward', 'detect', 'train_step'}
   assert s['programs']['train_step'] > s['programs']['forward'] > 100
   assert s['streams'] == 2 and s['events'] >= 2      # the two head chains: one fork + one join per pass at least
   got = plan.read_plan(recorded['path'])
@@ -72,6 +130,11 @@ def test_replay_in_process_equals_the_python_host(recorded):
       cnet.forward(st.cuda_stream)
       st.synchronize()
       _logits_equal(cnet, recorded['expected'], recorded['config'])
+    # raw images -> detections, eager then captured then replayed
+    for _ in range(3):
+      cnet.detect(st.cuda_stream)
+      st.synchronize()
+      _detections_equal(cnet, recorded['expected'])
     cnet.use_graph(False)
     cnet.train_step(LR, DECAY)
     for k in ('params', 'ema', 'velocity', 'bn_state', 'loss_sums'):
@@ -139,6 +202,9 @@ def test_c_host_without_an_interpreter(recorded):
     for k in ('params', 'ema', 'velocity', 'bn_state', 'loss_sums'):
       got = np.fromfile(os.path.join(out, k + '.step0.bin'), dtype=np.uint32)
       assert np.array_equal(got, exp[k].view(np.uint32).reshape(-1)), (mode, k)
+    for k, dt in DET_DTYPES.items():
+      got = np.fromfile(os.path.join(out, 'detections.%s.bin' % k), dtype=np.uint32)
+      assert np.array_equal(got, exp['detections.' + k].view(np.uint32).reshape(-1)), (mode, k)
     c = recorded['config']
     for level in range(c.min_level, c.max_level + 1):
       for kind, ch in (('cls', c.num_classes * 9), ('box', 36)):
