@@ -93,7 +93,9 @@ __device__ __forceinline__ void sample_input(const FuseArgs& a, int i, const Vie
     load8<T>(base + ((size_t)(n * v.h + oy) * v.w + ox) * v.ld + c0, x);
     affine8(v, k, x);
   } else if (a.mode[i] == EDET_RS_UP2) {
-    int sy = (int)(((int64_t)oy * v.h) / a.oh), sx = (int)(((int64_t)ox * v.w) / a.ow);
+    // nearest source pixel floor(o * in / out); exactly o >> 1 for the 2x pyramids
+    int sy = a.oh == 2 * v.h ? oy >> 1 : (int)((uint32_t)(oy * v.h) / (uint32_t)a.oh);
+    int sx = a.ow == 2 * v.w ? ox >> 1 : (int)((uint32_t)(ox * v.w) / (uint32_t)a.ow);
     sy = sy < v.h - 1 ? sy : v.h - 1;
     sx = sx < v.w - 1 ? sx : v.w - 1;
     load8<T>(base + ((size_t)(n * v.h + sy) * v.w + sx) * v.ld + c0, x);
@@ -160,7 +162,9 @@ __device__ __forceinline__ void fuse_body(const FuseArgs& a, T* __restrict__ out
   }
   float dw_acc[3] = {0.f, 0.f, 0.f};
   float dwc[PCDW ? 3 : 1][8];
-  int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, qstride = (int64_t)gridDim.x * blockDim.x;
+  // index arithmetic in 32 bits (round 6: the three int64 divisions per 16-byte chunk were most of the kernel's
+  // instructions; the entry points refuse tensors of 2^31 chunks or more)
+  uint32_t q0 = blockIdx.x * blockDim.x + threadIdx.x, qstride = gridDim.x * blockDim.x;
   const int slices = PCDW ? THREADS / nvec : 1;      // (host: c <= 8 * THREADS)
   if (PCDW) {
 #pragma unroll
@@ -168,16 +172,17 @@ __device__ __forceinline__ void fuse_body(const FuseArgs& a, T* __restrict__ out
 #pragma unroll
       for (int e = 0; e < 8; ++e) dwc[PCDW ? i : 0][e] = 0.f;
     const int chunk = threadIdx.x % nvec, slice = threadIdx.x / nvec;
-    q0 = slice < slices ? ((int64_t)blockIdx.x * slices + slice) * nvec + chunk : total;
-    qstride = (int64_t)gridDim.x * slices * nvec;
+    q0 = slice < slices ? (uint32_t)((blockIdx.x * slices + slice) * nvec + chunk) : (uint32_t)total;
+    qstride = (uint32_t)(gridDim.x * slices * nvec);
   }
-  for (int64_t q = q0; q < total; q += qstride) {
-    const int c0 = (int)(q % nvec) * 8;
-    int64_t pix = q / nvec;
-    const int ox = (int)(pix % a.ow);
-    pix /= a.ow;
-    const int oy = (int)(pix % a.oh);
-    const int n = (int)(pix / a.oh);
+  const uint32_t total32 = (uint32_t)total, unvec = (uint32_t)nvec, uow = (uint32_t)a.ow, uoh = (uint32_t)a.oh;
+  for (uint32_t q = q0; q < total32; q += qstride) {
+    uint32_t pix = q / unvec;
+    const int c0 = (int)(q - pix * unvec) * 8;
+    const uint32_t prow = pix / uow;
+    const int ox = (int)(pix - prow * uow);
+    const int n = (int)(prow / uoh);
+    const int oy = (int)(prow - (uint32_t)n * uoh);
     float s[8], xi[3][8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = 0.f;
@@ -372,14 +377,14 @@ __global__ __launch_bounds__(THREADS) void k_fuse_bwd_input(const FuseInArgs a, 
   const int64_t total = (int64_t)v.n * v.h * v.w * nvec;
   const float wn = a.wc > 1 ? 0.f : a.wn[a.idx];
   const T* base = reinterpret_cast<const T*>(v.data);
-  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
-       q += (int64_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)(q % nvec) * 8;
-    int64_t pix = q / nvec;
-    const int sx = (int)(pix % v.w);
-    pix /= v.w;
-    const int sy = (int)(pix % v.h);
-    const int n = (int)(pix / v.h);
+  const uint32_t total32 = (uint32_t)total, unvec = (uint32_t)nvec, uw = (uint32_t)v.w, uh = (uint32_t)v.h;
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total32; q += gridDim.x * blockDim.x) {
+    const uint32_t pix = q / unvec;
+    const int c0 = (int)(q - pix * unvec) * 8;
+    const uint32_t prow = pix / uw;
+    const int sx = (int)(pix - prow * uw);
+    const int n = (int)(prow / uh);
+    const int sy = (int)(prow - (uint32_t)n * uh);
     float g[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) g[e] = 0.f;
@@ -387,10 +392,11 @@ __global__ __launch_bounds__(THREADS) void k_fuse_bwd_input(const FuseInArgs a, 
       load8<T>(ds + ((size_t)(n * a.oh + sy) * a.ow + sx) * a.ldds + c0, g);
     } else if (a.mode == EDET_RS_UP2) {
       // destination pixels whose nearest source is (sy, sx): oy with floor(oy*h/oh) == sy
-      const int oy_lo = (int)(((int64_t)sy * a.oh + v.h - 1) / v.h);
-      int oy_hi = (int)(((int64_t)(sy + 1) * a.oh + v.h - 1) / v.h);
-      const int ox_lo = (int)(((int64_t)sx * a.ow + v.w - 1) / v.w);
-      int ox_hi = (int)(((int64_t)(sx + 1) * a.ow + v.w - 1) / v.w);
+      const bool x2 = a.oh == 2 * v.h && a.ow == 2 * v.w;      // the 2x pyramids: destination rows / columns 2s, 2s + 1
+      const int oy_lo = x2 ? 2 * sy : (int)(((uint32_t)(sy * a.oh) + uh - 1) / uh);
+      int oy_hi = x2 ? 2 * sy + 2 : (int)(((uint32_t)((sy + 1) * a.oh) + uh - 1) / uh);
+      const int ox_lo = x2 ? 2 * sx : (int)(((uint32_t)(sx * a.ow) + uw - 1) / uw);
+      int ox_hi = x2 ? 2 * sx + 2 : (int)(((uint32_t)((sx + 1) * a.ow) + uw - 1) / uw);
       if (sy == v.h - 1) oy_hi = a.oh;
       if (sx == v.w - 1) ox_hi = a.ow;
       for (int oy = oy_lo; oy < oy_hi; ++oy)
@@ -589,6 +595,7 @@ extern "C" int edet_fuse_fwd(const edet_tview_t* in0, const edet_tview_t* in1, c
     a.wn_out = wn;
     a.method = method;
   }
+  EDET_CHECK((int64_t)a.n * oh * ow * (a.c / 8) < (1ll << 31), "edet_fuse_fwd: tensor too large for the 32-bit index arithmetic");
   const int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8), dtype == EDET_BF16 ? reinterpret_cast<const void*>(&k_fuse<bf16_t, false>) : nullptr);
   if (dtype == EDET_BF16) edet_launch(k_fuse<bf16_t, false>, grid, dim3(THREADS), 0, to_stream(stream), a, (bf16_t*)out, nullptr, nullptr, nullptr, nullptr, nullptr);
   else if (dtype == EDET_F32) edet_launch(k_fuse<float, false>, grid, dim3(THREADS), 0, to_stream(stream), a, (float*)out, nullptr, nullptr, nullptr, nullptr, nullptr);
@@ -615,6 +622,7 @@ extern "C" int edet_fuse_bwd_pre(const edet_tview_t* in0, const edet_tview_t* in
   const bool pcdw = wc > 1 && dwn;
   EDET_CHECK(!pcdw || a.c <= 8 * THREADS, "edet_fuse_bwd_pre: per-channel fusion weights need c <= %d", 8 * THREADS);
   const size_t lds = pcdw ? (size_t)(THREADS / (a.c / 8)) * nin * a.c * sizeof(float) : 0;
+  EDET_CHECK((int64_t)a.n * oh * ow * (a.c / 8) < (1ll << 31), "edet_fuse_bwd_pre: tensor too large for the 32-bit index arithmetic");
   int grid = ew_grid((int64_t)a.n * oh * ow * (a.c / 8), dtype == EDET_BF16 ? (pcdw ? reinterpret_cast<const void*>(&k_fuse_pc<bf16_t>) : reinterpret_cast<const void*>(&k_fuse<bf16_t, true>)) : nullptr, lds);
   // ordered partial rows through the workspace -- [grid][4] for scalar fusion weights, [grid][nin * c] for per-channel ones;
   // without a workspace that holds them ONE workgroup adds its sums into dwn (no atomics either way)
@@ -669,6 +677,7 @@ extern "C" int edet_fuse_bwd_input(const edet_tview_t* in, int mode, const float
     a.pad_t = same_pad_before(in->h, 3, 2);
     a.pad_l = same_pad_before(in->w, 3, 2);
   }
+  EDET_CHECK((int64_t)in->n * in->h * in->w * (in->c / 8) < (1ll << 31), "edet_fuse_bwd_input: tensor too large for the 32-bit index arithmetic");
   const int grid = ew_grid((int64_t)in->n * in->h * in->w * (in->c / 8), dtype == EDET_BF16 ? reinterpret_cast<const void*>(&k_fuse_bwd_input<bf16_t>) : nullptr);
   const unsigned char* am = mode == EDET_RS_POOL ? reinterpret_cast<const unsigned char*>(pool_argmax) : nullptr;
   if (dtype == EDET_BF16) edet_launch(k_fuse_bwd_input<bf16_t>, grid, dim3(THREADS), 0, to_stream(stream), a, (const bf16_t*)ds, (bf16_t*)gout, am);

@@ -28,6 +28,7 @@ def main():
   ap.add_argument('--steps', type=int, default=20)
   ap.add_argument('--warmup', type=int, default=3)
   ap.add_argument('--plan', default='')
+  ap.add_argument('--detect', action='store_true', help='also measure edet_detect (an inference-only plan)')
   args = ap.parse_args()
   config = hparams_config.get_efficientdet_config(args.model)
   net = train_lib.EfficientDetNetTrain(config=config, dtype='bf16', seed=0)
@@ -76,6 +77,40 @@ def main():
   cnet.close()
   if not args.plan:
     os.remove(path)
+  if args.detect:
+    # the serving direction: raw uint8 images -> detections through edet_detect (preprocessing + network with inference
+    # BatchNorm + pre_nms + global NMS), an inference-only plan, hipGraph replay
+    from automl_amd import efficientdet_net
+    del net, eng, dimages, dl, expected
+    torch.cuda.empty_cache()
+    config = hparams_config.get_efficientdet_config(args.model)
+    config.override('image_size=%d' % args.image_size)
+    inet = efficientdet_net.EfficientDetNet(config=config, dtype='bf16', seed=0)
+    rh, rw = args.image_size * 3 // 4, args.image_size
+    raw = torch.from_numpy(np.random.default_rng(5).integers(0, 256, (args.batch, rh, rw, 3), dtype=np.uint8))
+    dpath = path + '.detect'
+    dsummary, dexp = plan.record_network(inet, images, None, dpath, detect_raw_hw=(rh, rw), raw_images=raw,
+                                         max_init_bytes=1 << 20)
+    dnet = net_c.CNet(dpath)
+    dnet.use_graph(True)
+    for _ in range(3):
+      dnet.detect(st.cuda_stream)
+    st.synchronize()
+    ok = bool(np.array_equal(dnet.read('detections.boxes').view(np.uint32), dexp['detections.boxes'].view(np.uint32).reshape(-1)))
+    e0.record(st)
+    for _ in range(args.steps):
+      dnet.detect(st.cuda_stream)
+    e1.record(st)
+    st.synchronize()
+    dms = e0.elapsed_time(e1) / args.steps
+    print(json.dumps({
+        'workload': '%s %dx%d batch %d bf16 detection through edet_detect (raw %dx%d uint8 images -> preprocess -> network -> '
+                    'global NMS; C host runtime, hipGraph replay)' % (args.model, args.image_size, args.image_size, args.batch, rh, rw),
+        'ms_per_batch': dms, 'images_per_sec': args.batch / dms * 1e3, 'steps': args.steps,
+        'plan': {**dsummary, 'file_bytes': os.path.getsize(dpath)}, 'detections_equal_recorded_pass': ok,
+        'mean_valid_detections': float(dexp['detections.valid_len'].mean())}))
+    dnet.close()
+    os.remove(dpath)
 
 
 if __name__ == '__main__':

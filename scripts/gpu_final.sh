@@ -32,7 +32,7 @@ tail -4 gpurun_out/${T}_pytest_gpu.log | cut -c1-300
 (timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${T}_v2s -o v2s --output-format csv -- python scripts/bench_v2s.py --steps 10 --dump_launches gpurun_out/${T}_launches_v2s_224_b256.txt 2>&1 | grep "^{" | tail -1) > gpurun_out/${T}_bench_v2s.json
 (timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${T}_d7x -o d7x --output-format csv -- python bench.py --model efficientdet-d7x --image_size 1536 --batch 8 --steps 3 --warmup 1 --no_cpu_baseline --no_other_configs --dump_launches gpurun_out/${T}_launches_d7x_1536_b8.txt 2>&1 | grep "^{" | tail -1) > gpurun_out/${T}_bench_d7x.json
 find gpurun_out/prof_${T}_v2s gpurun_out/prof_${T}_d7x -name "*kernel_trace.csv" -delete
-(timeout 600 python scripts/bench_plan.py --steps 20 2>&1 | grep "^{" | tail -1) > gpurun_out/${T}_plan_bench.json      # the step through edet_train_step (C host runtime)
+(timeout 600 python scripts/bench_plan.py --steps 20 --detect 2>&1 | grep "^{" | tail -2) > gpurun_out/${T}_plan_bench.json      # the step through edet_train_step (C host runtime)
 (timeout 120 python scripts/bench_labeling.py 2>&1 | tail -1) > gpurun_out/${T}_labeling.json
 (timeout 200 python scripts/bench_postprocess.py 2>&1 | tail -12) > gpurun_out/${T}_postprocess_bench_b128.jsonl
 tail -8 gpurun_out/${T}_pytest_gpu.log | cut -c1-400; cat gpurun_out/${T}_smoke.log; cut -c1-1500 gpurun_out/${T}_bench_b128.log; head -4 gpurun_out/${T}_pmc_fetch.txt | cut -c1-200; cut -c1-300 gpurun_out/${T}_bench_v2s.json; cut -c1-300 gpurun_out/${T}_bench_d7x.json; cut -c1-400 gpurun_out/${T}_plan_bench.json; cat gpurun_out/${T}_labeling.json
