@@ -639,11 +639,35 @@ extern "C" int edet_compact_rows(const void* src, int64_t rows, int c, int ld, v
   return 0;
 }
 
+namespace {
+// A kernel, not hipMemsetAsync: a memset NODE of a captured graph costs a ~50 us bubble in front of it on this runtime
+// (r06zz timeline: two fillBufferAligned nodes and the kernel behind them, 0.2 ms of idle queue per step)
+__global__ __launch_bounds__(THREADS) void k_zero(uint4* __restrict__ dst16, size_t n16, unsigned char* __restrict__ tail, int ntail) {
+  const size_t stride = (size_t)gridDim.x * THREADS;
+  for (size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x; i < n16; i += stride) dst16[i] = make_uint4(0, 0, 0, 0);
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+}  // namespace
+
 extern "C" int edet_zero(void* dst, size_t bytes, void* stream) {
   EDET_CHECK(dst || bytes == 0, "edet_zero: null pointer");
   if (bytes == 0) return 0;
-  const hipError_t e = hipMemsetAsync(dst, 0, bytes, to_stream(stream));
-  EDET_CHECK(e == hipSuccess, "edet_zero: hipMemsetAsync: %s", hipGetErrorString(e));
+  // head up to the first 16-byte boundary and tail behind the last one: byte stores of block 0 (at most 15 + 15)
+  unsigned char* p = reinterpret_cast<unsigned char*>(dst);
+  const size_t mis = (16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15;
+  if (mis >= bytes || mis != 0) {
+    // unaligned start (not what the engine passes: its buffers are 256-byte aligned): the memset path
+    const hipError_t e = hipMemsetAsync(dst, 0, bytes, to_stream(stream));
+    EDET_CHECK(e == hipSuccess, "edet_zero: hipMemsetAsync: %s", hipGetErrorString(e));
+    return 0;
+  }
+  const size_t n16 = bytes / 16;
+  const int ntail = (int)(bytes - n16 * 16);
+  size_t grid = (n16 + THREADS - 1) / THREADS;
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  edet_launch(k_zero, dim3((unsigned)grid), dim3(THREADS), 0, to_stream(stream), reinterpret_cast<uint4*>(p), n16, p + n16 * 16, ntail);
+  EDET_LAUNCH_CHECK("edet_zero");
   return 0;
 }
 
