@@ -925,6 +925,18 @@ static int big_tpw(int ntm) {
   return t;
 }
 
+// the LDS-DMA forward kernel (pw_glds.hip); same return convention
+int pwg_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bias, void* out, int cout,
+                int ldo, float* stat_partials, int* nparts_out, int tpw, hipStream_t st);
+// Which wide forward layers go to the LDS-DMA kernel: the SE-gated views (the MBConv project layers: 5-19 % faster there,
+// r06al); it ties or loses a few per cent on the others.  EDET_PW_GLDS = 0: never; 2: every shape of its envelope (read
+// per call: lab switch and the bit-equality test).  The two kernels give the same bits, so the rule is free to change.
+static bool glds_wanted(const edet_tview_t* in) {
+  const char* e = getenv("EDET_PW_GLDS");
+  const int mode = e && e[0] ? atoi(e) : 1;
+  return mode == 2 || (mode == 1 && in->gate != nullptr);
+}
+
 // return 1 = handled, 0 = shape outside the envelope (caller falls back), < 0 = error
 int pwb_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bias, void* out, int cout,
                 int ldo, float* stat_partials, int* nparts_out, hipStream_t st) {
@@ -939,6 +951,10 @@ int pwb_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
   a.bias = bias; a.out = reinterpret_cast<bf16_t*>(out); a.ldo = ldo; a.stat_partials = stat_partials;
   a.ntm = (a.M + BM - 1) / BM; a.ntj = (N + BJ - 1) / BJ;
   a.tpw = big_tpw(a.ntm);
+  if (glds_wanted(in)) {
+    const int rc = pwg_try_fwd(in, wt, ldw, bias, out, cout, ldo, stat_partials, nparts_out, a.tpw, st);
+    if (rc != 0) return rc;
+  }
   a.ngrp = (a.ntm + a.tpw - 1) / a.tpw;
   if (nparts_out) *nparts_out = a.ngrp;
   static const bool ok = big_lds_ok(reinterpret_cast<const void*>(&k_big_gemm<false, false>)) &&

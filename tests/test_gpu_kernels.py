@@ -139,6 +139,59 @@ def test_pw_fwd(dt, shape, mode, pw_impl):
   gu.check(s2, (want * want).sum((0, 1, 2)), name, 'pw_fwd sumsq', rtol=3e-2 if name == 'bf16' else 1e-3)
 
 
+# r06: the LDS-DMA forward kernel (pw_glds.hip) against the register-staged one it replaces on the wide layers.  Same tile,
+# same operand values, same accumulation order and epilogue: the outputs and the statistic partials must be EQUAL, bit for
+# bit.  Shapes: reduction lengths with 2 / 3 / many steps and ragged tails (144, 240, 480, 672), row tiles inside two
+# images (13x11, 20x20 at two images), ragged last row tile, column counts that are not multiples of 128 / of 8 (36, 810),
+# one case with more row tiles than EDET_MAX_PARTS (several row tiles per workgroup).
+@pytest.mark.parametrize('shape', [(3, 13, 11, 144, 24), (2, 20, 20, 1152, 192), (2, 20, 20, 1152, 320), (2, 12, 12, 480, 80),
+                                   (2, 40, 40, 672, 112), (3, 17, 9, 240, 40), (2, 20, 20, 192, 1152), (1, 40, 40, 128, 810),
+                                   (2, 16, 16, 384, 36), (1, 24, 24, 3840, 640), (33, 64, 64, 128, 64)])
+@pytest.mark.parametrize('mode', ['plain', 'bn', 'bn_swish', 'bn_swish_gate'])
+def test_pw_fwd_glds_equals_register_staged(shape, mode, monkeypatch):
+  n, h, w, cin, cout = shape
+  _, edt, tdt = [d for d in gu.DTYPES if d[0] == 'bf16'][0]
+  rng = np.random.default_rng(gu.seed_of(('glds', shape, mode)))
+  xd = gu.to_dev(gu.rnd(rng, (n, h, w, cin), tdt), tdt)
+  wk = gu.rnd(rng, (cin, cout), tdt, 1.0 / np.sqrt(cin))
+  bd = gu.fdev(torch.from_numpy(rng.standard_normal(cout).astype(np.float32)))
+  sc = sh = gt = None
+  act = ACT_NONE
+  if mode != 'plain':
+    sc = gu.fdev(torch.from_numpy((1 + 0.3 * rng.standard_normal(cin)).astype(np.float32)))
+    sh = gu.fdev(torch.from_numpy((0.3 * rng.standard_normal(cin)).astype(np.float32)))
+  if mode.startswith('bn_swish'):
+    act = ACT_SWISH
+  if mode == 'bn_swish_gate':
+    gt = gu.fdev(torch.from_numpy(rng.uniform(0.2, 1.0, (n, cin)).astype(np.float32)))
+  ldk, ldo = gu.pad8(cin), gu.pad8(cout)
+  wt = torch.zeros(cout, ldk, dtype=tdt, device=gu.DEV)
+  call('edet_cast_matrix', ptr(gu.fdev(wk)), ptr(wt), cin, cout, ldk, 1, edt, gu.stream())
+  tv = gu.tview(xd, cin, sc, sh, gt, act)
+  monkeypatch.setenv('EDET_PW_IMPL', 'big')
+  res = {}
+  for glds in ('0', '2'):      # register-staged for every shape / LDS-DMA for every shape of its envelope
+    monkeypatch.setenv('EDET_PW_GLDS', glds)
+    out = torch.full((n, h, w, ldo), float('nan'), dtype=tdt, device=gu.DEV)
+    parts = partial_buf(cout)
+    npart = NP(0)
+    _lib.launch_log_start()
+    try:
+      call('edet_pw_fwd', ctypes.byref(tv), ptr(wt), ldk, ptr(bd), ptr(out), cout, ldo, ptr(parts),
+           ctypes.byref(npart), edt, gu.stream())
+      torch.cuda.synchronize()
+    finally:
+      log = _lib.launch_log_stop()
+    want = {'0': 'pwb::k_big_gemm<', '2': 'pwg::k_wide_fwd<32'}[glds]
+    assert any(want in k for k in log) and not any(('k_wide_fwd' in k or 'k_big_gemm' in k) and want not in k for k in log), sorted(log)
+    res[glds] = (out, parts[:npart.value * 2 * cout].clone(), npart.value)
+  for glds in ('2',):
+    assert res['0'][2] == res[glds][2]
+    assert torch.equal(res['0'][0].view(torch.int16), res[glds][0].view(torch.int16)), 'outputs differ (EDET_PW_GLDS=%s)' % glds
+    assert torch.equal(res['0'][1], res[glds][1]), 'statistic partials differ (EDET_PW_GLDS=%s)' % glds
+  assert bool(torch.isfinite(res['2'][0][..., :cout].float()).all())
+
+
 # ------------------------------------------------------------------------------------ pointwise bwd
 def make_grad_view(rng, n, h, w, c, tdt, with_bn):
   dz = gu.rnd(rng, (n, h, w, c), tdt)
