@@ -85,3 +85,42 @@ def test_fused_mbconv_kernels_do_not_spill_registers():
   assert len(names) == len(spills) == len(scratch) and len(names) >= 30, (len(names), len(spills))
   bad = [(n, s, c) for n, s, c in zip(names, spills, scratch) if 'k_exp_dw_fwd' in n and (s or c)]
   assert not bad, bad
+
+
+def test_lds_dma_kernel_keeps_its_prefetch_in_flight():
+  """automl_amd/csrc/pw_glds.hip: between an LDS-DMA and the LDS accesses that follow it hipcc inserts `s_waitcnt vmcnt(0)`
+  unless the accesses carry an alias scope (the `__restrict__` helpers of that file) -- one merged store or one plain
+  dereference in the main loop and the three reduction steps in flight become none, silently (the results stay right).
+  Checked in the compiler's own assembly of every instantiation: inside the reduction loop -- from the first counted wait
+  to the last hand-written `s_barrier` -- the only `vmcnt` waits are the hand-written ones
+  (between ;;#ASMSTART / ;;#ASMEND); and no instantiation spills vector registers."""
+  import os
+  import re
+  import subprocess
+  import tempfile
+  from automl_amd import build
+  src = os.path.join(build.CSRC, 'pw_glds.hip')
+  with tempfile.TemporaryDirectory() as tmp:
+    r = subprocess.run([build.HIPCC] + build.FLAGS + ['-c', src, '-o', os.path.join(tmp, 'g.o'), '-save-temps=obj',
+                        '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True, timeout=900, cwd=tmp)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = [f for f in os.listdir(tmp) if f.endswith('gfx950.s')]
+    assert len(asm) == 1, os.listdir(tmp)
+    text = open(os.path.join(tmp, asm[0])).read()
+  spills = [int(v) for v in re.findall(r'VGPRs Spill: (\d+)', r.stderr)]
+  assert len(spills) >= 4 and not any(spills), spills
+  kernels = re.findall(r'^(_ZN3pwg10k_wide_fwd\w+):[^\n]*\n(.*?)s_endpgm', text, re.S | re.M)
+  assert len(kernels) >= 4, [k for k, _ in kernels]
+  for name, body in kernels:
+    lines = body.splitlines()
+    # hand-written waits: the line after ;;#ASMSTART
+    mine = {i + 1 for i, l in enumerate(lines) if 'ASMSTART' in l and i + 1 < len(lines) and 'vmcnt' in lines[i + 1]}
+    assert len(mine) >= 6, (name, len(mine))
+    # the loop's barriers are the hand-written ones (s_waitcnt lgkmcnt(0) + s_barrier in one asm block); the epilogue's
+    # __syncthreads() come after the last of them
+    barriers = [i for i, l in enumerate(lines) if re.search(r'\bs_barrier\b', l) and any('ASMSTART' in p for p in lines[max(0, i - 3):i])]
+    dmas = [i for i, l in enumerate(lines) if 'global_load_lds_dwordx4' in l]
+    assert dmas and len(barriers) >= 2, name
+    lo, hi = dmas[0], barriers[-1]
+    drained = [i for i in range(lo, hi) if re.search(r's_waitcnt.*vmcnt\(0\)', lines[i]) and i not in mine]
+    assert not drained, (name, [lines[i].strip() for i in drained][:4], lo, hi)
