@@ -691,6 +691,9 @@ class Engine(object):
     its dbeta is exactly that sum."""
     r = vout.raw
     assert r.grad is not None and r.grad_written, 'bias gradient of %s before its output gradient is complete' % bias
+    # main chain only: the constant vector is filled once, on the stream that is current at its creation, and nothing
+    # orders a later reader on ANOTHER stream against that fill (ADVICE r05; the resample convolutions are BiFPN layers)
+    assert self._branch is self._main, 'bias gradient of %s on the side chain' % bias
     fresh = ('ones:c:%d' % r.c) not in self._bufs
     ones = self.buf('ones:c:%d' % r.c, (r.c,), torch.float32)
     if fresh:
