@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libedet_hip.so')
-SOURCES = ['pw_gemm.hip', 'pw_stream.hip', 'pw_big.hip', 'pw_glds.hip', 'pw_tile_bwd.hip', 'conv.hip', 'dwconv.hip', 'dw_march.hip', 'mbconv_fused.hip', 'stem.hip', 'bn_se.hip', 'fuse.hip', 'loss_opt.hip', 'postprocess.hip', 'labeling.hip', 'preprocess.hip', 'error.cpp', 'net_runtime.cpp']
+SOURCES = ['pw_gemm.hip', 'pw_stream.hip', 'pw_big.hip', 'pw_glds.hip', 'pw_tile_bwd.hip', 'conv.hip', 'conv_halo.hip', 'dwconv.hip', 'dw_march.hip', 'mbconv_fused.hip', 'stem.hip', 'bn_se.hip', 'fuse.hip', 'loss_opt.hip', 'postprocess.hip', 'labeling.hip', 'preprocess.hip', 'error.cpp', 'net_runtime.cpp']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
 # files that restate float32 numpy / TensorFlow expressions operation by operation (argmax ties, 1e-6 parities):

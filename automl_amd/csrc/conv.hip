@@ -12,6 +12,8 @@
 // output channels, weights read through L1 -- correct, not fast.
 #include "common.h"
 
+int cvh_try_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, int k, int s, void* out, int cout, int ldo,
+                     float* stat_partials, int* nparts_out, hipStream_t st);
 int pwb_try_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, int k, int s, const float* bias, void* out,
                      int cout, int ldo, float* stat_partials, int* nparts_out, hipStream_t st);
 
@@ -258,6 +260,9 @@ extern "C" int edet_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, in
   EDET_CHECK(cout <= 1024, "edet_conv_fwd: cout %d unsupported", cout);
   hipStream_t st = to_stream(stream);
   if (dtype == EDET_BF16) {
+    // 3 x 3 stride 1 on 24 / 48 / 64 channels: from an LDS-resident halo tile (conv_halo.hip); else the implicit GEMM
+    const int rh = cvh_try_conv_fwd(in, wt, ldw, k, stride, out, cout, ldo, stat_partials, nparts_out, st);
+    if (rh != 0) return rh < 0 ? rh : 0;
     const int rc = pwb_try_conv_fwd(in, wt, ldw, k, stride, nullptr, out, cout, ldo, stat_partials, nparts_out, st);
     if (rc != 0) return rc < 0 ? rc : 0;
   }

@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from automl_amd import effnetv2_configs, effnetv2_model
+from automl_amd import _lib
 from automl_amd._lib import ACT_NONE, ACT_SWISH, call, ptr
 from oracle import effnetv2_oracle as v2orc
 from oracle import efficientdet_oracle as orc
@@ -127,6 +128,26 @@ def test_conv_fwd(dt, shape, ks, mode):
   gu.check(s1, want.sum((0, 1, 2)), name, 'conv_fwd sum', rtol=3e-2 if name == 'bf16' else 1e-3,
            atol=1e-2 * rows if name == 'bf16' else 1e-4 * rows, scale_by_max=False)
   gu.check(s2, (want * want).sum((0, 1, 2)), name, 'conv_fwd sumsq', rtol=3e-2 if name == 'bf16' else 1e-3)
+
+
+# r06: the 3 x 3 stride-1 convolution from an LDS-resident halo tile (conv_halo.hip: 24 / 48 / 64 input channels).  Maps of
+# several 8 x 16 tiles with ragged right / bottom edges, 32- and 128-column tiles with ragged column counts, more tiles than
+# EDET_MAX_PARTS (a workgroup then walks several tiles), against the oracle; and the implicit GEMM it replaces
+# (EDET_CONV_HALO=0) must still be reachable.
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 40, 37, 24, 24), (1, 33, 50, 48, 192), (2, 17, 35, 64, 256), (1, 24, 32, 24, 96),
+                                   (2, 9, 16, 48, 40), (9, 96, 160, 24, 24), (1, 8, 16, 64, 136)])
+@pytest.mark.parametrize('mode', ['plain', 'bn_swish'])
+def test_conv_fwd_halo_tiles(shape, mode, monkeypatch):
+  bf16 = [d for d in gu.DTYPES if d[0] == 'bf16'][0]
+  for halo, want in (('1', 'cvh::k_conv3_halo<'), ('0', 'pwb::k_big_gemm<')):
+    monkeypatch.setenv('EDET_CONV_HALO', halo)
+    _lib.launch_log_start()
+    try:
+      test_conv_fwd(bf16, shape, (3, 1), mode)
+    finally:
+      log = _lib.launch_log_stop()
+    assert any(want in k for k in log) and not any('k_conv3_halo' in k for k in log if halo == '0'), sorted(log)
 
 
 def _perturbed(spec, seed):
