@@ -8,7 +8,8 @@
 //   * the 10 x 18 input halo of the tile is loaded ONCE, transformed once (BatchNorm / activation of the producing layer;
 //     'SAME' padding is zero in the activated domain) and parked in LDS, pixel-major, channels padded to a multiple of 16;
 //   * the A fragments of tap (ky, kx) are plain ds_read_b128 at halo pixel (py + ky, px + kx): no im2col, no gather;
-//   * the weights of one tap ([columns][cin], 6-16 KiB) stream through two LDS stages, requested one tap ahead;
+//   * the weights of one tap ([columns][cin], 6-16 KiB) stream through two LDS stages, requested one tap ahead; the (at
+//     most two) 128-column tiles of the layer are walked one after the other on the SAME halo;
 //   * 128-column tiles as 2 x 2 waves of 2 x 2 v_mfma_f32_32x32x16_bf16, or -- layers with at most 32 output channels --
 //     32-column tiles as 4 x 1 waves of one MFMA tile each (no multiply-adds on 96 columns that do not exist);
 //   * epilogue as k_big_gemm's forward: C tile through LDS, 16-byte stores, BatchNorm statistic partials in a fixed order
@@ -89,8 +90,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3_halo(const Args a) {
   float* coef = reinterpret_cast<float*>(smem + G::HALO_PAD + G::R);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = WIDE ? (wave & 1) : wave, wj = WIDE ? (wave >> 1) : 0;
-  const int jt = blockIdx.x % a.ntj, grp = blockIdx.x / a.ntj;
-  const int j0 = jt * BJ;
+  const int grp = blockIdx.x;
   const int H = a.tv.h, W = a.tv.w;
   const bool want_stats = a.stat_partials != nullptr;
   const bool affine = a.tv.scale != nullptr;
@@ -99,9 +99,10 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3_halo(const Args a) {
   // epilogue geometry: thread -> 8 output columns ec*8.., rows er + ER*i
   constexpr int ECN = BJ / 8, ER = THREADS / ECN;        // 16 x 16 or 4 x 64
   const int ec = tid % ECN, er = tid / ECN;
-  const int ej = j0 + ec * 8;
-  const bool ecol_ok = ej < a.J;
-  float tot1 = 0.f, tot2 = 0.f;
+  constexpr int MAXJT = WIDE ? 2 : 1;           // column tiles walked by a workgroup (cout <= 256 / 32: host check)
+  float tot1[MAXJT], tot2[MAXJT];
+#pragma unroll
+  for (int t = 0; t < MAXJT; ++t) tot1[t] = tot2[t] = 0.f;
   for (int i = tid; i < 2 * KP; i += THREADS) {
     const int c = i < KP ? i : i - KP;
     coef[i] = affine && c < CIN ? (i < KP ? a.tv.scale[c] : a.tv.shift[c]) : (i < KP ? 1.f : 0.f);
@@ -111,14 +112,16 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3_halo(const Args a) {
   const bf16_t* bsrc[BPT];
   int bdst[BPT];
   bool bok[BPT];
+  auto b_setup = [&](int j0) {
 #pragma unroll
-  for (int i = 0; i < BPT; ++i) {
-    const int q = tid + THREADS * i;
-    const int col = q / CPP, cc = q - col * CPP;
-    bok[i] = q < G::BCH && cc < CPC && j0 + col < a.J;
-    bsrc[i] = a.Bm + (size_t)min(j0 + col, a.J - 1) * a.ldb + min(cc, CPC - 1) * 8;
-    bdst[i] = q < G::BCH ? col * BS + cc * 16 : -1;
-  }
+    for (int i = 0; i < BPT; ++i) {
+      const int q = tid + THREADS * i;
+      const int col = q / CPP, cc = q - col * CPP;
+      bok[i] = q < G::BCH && cc < CPC && j0 + col < a.J;
+      bsrc[i] = a.Bm + (size_t)min(j0 + col, a.J - 1) * a.ldb + min(cc, CPC - 1) * 8;
+      bdst[i] = q < G::BCH ? col * BS + cc * 16 : -1;
+    }
+  };
   // Weight prefetch: ND register sets, the set of tap t is requested ND taps before its MFMAs (the tap loop is unrolled, the
   // set index static).  r06ar: ND = 3 instead of 1 changes nothing (56x56x48->192 0.238 ms either way) at +25 VGPRs -- the
   // weight requests are not what a tile waits for
@@ -144,6 +147,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3_halo(const Args a) {
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
     const int oy0 = ty * TH, ox0 = tx * TW;
     __syncthreads();                        // the previous tile's epilogue is done with the LDS (first tile: coef is written)
+    b_setup(0);
 #pragma unroll
     for (int t = 0; t < ND; ++t) b_issue(t, rb[t]);
     // ---- halo: loaded (every request of the thread first), transformed and parked once
@@ -185,6 +189,19 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3_halo(const Args a) {
         }
         *reinterpret_cast<uint4*>(halo + (hdst[i] & 0x3fffffff)) = v;
       }
+    }
+    // ---- the column tiles of this pixel tile, one after the other on the same halo
+#pragma unroll
+    for (int jt = 0; jt < MAXJT; ++jt) {
+    if (jt < a.ntj) {
+    const int j0 = jt * BJ;
+    const int ej = j0 + ec * 8;
+    const bool ecol_ok = ej < a.J;
+    if (jt > 0) {
+      __syncthreads();                      // the previous column tile's epilogue is done with the weight stages
+      b_setup(j0);
+#pragma unroll
+      for (int t = 0; t < ND; ++t) b_issue(t, rb[t]);
     }
     b_commit(reg, rb[0]);
     b_issue(ND, rb[0]);
@@ -276,14 +293,20 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3_halo(const Args a) {
       }
       __syncthreads();
       if (tid < BJ) {
-        for (int i = 0; i < ER; ++i) { tot1 += red[i * BJ + tid]; tot2 += red[(ER + i) * BJ + tid]; }
+        for (int i = 0; i < ER; ++i) { tot1[jt] += red[i * BJ + tid]; tot2[jt] += red[(ER + i) * BJ + tid]; }
       }
     }
+    }
+    }
   }
-  if (want_stats && tid < BJ && j0 + tid < a.J) {
+  if (want_stats && tid < BJ) {
     float* dst = a.stat_partials + (size_t)grp * 2 * a.J;
-    dst[j0 + tid] = tot1;
-    dst[a.J + j0 + tid] = tot2;
+#pragma unroll
+    for (int jt = 0; jt < MAXJT; ++jt)
+      if (jt < a.ntj && jt * BJ + tid < a.J) {
+        dst[jt * BJ + tid] = tot1[jt];
+        dst[a.J + jt * BJ + tid] = tot2[jt];
+      }
   }
 }
 
@@ -292,7 +315,7 @@ template <int CIN, bool WIDE> int launch(const Args& a, hipStream_t st) {
   static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_halo<CIN, WIDE>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM_BYTES) == hipSuccess;
   if (!ok) return 0;
-  edet_launch(k_conv3_halo<CIN, WIDE>, dim3(a.ngrp * a.ntj), dim3(THREADS), G::SMEM_BYTES, st, a);
+  edet_launch(k_conv3_halo<CIN, WIDE>, dim3(a.ngrp), dim3(THREADS), G::SMEM_BYTES, st, a);
   return 1;
 }
 
@@ -300,7 +323,7 @@ template <int CIN, bool WIDE> int launch(const Args& a, hipStream_t st) {
 
 // return 1 = handled, 0 = shape outside the envelope (the caller goes on to the implicit GEMM), < 0 = error.
 // Envelope: 3 x 3, stride 1, 24 / 48 / 64 input channels (the Fused-MBConv widths of EfficientNetV2-S; further widths are
-// one instantiation each), no SE gate on the input view.
+// one instantiation each), at most 256 output channels, no SE gate on the input view.
 int cvh_try_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, int k, int s, void* out, int cout, int ldo,
                      float* stat_partials, int* nparts_out, hipStream_t st) {
   using namespace cvh;
@@ -317,6 +340,7 @@ int cvh_try_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, int k, int
   a.out = reinterpret_cast<bf16_t*>(out); a.ldo = ldo; a.stat_partials = stat_partials;
   a.tiles_y = (in->h + TH - 1) / TH; a.tiles_x = (in->w + TW - 1) / TW;
   a.ntiles = in->n * a.tiles_y * a.tiles_x;
+  if (cout > 256) return 0;                 // a workgroup walks at most two 128-column tiles
   const bool wide = cout > 32;
   a.ntj = (cout + (wide ? 128 : 32) - 1) / (wide ? 128 : 32);
   a.tpw = (a.ntiles + EDET_MAX_PARTS - 1) / EDET_MAX_PARTS;
