@@ -3,7 +3,7 @@
 // The implicit GEMM of pw_big.hip (k_big_gemm<.., CONV>) gathers, bounds-checks and transforms every input element once
 // per TAP and per 128-column tile (9 x ntj times), with an integer division per 16-byte chunk: on the Fused-MBConv layers
 // of EfficientNetV2-S (112x112x24 -> 24, 56x56x48 -> 192, 28x28x64 -> 256) it reaches 0.75-1.1 TB/s and 3-15 % of the MFMA
-// peak.  Here a workgroup owns an 8 x 16 tile of output pixels (= the 128 rows of the MFMA tile):
+// peak (0.5 TB/s on the 16- and 32-channel layers of the b0-b3 / L variants).  Here a workgroup owns an 8 x 16 tile of output pixels (= the 128 rows of the MFMA tile):
 //
 //   * the 10 x 18 input halo of the tile is loaded ONCE, transformed once (BatchNorm / activation of the producing layer;
 //     'SAME' padding is zero in the activated domain) and parked in LDS, pixel-major, channels padded to a multiple of 16;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3_halo(const Args a) {
   // epilogue geometry: thread -> 8 output columns ec*8.., rows er + ER*i
   constexpr int ECN = BJ / 8, ER = THREADS / ECN;        // 16 x 16 or 4 x 64
   const int ec = tid % ECN, er = tid / ECN;
-  constexpr int MAXJT = WIDE ? 2 : 1;           // column tiles walked by a workgroup (cout <= 256 / 32: host check)
+  constexpr int MAXJT = WIDE ? 4 : 1;           // column tiles walked by a workgroup (cout <= 512 / 32: host check)
   float tot1[MAXJT], tot2[MAXJT];
 #pragma unroll
   for (int t = 0; t < MAXJT; ++t) tot1[t] = tot2[t] = 0.f;
@@ -150,13 +150,15 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3_halo(const Args a) {
     b_setup(0);
 #pragma unroll
     for (int t = 0; t < ND; ++t) b_issue(t, rb[t]);
-    // ---- halo: loaded (every request of the thread first), transformed and parked once
-    {
-      uint4 raw[G::NHL];
-      int hdst[G::NHL];
+    // ---- halo: loaded (the requests of a pass of at most six chunks per thread first), transformed and parked once
+    constexpr int NB = G::NHL < 6 ? G::NHL : 6;
+#pragma unroll 1
+    for (int base = 0; base < G::NHL; base += NB) {
+      uint4 raw[NB];
+      int hdst[NB];
 #pragma unroll
-      for (int i = 0; i < G::NHL; ++i) {
-        const int e = tid + THREADS * i;
+      for (int i = 0; i < NB; ++i) {
+        const int e = tid + THREADS * (base + i);
         const int p = e / CPP, c = e - p * CPP;
         const int hy = p / HW, hx = p - hy * HW;
         const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
@@ -167,11 +169,11 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3_halo(const Args a) {
         if (inside) raw[i] = *reinterpret_cast<const uint4*>(X + ((size_t)(img * H + iy) * W + ix) * a.tv.ld + c * 8);
       }
 #pragma unroll
-      for (int i = 0; i < G::NHL; ++i) {
+      for (int i = 0; i < NB; ++i) {
         if (hdst[i] < 0) continue;
         uint4 v = raw[i];
         if ((hdst[i] >> 30) && (affine || act != EDET_ACT_NONE)) {
-          const int c = ((tid + THREADS * i) % CPP) * 8;
+          const int c = ((tid + THREADS * (base + i)) % CPP) * 8;
           float x[8];
           unpack8(v, x);
           if (affine) {
@@ -322,14 +324,16 @@ template <int CIN, bool WIDE> int launch(const Args& a, hipStream_t st) {
 }  // namespace cvh
 
 // return 1 = handled, 0 = shape outside the envelope (the caller goes on to the implicit GEMM), < 0 = error.
-// Envelope: 3 x 3, stride 1, 24 / 48 / 64 input channels (the Fused-MBConv widths of EfficientNetV2-S; further widths are
-// one instantiation each), at most 256 output channels, no SE gate on the input view.
+// Envelope: 3 x 3, stride 1, the Fused-MBConv widths of the EfficientNetV2 family (effnetv2_configs.py: 16 / 24 / 32 / 48 /
+// 64 / 80 / 96 input channels), at most 512 output channels, no SE gate on the input view.
 int cvh_try_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, int k, int s, void* out, int cout, int ldo,
                      float* stat_partials, int* nparts_out, hipStream_t st) {
   using namespace cvh;
   if (k != 3 || s != 1 || in->gate) return 0;
   const int cin = in->c;
-  if (cin != 24 && cin != 48 && cin != 64) return 0;
+  // every width measured faster than the implicit GEMM (r06at, batch 128: 16 / 32 channels 4.6-5x, 24: 4.1x, 48 / 64: 1.8-1.9x,
+  // 80: 1.8x, 96: 1.2-1.6x)
+  if (cin != 16 && cin != 24 && cin != 32 && cin != 48 && cin != 64 && cin != 80 && cin != 96) return 0;
   if (in->ld % 8 != 0 || ldw % 8 != 0 || ldo % 8 != 0 || ldo < (cout + 7) / 8 * 8) return 0;
   const char* e = getenv("EDET_CONV_HALO");
   if (e && e[0] == '0') return 0;           // lab switch: the implicit GEMM for every shape
@@ -340,15 +344,21 @@ int cvh_try_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, int k, int
   a.out = reinterpret_cast<bf16_t*>(out); a.ldo = ldo; a.stat_partials = stat_partials;
   a.tiles_y = (in->h + TH - 1) / TH; a.tiles_x = (in->w + TW - 1) / TW;
   a.ntiles = in->n * a.tiles_y * a.tiles_x;
-  if (cout > 256) return 0;                 // a workgroup walks at most two 128-column tiles
+  if (cout > 512) return 0;                 // a workgroup walks at most four 128-column tiles
   const bool wide = cout > 32;
   a.ntj = (cout + (wide ? 128 : 32) - 1) / (wide ? 128 : 32);
   a.tpw = (a.ntiles + EDET_MAX_PARTS - 1) / EDET_MAX_PARTS;
   a.ngrp = (a.ntiles + a.tpw - 1) / a.tpw;
   int rc = 0;
-  if (cin == 24) rc = wide ? launch<24, true>(a, st) : launch<24, false>(a, st);
-  else if (cin == 48) rc = wide ? launch<48, true>(a, st) : launch<48, false>(a, st);
-  else rc = wide ? launch<64, true>(a, st) : launch<64, false>(a, st);
+  switch (cin) {
+    case 16: rc = wide ? launch<16, true>(a, st) : launch<16, false>(a, st); break;
+    case 24: rc = wide ? launch<24, true>(a, st) : launch<24, false>(a, st); break;
+    case 32: rc = wide ? launch<32, true>(a, st) : launch<32, false>(a, st); break;
+    case 48: rc = wide ? launch<48, true>(a, st) : launch<48, false>(a, st); break;
+    case 64: rc = wide ? launch<64, true>(a, st) : launch<64, false>(a, st); break;
+    case 80: rc = wide ? launch<80, true>(a, st) : launch<80, false>(a, st); break;
+    default: rc = wide ? launch<96, true>(a, st) : launch<96, false>(a, st); break;
+  }
   if (rc != 1) return rc;
   if (nparts_out) *nparts_out = a.ngrp;
   EDET_LAUNCH_CHECK("edet_conv_fwd(halo)");

@@ -136,7 +136,10 @@ def test_conv_fwd(dt, shape, ks, mode):
 # (EDET_CONV_HALO=0) must still be reachable.
 @pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(2, 40, 37, 24, 24), (1, 33, 50, 48, 192), (2, 17, 35, 64, 256), (1, 24, 32, 24, 96),
-                                   (2, 9, 16, 48, 40), (9, 96, 160, 24, 24), (1, 8, 16, 64, 136)])
+                                   (2, 9, 16, 48, 40), (9, 96, 160, 24, 24), (1, 8, 16, 64, 136),
+                                   # the other Fused-MBConv widths of the EfficientNetV2 family (effnetv2_configs.py)
+                                   (2, 19, 21, 16, 16), (1, 20, 33, 32, 128), (2, 9, 17, 80, 320), (1, 12, 18, 96, 384),
+                                   (1, 10, 20, 32, 16), (1, 16, 16, 64, 512)])
 @pytest.mark.parametrize('mode', ['plain', 'bn_swish'])
 def test_conv_fwd_halo_tiles(shape, mode, monkeypatch):
   bf16 = [d for d in gu.DTYPES if d[0] == 'bf16'][0]
