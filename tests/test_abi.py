@@ -124,3 +124,25 @@ def test_lds_dma_kernel_keeps_its_prefetch_in_flight():
     lo, hi = dmas[0], barriers[-1]
     drained = [i for i in range(lo, hi) if re.search(r's_waitcnt.*vmcnt\(0\)', lines[i]) and i not in mine]
     assert not drained, (name, [lines[i].strip() for i in drained][:4], lo, hi)
+
+
+def test_halo_convolution_kernels_do_not_spill_registers():
+  """automl_amd/csrc/conv_halo.hip: fourteen instantiations (seven input widths x two column-tile layouts); the halo is loaded
+  in passes of at most six chunks per thread because nine at once spilled vector registers at 96 channels (r06at).  No
+  instantiation may spill or use scratch memory."""
+  import os
+  import re
+  import subprocess
+  import tempfile
+  from automl_amd import build
+  src = os.path.join(build.CSRC, 'conv_halo.hip')
+  with tempfile.TemporaryDirectory() as tmp:
+    r = subprocess.run([build.HIPCC] + build.FLAGS + ['-c', src, '-o', os.path.join(tmp, 'c.o'),
+                        '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0, r.stderr[-2000:]
+  names = re.findall(r'Function Name: (\S+)', r.stderr)
+  spills = [int(v) for v in re.findall(r'VGPRs Spill: (\d+)', r.stderr)]
+  scratch = [int(v) for v in re.findall(r'ScratchSize \[bytes/lane\]: (\d+)', r.stderr)]
+  assert len(names) == len(spills) == len(scratch) == 14, (len(names), len(spills), len(scratch))
+  bad = [(n, s, c) for n, s, c in zip(names, spills, scratch) if s or c]
+  assert not bad, bad
