@@ -1,13 +1,13 @@
-// Dense 3x3 stride-1 convolution (TF 'SAME'), forward, from an LDS-resident halo tile.
+// Dense 3x3 convolution (TF 'SAME', stride 1 or 2), forward, from an LDS-resident halo tile.
 //
 // The implicit GEMM of pw_big.hip (k_big_gemm<.., CONV>) gathers, bounds-checks and transforms every input element once
 // per TAP and per 128-column tile (9 x ntj times), with an integer division per 16-byte chunk: on the Fused-MBConv layers
 // of EfficientNetV2-S (112x112x24 -> 24, 56x56x48 -> 192, 28x28x64 -> 256) it reaches 0.75-1.1 TB/s and 3-15 % of the MFMA
 // peak (0.5 TB/s on the 16- and 32-channel layers of the b0-b3 / L variants).  Here a workgroup owns an 8 x 16 tile of output pixels (= the 128 rows of the MFMA tile):
 //
-//   * the 10 x 18 input halo of the tile is loaded ONCE, transformed once (BatchNorm / activation of the producing layer;
+//   * the 10 x 18 (stride 2: 17 x 33) input halo of the tile is loaded ONCE, transformed once (BatchNorm / activation of the producing layer;
 //     'SAME' padding is zero in the activated domain) and parked in LDS, pixel-major, channels padded to a multiple of 16;
-//   * the A fragments of tap (ky, kx) are plain ds_read_b128 at halo pixel (py + ky, px + kx): no im2col, no gather;
+//   * the A fragments of tap (ky, kx) are plain ds_read_b128 at halo pixel (S py + ky, S px + kx): no im2col, no gather;
 //   * the weights of one tap ([columns][cin], 6-16 KiB) stream through two LDS stages, requested one tap ahead; the (at
 //     most two) 128-column tiles of the layer are walked one after the other on the SAME halo;
 //   * 128-column tiles as 2 x 2 waves of 2 x 2 v_mfma_f32_32x32x16_bf16, or -- layers with at most 32 output channels --
@@ -28,7 +28,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int THREADS = 256;
 constexpr int TH = 8, TW = 16, BM = TH * TW;     // output pixels per tile
-constexpr int HH = TH + 2, HW = TW + 2;          // halo
+// halo of a tile at stride S: (TH - 1) S + 3 rows, (TW - 1) S + 3 columns
 constexpr int LDC_BF = 128 * 2 + 16;             // bf16 C tile row stride (272), BJ <= 128
 
 struct Args {
@@ -37,6 +37,7 @@ struct Args {
   int ldb, J;
   bf16_t* out;
   int ldo;
+  int oh, ow, pad_t, pad_l;          // output map, 'SAME' padding before
   int tiles_y, tiles_x, ntiles;      // per image / total
   int ntj, tpw, ngrp;
   float* stat_partials;
@@ -56,8 +57,9 @@ __device__ __forceinline__ uint4 pack8(const float x[8]) {
 }
 
 // CIN: input channels (multiple of 8).  WIDE: 128-column tiles (2 x 2 waves of 64 x 64), else 32-column tiles (4 x 1
-// waves of 32 x 32).
-template <int CIN, bool WIDE> struct Geo {
+// waves of 32 x 32).  S: stride (1, 2).
+template <int CIN, bool WIDE, int S> struct Geo {
+  static constexpr int HH = (TH - 1) * S + 3, HW = (TW - 1) * S + 3;
   static constexpr int KP = (CIN + 15) / 16 * 16;      // channels per tap in LDS (zero-padded)
   static constexpr int CPC = CIN / 8, CPP = KP / 8;    // 16-byte chunks per pixel: loaded / stored
   static constexpr int PS = KP * 2 + 16;               // halo pixel stride (bytes; +16: fragment reads of 32 pixels spread over the banks)
@@ -78,9 +80,10 @@ template <int CIN, bool WIDE> struct Geo {
   static constexpr int WMT = WIDE ? 2 : 1, WJT = WIDE ? 2 : 1;     // MFMA tiles per wave
 };
 
-template <int CIN, bool WIDE>
+template <int CIN, bool WIDE, int S>
 __global__ __launch_bounds__(THREADS, 2) void k_conv3_halo(const Args a) {
-  using G = Geo<CIN, WIDE>;
+  using G = Geo<CIN, WIDE, S>;
+  constexpr int HH = G::HH, HW = G::HW;
   constexpr int KP = G::KP, CPC = G::CPC, CPP = G::CPP, PS = G::PS, BJ = G::BJ, BS = G::BS, BPT = G::BPT;
   constexpr int WMT = G::WMT, WJT = G::WJT;
   constexpr int LDC = WIDE ? LDC_BF : 32 * 2 + 16;
@@ -91,7 +94,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3_halo(const Args a) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = WIDE ? (wave & 1) : wave, wj = WIDE ? (wave >> 1) : 0;
   const int grp = blockIdx.x;
-  const int H = a.tv.h, W = a.tv.w;
+  const int H = a.tv.h, W = a.tv.w;                    // input map
+  const int OH = a.oh, OW = a.ow;                      // output map
   const bool want_stats = a.stat_partials != nullptr;
   const bool affine = a.tv.scale != nullptr;
   const int act = a.tv.act;
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3_halo(const Args a) {
         const int e = tid + THREADS * (base + i);
         const int p = e / CPP, c = e - p * CPP;
         const int hy = p / HW, hx = p - hy * HW;
-        const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+        const int iy = oy0 * S + hy - a.pad_t, ix = ox0 * S + hx - a.pad_l;
         raw[i] = make_uint4(0, 0, 0, 0);
         const bool inside = e < HH * HW * CPP && c < CPC && iy >= 0 && iy < H && ix >= 0 && ix < W;
         // hdst: byte offset in the halo; bit 30: the chunk holds data (else zeros: padding pixel or padding channels)
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3_halo(const Args a) {
 #pragma unroll
     for (int mi = 0; mi < WMT; ++mi) {
       const int m = (WIDE ? wm * 64 : wm * 32) + mi * 32 + r;
-      apix[mi] = (m / TW) * HW + (m % TW);
+      apix[mi] = (m / TW) * S * HW + (m % TW) * S;
     }
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -274,9 +278,9 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3_halo(const Args a) {
     for (int i = 0; i < BM / ER; ++i) {
       const int row = er + ER * i;
       const int oy = oy0 + row / TW, ox = ox0 + row % TW;
-      if (ecol_ok && oy < H && ox < W) {
+      if (ecol_ok && oy < OH && ox < OW) {
         const uint4 v = *reinterpret_cast<const uint4*>(reg + row * LDC + ec * 16);
-        *reinterpret_cast<uint4*>(a.out + ((size_t)(img * H + oy) * W + ox) * a.ldo + ej) = v;
+        *reinterpret_cast<uint4*>(a.out + ((size_t)(img * OH + oy) * OW + ox) * a.ldo + ej) = v;
         if (want_stats) {
           float x[8];
           unpack8(v, x);
@@ -312,28 +316,31 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3_halo(const Args a) {
   }
 }
 
-template <int CIN, bool WIDE> int launch(const Args& a, hipStream_t st) {
-  using G = Geo<CIN, WIDE>;
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_halo<CIN, WIDE>),
+template <int CIN, bool WIDE, int S> int launch(const Args& a, hipStream_t st) {
+  using G = Geo<CIN, WIDE, S>;
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_halo<CIN, WIDE, S>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM_BYTES) == hipSuccess;
   if (!ok) return 0;
-  edet_launch(k_conv3_halo<CIN, WIDE>, dim3(a.ngrp), dim3(THREADS), G::SMEM_BYTES, st, a);
+  edet_launch(k_conv3_halo<CIN, WIDE, S>, dim3(a.ngrp), dim3(THREADS), G::SMEM_BYTES, st, a);
   return 1;
 }
 
 }  // namespace cvh
 
 // return 1 = handled, 0 = shape outside the envelope (the caller goes on to the implicit GEMM), < 0 = error.
-// Envelope: 3 x 3, stride 1, the Fused-MBConv widths of the EfficientNetV2 family (effnetv2_configs.py: 16 / 24 / 32 / 48 /
+// Envelope: 3 x 3, stride 1 (stride 2 up to 32 input channels), the Fused-MBConv widths of the EfficientNetV2 family (effnetv2_configs.py: 16 / 24 / 32 / 48 /
 // 64 / 80 / 96 input channels), at most 512 output channels, no SE gate on the input view.
 int cvh_try_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, int k, int s, void* out, int cout, int ldo,
                      float* stat_partials, int* nparts_out, hipStream_t st) {
   using namespace cvh;
-  if (k != 3 || s != 1 || in->gate) return 0;
+  if (k != 3 || (s != 1 && s != 2) || in->gate) return 0;
   const int cin = in->c;
   // every width measured faster than the implicit GEMM (r06at, batch 128: 16 / 32 channels 4.6-5x, 24: 4.1x, 48 / 64: 1.8-1.9x,
   // 80: 1.8x, 96: 1.2-1.6x)
   if (cin != 16 && cin != 24 && cin != 32 && cin != 48 && cin != 64 && cin != 80 && cin != 96) return 0;
+  // stride 2: a 17 x 33 halo.  r06au (per launch, implicit GEMM -> halo tile): 16 / 24 / 32 channels 1.26-1.48x faster; 48
+  // channels (63 KiB of halo, one workgroup per CU) 0.126 -> 0.138 ms: stays on the implicit GEMM
+  if (s == 2 && cin > 32) return 0;
   if (in->ld % 8 != 0 || ldw % 8 != 0 || ldo % 8 != 0 || ldo < (cout + 7) / 8 * 8) return 0;
   const char* e = getenv("EDET_CONV_HALO");
   if (e && e[0] == '0') return 0;           // lab switch: the implicit GEMM for every shape
@@ -342,7 +349,9 @@ int cvh_try_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, int k, int
   a.tv = *in;
   a.Bm = reinterpret_cast<const bf16_t*>(wt); a.ldb = ldw; a.J = cout;
   a.out = reinterpret_cast<bf16_t*>(out); a.ldo = ldo; a.stat_partials = stat_partials;
-  a.tiles_y = (in->h + TH - 1) / TH; a.tiles_x = (in->w + TW - 1) / TW;
+  a.oh = same_out(in->h, s); a.ow = same_out(in->w, s);
+  a.pad_t = same_pad_before(in->h, 3, s); a.pad_l = same_pad_before(in->w, 3, s);
+  a.tiles_y = (a.oh + TH - 1) / TH; a.tiles_x = (a.ow + TW - 1) / TW;
   a.ntiles = in->n * a.tiles_y * a.tiles_x;
   if (cout > 512) return 0;                 // a workgroup walks at most four 128-column tiles
   const bool wide = cout > 32;
@@ -350,14 +359,22 @@ int cvh_try_conv_fwd(const edet_tview_t* in, const void* wt, int ldw, int k, int
   a.tpw = (a.ntiles + EDET_MAX_PARTS - 1) / EDET_MAX_PARTS;
   a.ngrp = (a.ntiles + a.tpw - 1) / a.tpw;
   int rc = 0;
-  switch (cin) {
-    case 16: rc = wide ? launch<16, true>(a, st) : launch<16, false>(a, st); break;
-    case 24: rc = wide ? launch<24, true>(a, st) : launch<24, false>(a, st); break;
-    case 32: rc = wide ? launch<32, true>(a, st) : launch<32, false>(a, st); break;
-    case 48: rc = wide ? launch<48, true>(a, st) : launch<48, false>(a, st); break;
-    case 64: rc = wide ? launch<64, true>(a, st) : launch<64, false>(a, st); break;
-    case 80: rc = wide ? launch<80, true>(a, st) : launch<80, false>(a, st); break;
-    default: rc = wide ? launch<96, true>(a, st) : launch<96, false>(a, st); break;
+  if (s == 1) {
+    switch (cin) {
+      case 16: rc = wide ? launch<16, true, 1>(a, st) : launch<16, false, 1>(a, st); break;
+      case 24: rc = wide ? launch<24, true, 1>(a, st) : launch<24, false, 1>(a, st); break;
+      case 32: rc = wide ? launch<32, true, 1>(a, st) : launch<32, false, 1>(a, st); break;
+      case 48: rc = wide ? launch<48, true, 1>(a, st) : launch<48, false, 1>(a, st); break;
+      case 64: rc = wide ? launch<64, true, 1>(a, st) : launch<64, false, 1>(a, st); break;
+      case 80: rc = wide ? launch<80, true, 1>(a, st) : launch<80, false, 1>(a, st); break;
+      default: rc = wide ? launch<96, true, 1>(a, st) : launch<96, false, 1>(a, st); break;
+    }
+  } else {
+    switch (cin) {
+      case 16: rc = wide ? launch<16, true, 2>(a, st) : launch<16, false, 2>(a, st); break;
+      case 24: rc = wide ? launch<24, true, 2>(a, st) : launch<24, false, 2>(a, st); break;
+      default: rc = wide ? launch<32, true, 2>(a, st) : launch<32, false, 2>(a, st); break;
+    }
   }
   if (rc != 1) return rc;
   if (nparts_out) *nparts_out = a.ngrp;

@@ -18,6 +18,7 @@ def main():
   ap.add_argument('--ab', default='')
   ap.add_argument('--env', default='', help='VAR=val,... set for the whole run')
   ap.add_argument('--reps', type=int, default=20)
+  ap.add_argument('--stride', type=int, default=1)
   args = ap.parse_args()
   for kv in filter(None, args.env.split(',')):
     k, v = kv.split('=')
@@ -31,7 +32,8 @@ def main():
     n, h, w, cin, cout = [int(x) for x in sh.split('x')]
     x = torch.randn(n, h, w, cin, device=gu.DEV).to(tdt)
     wt = (torch.randn(cout, 9 * cin, device=gu.DEV) / (9 * cin) ** 0.5).to(tdt)
-    out = torch.empty(n, h, w, gu.pad8(cout), dtype=tdt, device=gu.DEV)
+    oh, ow = (h + args.stride - 1) // args.stride, (w + args.stride - 1) // args.stride
+    out = torch.empty(n, oh, ow, gu.pad8(cout), dtype=tdt, device=gu.DEV)
     sc = torch.rand(cin, device=gu.DEV) + 0.5
     shf = torch.rand(cin, device=gu.DEV) - 0.5
     tv = gu.tview(x, cin, sc, shf, None, _lib.ACT_NONE)
@@ -39,7 +41,7 @@ def main():
     for v in vals:
       if var:
         os.environ[var] = v
-      fn = lambda: call('edet_conv_fwd', ctypes.byref(tv), ptr(wt), 9 * cin, 3, 1, ptr(out), cout, gu.pad8(cout), None,
+      fn = lambda: call('edet_conv_fwd', ctypes.byref(tv), ptr(wt), 9 * cin, 3, args.stride, ptr(out), cout, gu.pad8(cout), None,
                         ctypes.byref(npart), edt, gu.stream())
       for _ in range(3):
         fn()
@@ -53,8 +55,8 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / args.reps)
-      mb = n * h * w * (cin + cout) * 2 / 1e6
-      print('conv3x3 %-22s %s=%-4s %8.4f ms %8.1f MB %8.1f GB/s' % (sh, var, v, best, mb, mb / best))
+      mb = (n * h * w * cin + n * oh * ow * cout) * 2 / 1e6
+      print('conv3x3 s%d %-22s %s=%-4s %8.4f ms %8.1f MB %8.1f GB/s' % (args.stride, sh, var, v, best, mb, mb / best))
 
 
 if __name__ == '__main__':

@@ -127,7 +127,7 @@ def test_lds_dma_kernel_keeps_its_prefetch_in_flight():
 
 
 def test_halo_convolution_kernels_do_not_spill_registers():
-  """automl_amd/csrc/conv_halo.hip: fourteen instantiations (seven input widths x two column-tile layouts); the halo is loaded
+  """automl_amd/csrc/conv_halo.hip: 20 instantiations (seven input widths at stride 1, three at stride 2, x two column-tile layouts); the halo is loaded
   in passes of at most six chunks per thread because nine at once spilled vector registers at 96 channels (r06at).  No
   instantiation may spill or use scratch memory."""
   import os
@@ -143,6 +143,6 @@ def test_halo_convolution_kernels_do_not_spill_registers():
   names = re.findall(r'Function Name: (\S+)', r.stderr)
   spills = [int(v) for v in re.findall(r'VGPRs Spill: (\d+)', r.stderr)]
   scratch = [int(v) for v in re.findall(r'ScratchSize \[bytes/lane\]: (\d+)', r.stderr)]
-  assert len(names) == len(spills) == len(scratch) == 14, (len(names), len(spills), len(scratch))
+  assert len(names) == len(spills) == len(scratch) == 20, (len(names), len(spills), len(scratch))
   bad = [(n, s, c) for n, s, c in zip(names, spills, scratch) if s or c]
   assert not bad, bad
