@@ -6,7 +6,7 @@
 //
 //   * global_load_lds_dwordx4 (1 KiB per wave instruction, lane-linear destination) brings the RAW 128 x BK chunk of the
 //     streamed operand, the 128 x BK weight chunk and a block of per-channel coefficients (BatchNorm scale / shift, the
-//     SE gate rows of the tile's two images; one copy per wave) into one of NST = 4 LDS stages: the loads of THREE
+//     SE gate rows of the up to four images of the tile; one copy per wave) into one of NST = 4 LDS stages: the loads of THREE
 //     reduction steps are in flight, counted by hand (s_waitcnt vmcnt(2 G) before a stage is touched);
 //   * chunk c of row r lives in slot c ^ swz(r) (the permutation is applied to the per-lane GLOBAL address, the LDS image
 //     of an LDS-DMA is fixed): ds_read_b128 fragment reads without padding;
@@ -50,7 +50,10 @@ template <int BK> struct Geo {
   static constexpr int ROWB = BK * 2;                 // bytes per row
   static constexpr int RP = 128 / ROWB;               // rows per 128 bytes of LDS
   static constexpr int TILE_BYTES = BM * ROWB;
-  static constexpr int CW = 4 * BK * 4;               // coefficient block of one wave: scale | shift | gate(img0) | gate(img1)
+  static constexpr int NG = BK == 32 ? 4 : 2;         // gate rows (images a row tile may touch): 4 -> maps down to 7 x 7
+  static constexpr int NT = 2 + NG;                   // tables of a coefficient block: scale | shift | gate(img0 ..)
+  static_assert(NT * (BK / 4) <= 64, "one DMA instruction per coefficient block");
+  static constexpr int CW = NT * BK * 4;              // coefficient block of one wave
   static constexpr int STAGE_BYTES = 2 * TILE_BYTES + 4 * CW;
   static constexpr int SMEM_BYTES = NST * STAGE_BYTES;
   static_assert(BM * LDC_BF <= SMEM_BYTES, "the C tile must fit in the stages");
@@ -63,7 +66,7 @@ struct Args {
   const bf16_t* Bm;   // [J][ldb], reduction index contiguous
   int ldb;
   int M, R, J;        // rows, reduction length, output columns
-  int hw;             // pixels per image (>= BM when gated: a row tile touches at most two images)
+  int hw;             // pixels per image (>= 43 when gated: a row tile touches at most four images)
   int ntm, ntj, tpw, ngrp;
   const float* bias;
   bf16_t* out;
@@ -143,31 +146,29 @@ __global__ __launch_bounds__(THREADS, BK == 64 ? 1 : 2) void k_wide_fwd(const Ar
     const int m0 = mt * BM;
     const bf16_t* arow[NI];
     const bf16_t* brow[NI];
-    unsigned g1mask = 0, bzero = 0;
+    unsigned gsel = 0, bzero = 0;                          // gsel: 2 bits per chunk = the row's image - img0
     const int img0 = m0 / a.hw;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int r = (wave * NI + i) * GE::RPD + lrow;
       const int m = min(m0 + r, a.M - 1);                 // rows past M re-read row M-1 (never stored)
       arow[i] = SRC + (size_t)m * a.tv.ld;
-      if (gated && m / a.hw != img0) g1mask |= 1u << i;
+      if (gated) gsel |= (unsigned)(m / a.hw - img0) << (2 * i);
       const int j = j0 + r;
       if (j >= a.J) bzero |= 1u << i;                     // weight rows past J: zeroed in LDS by their owner
       brow[i] = a.Bm + (size_t)min(j, a.J - 1) * a.ldb;
     }
-    // coefficient block of this wave: 4 tables x BK floats; lane -> table lane / (BK / 4), 4 floats at lane % (BK / 4)
-    // (BK = 32: the upper half of the wave sits the instruction out)
+    // coefficient block of this wave: NT tables x BK floats; lane -> table lane / (BK / 4), 4 floats at lane % (BK / 4)
+    // (the lanes past the last table sit the instruction out)
     const float* crow = nullptr;
-    const bool clane = lane < BK;
+    const bool clane = lane < GE::NT * (BK / 4);
     if (COEF) {
-      const int b = (lane / (BK / 4)) & 3;
-      const int img1 = min(img0 + 1, a.tv.n - 1);
-      // a missing table reads the other one (its values are not used)
+      const int b = min(lane / (BK / 4), GE::NT - 1);
+      // a missing table reads the other one (its values are not used); images past the last one re-read the last
       const float* sc = affine ? a.tv.scale : a.tv.gate;
       const float* sh = affine ? a.tv.shift : a.tv.gate;
-      const float* g0 = gated ? a.tv.gate + (size_t)img0 * a.R : a.tv.scale;
-      const float* g1 = gated ? a.tv.gate + (size_t)img1 * a.R : a.tv.scale;
-      crow = b == 0 ? sc : (b == 1 ? sh : (b == 2 ? g0 : g1));
+      const float* gr = gated ? a.tv.gate + (size_t)min(img0 + max(b - 2, 0), a.tv.n - 1) * a.R : a.tv.scale;
+      crow = b == 0 ? sc : (b == 1 ? sh : gr);
     }
 
     auto issue = [&](int kt, unsigned char* stage) {
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(THREADS, BK == 64 ? 1 : 2) void k_wide_fwd(const Ar
       for (int i = 0; i < NI; ++i) dma16(brow[i] + kc, Bs + i * 1024);
       if (COEF) {
         const int kk = min(kt * BK + (lane % (BK / 4)) * 4, a.R - 4);
-        if (BK == 64 || clane) dma16(crow + kk, stage + 2 * TILE_BYTES + wave * CW);
+        if (clane) dma16(crow + kk, stage + 2 * TILE_BYTES + wave * CW);
       }
     };
     // in-place transform of the thread's own chunks of the streamed operand (and zeroing of weight rows past J).
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(THREADS, BK == 64 ? 1 : 2) void k_wide_fwd(const Ar
           }
           if (COEF && gated) {
             float gt[8];
-            ld8f(cf + (((g1mask >> i) & 1u) ? 3 * BK : 2 * BK), gt);     // the row's image: an address, not 8 selects
+            ld8f(cf + (2 + ((gsel >> (2 * i)) & 3u)) * BK, gt);     // the row's image: an address, not 8 selects
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] *= gt[e];
           }
@@ -357,7 +358,7 @@ template <int BK> int launch_bk(const Args& a, int grid, bool coef, bool sw, hip
 }  // namespace pwg
 
 // return 1 = handled, 0 = shape outside the envelope (the caller goes on to k_big_gemm), < 0 = error.
-// Envelope: swish / linear views; with an SE gate at least BM pixels per image (a row tile inside two images);
+// Envelope: swish / linear views; with an SE gate at least 43 pixels per image (a row tile touches at most four images);
 // reduction length a multiple of 8 and at least 2 x 64 (shorter reductions have nothing to prefetch).
 int pwg_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bias, void* out, int cout,
                 int ldo, float* stat_partials, int* nparts_out, int tpw, hipStream_t st) {
@@ -365,7 +366,7 @@ int pwg_try_fwd(const edet_tview_t* in, const void* wt, int ldw, const float* bi
   const int K = in->c, N = cout;
   if (K % 8 != 0 || in->ld % 8 != 0 || ldw % 8 != 0 || ldo % 8 != 0 || ldo < (N + 7) / 8 * 8) return 0;
   if (in->act > EDET_ACT_SWISH || K < 128) return 0;
-  if (in->gate && in->h * in->w < BM) return 0;
+  if (in->gate && (BM - 1) / (in->h * in->w) + 2 > Geo<32>::NG) return 0;      // images a row tile may touch
   Args a;
   memset(&a, 0, sizeof(a));
   a.tv = *in;

@@ -146,7 +146,9 @@ def test_pw_fwd(dt, shape, mode, pw_impl):
 # one case with more row tiles than EDET_MAX_PARTS (several row tiles per workgroup).
 @pytest.mark.parametrize('shape', [(3, 13, 11, 144, 24), (2, 20, 20, 1152, 192), (2, 20, 20, 1152, 320), (2, 12, 12, 480, 80),
                                    (2, 40, 40, 672, 112), (3, 17, 9, 240, 40), (2, 20, 20, 192, 1152), (1, 40, 40, 128, 810),
-                                   (2, 16, 16, 384, 36), (1, 24, 24, 3840, 640), (33, 64, 64, 128, 64)])
+                                   (2, 16, 16, 384, 36), (1, 24, 24, 3840, 640), (33, 64, 64, 128, 64),
+                                   # small maps: a row tile touches up to four images (four gate rows in the coefficient block)
+                                   (11, 7, 7, 256, 64), (7, 9, 5, 384, 160), (5, 7, 7, 1536, 256)])
 @pytest.mark.parametrize('mode', ['plain', 'bn', 'bn_swish', 'bn_swish_gate'])
 def test_pw_fwd_glds_equals_register_staged(shape, mode, monkeypatch):
   n, h, w, cin, cout = shape
